@@ -1,0 +1,290 @@
+"""Scene inputs for the adapter path: the reference's two golden scenes, the BASELINE.json
+synthetic configurations, and tiny OBJ / PLY readers.  Pure numpy, no device code.
+
+Citations are relative to the GraviT tree (/root/reference in the build container).
+"""
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from .types import LIGHT_DTYPE, MATERIAL_DTYPE, default_material, point_light
+
+F = np.float32
+
+
+@dataclass
+class MeshData:
+    """gvt::render::data::primitives::Mesh inputs (Mesh.h:87-100): 0-based faces."""
+
+    verts: np.ndarray  # (nV,3) f32
+    tris: np.ndarray  # (nT,3) i32
+    material: np.ndarray = field(default_factory=default_material)  # Mesh::mat
+    vnormals: Optional[np.ndarray] = None
+    vcolors: Optional[np.ndarray] = None
+    materials: Optional[np.ndarray] = None  # faces_to_materials table
+    face_mat: Optional[np.ndarray] = None
+
+    def bbox(self):
+        return self.verts.min(axis=0).astype(F), self.verts.max(axis=0).astype(F)
+
+
+@dataclass
+class Camera:
+    """gvtPerspectiveCamera parameters (gvtCamera.cpp:233-312); fov in radians."""
+
+    eye: tuple
+    focus: tuple
+    up: tuple
+    fov: float
+    width: int
+    height: int
+    samples: int = 1
+    depth: int = 1
+    jitter: float = 0.0
+
+
+@dataclass
+class Scene:
+    meshes: List[MeshData]
+    inst_mesh: List[int]  # instance -> mesh index
+    m: np.ndarray  # (nInst,16) glm column-major
+    minv: np.ndarray  # (nInst,16)
+    normi: np.ndarray  # (nInst,9)
+    inst_lo: np.ndarray  # (nInst,3) world AABB (api.cpp:309-312)
+    inst_hi: np.ndarray
+    lights: np.ndarray  # LIGHT_DTYPE
+    camera: Camera
+    name: str = ""
+
+    @property
+    def n_inst(self):
+        return len(self.inst_mesh)
+
+
+# ------------------------------------------------------------------ matrices (glm, column-major)
+def mat_translate_scale(t, s):
+    """glm::scale(glm::translate(I, t), s) as 16 floats, column-major (SimpleApp.cpp:166-168)."""
+    m = np.zeros((4, 4), F)  # m[col][row]
+    m[0, 0], m[1, 1], m[2, 2] = F(s[0]), F(s[1]), F(s[2])
+    m[3, 0], m[3, 1], m[3, 2], m[3, 3] = F(t[0]), F(t[1]), F(t[2]), F(1)
+    return m.reshape(16)
+
+
+def instance_matrices(m16):
+    """minv = inverse(m), normi = transpose(inverse(mat3(m)))  (api.cpp:307-308)."""
+    M = m16.reshape(4, 4).T.astype(np.float64)  # row-major math matrix
+    Minv = np.linalg.inv(M)
+    minv = Minv.T.astype(F).reshape(16)
+    N = np.linalg.inv(M[:3, :3]).T  # math matrix of normi
+    normi = N.T.astype(F).reshape(9)  # column-major storage
+    return minv, normi
+
+
+def instance_bbox(m16, lo, hi):
+    """Box3D(M*min, M*max): only the two corners are transformed (api.cpp:309-312)."""
+    M = m16.reshape(4, 4).T
+    a = (M @ np.array([lo[0], lo[1], lo[2], 1], F)).astype(F)[:3]
+    b = (M @ np.array([hi[0], hi[1], hi[2], 1], F)).astype(F)[:3]
+    return np.minimum(a, b), np.maximum(a, b)
+
+
+def add_faces_1based(verts, faces1):
+    """Mesh::addFace (Mesh.cpp:102-112): 1-based indices, faces with coincident vertices are dropped."""
+    out = []
+    for a, b, c in np.asarray(faces1).reshape(-1, 3):
+        va, vb, vc = verts[a - 1], verts[b - 1], verts[c - 1]
+        if (va == vb).all() or (vb == vc).all() or (vc == va).all():
+            continue
+        out.append((a - 1, b - 1, c - 1))
+    return np.array(out, np.int32).reshape(-1, 3)
+
+
+def _assemble(meshes, inst_mesh, mats, lights, camera, name):
+    minv, normi, lo, hi = [], [], [], []
+    for i, m in zip(inst_mesh, mats):
+        a, b = instance_matrices(m)
+        minv.append(a)
+        normi.append(b)
+        l, h = instance_bbox(m, *meshes[i].bbox())
+        lo.append(l)
+        hi.append(h)
+    return Scene(meshes, list(inst_mesh), np.array(mats, F).reshape(-1, 16), np.array(minv, F).reshape(-1, 16),
+                 np.array(normi, F).reshape(-1, 9), np.array(lo, F).reshape(-1, 3), np.array(hi, F).reshape(-1, 3),
+                 np.ascontiguousarray(lights, LIGHT_DTYPE), camera, name)
+
+
+# ------------------------------------------------------------------ golden scene 1: gvtSimple
+def simple_scene(width=512, height=512):
+    """The 5x5 cone/cube grid of src/apps/render/SimpleApp.cpp:82-233 (golden simple.ppm)."""
+    cone_v = np.array([0.5, 0.0, 0.0, -0.5, 0.5, 0.0, -0.5, 0.25, 0.433013, -0.5, -0.25, 0.43013, -0.5, -0.5, 0.0, -0.5, -0.25,
+                       -0.433013, -0.5, 0.25, -0.433013], F).reshape(-1, 3)
+    cone_f = [1, 2, 3, 1, 3, 4, 1, 4, 5, 1, 5, 6, 1, 6, 7, 1, 7, 2]
+    cube_v = np.array([-0.5, -0.5, 0.5, 0.5, -0.5, 0.5, 0.5, 0.5, 0.5, -0.5, 0.5, 0.5, -0.5, -0.5, -0.5, 0.5, -0.5, -0.5, 0.5, 0.5,
+                       -0.5, -0.5, 0.5, -0.5, 0.5, 0.5, 0.5, -0.5, 0.5, 0.5, 0.5, 0.5, -0.5, -0.5, 0.5, -0.5, -0.5, -0.5, 0.5, 0.5,
+                       -0.5, 0.5, -0.5, -0.5, -0.5, 0.5, -0.5, -0.5, 0.5, -0.5, 0.5, 0.5, 0.5, 0.5, 0.5, -0.5, -0.5, 0.5, 0.5, -0.5,
+                       -0.5, -0.5, 0.5, -0.5, 0.5, 0.5, -0.5, -0.5, -0.5, -0.5, 0.5, -0.5], F).reshape(-1, 3)
+    cube_f = [1, 2, 3, 1, 3, 4, 17, 19, 20, 17, 20, 18, 6, 5, 8, 6, 8, 7, 23, 21, 22, 23, 22, 24, 10, 9, 11, 10, 11, 12, 13, 15,
+              16, 13, 16, 14]
+    white = default_material(kd=(1.0, 1.0, 1.0))  # addMeshMaterial(LAMBERT, kd=1, alpha=1) api.cpp:228-236
+    cone = MeshData(cone_v, add_faces_1based(cone_v, cone_f), white)
+    cube = MeshData(cube_v, add_faces_1based(cube_v, cube_f), white)
+    mats, inst_mesh = [], []
+    inst = 0
+    for i in range(-2, 3):
+        for j in range(-2, 3):
+            mats.append(mat_translate_scale((0.0, i * 0.5, j * 0.5), (0.4, 0.4, 0.4)))
+            inst_mesh.append(1 if inst % 2 else 0)
+            inst += 1
+    cam = Camera((4.0, 0.0, 0.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), float(F(45.0 * np.pi / 180.0)), width, height, 1, 1, 0.5)
+    return _assemble([cone, cube], inst_mesh, mats, point_light((1.0, 0.0, -1.0)), cam, "simple")
+
+
+# ------------------------------------------------------------------ readers
+def read_obj(path):
+    """Vertices and triangles of a Wavefront OBJ (faces 0-based, no degenerate filter, like
+    data/reader/ObjReader.cpp:122-135 which pushes tinyobj faces straight into Mesh::faces)."""
+    vs, fs = [], []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("v "):
+                p = line.split()
+                vs.append((float(p[1]), float(p[2]), float(p[3])))
+            elif line.startswith("f "):
+                idx = [int(tok.split("/")[0]) for tok in line.split()[1:]]
+                idx = [i - 1 if i > 0 else len(vs) + i for i in idx]
+                for k in range(1, len(idx) - 1):  # fan-triangulate like tinyobj
+                    fs.append((idx[0], idx[k], idx[k + 1]))
+    return np.array(vs, F).reshape(-1, 3), np.array(fs, np.int32).reshape(-1, 3)
+
+
+def read_ply(path):
+    """ASCII PLY with x y z [..] vertices and 3-vertex faces (data/geom/bunny/reconstruction/*.ply)."""
+    with open(path, "rb") as f:
+        nv = nf = 0
+        nprops = 0
+        in_vertex = False
+        while True:
+            line = f.readline().decode("ascii", "replace").strip()
+            if line.startswith("element vertex"):
+                nv = int(line.split()[2])
+                in_vertex = True
+            elif line.startswith("element face"):
+                nf = int(line.split()[2])
+                in_vertex = False
+            elif line.startswith("property") and in_vertex:
+                nprops += 1
+            elif line == "end_header":
+                break
+        body = f.read().split()
+    v = np.array(body[: nv * nprops], dtype=np.float64).reshape(nv, nprops)[:, :3].astype(F)
+    fa = np.array(body[nv * nprops : nv * nprops + nf * 4], dtype=np.int64).reshape(nf, 4)
+    assert (fa[:, 0] == 3).all()
+    return v, fa[:, 1:].astype(np.int32)
+
+
+def load_mesh_file(path):
+    if path.endswith(".npz"):
+        d = np.load(path)
+        return d["verts"].astype(F), d["tris"].astype(np.int32)
+    if path.endswith(".ply"):
+        return read_ply(path)
+    return read_obj(path)
+
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+# ------------------------------------------------------------------ golden scene 2: bunny.obj
+def bunny_scene(width=512, height=512, path=None):
+    """src/apps/render/SimpleFileLoadApp.cpp:186-241 (golden bunny.ppm): identity instance, default material."""
+    v, t = load_mesh_file(path or os.path.join(GOLDEN_DIR, "bunny.obj"))
+    mesh = MeshData(v, t, default_material())
+    cam = Camera((0.0, 0.1, 0.3), (0.0, 0.1, -0.3), (0.0, 1.0, 0.0), float(F(45.0 * np.pi / 180.0)), width, height, 1, 1, 0.0)
+    return _assemble([mesh], [0], [mat_translate_scale((0, 0, 0), (1, 1, 1))], point_light((0.0, 0.1, 0.5)), cam, "bunny")
+
+
+def bunny70k_scene(width=1920, height=1080, path=None):
+    """BASELINE config 2: bun_zipper (69,451 tris), single domain, depth 1, camera framing the bbox."""
+    v, t = load_mesh_file(path or os.path.join(GOLDEN_DIR, "bun_zipper.npz"))
+    mesh = MeshData(v, t, default_material())
+    lo, hi = mesh.bbox()
+    c = 0.5 * (lo + hi)
+    cam = Camera((float(c[0]), float(c[1]), float(c[2] + 0.35)), (float(c[0]), float(c[1]), float(c[2])), (0.0, 1.0, 0.0),
+                 float(F(30.0 * np.pi / 180.0)), width, height, 1, 1, 0.0)
+    light = point_light((float(c[0]), float(c[1] + 0.1), float(c[2] + 0.5)))
+    return _assemble([mesh], [0], [mat_translate_scale((0, 0, 0), (1, 1, 1))], light, cam, "bunny70k")
+
+
+def bunny_grid_scene(nx=4, ny=2, pitch=0.3, width=1900, height=1080, path=None):
+    """BASELINE config 4: nx*ny bunny instances on a grid (pitch like data/bunny.conf:27-29, film data/bunny.conf:8)."""
+    v, t = load_mesh_file(path or os.path.join(GOLDEN_DIR, "bunny.obj"))
+    mesh = MeshData(v, t, default_material())
+    mats = []
+    for j in range(ny):
+        for i in range(nx):
+            mats.append(mat_translate_scale(((i - (nx - 1) / 2) * pitch, (j - (ny - 1) / 2) * pitch, 0.0), (1, 1, 1)))
+    cam = Camera((0.0, 0.1, 1.6), (0.0, 0.1, 0.0), (0.0, 1.0, 0.0), float(F(40.0 * np.pi / 180.0)), width, height, 1, 1, 0.0)
+    return _assemble([mesh], [0] * (nx * ny), mats, point_light((0.0, 0.3, 1.2)), cam, "bunny-grid-%dx%d" % (nx, ny))
+
+
+# ------------------------------------------------------------------ synthetic soups
+def triangle_soup(n_tris, seed=12345, half_extent=0.005):
+    """BASELINE config 3 geometry: centres U[0,1]^3, 3 offsets U[-s,s]^3 each, unshared vertices.
+    Generator: numpy Philox(seed), float32 draws."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    c = rng.random((n_tris, 1, 3), dtype=F)
+    o = (rng.random((n_tris, 3, 3), dtype=F) * F(2.0) - F(1.0)) * F(half_extent)
+    verts = (c + o).reshape(-1, 3).astype(F)
+    tris = np.arange(n_tris * 3, dtype=np.int32).reshape(-1, 3)
+    return verts, tris
+
+
+def soup_scene(n_tris=10_000_000, width=1920, height=1080, seed=12345, half_extent=0.005):
+    """BASELINE config 3: eye (.5,.5,3) -> (.5,.5,.5), fov 30 deg, light at the eye, kd .5, depth 1."""
+    v, t = triangle_soup(n_tris, seed, half_extent)
+    mesh = MeshData(v, t, default_material())
+    cam = Camera((0.5, 0.5, 3.0), (0.5, 0.5, 0.5), (0.0, 1.0, 0.0), float(F(30.0 * np.pi / 180.0)), width, height, 1, 1, 0.0)
+    return _assemble([mesh], [0], [mat_translate_scale((0, 0, 0), (1, 1, 1))], point_light((0.5, 0.5, 3.0)), cam,
+                     "soup-%d" % n_tris)
+
+
+def cathedral_scene(width=512, height=512, samples=2, depth=2, seed=7):
+    """BASELINE config 5 stand-in (sibenik.obj is missing from the reference, .MISSING_LARGE_BLOBS):
+    a closed hall of long thin triangles (~80 K) -- deep BVH, AO-style secondary rays."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    vs, fs = [], []
+
+    def quad_strip(p0, du, dv, nu, nv):
+        base = len(vs)
+        for j in range(nv + 1):
+            for i in range(nu + 1):
+                vs.append(p0 + du * (i / nu) + dv * (j / nv))
+        for j in range(nv):
+            for i in range(nu):
+                a = base + j * (nu + 1) + i
+                fs.append((a, a + 1, a + nu + 2))
+                fs.append((a, a + nu + 2, a + nu + 1))
+
+    X, Y, Z = 4.0, 3.0, 10.0
+    e = lambda *a: np.array(a, np.float64)
+    n_long, n_thin = 4, 1250  # long thin slivers along z
+    quad_strip(e(-X, 0, -Z), e(2 * X, 0, 0), e(0, 0, 2 * Z), n_thin, n_long)  # floor
+    quad_strip(e(-X, Y, -Z), e(0, 0, 2 * Z), e(2 * X, 0, 0), n_long, n_thin)  # ceiling
+    quad_strip(e(-X, 0, -Z), e(0, 0, 2 * Z), e(0, Y, 0), n_long, n_thin)  # left wall
+    quad_strip(e(X, 0, -Z), e(0, Y, 0), e(0, 0, 2 * Z), n_thin, n_long)  # right wall
+    quad_strip(e(-X, 0, -Z), e(0, Y, 0), e(2 * X, 0, 0), 50, 50)  # back
+    for k in range(12):  # columns: thin tall quads
+        cx = (-1 if k % 2 else 1) * 2.0
+        cz = -8.0 + (k // 2) * 3.0
+        for s in range(16):
+            a0, a1 = 2 * np.pi * s / 16, 2 * np.pi * (s + 1) / 16
+            p0 = e(cx + 0.3 * np.cos(a0), 0, cz + 0.3 * np.sin(a0))
+            p1 = e(cx + 0.3 * np.cos(a1), 0, cz + 0.3 * np.sin(a1))
+            quad_strip(p0, p1 - p0, e(0, Y, 0), 1, 150)
+    v = np.array(vs, F)
+    v += (rng.random(v.shape, dtype=F) - F(0.5)) * F(1e-3)
+    mesh = MeshData(v, np.array(fs, np.int32), default_material(kd=(0.8, 0.8, 0.8)))
+    cam = Camera((0.0, 1.5, 9.0), (0.0, 1.4, 0.0), (0.0, 1.0, 0.0), float(F(60.0 * np.pi / 180.0)), width, height, samples, depth, 0.0)
+    return _assemble([mesh], [0], [mat_translate_scale((0, 0, 0), (1, 1, 1))], point_light((0.0, 2.5, 4.0)), cam, "cathedral")
