@@ -1,0 +1,67 @@
+"""Build libgvt_hip.so (the C-ABI adapter library) for gfx950 with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU; the built .so is git-ignored but travels with the tree to
+the GPU box.  -ffp-contract=off is part of the contract: the parity-critical arithmetic must not
+be fused (see csrc/gvt_device.h).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libgvt_hip.so")
+SOURCES = ["api.hip", "lbvh.hip", "trace.hip", "sched.hip"]
+HEADERS = ["gvt_device.h", "gvt_internal.h", os.path.join("..", "..", "include", "gvt_hip.h")]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-Wall",
+         "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
+
+
+def hipcc():
+    for c in ("hipcc", "/opt/rocm/bin/hipcc"):
+        p = shutil.which(c)
+        if p:
+            return p
+    raise RuntimeError("hipcc not found: cannot build the gfx950 adapter library")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    procs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [cc] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (s, out.decode(errors="replace")))
+        if verbose and out:
+            print(out.decode(errors="replace"), file=sys.stderr)
+    if force or _stale(LIB, objs):
+        cmd = [cc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if out.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % out.stdout.decode(errors="replace"))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

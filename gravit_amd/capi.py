@@ -1,0 +1,120 @@
+"""ctypes binding of libgvt_hip.so (include/gvt_hip.h) -- the only way the Python host side reaches
+the device.  There is NO CPU fallback: a missing library or a failing call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .layouts import HIT_DTYPE, LIGHT_DTYPE, MATERIAL_DTYPE, RAY_DTYPE
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgvt_hip.so")
+
+# every symbol include/gvt_hip.h declares
+SYMBOLS = [
+    "gvt_hip_init", "gvt_hip_set_stream", "gvt_hip_synchronize", "gvt_hip_last_error",
+    "gvt_hip_mesh_create", "gvt_hip_mesh_destroy", "gvt_hip_mesh_get_info", "gvt_hip_mesh_get_normals",
+    "gvt_hip_trace", "gvt_hip_intersect", "gvt_hip_occluded",
+    "gvt_hip_queue_create", "gvt_hip_queue_destroy", "gvt_hip_queue_reserve", "gvt_hip_queue_clear", "gvt_hip_queue_size",
+    "gvt_hip_queue_append", "gvt_hip_queue_export", "gvt_hip_trace_queue",
+    "gvt_hip_camera_generate",
+    "gvt_hip_top_create", "gvt_hip_top_destroy", "gvt_hip_top_order", "gvt_hip_shuffle", "gvt_hip_queue_sizes",
+    "gvt_hip_fb_create", "gvt_hip_fb_destroy", "gvt_hip_fb_clear", "gvt_hip_fb_download", "gvt_hip_fb_device_ptr",
+    "gvt_hip_fb_write_ppm_bytes",
+    "gvt_hip_profile", "gvt_hip_stats_read", "gvt_hip_stats_reset",
+]
+
+
+class GvtHipError(RuntimeError):
+    pass
+
+
+class MeshInfo(C.Structure):
+    _fields_ = [("n_tris", C.c_uint64), ("n_verts", C.c_uint64), ("n_nodes", C.c_uint64), ("n_leaves", C.c_uint64),
+                ("bbox_lo", C.c_float * 3), ("bbox_hi", C.c_float * 3), ("build_ms", C.c_float), ("max_leaf", C.c_uint32),
+                ("pad", C.c_uint32), ("bytes_nodes", C.c_uint64), ("bytes_tris", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays_closest", C.c_uint64), ("rays_any", C.c_uint64), ("rays_shaded", C.c_uint64),
+                ("rays_forwarded", C.c_uint64), ("trace_calls", C.c_uint64),
+                ("ms_closest", C.c_double), ("ms_any", C.c_double), ("ms_shade", C.c_double), ("ms_convert", C.c_double),
+                ("ms_shuffle", C.c_double), ("ms_camera", C.c_double), ("ms_build", C.c_double),
+                ("launches_closest", C.c_uint64), ("launches_any", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def load():
+    """Load the library (no device call).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GvtHipError("%s is missing: build it with `python -m gravit_amd._build` (hipcc, gfx950). "
+                              "There is no CPU fallback for the adapter." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for s in SYMBOLS:
+            getattr(lib, s)  # AttributeError if the ABI is incomplete
+        lib.gvt_hip_last_error.restype = C.c_char_p
+        for f in ("gvt_hip_mesh_create", "gvt_hip_queue_create", "gvt_hip_top_create", "gvt_hip_fb_create", "gvt_hip_fb_device_ptr"):
+            getattr(lib, f).restype = C.c_void_p
+        for f in ("gvt_hip_mesh_destroy", "gvt_hip_queue_destroy", "gvt_hip_top_destroy", "gvt_hip_fb_destroy"):
+            getattr(lib, f).restype = None
+            getattr(lib, f).argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().gvt_hip_last_error().decode(errors="replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise GvtHipError("%s failed (%d): %s" % (what, rc, last_error()))
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a if shape is None else a.reshape(shape)
+
+
+def init(device=0):
+    check(load().gvt_hip_init(C.c_int(device)), "gvt_hip_init")
+
+
+def set_stream(stream_handle):
+    check(load().gvt_hip_set_stream(C.c_void_p(stream_handle)), "gvt_hip_set_stream")
+
+
+def synchronize():
+    check(load().gvt_hip_synchronize(), "gvt_hip_synchronize")
+
+
+def profile(enable):
+    check(load().gvt_hip_profile(C.c_int(int(enable))), "gvt_hip_profile")
+
+
+def stats(reset=False):
+    s = Stats()
+    check(load().gvt_hip_stats_read(C.byref(s)), "gvt_hip_stats_read")
+    if reset:
+        check(load().gvt_hip_stats_reset(), "gvt_hip_stats_reset")
+    return s.as_dict()
+
+
+def stats_reset():
+    check(load().gvt_hip_stats_reset(), "gvt_hip_stats_reset")
+
+
+__all__ = ["load", "init", "check", "ptr", "f32", "GvtHipError", "MeshInfo", "Stats", "SYMBOLS", "RAY_DTYPE", "HIT_DTYPE",
+           "LIGHT_DTYPE", "MATERIAL_DTYPE"]

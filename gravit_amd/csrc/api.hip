@@ -1,0 +1,431 @@
+// api.hip -- C ABI glue of include/gvt_hip.h: context, meshes, device ray queues, Adapter::trace.
+#include <cmath>
+#include <mutex>
+
+#include "gvt_internal.h"
+
+size_t trav_spill_ints_per_thread();
+int trav_block_threads();
+
+static thread_local std::string g_err;
+static Ctx g_ctx;
+Ctx &gctx() { return g_ctx; }
+
+void set_error(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+extern "C" const char *gvt_hip_last_error(void) { return g_err.c_str(); }
+
+extern "C" int gvt_hip_init(int device) {
+  Ctx &C = g_ctx;
+  if (C.ready && C.device == device) return 0;
+  if (C.ready) { set_error("gvt_hip_init: already initialised on device %d", C.device); return GVT_HIP_ERR_INVALID; }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { set_error("no HIP device visible"); return GVT_HIP_ERR_NODEVICE; }
+  if (device < 0 || device >= count) { set_error("device %d out of range (%d visible)", device, count); return GVT_HIP_ERR_INVALID; }
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("device %d is %s; this library carries gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+    return GVT_HIP_ERR_NODEVICE;
+  }
+  C.device = device;
+  C.n_cu = prop.multiProcessorCount;
+  HIPCHK(hipStreamCreateWithFlags(&C.own_stream, hipStreamNonBlocking));
+  C.stream = C.own_stream;
+  // traversal kernels: 24 KiB LDS per 256-thread block -> 6 blocks/CU; grid = resident blocks, waves pull work
+  C.trav_blocks = C.n_cu * 6;
+  const size_t spill_ints = (size_t)C.trav_blocks * trav_block_threads() * trav_spill_ints_per_thread();
+  HIPCHK(hipMalloc((void **)&C.d_spill, spill_ints * sizeof(int)));
+  HIPCHK(hipMalloc((void **)&C.d_counters, 64 * sizeof(unsigned)));
+  HIPCHK(hipMemset(C.d_counters, 0, 64 * sizeof(unsigned)));
+  HIPCHK(hipHostMalloc((void **)&C.h_pinned, 64 * sizeof(unsigned), hipHostMallocDefault));
+  C.ready = true;
+  return 0;
+}
+
+int ensure_init() {
+  if (g_ctx.ready) return 0;
+  return gvt_hip_init(0);
+}
+
+extern "C" int gvt_hip_set_stream(void *s) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  g_ctx.stream = s ? (hipStream_t)s : g_ctx.own_stream;
+  return 0;
+}
+extern "C" int gvt_hip_synchronize(void) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+void *scratch_get(int slot, size_t bytes) {
+  Ctx &C = g_ctx;
+  if (bytes <= C.scratch_bytes[slot] && C.scratch[slot]) return C.scratch[slot];
+  hipStreamSynchronize(C.stream);
+  if (C.scratch[slot]) hipFree(C.scratch[slot]);
+  size_t want = bytes + bytes / 4 + 4096;
+  C.scratch[slot] = nullptr;
+  C.scratch_bytes[slot] = 0;
+  if (hipMalloc(&C.scratch[slot], want) != hipSuccess) { set_error("scratch hipMalloc(%zu) failed", want); return nullptr; }
+  C.scratch_bytes[slot] = want;
+  return C.scratch[slot];
+}
+
+// ---- profiling: HIP events on the launch stream ----
+ProfScope::ProfScope(int c) : cls(c) {
+  Ctx &C = g_ctx;
+  if (!C.profile) return;
+  auto take = [&]() {
+    hipEvent_t e;
+    if (!C.event_pool.empty()) { e = C.event_pool.back(); C.event_pool.pop_back(); }
+    else hipEventCreate(&e);
+    return e;
+  };
+  a = take(); b = take();
+  hipEventRecord(a, C.stream);
+}
+ProfScope::~ProfScope() {
+  Ctx &C = g_ctx;
+  if (!a) return;
+  hipEventRecord(b, C.stream);
+  C.pending.push_back({ a, b, cls });
+}
+static void drain_events() {
+  Ctx &C = g_ctx;
+  for (auto &p : C.pending) {
+    hipEventSynchronize(p.b);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, p.a, p.b);
+    double *slot[KC_COUNT] = { &C.stats.ms_closest, &C.stats.ms_any, &C.stats.ms_shade, &C.stats.ms_convert, &C.stats.ms_shuffle,
+                               &C.stats.ms_camera, &C.stats.ms_build };
+    *slot[p.cls] += ms;
+    C.event_pool.push_back(p.a);
+    C.event_pool.push_back(p.b);
+  }
+  C.pending.clear();
+}
+extern "C" int gvt_hip_profile(int enable) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  drain_events();
+  g_ctx.profile = enable != 0;
+  return 0;
+}
+extern "C" int gvt_hip_stats_read(gvt_hip_stats *out) {
+  if (!out) { set_error("stats_read: null"); return GVT_HIP_ERR_INVALID; }
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  drain_events();
+  *out = g_ctx.stats;
+  return 0;
+}
+extern "C" int gvt_hip_stats_reset(void) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  drain_events();
+  g_ctx.stats = gvt_hip_stats{};
+  return 0;
+}
+
+// ---- meshes ----
+static void default_material(gvt_hip_material *m) { // Material.h:62-77
+  std::memset(m, 0, sizeof *m);
+  m->type = 0;
+  m->kd[0] = m->kd[1] = m->kd[2] = .5f;
+  m->ks[0] = m->ks[1] = m->ks[2] = .5f;
+  m->alpha = 1.f;
+  m->eta[0] = .19f; m->eta[1] = 1.45f; m->eta[2] = 1.50f;
+  m->k[0] = 3.06f; m->k[1] = 2.40f; m->k[2] = 1.88f;
+  m->roughness = 0.05f;
+}
+
+// Mesh::generateNormals (Mesh.cpp:116-154).  Host side, one-off per mesh like the reference; the sum is
+// order dependent (unweighted accumulation in face order), so it is kept sequential for bit parity.
+static void generate_normals(const float *verts, size_t nV, const int32_t *tris, size_t nT, std::vector<float> &normals) {
+  normals.assign(nV * 3, 0.0f);
+  for (size_t i = 0; i < nT; i++) {
+    int I = tris[3 * i], J = tris[3 * i + 1], K = tris[3 * i + 2];
+    V3 a = ld3(verts + 3 * I), b = ld3(verts + 3 * J), c = ld3(verts + 3 * K);
+    V3 u = sub3(b, a), v = sub3(c, a), n;
+    n.x = u.y * v.z - u.z * v.y;
+    n.y = u.z * v.x - u.x * v.z;
+    n.z = u.x * v.y - u.y * v.x;
+    n = norm3(n);
+    int idx[3] = { I, J, K };
+    for (int k = 0; k < 3; k++) {
+      float *d = &normals[3 * idx[k]];
+      d[0] += n.x; d[1] += n.y; d[2] += n.z;
+    }
+  }
+  for (size_t i = 0; i < nV; i++) {
+    V3 n = norm3(ld3(&normals[3 * i]));
+    normals[3 * i] = n.x; normals[3 * i + 1] = n.y; normals[3 * i + 2] = n.z;
+  }
+}
+
+template <typename T> static bool upload(T **dst, const T *src, size_t n) {
+  *dst = nullptr;
+  if (hipMalloc((void **)dst, sizeof(T) * (n ? n : 1)) != hipSuccess) return false;
+  if (n && hipMemcpy(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice) != hipSuccess) return false;
+  return true;
+}
+
+extern "C" gvt_hip_mesh *gvt_hip_mesh_create(const float *verts, size_t nV, const int32_t *tris, size_t nT, const float *vnormals,
+                                             const float *vcolors, const gvt_hip_material *materials, size_t nMat,
+                                             const int32_t *face_mat, const gvt_hip_material *mesh_mat) {
+  if (ensure_init()) return nullptr;
+  if ((nV && !verts) || (nT && !tris)) { set_error("mesh_create: null vertex/triangle array"); return nullptr; } // GVT_ASSERT :128
+  if (nT >= (1u << 28)) { set_error("mesh_create: %zu triangles exceed the 2^28 leaf-slot encoding", nT); return nullptr; }
+  for (size_t i = 0; i < nT * 3; i++)
+    if (tris[i] < 0 || (size_t)tris[i] >= nV) { set_error("mesh_create: triangle %zu references vertex %d (nV=%zu)", i / 3, tris[i], nV); return nullptr; }
+  if (face_mat)
+    for (size_t i = 0; i < nT; i++)
+      if (face_mat[i] >= 0 && (size_t)face_mat[i] >= nMat) { set_error("mesh_create: face_mat[%zu]=%d out of range", i, face_mat[i]); return nullptr; }
+  gvt_hip_mesh *M = new gvt_hip_mesh();
+  M->nV = nV; M->nT = nT; M->nMat = materials ? nMat : 0;
+  if (mesh_mat) M->mesh_mat = *mesh_mat; else default_material(&M->mesh_mat);
+  std::vector<float> gen;
+  const float *nrm = vnormals;
+  if (!nrm) { generate_normals(verts, nV, tris, nT, gen); nrm = gen.data(); } // EmbreeMeshAdapter.cpp:129
+  bool ok = upload(&M->d_verts, verts, nV * 3) && upload(&M->d_tris, tris, nT * 3) && upload(&M->d_normals, nrm, nV * 3);
+  if (ok && vcolors) ok = upload(&M->d_vcolors, vcolors, nV * 3);
+  if (ok && M->nMat) ok = upload(&M->d_materials, materials, M->nMat);
+  if (ok && face_mat && M->nMat) ok = upload(&M->d_face_mat, face_mat, nT);
+  if (!ok) { set_error("mesh_create: device upload failed (%s)", hipGetErrorString(hipGetLastError())); gvt_hip_mesh_destroy(M); return nullptr; }
+  if (build_lbvh(M) != 0) { gvt_hip_mesh_destroy(M); return nullptr; }
+  return M;
+}
+
+extern "C" void gvt_hip_mesh_destroy(gvt_hip_mesh *M) {
+  if (!M) return;
+  if (g_ctx.ready) hipStreamSynchronize(g_ctx.stream);
+  hipFree(M->d_verts); hipFree(M->d_tris); hipFree(M->d_normals); hipFree(M->d_vcolors); hipFree(M->d_materials);
+  hipFree(M->d_face_mat); hipFree(M->d_nodes); hipFree(M->d_tri);
+  delete M;
+}
+
+extern "C" int gvt_hip_mesh_get_info(const gvt_hip_mesh *M, gvt_hip_mesh_info *o) {
+  if (!M || !o) { set_error("mesh_get_info: null"); return GVT_HIP_ERR_INVALID; }
+  std::memset(o, 0, sizeof *o);
+  o->n_tris = M->nT; o->n_verts = M->nV; o->n_nodes = M->nNodes; o->n_leaves = M->nLeaves;
+  for (int k = 0; k < 3; k++) { o->bbox_lo[k] = M->lo[k]; o->bbox_hi[k] = M->hi[k]; }
+  o->build_ms = M->build_ms; o->max_leaf = GVT_LEAF_MAX;
+  o->bytes_nodes = M->nNodes * sizeof(BvhNode); o->bytes_tris = M->nT * 48;
+  return 0;
+}
+extern "C" int gvt_hip_mesh_get_normals(const gvt_hip_mesh *M, float *out) {
+  if (!M || !out) { set_error("mesh_get_normals: null"); return GVT_HIP_ERR_INVALID; }
+  HIPCHK(hipMemcpy(out, M->d_normals, sizeof(float) * 3 * M->nV, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- device ray queues ----
+int queue_reserve(gvt_hip_queue *q, size_t cap) {
+  if (cap <= q->cap) return 0;
+  Ctx &C = g_ctx;
+  size_t ncap = cap + cap / 8 + 1024;
+  if (ncap >= 0xffffffffull) { set_error("queue_reserve: %zu rays exceed the 32-bit slot counter", ncap); return GVT_HIP_ERR_INVALID; }
+  float4 *np = nullptr;
+  HIPCHK(hipMalloc((void **)&np, sizeof(float4) * 4 * ncap));
+  if (q->size) {
+    for (int k = 0; k < 4; k++)
+      HIPCHK(hipMemcpyAsync(np + (size_t)k * ncap, q->d_planes + (size_t)k * q->cap, sizeof(float4) * q->size, hipMemcpyDeviceToDevice, C.stream));
+  }
+  HIPCHK(hipStreamSynchronize(C.stream));
+  if (q->d_planes) HIPCHK(hipFree(q->d_planes));
+  q->d_planes = np;
+  q->cap = ncap;
+  return 0;
+}
+
+extern "C" gvt_hip_queue *gvt_hip_queue_create(size_t capacity) {
+  if (ensure_init()) return nullptr;
+  gvt_hip_queue *q = new gvt_hip_queue();
+  if (hipMalloc((void **)&q->d_count, 64) != hipSuccess || hipMemset(q->d_count, 0, 64) != hipSuccess) {
+    set_error("queue_create: hipMalloc failed"); delete q; return nullptr;
+  }
+  if (capacity && queue_reserve(q, capacity) != 0) { gvt_hip_queue_destroy(q); return nullptr; }
+  return q;
+}
+extern "C" void gvt_hip_queue_destroy(gvt_hip_queue *q) {
+  if (!q) return;
+  if (g_ctx.ready) hipStreamSynchronize(g_ctx.stream);
+  hipFree(q->d_planes); hipFree(q->d_count);
+  delete q;
+}
+extern "C" int gvt_hip_queue_reserve(gvt_hip_queue *q, size_t cap) {
+  if (!q) { set_error("queue_reserve: null"); return GVT_HIP_ERR_INVALID; }
+  return queue_reserve(q, cap);
+}
+extern "C" int gvt_hip_queue_clear(gvt_hip_queue *q) {
+  if (!q) { set_error("queue_clear: null"); return GVT_HIP_ERR_INVALID; }
+  q->size = 0;
+  HIPCHK(hipMemsetAsync(q->d_count, 0, sizeof(unsigned), g_ctx.stream));
+  return 0;
+}
+extern "C" int gvt_hip_queue_size(gvt_hip_queue *q, size_t *n) {
+  if (!q || !n) { set_error("queue_size: null"); return GVT_HIP_ERR_INVALID; }
+  *n = q->size;
+  return 0;
+}
+extern "C" int gvt_hip_queue_sizes(gvt_hip_queue *const *queues, size_t n, uint64_t *out) {
+  if ((n && !queues) || !out) { set_error("queue_sizes: null"); return GVT_HIP_ERR_INVALID; }
+  for (size_t i = 0; i < n; i++) out[i] = queues[i] ? queues[i]->size : 0;
+  return 0;
+}
+
+extern "C" int gvt_hip_queue_append(gvt_hip_queue *q, const gvt_hip_ray *rays, size_t n, int src_on_device) {
+  if (!q || (n && !rays)) { set_error("queue_append: null"); return GVT_HIP_ERR_INVALID; }
+  if (!n) return 0;
+  Ctx &C = g_ctx;
+  int rc = queue_reserve(q, q->size + n);
+  if (rc) return rc;
+  const gvt_hip_ray *d_src = rays;
+  if (!src_on_device) {
+    void *stage = scratch_get(0, sizeof(gvt_hip_ray) * n);
+    if (!stage) return GVT_HIP_ERR_DEVICE;
+    HIPCHK(hipMemcpyAsync(stage, rays, sizeof(gvt_hip_ray) * n, hipMemcpyHostToDevice, C.stream));
+    d_src = (const gvt_hip_ray *)stage;
+  }
+  rc = convert_aos_to_planes(d_src, n, make_planes(q->d_planes, q->cap), q->size);
+  if (rc) return rc;
+  q->size += n;
+  C.h_pinned[9] = (unsigned)q->size;
+  HIPCHK(hipMemcpyAsync(q->d_count, &C.h_pinned[9], sizeof(unsigned), hipMemcpyHostToDevice, C.stream));
+  HIPCHK(hipStreamSynchronize(C.stream));
+  return 0;
+}
+
+extern "C" int gvt_hip_queue_export(gvt_hip_queue *q, gvt_hip_ray *dst, size_t cap, size_t *n, int dst_on_device) {
+  if (!q || !n) { set_error("queue_export: null"); return GVT_HIP_ERR_INVALID; }
+  *n = q->size;
+  if (q->size > cap) { set_error("queue_export: %zu rays, capacity %zu", q->size, cap); return GVT_HIP_ERR_CAPACITY; }
+  if (!q->size) return 0;
+  if (!dst) { set_error("queue_export: null destination"); return GVT_HIP_ERR_INVALID; }
+  Ctx &C = g_ctx;
+  gvt_hip_ray *d_dst = dst;
+  if (!dst_on_device) {
+    d_dst = (gvt_hip_ray *)scratch_get(0, sizeof(gvt_hip_ray) * q->size);
+    if (!d_dst) return GVT_HIP_ERR_DEVICE;
+  }
+  int rc = convert_planes_to_aos(make_planes(q->d_planes, q->cap), 0, q->size, d_dst);
+  if (rc) return rc;
+  if (!dst_on_device) HIPCHK(hipMemcpyAsync(dst, d_dst, sizeof(gvt_hip_ray) * q->size, hipMemcpyDeviceToHost, C.stream));
+  HIPCHK(hipStreamSynchronize(C.stream));
+  return 0;
+}
+
+// ---- Adapter::trace ----
+static int fill_params(TraceParams &P, const float m[16], const float minv[16], const float normi[9], size_t n_lights, int normal_mode,
+                       uint32_t seed, const gvt_hip_light *lights) {
+  if (!m || !minv || !normi) { set_error("trace: null matrix"); return GVT_HIP_ERR_INVALID; }
+  if (n_lights && !lights) { set_error("trace: null lights"); return GVT_HIP_ERR_INVALID; }
+  if (n_lights > 64) { set_error("trace: %zu lights (max 64)", n_lights); return GVT_HIP_ERR_INVALID; }
+  if (normal_mode != GVT_HIP_NORMALS_FLAT && normal_mode != GVT_HIP_NORMALS_SMOOTH) { set_error("trace: bad normal_mode %d", normal_mode); return GVT_HIP_ERR_INVALID; }
+  std::memcpy(P.m.m, m, 64); std::memcpy(P.minv.m, minv, 64); std::memcpy(P.normi.n, normi, 36);
+  P.normal_mode = normal_mode; P.seed = seed; P.n_lights = (int)n_lights;
+  return 0;
+}
+
+extern "C" int gvt_hip_trace_queue(gvt_hip_mesh *M, gvt_hip_queue *q_in, gvt_hip_queue *q_out, const float m[16], const float minv[16],
+                                   const float normi[9], const gvt_hip_light *lights, size_t n_lights, int normal_mode, uint32_t seed) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!M || !q_in || !q_out || q_in == q_out) { set_error("trace_queue: null or aliased queue"); return GVT_HIP_ERR_INVALID; }
+  TraceParams P;
+  int rc = fill_params(P, m, minv, normi, n_lights, normal_mode, seed, lights);
+  if (rc) return rc;
+  const size_t n = q_in->size;
+  rc = queue_reserve(q_out, q_out->size + n * (1 + n_lights));
+  if (rc) return rc;
+  rc = trace_core(M, make_planes(q_in->d_planes, q_in->cap), n, 0, q_out, P, lights);
+  if (rc) return rc;
+  return gvt_hip_queue_clear(q_in); // the caller's queue[instTarget].clear(), ImageTracer.h:248
+}
+
+extern "C" int gvt_hip_trace(gvt_hip_mesh *M, gvt_hip_ray *rays, size_t n_rays, size_t begin, size_t end, gvt_hip_ray *rays_out, size_t cap,
+                             size_t *n_out, const float m[16], const float minv[16], const float normi[9], const gvt_hip_light *lights,
+                             size_t n_lights, int normal_mode, uint32_t seed) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!M || !n_out || (n_rays && !rays)) { set_error("trace: null argument"); return GVT_HIP_ERR_INVALID; }
+  if (end == 0) end = n_rays; // EmbreeMeshAdapter.cpp:642
+  if (begin > end || end > n_rays) { set_error("trace: bad range [%zu,%zu) of %zu", begin, end, n_rays); return GVT_HIP_ERR_INVALID; }
+  TraceParams P;
+  int rc = fill_params(P, m, minv, normi, n_lights, normal_mode, seed, lights);
+  if (rc) return rc;
+  Ctx &C = g_ctx;
+  const size_t n = end - begin;
+  *n_out = 0;
+  if (!n) return 0;
+  static gvt_hip_queue *qin = nullptr, *qout = nullptr;
+  if (!qin) { qin = gvt_hip_queue_create(0); qout = gvt_hip_queue_create(0); }
+  if (!qin || !qout) return GVT_HIP_ERR_DEVICE;
+  if ((rc = gvt_hip_queue_clear(qin)) || (rc = gvt_hip_queue_clear(qout))) return rc;
+  if ((rc = gvt_hip_queue_append(qin, rays + begin, n, 0))) return rc;
+  if ((rc = queue_reserve(qout, n * (1 + n_lights)))) return rc;
+  if ((rc = trace_core(M, make_planes(qin->d_planes, qin->cap), n, begin, qout, P, lights))) return rc;
+  *n_out = qout->size;
+  if (qout->size > cap) { set_error("trace: %zu outgoing rays, capacity %zu", qout->size, cap); return GVT_HIP_ERR_CAPACITY; }
+  // rayList is updated in place (r.mice.t, bounce state)
+  size_t got = 0;
+  if ((rc = gvt_hip_queue_export(qin, rays + begin, n, &got, 0))) return rc;
+  if (qout->size) {
+    if (!rays_out) { set_error("trace: null rays_out"); return GVT_HIP_ERR_INVALID; }
+    if ((rc = gvt_hip_queue_export(qout, rays_out, cap, &got, 0))) return rc;
+  }
+  (void)C;
+  return 0;
+}
+
+// ---- rtcIntersect / rtcOccluded equivalents on object-space rays ----
+static int stage_od(const float *org, const float *dir, size_t n, RayPlanes &planes) {
+  Ctx &C = g_ctx;
+  float *d_org = (float *)scratch_get(2, sizeof(float) * 6 * n);
+  float4 *d_pl = (float4 *)scratch_get(3, sizeof(float4) * 2 * n);
+  if (!d_org || !d_pl) return GVT_HIP_ERR_DEVICE;
+  float *d_dir = d_org + 3 * n;
+  HIPCHK(hipMemcpyAsync(d_org, org, sizeof(float) * 3 * n, hipMemcpyHostToDevice, C.stream));
+  HIPCHK(hipMemcpyAsync(d_dir, dir, sizeof(float) * 3 * n, hipMemcpyHostToDevice, C.stream));
+  planes.p0 = d_pl; planes.p1 = d_pl + n; planes.p2 = nullptr; planes.p3 = nullptr;
+  return convert_od_to_planes(d_org, d_dir, n, planes);
+}
+
+extern "C" int gvt_hip_intersect(gvt_hip_mesh *M, const float *org, const float *dir, size_t n, float tnear, gvt_hip_hit *hits) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!M || (n && (!org || !dir || !hits))) { set_error("intersect: null argument"); return GVT_HIP_ERR_INVALID; }
+  if (!n) return 0;
+  Ctx &C = g_ctx;
+  RayPlanes pl;
+  int rc = stage_od(org, dir, n, pl);
+  if (rc) return rc;
+  gvt_hip_hit *d_hits = (gvt_hip_hit *)scratch_get(0, sizeof(gvt_hip_hit) * n);
+  if (!d_hits) return GVT_HIP_ERR_DEVICE;
+  Mat4 id{};
+  if ((rc = launch_closest(M, pl, nullptr, n, false, id, tnear, d_hits))) return rc;
+  HIPCHK(hipMemcpyAsync(hits, d_hits, sizeof(gvt_hip_hit) * n, hipMemcpyDeviceToHost, C.stream));
+  HIPCHK(hipStreamSynchronize(C.stream));
+  return 0;
+}
+
+extern "C" int gvt_hip_occluded(gvt_hip_mesh *M, const float *org, const float *dir, size_t n, float tnear, int32_t *out) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!M || (n && (!org || !dir || !out))) { set_error("occluded: null argument"); return GVT_HIP_ERR_INVALID; }
+  if (!n) return 0;
+  Ctx &C = g_ctx;
+  RayPlanes pl;
+  int rc = stage_od(org, dir, n, pl);
+  if (rc) return rc;
+  int *d_flags = (int *)scratch_get(0, sizeof(int) * n);
+  if (!d_flags) return GVT_HIP_ERR_DEVICE;
+  Mat4 id{};
+  if ((rc = launch_any_flags(M, pl, n, false, id, tnear, d_flags))) return rc;
+  HIPCHK(hipMemcpyAsync(out, d_flags, sizeof(int) * n, hipMemcpyDeviceToHost, C.stream));
+  HIPCHK(hipStreamSynchronize(C.stream));
+  return 0;
+}

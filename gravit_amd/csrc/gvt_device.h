@@ -1,0 +1,178 @@
+// gvt_device.h -- shared device-side types and arithmetic of the gfx950 adapter.
+//
+// Parity rule: every function here that feeds a value the reference would produce (ray transform,
+// triangle test, normals, Shade, light contribution, camera) is written in the evaluation order of
+// the reference source it cites (glm 0.9.8.1 order for vector ops) and this library is compiled with
+// -ffp-contract=off, so the results are bit-identical to a strict-IEEE CPU evaluation.  Only the BVH
+// slab test (our own structure, results do not depend on it as long as it is conservative) uses
+// explicit fused multiply-adds.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gvt_hip.h"
+
+#define GVT_RAY_EPSILON 1.e-6f   // actor/Ray.cpp:33
+#define GVT_FLT_MAX 3.402823466e+38f
+#define GVT_FLT_EPSILON 1.192092896e-07f
+
+struct V3 {
+  float x, y, z;
+};
+__host__ __device__ inline V3 mk3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__host__ __device__ inline V3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
+__host__ __device__ inline V3 add3(V3 a, V3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__host__ __device__ inline V3 sub3(V3 a, V3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__host__ __device__ inline V3 mul3(V3 a, V3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__host__ __device__ inline V3 scl3(V3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__host__ __device__ inline V3 neg3(V3 a) { return mk3(-a.x, -a.y, -a.z); }
+// glm compute_dot<tvec3>: tmp = x*y; tmp.x + tmp.y + tmp.z  (func_geometric.inl:54-61)
+__host__ __device__ inline float dot3(V3 a, V3 b) { V3 t = mul3(a, b); return t.x + t.y + t.z; }
+// glm compute_cross (func_geometric.inl:74-85)
+__host__ __device__ inline V3 cross3(V3 x, V3 y) {
+  return mk3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+__host__ __device__ inline float len3(V3 a) { return sqrtf(dot3(a, a)); }
+// glm compute_normalize: v * inversesqrt(dot(v,v)), inversesqrt(x) = 1/sqrt(x)
+__host__ __device__ inline V3 norm3(V3 a) { return scl3(a, 1.0f / sqrtf(dot3(a, a))); }
+
+// glm mat4 * vec4 (column-major m[c*4+r]): (m0*v0 + m1*v1) + (m2*v2 + m3*v3)  (type_mat4x4.inl)
+struct Mat4 {
+  float m[16];
+};
+struct Mat3 {
+  float n[9];
+};
+__host__ __device__ inline V3 xfm_point(const Mat4 &M, V3 p) {
+  const float *m = M.m;
+  return mk3((m[0] * p.x + m[4] * p.y) + (m[8] * p.z + m[12] * 1.0f), (m[1] * p.x + m[5] * p.y) + (m[9] * p.z + m[13] * 1.0f),
+             (m[2] * p.x + m[6] * p.y) + (m[10] * p.z + m[14] * 1.0f));
+}
+__host__ __device__ inline V3 xfm_vector(const Mat4 &M, V3 d) {
+  const float *m = M.m;
+  return mk3((m[0] * d.x + m[4] * d.y) + (m[8] * d.z + m[12] * 0.0f), (m[1] * d.x + m[5] * d.y) + (m[9] * d.z + m[13] * 0.0f),
+             (m[2] * d.x + m[6] * d.y) + (m[10] * d.z + m[14] * 0.0f));
+}
+// glm mat3 * vec3 (n[c*3+r]): m00*x + m10*y + m20*z left to right (type_mat3x3.inl)
+__host__ __device__ inline V3 mat3_mul(const Mat3 &N, V3 v) {
+  const float *n = N.n;
+  return mk3(n[0] * v.x + n[3] * v.y + n[6] * v.z, n[1] * v.x + n[4] * v.y + n[7] * v.z, n[2] * v.x + n[5] * v.y + n[8] * v.z);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device ray queue: four planes of float4 ("SoA of 16-byte columns"): every lane of a wave reads one
+// float4 per plane, 1 KiB contiguous per wave-instruction.
+//   plane0 = (origin.xyz, t_min)   plane1 = (direction.xyz, t_max)
+//   plane2 = (color.rgb, t)        plane3 = (id, depth, w, type) bit-cast
+// The traversal kernels touch planes 0 and 1 only (32 B/ray).
+// ---------------------------------------------------------------------------------------------
+struct RayPlanes {
+  float4 *p0, *p1, *p2, *p3;
+};
+__host__ __device__ inline RayPlanes make_planes(float4 *base, size_t cap) {
+  RayPlanes r;
+  r.p0 = base; r.p1 = base + cap; r.p2 = base + 2 * cap; r.p3 = base + 3 * cap;
+  return r;
+}
+
+struct RayRec { // unpacked ray in registers
+  V3 o; float t_min;
+  V3 d; float t_max;
+  V3 c; float t;
+  int id, depth; float w; int type;
+};
+__device__ inline RayRec load_ray(const RayPlanes &q, size_t i) {
+  float4 a = q.p0[i], b = q.p1[i], c = q.p2[i], d = q.p3[i];
+  RayRec r;
+  r.o = mk3(a.x, a.y, a.z); r.t_min = a.w;
+  r.d = mk3(b.x, b.y, b.z); r.t_max = b.w;
+  r.c = mk3(c.x, c.y, c.z); r.t = c.w;
+  r.id = __float_as_int(d.x); r.depth = __float_as_int(d.y); r.w = d.z; r.type = __float_as_int(d.w);
+  return r;
+}
+__device__ inline void store_ray(const RayPlanes &q, size_t i, const RayRec &r) {
+  q.p0[i] = make_float4(r.o.x, r.o.y, r.o.z, r.t_min);
+  q.p1[i] = make_float4(r.d.x, r.d.y, r.d.z, r.t_max);
+  q.p2[i] = make_float4(r.c.x, r.c.y, r.c.z, r.t);
+  q.p3[i] = make_float4(__int_as_float(r.id), __int_as_float(r.depth), r.w, __int_as_float(r.type));
+}
+
+// ---------------------------------------------------------------------------------------------
+// BVH node: 64 B, both children's boxes in the parent (one fetch decides both).
+//   n0 = (c0.lo.x, c0.hi.x, c0.lo.y, c0.hi.y)   n1 = (c1.lo.x, c1.hi.x, c1.lo.y, c1.hi.y)
+//   n2 = (c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z)   n3 = (child0, child1, -, -) bit-cast ints
+// child >= 0: inner node index.  child < 0: leaf, ~child = (first_tri_slot << 3) | count (count <= 4).
+// Triangle slot (48 B, leaf order): t0 = (v0.xyz, primID), t1 = (e1 = v0-v1, 0), t2 = (e2 = v2-v0, 0).
+// ---------------------------------------------------------------------------------------------
+struct BvhNode {
+  float4 n0, n1, n2, n3;
+};
+#define GVT_LEAF_MAX 4
+__host__ __device__ inline int leaf_ref(uint32_t first, uint32_t count) { return ~(int)((first << 3) | count); }
+
+// Embree 2.x Moeller-Trumbore (kernels/geometry/triangle_intersector_moeller.h), restated like
+// oracle/gvt_oracle.c orc_tri_test; reached through rtcIntersect/rtcOccluded at
+// EmbreeMeshAdapter.cpp:474,375.  True division instead of rcp+Newton.
+__device__ inline bool tri_test(V3 O, V3 D, V3 v0, V3 e1, V3 e2, float tnear, float &t, float &u, float &v) {
+  V3 Ng = cross3(e1, e2);
+  V3 C = sub3(v0, O);
+  V3 R = cross3(D, C);
+  float den = dot3(Ng, D);
+  float absDen = fabsf(den);
+  float sgn = (den < 0.f) ? -1.f : 1.f;
+  float U = dot3(R, e2) * sgn;
+  float V = dot3(R, e1) * sgn;
+  if (!(den != 0.f && U >= 0.f && V >= 0.f && U + V <= absDen)) return false;
+  float T = dot3(Ng, C) * sgn;
+  if (!(absDen * tnear < T)) return false;
+  float tt = T / absDen;
+  if (!(tt <= GVT_FLT_MAX)) return false;
+  t = tt; u = U / absDen; v = V / absDen;
+  return true;
+}
+
+// RandEngine::rng (core/math/RandEngine.h:43-56)
+__host__ __device__ inline uint32_t rotl32(uint32_t r, int n) { return (r << n) | (r >> (32 - n)); }
+__host__ __device__ inline float gvt_rng(uint32_t &seed) {
+  uint32_t x, y, z;
+  x = (seed >> 16) + 4125832013u;
+  y = (seed & 0xffff) + 814584116u;
+  z = 542;
+  x *= 255519323u;
+  x = rotl32(x, 13);
+  y *= 3166389663u;
+  y = rotl32(y, 17);
+  z -= rotl32(z, 11);
+  z = rotl32(z, 27);
+  seed = x ^ y ^ z;
+  return ((float)(seed & 0x00FFFFFF) / (float)0x01000000);
+}
+__host__ __device__ inline float gvt_fastrand01(uint32_t &seed) { return 0.0f + gvt_rng(seed) * (1.0f - 0.0f); }
+// RandEngine::fastrand(uint*,min,max) LCG (:78-81)
+__host__ __device__ inline float gvt_fastrand_lcg(uint32_t &seed, float mn, float mx) {
+  const float ff = (1.0f / 65535.0f);
+  seed = 214013u * seed + 2531011u;
+  return mn + (seed >> 16) * ff * (mx - mn);
+}
+// one stream per ray, keyed on (call seed, index in rayList): see oracle ray_stream_seed
+__host__ __device__ inline uint32_t ray_stream_seed(uint32_t seed, uint64_t index) {
+  uint32_t s = seed ^ (uint32_t)(index * 0x9E3779B9u) ^ (uint32_t)(index >> 32);
+  s ^= s >> 16; s *= 0x85EBCA6Bu; s ^= s >> 13; s *= 0xC2B2AE35u; s ^= s >> 16;
+  return s;
+}
+
+// wave64 helpers
+__device__ inline unsigned lane_id() { return __lane_id(); }
+__device__ inline unsigned lanes_below(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+// wave-aggregated slot allocation: one atomic per wave for all lanes with `want`
+__device__ inline unsigned wave_alloc(unsigned *counter, bool want) {
+  unsigned long long mask = __ballot(want);
+  if (mask == 0ull) return 0u;
+  unsigned base = 0;
+  int leader = __ffsll((long long)mask) - 1;
+  if ((int)lane_id() == leader) base = atomicAdd(counter, (unsigned)__popcll(mask));
+  base = __shfl(base, leader);
+  return base + lanes_below(mask);
+}

@@ -1,0 +1,128 @@
+// gvt_internal.h -- host-side objects behind the opaque handles of include/gvt_hip.h
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gvt_device.h"
+
+enum KernelClass { KC_CLOSEST = 0, KC_ANY, KC_SHADE, KC_CONVERT, KC_SHUFFLE, KC_CAMERA, KC_BUILD, KC_COUNT };
+
+struct PendingEvent {
+  hipEvent_t a, b;
+  int cls;
+};
+
+struct Ctx {
+  bool ready = false;
+  int device = -1;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  bool profile = false;
+  std::vector<PendingEvent> pending;
+  std::vector<hipEvent_t> event_pool;
+  gvt_hip_stats stats{};
+  // traversal launch geometry + per-thread stack spill area
+  int n_cu = 256;
+  int trav_blocks = 0;
+  int *d_spill = nullptr;
+  unsigned *d_counters = nullptr; // small array of device counters (work fetch, temps)
+  // pinned host scratch for small read-backs
+  unsigned *h_pinned = nullptr;
+  // grow-only device scratch arenas (never freed inside hot calls)
+  void *scratch[8] = { nullptr };
+  size_t scratch_bytes[8] = { 0 };
+};
+Ctx &gctx();
+void set_error(const char *fmt, ...);
+int ensure_init();
+void *scratch_get(int slot, size_t bytes); // grow-only; contents NOT preserved on growth
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);       \
+      return GVT_HIP_ERR_DEVICE;                                                                  \
+    }                                                                                             \
+  } while (0)
+
+// profiling bracket: records HIP events on the launch stream around `stmt` when enabled
+struct ProfScope {
+  int cls;
+  hipEvent_t a = nullptr, b = nullptr;
+  explicit ProfScope(int cls);
+  ~ProfScope();
+};
+
+struct gvt_hip_mesh {
+  size_t nV = 0, nT = 0;
+  float *d_verts = nullptr;   // nV*3
+  int *d_tris = nullptr;      // nT*3
+  float *d_normals = nullptr; // nV*3
+  float *d_vcolors = nullptr; // nV*3 or null
+  gvt_hip_material *d_materials = nullptr;
+  size_t nMat = 0;
+  int *d_face_mat = nullptr;
+  gvt_hip_material mesh_mat;
+  // acceleration structure
+  BvhNode *d_nodes = nullptr;
+  size_t nNodes = 0;
+  float4 *d_tri = nullptr; // 3 float4 per slot, leaf order
+  size_t nLeaves = 0;
+  float lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
+  float build_ms = 0.f;
+};
+
+struct gvt_hip_queue {
+  float4 *d_planes = nullptr; // 4 planes of `cap`
+  size_t cap = 0;
+  size_t size = 0;            // host mirror, always valid between API calls
+  unsigned *d_count = nullptr;
+};
+
+struct gvt_hip_top {
+  size_t n = 0;
+  std::vector<int> order;   // DFS leaf order of the reference's top-level BVH
+  float4 *d_lo = nullptr;   // in `order` order: (lo.xyz, inst id)
+  float4 *d_hi = nullptr;
+  unsigned *d_hist = nullptr; // n counters
+  void **d_qdesc = nullptr;   // device array of queue descriptors
+};
+
+struct gvt_hip_fb {
+  int w = 0, h = 0;
+  float *d_rgba = nullptr;
+};
+
+struct QueueDesc { // device-visible view of one destination queue
+  float4 *planes;
+  unsigned long long cap;
+  unsigned *count;
+  unsigned keep;
+};
+
+struct TraceParams {
+  Mat4 m, minv;
+  Mat3 normi;
+  int normal_mode;
+  uint32_t seed;
+  int n_lights;
+};
+
+// lbvh.hip
+int build_lbvh(gvt_hip_mesh *M);
+// trace.hip
+int queue_reserve(gvt_hip_queue *q, size_t cap);
+int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt_hip_queue *out, const TraceParams &P,
+               const gvt_hip_light *lights_host);
+int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, bool xform, const Mat4 &minv, float tnear,
+                   gvt_hip_hit *d_hits);
+int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const Mat4 &minv, float tnear, int *d_flags);
+int convert_aos_to_planes(const gvt_hip_ray *d_src, size_t n, RayPlanes dst, size_t dst_off);
+int convert_planes_to_aos(RayPlanes src, size_t src_off, size_t n, gvt_hip_ray *d_dst);
+int convert_od_to_planes(const float *d_org, const float *d_dir, size_t n, RayPlanes dst);

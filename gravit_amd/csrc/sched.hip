@@ -1,0 +1,376 @@
+// sched.hip -- the steps either side of Adapter::trace, kept on the device so that ray queues never
+// cross PCIe between adapter calls:
+//   k_camera        gvtPerspectiveCamera::generateRays       (data/scene/gvtCamera.cpp:233-312)
+//   k_top_classify  BVH::intersect + RayPacketIntersection   (data/accel/BVH.h:61-135, actor/RayPacket.h:83-211)
+//   k_top_scatter   AbstractTrace::shuffleRays, mesh branch  (algorithm/TracerBase.h:392-400) and
+//                   Tracer<DomainScheduler>::shuffleDropRays (algorithm/DomainTracer.h:148-183)
+//   framebuffer     IceTComposite::localAdd / reset / write  (composite/IceTComposite.cpp:79-157)
+#include "gvt_internal.h"
+
+namespace {
+
+struct CamArgs {
+  V3 eye, u, v, w;
+  float vert, horz, wmult, hmult, half_sample, offset, contri;
+  int W, H, samples, depth;
+};
+
+__global__ __launch_bounds__(256) void k_camera(CamArgs A, RayPlanes q, unsigned long long n) {
+  const unsigned long long ridx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ridx >= n) return;
+  const unsigned samples2 = (unsigned)(A.samples * A.samples);
+  const unsigned pix = (unsigned)(ridx / samples2);
+  const unsigned sub = (unsigned)(ridx % samples2);
+  const int k = (int)(sub / (unsigned)A.samples), ww = (int)(sub % (unsigned)A.samples);
+  const int i = (int)(pix % (unsigned)A.W), j = (int)(pix / (unsigned)A.W);
+  // float(i)*wmult - 1.0 : the double subtraction of the reference is exact here, so the float form has the same bits
+  const float x0 = (float)i * A.wmult - 1.0f, y0 = (float)j * A.hmult - 1.0f;
+  float x = x0 + ((float)ww - A.half_sample) * A.offset;
+  x *= A.horz;
+  float y = y0 + ((float)k - A.half_sample) * A.offset;
+  y *= A.vert;
+  V3 d;
+  d.x = A.u.x * x + A.v.x * y + A.w.x;
+  d.y = A.u.y * x + A.v.y * y + A.w.y;
+  d.z = A.u.z * x + A.v.z * y + A.w.z;
+  RayRec r;
+  r.o = A.eye; r.t_min = GVT_RAY_EPSILON;
+  r.d = norm3(d); r.t_max = GVT_FLT_MAX;
+  r.c = mk3(0.f, 0.f, 0.f); r.t = GVT_FLT_MAX;
+  r.id = (int)pix; r.depth = A.depth; r.w = A.contri; r.type = 0;
+  store_ray(q, ridx, r);
+}
+
+// RayPacket.h fastmin/fastmax: (a<b)?a:b / (a>b)?a:b
+__device__ inline float fmin_ref(float a, float b) { return (a < b) ? a : b; }
+__device__ inline float fmax_ref(float a, float b) { return (a > b) ? a : b; }
+
+// per ray: nearest other instance box with tfar>tnear && tnear>eps && t>tnear; instances visited in the
+// reference BVH's leaf order so that equal entry distances resolve identically.
+__global__ __launch_bounds__(256) void k_top_classify(RayPlanes q, unsigned n, const float4 *__restrict__ blo, const float4 *__restrict__ bhi,
+                                                      int n_inst, int from, int *__restrict__ next_out, float *__restrict__ t_out,
+                                                      unsigned *__restrict__ hist) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  int next = -1;
+  float ret_t = GVT_FLT_MAX;
+  if (i < n) {
+    const float4 a = q.p0[i], b = q.p1[i];
+    const float ox = a.x, oy = a.y, oz = a.z;
+    const float dx = 1.f / b.x, dy = 1.f / b.y, dz = 1.f / b.z;
+    float t = b.w; // ray t_max
+    for (int k = 0; k < n_inst; k++) {
+      const float4 lo = blo[k], hi = bhi[k];
+      const int inst = __float_as_int(lo.w);
+      if (from == inst) continue;
+      const float lx = (lo.x - ox) * dx, ly = (lo.y - oy) * dy, lz = (lo.z - oz) * dz;
+      const float ux = (hi.x - ox) * dx, uy = (hi.y - oy) * dy, uz = (hi.z - oz) * dz;
+      const float minx = fmin_ref(lx, ux), maxx = fmax_ref(lx, ux);
+      const float miny = fmin_ref(ly, uy), maxy = fmax_ref(ly, uy);
+      const float minz = fmin_ref(lz, uz), maxz = fmax_ref(lz, uz);
+      const float tnear = fmax_ref(fmax_ref(minx, miny), minz);
+      const float tfar = fmin_ref(fmin_ref(maxx, maxy), maxz);
+      if (tfar > tnear && tnear > GVT_RAY_EPSILON && t > tnear) {
+        t = tnear;
+        if (ret_t > t) { next = inst; ret_t = t; }
+      }
+    }
+    next_out[i] = next;
+    t_out[i] = ret_t;
+  }
+  // histogram of destinations: one atomic per (wave, destination)
+  unsigned long long todo = __ballot(next >= 0);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int d = __shfl(next, leader);
+    const unsigned long long m = __ballot(next == d);
+    if ((int)lane_id() == leader) atomicAdd(&hist[d], (unsigned)__popcll(m));
+    todo &= ~m;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_top_scatter(RayPlanes q, unsigned n, const int *__restrict__ next_in, const float *__restrict__ t_in,
+                                                     const QueueDesc *__restrict__ queues, float *__restrict__ fb, unsigned n_pix) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  int next = -1;
+  RayRec r;
+  if (i < n) {
+    next = next_in[i];
+    r = load_ray(q, i);
+    if (next >= 0) {
+      r.o = add3(r.o, scl3(r.d, t_in[i] * 0.95f)); // TracerBase.h:393
+    } else if (fb && r.type == 1 && len3(r.c) > 0.f) { // TracerBase.h:396-400 -> localAdd
+      if ((unsigned)r.id < n_pix) {
+        const V3 c = scl3(r.c, r.w);
+        float *px = fb + (size_t)4 * (unsigned)r.id;
+        atomicAdd(px + 0, c.x); atomicAdd(px + 1, c.y); atomicAdd(px + 2, c.z); atomicAdd(px + 3, 1.f);
+      }
+    }
+    if (next >= 0 && !queues[next].keep) next = -1; // shuffleDropRays: not this rank's domain
+  }
+  unsigned long long todo = __ballot(next >= 0);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int d = __shfl(next, leader);
+    const unsigned long long m = __ballot(next == d);
+    unsigned base = 0;
+    if ((int)lane_id() == leader) base = atomicAdd(queues[d].count, (unsigned)__popcll(m));
+    base = __shfl(base, leader);
+    if (next == d) {
+      const QueueDesc Q = queues[d];
+      const unsigned slot = base + lanes_below(m);
+      if (slot < Q.cap) store_ray(make_planes(Q.planes, Q.cap), slot, r);
+    }
+    todo &= ~m;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fb_clamp(const float *__restrict__ src, float *__restrict__ dst, unsigned long long n4, int clamp) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 v = ((const float4 *)src)[i];
+  if (clamp) { // IceTComposite::localAdd :111-117: c > 1 -> 1 (sums of non-negative terms: clamp-at-end == clamp-per-add)
+    v.x = v.x > 1.f ? 1.f : v.x; v.y = v.y > 1.f ? 1.f : v.y; v.z = v.z > 1.f ? 1.f : v.z;
+  }
+  ((float4 *)dst)[i] = v;
+}
+
+inline unsigned blocks_for(size_t n, unsigned b = 256) { return (unsigned)((n + b - 1) / b); }
+
+} // namespace
+
+extern "C" int gvt_hip_camera_generate(gvt_hip_queue *q, const float eye[3], const float focus[3], const float up[3], float fov, int W,
+                                       int H, int samples, int depth, float jitterF) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!q || W < 2 || H < 2 || samples < 1) { set_error("camera_generate: bad arguments"); return GVT_HIP_ERR_INVALID; }
+  const size_t n = (size_t)W * H * samples * samples;
+  int rc = queue_reserve(q, n);
+  if (rc) return rc;
+  // buildTransform, RIGHT_HAND_CAMERA (gvtCamera.cpp:89-139); host float arithmetic, same order as the reference
+  CamArgs A;
+  V3 e = ld3(eye), f = ld3(focus), upv = ld3(up);
+  V3 w = norm3(sub3(f, e));
+  V3 v = norm3(upv);
+  V3 u;
+  u.x = w.y * v.z - w.z * v.y; u.y = w.z * v.x - w.x * v.z; u.z = w.x * v.y - w.y * v.x;
+  u = norm3(u);
+  V3 up2;
+  up2.x = u.y * w.z - w.y * u.z; up2.y = u.z * w.x - w.z * u.x; up2.z = u.x * w.y - w.x * u.y;
+  v = norm3(up2);
+  const int jitterWindowSize = (int)jitterF; // setJitterWindowSize(int) truncates (gvtCamera.cpp:200)
+  const float aspectRatio = (float)W / (float)H;
+  A.eye = e; A.u = u; A.v = v; A.w = w;
+  A.vert = tanf((float)(fov * 0.5));
+  A.horz = tanf((float)(fov * 0.5)) * aspectRatio;
+  const float divider = (float)samples;
+  A.offset = (float)((1.0 / divider) * jitterWindowSize);
+  A.wmult = 2.f / (float)(W - 1);
+  A.hmult = 2.f / (float)(H - 1);
+  A.half_sample = samples * 0.5f;
+  A.contri = 1.f / (samples * samples);
+  A.W = W; A.H = H; A.samples = samples; A.depth = depth;
+  Ctx &C = gctx();
+  {
+    ProfScope ps(KC_CAMERA);
+    k_camera<<<blocks_for(n), 256, 0, C.stream>>>(A, make_planes(q->d_planes, q->cap), n);
+  }
+  HIPCHK(hipGetLastError());
+  q->size = n;
+  unsigned sz = (unsigned)n;
+  HIPCHK(hipMemcpyAsync(q->d_count, &sz, sizeof sz, hipMemcpyHostToDevice, C.stream));
+  HIPCHK(hipStreamSynchronize(C.stream));
+  return 0;
+}
+
+// ---- top-level BVH order: accel/BVH.cpp:77-216 restated on the host (tiny: <= #domains) ----
+namespace {
+struct TopBuild {
+  const float *lo, *hi;
+  std::vector<int> set, sorted;
+  float centroid(int inst, int ax) const { return 0.5f * lo[3 * inst + ax] + 0.5f * hi[3 * inst + ax]; } // BBox.cpp:128
+  static float fmn(float a, float b) { return (a < b) ? a : b; }
+  static float fmx(float a, float b) { return (a > b) ? a : b; }
+  void merge(float l[3], float h[3], int q) const {
+    for (int k = 0; k < 3; k++) { l[k] = fmn(lo[3 * q + k], l[k]); h[k] = fmx(hi[3 * q + k], h[k]); }
+  }
+  static float area(const float l[3], const float h[3]) { // BBox.cpp:130-133
+    float dx = h[0] - l[0], dy = h[1] - l[1], dz = h[2] - l[2];
+    return (2.f * (dx * dy + dy * dz + dz * dx));
+  }
+  float split_point(int ax, int start, int end) const { // BVH.cpp:173-216
+    float minCost = GVT_FLT_MAX, splitPoint = 0.f;
+    for (int i = start; i < end; ++i)
+      for (int e = 0; e < 2; ++e) {
+        float edge = (e == 0) ? lo[3 * set[i] + ax] : hi[3 * set[i] + ax];
+        float ll[3] = { GVT_FLT_MAX, GVT_FLT_MAX, GVT_FLT_MAX }, lh[3] = { -GVT_FLT_MAX, -GVT_FLT_MAX, -GVT_FLT_MAX };
+        float rl[3] = { GVT_FLT_MAX, GVT_FLT_MAX, GVT_FLT_MAX }, rh[3] = { -GVT_FLT_MAX, -GVT_FLT_MAX, -GVT_FLT_MAX };
+        int leftCount = 0;
+        for (int j = start; j < end; ++j) {
+          if (centroid(set[j], ax) < edge) { ++leftCount; merge(ll, lh, set[j]); } else merge(rl, rh, set[j]);
+        }
+        int rightCount = end - start - leftCount;
+        float cost = (float)(0.5 + (area(ll, lh) * leftCount) + (area(rl, rh) * rightCount));
+        if (cost < minCost) { minCost = cost; splitPoint = edge; }
+      }
+    return splitPoint;
+  }
+  void build(int start, int end) { // BVH.cpp:77-171 (LEAF_SIZE 1)
+    float l[3] = { GVT_FLT_MAX, GVT_FLT_MAX, GVT_FLT_MAX }, h[3] = { -GVT_FLT_MAX, -GVT_FLT_MAX, -GVT_FLT_MAX };
+    for (int i = start; i < end; ++i) merge(l, h, set[i]);
+    if (end - start <= 1) { for (int i = start; i < end; ++i) sorted.push_back(set[i]); return; }
+    float dx = h[0] - l[0], dy = h[1] - l[1], dz = h[2] - l[2];
+    int ax = (dx > dy && dx > dz) ? 0 : (dy > dz) ? 1 : 2; // BBox.cpp:117-126
+    float sp = split_point(ax, start, end);
+    int first = start, last = end; // std::partition (libstdc++ bidirectional __partition)
+    for (;;) {
+      bool done = false;
+      for (;;) { if (first == last) { done = true; break; } else if (centroid(set[first], ax) < sp) ++first; else break; }
+      if (done) break;
+      --last;
+      for (;;) { if (first == last) { done = true; break; } else if (!(centroid(set[last], ax) < sp)) --last; else break; }
+      if (done) break;
+      std::swap(set[first], set[last]);
+      ++first;
+    }
+    int splitIdx = first;
+    if (splitIdx == start || splitIdx == end) { for (int i = start; i < end; ++i) sorted.push_back(set[i]); return; }
+    build(start, splitIdx);
+    build(splitIdx, end);
+  }
+};
+} // namespace
+
+extern "C" gvt_hip_top *gvt_hip_top_create(const float *inst_lo, const float *inst_hi, size_t n) {
+  if (ensure_init()) return nullptr;
+  if (!inst_lo || !inst_hi) { set_error("top_create: null boxes"); return nullptr; }
+  gvt_hip_top *T = new gvt_hip_top();
+  T->n = n;
+  TopBuild B{ inst_lo, inst_hi, {}, {} };
+  B.set.resize(n);
+  for (size_t i = 0; i < n; i++) B.set[i] = (int)i;
+  if (n) B.build(0, (int)n);
+  T->order = B.sorted;
+  std::vector<float4> lo(n ? n : 1), hi(n ? n : 1);
+  for (size_t k = 0; k < n; k++) {
+    int q = T->order[k];
+    lo[k] = make_float4(inst_lo[3 * q], inst_lo[3 * q + 1], inst_lo[3 * q + 2], __builtin_bit_cast(float, q));
+    hi[k] = make_float4(inst_hi[3 * q], inst_hi[3 * q + 1], inst_hi[3 * q + 2], 0.f);
+  }
+  bool ok = hipMalloc((void **)&T->d_lo, sizeof(float4) * (n ? n : 1)) == hipSuccess &&
+            hipMalloc((void **)&T->d_hi, sizeof(float4) * (n ? n : 1)) == hipSuccess &&
+            hipMalloc((void **)&T->d_hist, sizeof(unsigned) * (n ? n : 1)) == hipSuccess &&
+            hipMalloc((void **)&T->d_qdesc, sizeof(QueueDesc) * (n ? n : 1)) == hipSuccess;
+  if (ok && n) {
+    ok = hipMemcpy(T->d_lo, lo.data(), sizeof(float4) * n, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(T->d_hi, hi.data(), sizeof(float4) * n, hipMemcpyHostToDevice) == hipSuccess;
+  }
+  if (!ok) { set_error("top_create: device allocation failed"); gvt_hip_top_destroy(T); return nullptr; }
+  return T;
+}
+extern "C" void gvt_hip_top_destroy(gvt_hip_top *T) {
+  if (!T) return;
+  hipFree(T->d_lo); hipFree(T->d_hi); hipFree(T->d_hist); hipFree(T->d_qdesc);
+  delete T;
+}
+extern "C" int gvt_hip_top_order(const gvt_hip_top *T, int32_t *out) {
+  if (!T || !out) { set_error("top_order: null"); return GVT_HIP_ERR_INVALID; }
+  for (size_t i = 0; i < T->n; i++) out[i] = T->order[i];
+  return 0;
+}
+
+extern "C" int gvt_hip_shuffle(gvt_hip_top *T, gvt_hip_queue *q_in, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
+                               gvt_hip_fb *fb) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!T || !q_in || (T->n && !queues)) { set_error("shuffle: null argument"); return GVT_HIP_ERR_INVALID; }
+  for (size_t i = 0; i < T->n; i++)
+    if (!queues[i] || queues[i] == q_in) { set_error("shuffle: queue %zu is null or aliases q_in", i); return GVT_HIP_ERR_INVALID; }
+  Ctx &C = gctx();
+  const size_t n = q_in->size;
+  if (!n) return 0;
+  hipStream_t st = C.stream;
+  int *d_next = (int *)scratch_get(6, sizeof(int) * n);
+  float *d_t = (float *)scratch_get(7, sizeof(float) * n);
+  if (!d_next || !d_t) return GVT_HIP_ERR_DEVICE;
+  RayPlanes in = make_planes(q_in->d_planes, q_in->cap);
+  const size_t nI = T->n;
+  if (nI) HIPCHK(hipMemsetAsync(T->d_hist, 0, sizeof(unsigned) * nI, st));
+  {
+    ProfScope ps(KC_SHUFFLE);
+    k_top_classify<<<blocks_for(n), 256, 0, st>>>(in, (unsigned)n, T->d_lo, T->d_hi, (int)nI, from, d_next, d_t, T->d_hist);
+  }
+  HIPCHK(hipGetLastError());
+  std::vector<unsigned> hist(nI ? nI : 1, 0u);
+  if (nI) HIPCHK(hipMemcpyAsync(hist.data(), T->d_hist, sizeof(unsigned) * nI, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  std::vector<QueueDesc> desc(nI ? nI : 1);
+  for (size_t i = 0; i < nI; i++) {
+    const bool keep = !keep_mask || keep_mask[i];
+    gvt_hip_queue *Q = queues[i];
+    if (keep && hist[i]) {
+      int rc = queue_reserve(Q, Q->size + hist[i]);
+      if (rc) return rc;
+    }
+    desc[i].planes = Q->d_planes; desc[i].cap = Q->cap; desc[i].count = Q->d_count; desc[i].keep = keep ? 1u : 0u;
+  }
+  if (nI) HIPCHK(hipMemcpyAsync(T->d_qdesc, desc.data(), sizeof(QueueDesc) * nI, hipMemcpyHostToDevice, st));
+  {
+    ProfScope ps(KC_SHUFFLE);
+    k_top_scatter<<<blocks_for(n), 256, 0, st>>>(in, (unsigned)n, d_next, d_t, (const QueueDesc *)T->d_qdesc, fb ? fb->d_rgba : nullptr,
+                                                 fb ? (unsigned)(fb->w * fb->h) : 0u);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st)); // desc/hist are host vectors
+  for (size_t i = 0; i < nI; i++)
+    if (desc[i].keep) queues[i]->size += hist[i];
+  q_in->size = 0; // rays.clear(), TracerBase.h:411
+  HIPCHK(hipMemsetAsync(q_in->d_count, 0, sizeof(unsigned), st));
+  return 0;
+}
+
+// ---- framebuffer ----
+extern "C" gvt_hip_fb *gvt_hip_fb_create(int w, int h) {
+  if (ensure_init()) return nullptr;
+  if (w <= 0 || h <= 0) { set_error("fb_create: bad size"); return nullptr; }
+  gvt_hip_fb *F = new gvt_hip_fb();
+  F->w = w; F->h = h;
+  if (hipMalloc((void **)&F->d_rgba, sizeof(float) * 4 * (size_t)w * h) != hipSuccess) { set_error("fb_create: hipMalloc failed"); delete F; return nullptr; }
+  hipMemsetAsync(F->d_rgba, 0, sizeof(float) * 4 * (size_t)w * h, gctx().stream);
+  return F;
+}
+extern "C" void gvt_hip_fb_destroy(gvt_hip_fb *F) {
+  if (!F) return;
+  hipFree(F->d_rgba);
+  delete F;
+}
+extern "C" int gvt_hip_fb_clear(gvt_hip_fb *F) {
+  if (!F) { set_error("fb_clear: null"); return GVT_HIP_ERR_INVALID; }
+  HIPCHK(hipMemsetAsync(F->d_rgba, 0, sizeof(float) * 4 * (size_t)F->w * F->h, gctx().stream));
+  return 0;
+}
+extern "C" void *gvt_hip_fb_device_ptr(gvt_hip_fb *F) { return F ? (void *)F->d_rgba : nullptr; }
+extern "C" int gvt_hip_fb_download(gvt_hip_fb *F, float *rgba, int clamp) {
+  if (!F || !rgba) { set_error("fb_download: null"); return GVT_HIP_ERR_INVALID; }
+  Ctx &C = gctx();
+  const size_t n4 = (size_t)F->w * F->h;
+  float *tmp = (float *)scratch_get(6, sizeof(float) * 4 * n4);
+  if (!tmp) return GVT_HIP_ERR_DEVICE;
+  k_fb_clamp<<<blocks_for(n4), 256, 0, C.stream>>>(F->d_rgba, tmp, n4, clamp);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(rgba, tmp, sizeof(float) * 4 * n4, hipMemcpyDeviceToHost, C.stream));
+  HIPCHK(hipStreamSynchronize(C.stream));
+  return 0;
+}
+extern "C" int gvt_hip_fb_write_ppm_bytes(gvt_hip_fb *F, unsigned char *rgb) {
+  if (!F || !rgb) { set_error("fb_write_ppm_bytes: null"); return GVT_HIP_ERR_INVALID; }
+  std::vector<float> host((size_t)F->w * F->h * 4);
+  int rc = gvt_hip_fb_download(F, host.data(), 1);
+  if (rc) return rc;
+  size_t o = 0; // IceTComposite::write :119-157 -- rows bottom-up, truncating cast
+  for (int j = F->h - 1; j >= 0; j--)
+    for (int i = 0; i < F->w; ++i) {
+      size_t index = 4 * ((size_t)j * F->w + i);
+      rgb[o++] = (unsigned char)(host[index + 0] * 255);
+      rgb[o++] = (unsigned char)(host[index + 1] * 255);
+      rgb[o++] = (unsigned char)(host[index + 2] * 255);
+    }
+  return 0;
+}

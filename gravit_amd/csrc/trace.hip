@@ -1,0 +1,543 @@
+// trace.hip -- the adapter hot path on gfx950: Adapter::trace
+// (src/gvt/render/Adapter.h:82-84, adapter/embree/EmbreeMeshAdapter.cpp:436-660).
+//
+//   k_closest   rtcIntersect   (EmbreeMeshAdapter.cpp:474): ray -> object space, nearest hit in (1e-6, inf)
+//   k_shade     per-lane block (:483-609): miss forward / shadow drop / normal / material / Shade /
+//               shadow-ray generation (:320-358) / Russian-roulette bounce (:584-602)
+//   k_any       rtcOccluded    (:364-385): un-occluded shadow rays are appended to moved_rays
+//
+// One lane per ray.  Waves fetch 64-ray batches from a device counter (work queue with an exit every
+// wave reaches), keep their traversal stacks in LDS (stack[level][lane]: lane-contiguous, bank
+// conflict free) and compact survivors with one atomic per wave (__ballot + mbcnt).
+#include "gvt_internal.h"
+
+#define TRAV_BLOCK 256
+#define TRAV_STACK 24   // LDS entries per lane; deeper levels spill to a per-thread global area
+#define TRAV_SPILL 104  // 24 + 104 = 128 >= 63 + 32 + margin levels of a 63-bit Karras tree
+
+namespace {
+
+struct Trav {
+  const BvhNode *__restrict__ nodes;
+  const float4 *__restrict__ tris;
+};
+
+template <bool ANY>
+__device__ inline bool traverse(const Trav &T, V3 O, V3 D, float tnear, int *__restrict__ lds /* &stack[0][tid] */, int *__restrict__ spill,
+                                float &best_t, int &best_prim, float &best_u, float &best_v) {
+  // reciprocal direction for the slab test only (never feeds a result)
+  float dx = fabsf(D.x) < 1e-30f ? copysignf(1e-30f, D.x) : D.x;
+  float dy = fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y;
+  float dz = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;
+  const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+  const float ox = O.x * ix, oy = O.y * iy, oz = O.z * iz;
+  int sp = 0;
+  int cur = 0;
+  for (;;) {
+    if (cur >= 0) {
+      const BvhNode *nd = T.nodes + cur;
+      const float4 n0 = nd->n0, n1 = nd->n1, n2 = nd->n2, n3 = nd->n3;
+      float a0 = __builtin_fmaf(n0.x, ix, -ox), a1 = __builtin_fmaf(n0.y, ix, -ox);
+      float b0 = __builtin_fmaf(n0.z, iy, -oy), b1 = __builtin_fmaf(n0.w, iy, -oy);
+      float c0 = __builtin_fmaf(n2.x, iz, -oz), c1 = __builtin_fmaf(n2.y, iz, -oz);
+      float tn0 = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.f));
+      float tf0 = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1)) * 1.0000004f;
+      a0 = __builtin_fmaf(n1.x, ix, -ox); a1 = __builtin_fmaf(n1.y, ix, -ox);
+      b0 = __builtin_fmaf(n1.z, iy, -oy); b1 = __builtin_fmaf(n1.w, iy, -oy);
+      c0 = __builtin_fmaf(n2.z, iz, -oz); c1 = __builtin_fmaf(n2.w, iz, -oz);
+      float tn1 = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.f));
+      float tf1 = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1)) * 1.0000004f;
+      const float lim = ANY ? GVT_FLT_MAX : best_t;
+      const bool h0 = (tn0 <= tf0) && (tn0 <= lim);
+      const bool h1 = (tn1 <= tf1) && (tn1 <= lim);
+      const int r0 = __float_as_int(n3.x), r1 = __float_as_int(n3.y);
+      if (h0 && h1) {
+        const bool swap = tn1 < tn0;
+        const int nearc = swap ? r1 : r0, farc = swap ? r0 : r1;
+        if (sp < TRAV_STACK) lds[sp * TRAV_BLOCK] = farc; else spill[sp - TRAV_STACK] = farc;
+        sp++;
+        cur = nearc;
+      } else if (h0) {
+        cur = r0;
+      } else if (h1) {
+        cur = r1;
+      } else {
+        if (sp == 0) break;
+        sp--;
+        cur = (sp < TRAV_STACK) ? lds[sp * TRAV_BLOCK] : spill[sp - TRAV_STACK];
+      }
+    } else {
+      const unsigned code = (unsigned)~cur;
+      const unsigned first = code >> 3, cnt = code & 7u;
+      for (unsigned k = 0; k < cnt; k++) {
+        const float4 t0 = T.tris[3 * (first + k)], t1 = T.tris[3 * (first + k) + 1], t2 = T.tris[3 * (first + k) + 2];
+        float t, u, v;
+        if (tri_test(O, D, mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), tnear, t, u, v)) {
+          if (ANY) return true;
+          const int prim = __float_as_int(t0.w);
+          if (best_prim < 0 || t < best_t || (t == best_t && prim < best_prim)) { best_t = t; best_prim = prim; best_u = u; best_v = v; }
+        }
+      }
+      if (sp == 0) break;
+      sp--;
+      cur = (sp < TRAV_STACK) ? lds[sp * TRAV_BLOCK] : spill[sp - TRAV_STACK];
+    }
+  }
+  return false;
+}
+
+// wave-level work fetch: 64 rays per grab; every wave leaves as soon as the counter passes n
+__device__ inline unsigned fetch_batch(unsigned *counter) {
+  unsigned base = 0;
+  if (lane_id() == 0) base = atomicAdd(counter, 64u);
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+}
+
+template <bool XFORM>
+__global__ __launch_bounds__(TRAV_BLOCK) void k_closest(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, Trav T,
+                                                         float tnear, gvt_hip_hit *__restrict__ hits, unsigned *counter, int *spill_base) {
+  __shared__ int stack[TRAV_STACK * TRAV_BLOCK];
+  int *lds = &stack[threadIdx.x];
+  int *spill = spill_base + (size_t)(blockIdx.x * TRAV_BLOCK + threadIdx.x) * TRAV_SPILL;
+  for (;;) {
+    const unsigned base = fetch_batch(counter);
+    if (base >= n) break;
+    const unsigned j = base + lane_id();
+    if (j < n) {
+      const unsigned i = idx ? idx[j] : j;
+      const float4 a = q.p0[i], b = q.p1[i];
+      V3 O = mk3(a.x, a.y, a.z), D = mk3(b.x, b.y, b.z);
+      if (XFORM) { O = xfm_point(minv, O); D = xfm_vector(minv, D); }
+      float bt = GVT_FLT_MAX, bu = 0.f, bv = 0.f;
+      int bp = -1;
+      if (T.nodes) traverse<false>(T, O, D, tnear, lds, spill, bt, bp, bu, bv);
+      gvt_hip_hit h; h.t = bt; h.prim = bp; h.u = bu; h.v = bv;
+      hits[j] = h;
+    }
+  }
+}
+
+// MODE 0: flags[j] = occluded.  MODE 1: un-occluded rays of q are appended to `out` (moved_rays).
+template <bool XFORM, int MODE>
+__global__ __launch_bounds__(TRAV_BLOCK) void k_any(RayPlanes q, unsigned n, Mat4 minv, Trav T, float tnear, int *__restrict__ flags,
+                                                     RayPlanes out, unsigned *out_count, unsigned *counter, int *spill_base) {
+  __shared__ int stack[TRAV_STACK * TRAV_BLOCK];
+  int *lds = &stack[threadIdx.x];
+  int *spill = spill_base + (size_t)(blockIdx.x * TRAV_BLOCK + threadIdx.x) * TRAV_SPILL;
+  for (;;) {
+    const unsigned base = fetch_batch(counter);
+    if (base >= n) break;
+    const unsigned j = base + lane_id();
+    bool survive = false;
+    if (j < n) {
+      const float4 a = q.p0[j], b = q.p1[j];
+      V3 O = mk3(a.x, a.y, a.z), D = mk3(b.x, b.y, b.z);
+      if (XFORM) { O = xfm_point(minv, O); D = xfm_vector(minv, D); }
+      float bt = GVT_FLT_MAX, bu, bv;
+      int bp = -1;
+      const bool occ = T.nodes ? traverse<true>(T, O, D, tnear, lds, spill, bt, bp, bu, bv) : false;
+      if (MODE == 0) flags[j] = occ ? 1 : 0;
+      survive = !occ;
+    }
+    if (MODE == 1) {
+      const unsigned slot = wave_alloc(out_count, survive);
+      if (survive) { out.p0[slot] = q.p0[j]; out.p1[slot] = q.p1[j]; out.p2[slot] = q.p2[j]; out.p3[slot] = q.p3[j]; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shading (Material.cpp:50-139, Light.cpp:58-133), in the oracle's evaluation order
+// ------------------------------------------------------------------------------------------------
+__device__ inline V3 light_contribution(const gvt_hip_light &L, V3 hit, V3 samplePos) {
+  V3 c = ld3(L.color);
+  if (L.type == GVT_HIP_LIGHT_AMBIENT) return c; // Light.cpp:70
+  V3 p = (L.type == GVT_HIP_LIGHT_AREA) ? samplePos : ld3(L.position);
+  float distance = 1.f / len3(sub3(p, hit));
+  distance = (distance > 1.f) ? 1.f : distance;
+  return scl3(c, distance);
+}
+
+__device__ inline V3 area_light_position(const gvt_hip_light &L, uint32_t &seed) { // Light.cpp:72-99,115-127
+  V3 v = ld3(L.normal), u, w;
+  if (v.x == 0.f && v.y == 1.f && v.z == 0.f) {
+    u = mk3(1, 0, 0); w = mk3(0, 0, 1);
+  } else {
+    const V3 up = mk3(0, 1, 0);
+    u.x = up.y * v.z - v.y * up.z; u.y = up.z * v.x - v.z * up.x; u.z = up.x * v.y - v.x * up.y;
+    w.x = v.y * u.z - u.y * v.z; w.y = v.z * u.x - u.z * v.x; w.z = v.x * u.y - u.x * v.y;
+  }
+  float xLocation = (float)(((double)gvt_fastrand_lcg(seed, 0, 1) - 0.5) * (double)L.width);
+  float zLocation = (float)(((double)gvt_fastrand_lcg(seed, 0, 1) - 0.5) * (double)L.height);
+  float xCoord = xLocation * u.x + zLocation * w.x;
+  float yCoord = xLocation * u.y + zLocation * w.y;
+  float zCoord = xLocation * u.z + zLocation * w.z;
+  return mk3(L.position[0] + xCoord, L.position[1] + yCoord, L.position[2] + zCoord);
+}
+
+// primitives::Shade (Material.cpp:90-139)
+__device__ inline bool shade(int mtype, V3 kd, V3 ks, float alpha, const RayRec &ray, V3 N, const gvt_hip_light &L, V3 lightPos, V3 &out) {
+  V3 hitPoint = add3(ray.o, scl3(ray.d, ray.t));
+  V3 wi = norm3(sub3(lightPos, hitPoint));
+  float dNw = dot3(N, wi);
+  float NdotL = (0.f < dNw) ? dNw : 0.f;
+  V3 Li = light_contribution(L, hitPoint, lightPos);
+  if (NdotL == 0.f || (Li.x == 0.f && Li.y == 0.f && Li.z == 0.f)) return false;
+  V3 color;
+  if (mtype == 0) { // lambertShade :50-57
+    color = scl3(kd, NdotL * ray.w);
+  } else if (mtype == 1) { // phongShade :59-70
+    V3 R = sub3(scl3(scl3(N, 2.f), NdotL), wi);
+    float vr = dot3(R, neg3(ray.d));
+    float VdotR = (0.f < vr) ? vr : 0.f;
+    float power = VdotR * powf(VdotR, alpha);
+    color = scl3(kd, NdotL * ray.w);
+    color = add3(color, scl3(ks, power * ray.w));
+  } else if (mtype == 2) { // blinnPhongShade :72-87
+    V3 H = norm3(sub3(wi, ray.d));
+    float hn = dot3(H, N);
+    float NdotH = (0.f < hn) ? hn : 0.f;
+    float power = NdotH * powf(NdotH, alpha);
+    V3 diffuse = scl3(kd, NdotL * ray.w);
+    V3 specular = scl3(ks, power * ray.w);
+    color = add3(diffuse, specular);
+  } else {
+    color = mk3(0, 0, 0);
+  }
+  color = mul3(color, Li);
+  float c[3] = { color.x, color.y, color.z };
+  for (int i = 0; i < 3; i++) {
+    float a = (c[i] < 0.f) ? 0.f : c[i];
+    c[i] = (1.f < a) ? 1.f : a;
+  }
+  out = mk3(c[0], c[1], c[2]);
+  return true;
+}
+
+// CosWeightedRandomHemisphereDirection2 (EmbreeMeshAdapter.cpp:289-318)
+__device__ inline V3 cos_weighted_dir(V3 n, uint32_t &seed) {
+  float Xi1 = gvt_fastrand01(seed);
+  float Xi2 = gvt_fastrand01(seed);
+  float theta = (float)acos(sqrt(1.0 - (double)Xi1));
+  float phi = (float)(2.0 * 3.1415926535897932384626433832795 * (double)Xi2);
+  float xs = sinf(theta) * cosf(phi);
+  float ys = cosf(theta);
+  float zs = sinf(theta) * sinf(phi);
+  V3 y = n, h = y;
+  if (fabsf(h.x) <= fabsf(h.y) && fabsf(h.x) <= fabsf(h.z)) h.x = 1.0f;
+  else if (fabsf(h.y) <= fabsf(h.x) && fabsf(h.y) <= fabsf(h.z)) h.y = 1.0f;
+  else h.z = 1.0f;
+  V3 x = cross3(h, y);
+  V3 z = cross3(x, y);
+  V3 d = add3(add3(scl3(x, xs), scl3(y, ys)), scl3(z, zs));
+  return norm3(d);
+}
+
+struct MeshView {
+  const float *verts;
+  const int *tris;
+  const float *normals;
+  const float *vcolors;
+  const gvt_hip_material *materials;
+  unsigned n_mat;
+  const int *face_mat;
+  int mtype;
+  float kd[3], ks[3], alpha; // Mesh::mat
+};
+
+struct ShadeArgs {
+  RayPlanes in;            // rayList (updated in place)
+  const unsigned *idx;     // active list or null (identity)
+  unsigned n;
+  unsigned long long index_base;
+  const gvt_hip_hit *hits;
+  uint32_t *rng;           // per-ray stream state, indexed like `in`
+  int first_pass;
+  RayPlanes out; unsigned *out_count;       // moved_rays
+  RayPlanes shadow; unsigned *shadow_count; // shadowRays of this pass
+  unsigned *next_idx; unsigned *next_count; // rays that bounce (valid[pi] stays set)
+  const gvt_hip_light *lights;
+  Mat3 normi;
+  int normal_mode, n_lights;
+  uint32_t seed;
+};
+
+__global__ __launch_bounds__(256) void k_shade(ShadeArgs A, MeshView M) {
+  const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in_range = j < A.n;
+  const unsigned i = in_range ? (A.idx ? A.idx[j] : j) : 0u;
+  RayRec r;
+  gvt_hip_hit h;
+  h.prim = -1; h.t = 0.f; h.u = 0.f; h.v = 0.f;
+  bool miss = false, shaded = false, bounce = false;
+  uint32_t g_seed = 0;
+  V3 N = mk3(0, 0, 0);
+  int mtype = 0;
+  V3 kd = mk3(0, 0, 0), ks = mk3(0, 0, 0);
+  float alpha = 1.f;
+  if (in_range) {
+    r = load_ray(A.in, i);
+    h = A.hits[j];
+    g_seed = A.first_pass ? ray_stream_seed(A.seed, A.index_base + i) : A.rng[i];
+    if (h.prim < 0) {
+      miss = true; // :605-609
+    } else if (r.type != 1) { // a SHADOW ray that hits is dropped :486-488
+      shaded = true;
+      float t = h.t;
+      r.t = t; // :491
+      const int ia = M.tris[3 * h.prim], ib = M.tris[3 * h.prim + 1], ic = M.tris[3 * h.prim + 2];
+      const V3 v0 = ld3(M.verts + 3 * ia), v1 = ld3(M.verts + 3 * ib), v2 = ld3(M.verts + 3 * ic);
+      const V3 negNg = cross3(sub3(v1, v0), sub3(v2, v0)); // -Ng of Embree (cf. OptixMeshAdapter.cu:280-287)
+      const V3 normalflat = norm3(mat3_mul(A.normi, negNg)); // :504
+      if (A.normal_mode == GVT_HIP_NORMALS_SMOOTH) { // :505-518
+        const V3 a = ld3(M.normals + 3 * ib), b = ld3(M.normals + 3 * ic), c = ld3(M.normals + 3 * ia);
+        const V3 mn = add3(add3(scl3(a, h.u), scl3(b, h.v)), scl3(c, 1.0f - h.u - h.v));
+        N = norm3(mat3_mul(A.normi, mn));
+      } else {
+        N = normalflat; // :520-522
+      }
+      if (dot3(neg3(r.d), normalflat) <= 0.f) N = neg3(N); // :527-529
+      // material pick :534-569
+      mtype = M.mtype; kd = ld3(M.kd); ks = ld3(M.ks); alpha = M.alpha;
+      if (M.vcolors) {
+        const V3 c0 = ld3(M.vcolors + 3 * ia), c1 = ld3(M.vcolors + 3 * ib), c2 = ld3(M.vcolors + 3 * ic);
+        kd = add3(add3(scl3(c0, 1.f - h.u - h.v), scl3(c1, h.u)), scl3(c2, h.v));
+        mtype = 0; ks = mk3(.5f, .5f, .5f); alpha = 1.f;
+      } else if (M.face_mat && M.face_mat[h.prim] >= 0 && (unsigned)M.face_mat[h.prim] < M.n_mat) {
+        const gvt_hip_material &fm = M.materials[M.face_mat[h.prim]];
+        mtype = fm.type; kd = ld3(fm.kd); ks = ld3(fm.ks); alpha = fm.alpha;
+      }
+      if (r.type == 2) { // SECONDARY :572-575
+        t = (t > 1) ? 1.f / t : t;
+        r.w = r.w * t;
+      }
+    }
+  }
+  // moved_rays: misses are forwarded as they are
+  {
+    const unsigned slot = wave_alloc(A.out_count, miss);
+    if (miss) store_ray(A.out, slot, r);
+  }
+  // generateShadowRays :320-358 -- one pass per light so that the wave allocates slots together
+  for (int li = 0; li < A.n_lights; li++) {
+    bool emit = false;
+    RayRec s;
+    if (shaded) {
+      const gvt_hip_light L = A.lights[li];
+      const V3 lightPos = (L.type == GVT_HIP_LIGHT_AREA) ? area_light_position(L, g_seed) : ld3(L.position);
+      V3 c;
+      if (shade(mtype, kd, ks, alpha, r, N, L, lightPos, c)) {
+        emit = true;
+        const float multiplier = 1.0f - GVT_RAY_EPSILON * 16;
+        const float t_shadow = multiplier * r.t;
+        const V3 origin = add3(r.o, scl3(r.d, t_shadow));
+        const V3 dir = sub3(lightPos, origin);
+        s.o = origin; s.t_min = GVT_RAY_EPSILON;
+        s.d = norm3(dir); // Ray ctor normalizes, Ray.h:109
+        s.t_max = 3.0f;   // dir.length() == glm component count (:347,355)
+        s.c = c; s.t = r.t;
+        s.id = r.id; s.depth = r.depth; s.w = r.w; s.type = 1;
+      }
+    }
+    const unsigned slot = wave_alloc(A.shadow_count, emit);
+    if (emit) store_ray(A.shadow, slot, s);
+  }
+  if (shaded) { // :584-602
+    const int ndepth = r.depth - 1;
+    const float p = 1.f - gvt_fastrand01(g_seed);
+    if (ndepth > 0 && r.w > p) {
+      r.type = 2;
+      const float multiplier = 1.0f - 16.0f * GVT_FLT_EPSILON;
+      const float t_secondary = multiplier * r.t;
+      r.o = add3(r.o, scl3(r.d, t_secondary));
+      const V3 nd = cos_weighted_dir(N, g_seed);
+      r.d = nd;
+      r.w = r.w * dot3(nd, N);
+      r.depth = ndepth;
+      bounce = true;
+    }
+    store_ray(A.in, i, r); // rayList is updated in place
+    A.rng[i] = g_seed;
+  }
+  {
+    const unsigned slot = wave_alloc(A.next_count, bounce);
+    if (bounce) A.next_idx[slot] = i;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout conversions at the ABI boundary: 80-byte Ray AoS <-> planes
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_aos_to_planes(const float4 *__restrict__ src /* 5 float4 per ray */, unsigned n, RayPlanes dst,
+                                                        unsigned long long off) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 *s = src + (size_t)5 * i;
+  dst.p0[off + i] = s[0]; dst.p1[off + i] = s[1]; dst.p2[off + i] = s[2]; dst.p3[off + i] = s[3];
+}
+__global__ __launch_bounds__(256) void k_planes_to_aos(RayPlanes src, unsigned long long off, unsigned n, float4 *__restrict__ dst) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 *d = dst + (size_t)5 * i;
+  d[0] = src.p0[off + i]; d[1] = src.p1[off + i]; d[2] = src.p2[off + i]; d[3] = src.p3[off + i];
+  d[4] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ __launch_bounds__(256) void k_od_to_planes(const float *__restrict__ org, const float *__restrict__ dir, unsigned n, RayPlanes dst) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  dst.p0[i] = make_float4(org[3 * i], org[3 * i + 1], org[3 * i + 2], GVT_RAY_EPSILON);
+  dst.p1[i] = make_float4(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2], GVT_FLT_MAX);
+}
+
+inline unsigned blocks_for(size_t n, unsigned b = 256) { return (unsigned)((n + b - 1) / b); }
+
+int trav_grid(size_t n) {
+  Ctx &C = gctx();
+  size_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
+  return (int)(need < (size_t)C.trav_blocks ? (need ? need : 1) : (size_t)C.trav_blocks);
+}
+
+} // namespace
+
+size_t trav_spill_ints_per_thread() { return TRAV_SPILL; }
+int trav_block_threads() { return TRAV_BLOCK; }
+
+int convert_aos_to_planes(const gvt_hip_ray *d_src, size_t n, RayPlanes dst, size_t dst_off) {
+  if (!n) return 0;
+  ProfScope ps(KC_CONVERT);
+  k_aos_to_planes<<<blocks_for(n), 256, 0, gctx().stream>>>((const float4 *)d_src, (unsigned)n, dst, dst_off);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int convert_planes_to_aos(RayPlanes src, size_t src_off, size_t n, gvt_hip_ray *d_dst) {
+  if (!n) return 0;
+  ProfScope ps(KC_CONVERT);
+  k_planes_to_aos<<<blocks_for(n), 256, 0, gctx().stream>>>(src, src_off, (unsigned)n, (float4 *)d_dst);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int convert_od_to_planes(const float *d_org, const float *d_dir, size_t n, RayPlanes dst) {
+  if (!n) return 0;
+  ProfScope ps(KC_CONVERT);
+  k_od_to_planes<<<blocks_for(n), 256, 0, gctx().stream>>>(d_org, d_dir, (unsigned)n, dst);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, bool xform, const Mat4 &minv, float tnear,
+                   gvt_hip_hit *d_hits) {
+  if (!n) return 0;
+  Ctx &C = gctx();
+  Trav T{ M->d_nodes, M->d_tri };
+  unsigned *counter = C.d_counters + 0;
+  HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), C.stream));
+  {
+    ProfScope ps(KC_CLOSEST);
+    if (xform) k_closest<true><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
+    else k_closest<false><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
+  }
+  HIPCHK(hipGetLastError());
+  C.stats.rays_closest += n;
+  C.stats.launches_closest++;
+  return 0;
+}
+
+int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const Mat4 &minv, float tnear, int *d_flags) {
+  if (!n) return 0;
+  Ctx &C = gctx();
+  Trav T{ M->d_nodes, M->d_tri };
+  unsigned *counter = C.d_counters + 0;
+  HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), C.stream));
+  RayPlanes none{};
+  {
+    ProfScope ps(KC_ANY);
+    if (xform) k_any<true, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
+    else k_any<false, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
+  }
+  HIPCHK(hipGetLastError());
+  C.stats.rays_any += n;
+  C.stats.launches_any++;
+  return 0;
+}
+
+// Adapter::trace on device planes.  `in` holds n rays at [0,n); `out` must have been reserved for
+// out->size + n*(1+n_lights).  On return out->size is exact (one small read-back).
+int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt_hip_queue *out, const TraceParams &P,
+               const gvt_hip_light *lights_host) {
+  Ctx &C = gctx();
+  C.stats.trace_calls++;
+  if (!n) return 0;
+  hipStream_t st = C.stream;
+  const int nL = P.n_lights;
+  // scratch: hits, rng, shadow queue, two index lists, lights
+  gvt_hip_hit *d_hits = (gvt_hip_hit *)scratch_get(0, sizeof(gvt_hip_hit) * n);
+  uint32_t *d_rng = (uint32_t *)scratch_get(1, sizeof(uint32_t) * n);
+  const size_t shadow_cap = n * (size_t)(nL > 0 ? nL : 1);
+  float4 *d_shadow = (float4 *)scratch_get(2, sizeof(float4) * 4 * shadow_cap);
+  unsigned *d_idx_a = (unsigned *)scratch_get(3, sizeof(unsigned) * n);
+  unsigned *d_idx_b = (unsigned *)scratch_get(4, sizeof(unsigned) * n);
+  gvt_hip_light *d_lights = (gvt_hip_light *)scratch_get(5, sizeof(gvt_hip_light) * (nL > 0 ? nL : 1));
+  if (!d_hits || !d_rng || !d_shadow || !d_idx_a || !d_idx_b || !d_lights) return GVT_HIP_ERR_DEVICE;
+  if (nL) HIPCHK(hipMemcpyAsync(d_lights, lights_host, sizeof(gvt_hip_light) * nL, hipMemcpyHostToDevice, st));
+  RayPlanes shadow = make_planes(d_shadow, shadow_cap);
+  RayPlanes outp = make_planes(out->d_planes, out->cap);
+  unsigned *c_shadow = C.d_counters + 1, *c_next = C.d_counters + 2;
+  {
+    unsigned sz = (unsigned)out->size;
+    C.h_pinned[8] = sz;
+    HIPCHK(hipMemcpyAsync(out->d_count, &C.h_pinned[8], sizeof(unsigned), hipMemcpyHostToDevice, st));
+  }
+
+  MeshView mv;
+  mv.verts = M->d_verts; mv.tris = M->d_tris; mv.normals = M->d_normals; mv.vcolors = M->d_vcolors;
+  mv.materials = M->d_materials; mv.n_mat = (unsigned)M->nMat; mv.face_mat = M->d_face_mat;
+  mv.mtype = M->mesh_mat.type; mv.alpha = M->mesh_mat.alpha;
+  for (int k = 0; k < 3; k++) { mv.kd[k] = M->mesh_mat.kd[k]; mv.ks[k] = M->mesh_mat.ks[k]; }
+
+  size_t n_active = n;
+  const unsigned *idx = nullptr;
+  unsigned *next = d_idx_a;
+  int pass = 0;
+  while (n_active) { // while (validRayLeft) :465
+    int rc = launch_closest(M, in, idx, n_active, true, P.minv, GVT_RAY_EPSILON, d_hits);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(c_shadow, 0, 2 * sizeof(unsigned), st)); // c_shadow, c_next adjacent
+    ShadeArgs A;
+    A.in = in; A.idx = idx; A.n = (unsigned)n_active; A.index_base = index_base; A.hits = d_hits; A.rng = d_rng;
+    A.first_pass = (pass == 0); A.out = outp; A.out_count = out->d_count; A.shadow = shadow; A.shadow_count = c_shadow;
+    A.next_idx = next; A.next_count = c_next; A.lights = d_lights; A.normi = P.normi; A.normal_mode = P.normal_mode;
+    A.n_lights = nL; A.seed = P.seed;
+    {
+      ProfScope ps(KC_SHADE);
+      k_shade<<<blocks_for(n_active), 256, 0, st>>>(A, mv);
+    }
+    HIPCHK(hipGetLastError());
+    C.stats.rays_shaded += n_active;
+    // counts of this pass: shadow rays to test, rays that bounce
+    HIPCHK(hipMemcpyAsync(C.h_pinned, c_shadow, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const unsigned n_shadow = C.h_pinned[0], n_next = C.h_pinned[1];
+    if (n_shadow) { // traceShadowRays :364-385
+      Trav T{ M->d_nodes, M->d_tri };
+      unsigned *counter = C.d_counters + 0;
+      HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
+      {
+        ProfScope ps(KC_ANY);
+        k_any<true, 1><<<trav_grid(n_shadow), TRAV_BLOCK, 0, st>>>(shadow, n_shadow, P.minv, T, GVT_RAY_EPSILON, nullptr, outp,
+                                                                    out->d_count, counter, C.d_spill);
+      }
+      HIPCHK(hipGetLastError());
+      C.stats.rays_any += n_shadow;
+      C.stats.launches_any++;
+    }
+    n_active = n_next;
+    idx = next;
+    next = (next == d_idx_a) ? d_idx_b : d_idx_a;
+    pass++;
+  }
+  HIPCHK(hipMemcpyAsync(C.h_pinned, out->d_count, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  C.stats.rays_forwarded += C.h_pinned[0] - out->size;
+  out->size = C.h_pinned[0];
+  return 0;
+}

@@ -9,7 +9,7 @@ from typing import List, Optional
 
 import numpy as np
 
-from .types import LIGHT_DTYPE, MATERIAL_DTYPE, default_material, point_light
+from .layouts import LIGHT_DTYPE, MATERIAL_DTYPE, default_material, point_light
 
 F = np.float32
 

@@ -1,0 +1,230 @@
+"""The two live GraviT schedulers around Adapter::trace, re-hosted on device-resident ray queues.
+
+  Tracer<ImageScheduler>::operator()   src/gvt/render/algorithm/ImageTracer.h:127-269
+  Tracer<DomainScheduler>::operator()  src/gvt/render/algorithm/DomainTracer.h:115-496
+  AbstractTrace::shuffleRays           src/gvt/render/algorithm/TracerBase.h:325-414
+
+The loops are the reference's (pick the fullest queue, trace it, shuffle the moved rays; Domain: trace
+until the local queues are dry, exchange, test for termination).  What changes is where the data
+lives: queues, the top-level test, the framebuffer and the adapter all stay in HBM; under the Domain
+scheduler the MPI ray exchange (DomainTracer.h:370-496) becomes point-to-point RCCL over xGMI through
+torch.distributed, carrying the reference's own 80-byte Ray image (actor/Ray.h:161-174).
+
+The device work goes through a small backend object so that the multi-rank control flow can be
+exercised on CPU (gloo) in the tests with a checker backend; the product backend is HipBackend.
+"""
+import numpy as np
+
+from . import capi
+from .adapter import FrameBuffer, HipMeshAdapter, RayQueue, TopLevel, camera_generate
+from .layouts import NORMALS_FLAT
+
+
+class HipBackend:
+    """One rank's device state: adapters (cached per mesh like adapterCache, ImageTracer.h:184-233),
+    per-instance queues, top-level set, framebuffer."""
+
+    def __init__(self, scene, normal_mode=NORMALS_FLAT, owned=None):
+        self.scene = scene
+        self.normal_mode = normal_mode
+        self.n_inst = scene.n_inst
+        self.owned = [True] * self.n_inst if owned is None else list(owned)
+        self.top = TopLevel(scene.inst_lo, scene.inst_hi)
+        self.queues = [RayQueue() for _ in range(self.n_inst)]
+        self.q_cam = RayQueue()
+        self.q_moved = RayQueue()
+        cam = scene.camera
+        self.fb = FrameBuffer(cam.width, cam.height)
+        self.adapter_cache = {}
+        self.calls = 0
+        for i in range(self.n_inst):  # adapters are built lazily in the reference; here up front, off the frame clock
+            if self.owned[i]:
+                self.adapter(i)
+
+    def adapter(self, inst):
+        mi = self.scene.inst_mesh[inst]
+        if mi not in self.adapter_cache:
+            self.adapter_cache[mi] = HipMeshAdapter(self.scene.meshes[mi], self.normal_mode)
+        return self.adapter_cache[mi]
+
+    # ---- frame steps
+    def begin_frame(self):
+        self.fb.clear()
+        for q in self.queues:
+            q.clear()
+        self.calls = 0
+
+    def generate_and_filter(self, keep_mask=None):
+        """camera rays -> FilterRaysLocally: shuffleRays(rays,-1) (ImageTracer.h:111-125) or, with a keep mask,
+        shuffleDropRays (DomainTracer.h:148-183)."""
+        camera_generate(self.q_cam, self.scene.camera)
+        self.top.shuffle(self.q_cam, -1, self.queues, self.fb, keep_mask)
+
+    def queue_sizes(self):
+        return [len(q) for q in self.queues]
+
+    def trace_and_shuffle(self, inst):
+        s = self.scene
+        self.adapter(inst).trace_queue(self.queues[inst], self.q_moved, s.m[inst], s.minv[inst], s.normi[inst], s.lights, seed=self.calls)
+        self.calls += 1
+        self.top.shuffle(self.q_moved, inst, self.queues, self.fb, None)
+
+    # ---- exchange (wire format: the reference's 80-byte Ray image)
+    def export_wire(self, insts, torch, device):
+        """Concatenate the queues `insts` into one wire tensor [n, 20] f32 and clear them."""
+        sizes = [len(self.queues[i]) for i in insts]
+        total = sum(sizes)
+        buf = torch.empty((total, 20), dtype=torch.float32, device=device)
+        off = 0
+        for i, n in zip(insts, sizes):
+            if n:
+                self.queues[i].export_device(buf.data_ptr() + off * 80, n)
+                self.queues[i].clear()
+            off += n
+        return buf
+
+    def append_wire(self, inst, buf, off, n):
+        if n:
+            self.queues[inst].append_device(buf.data_ptr() + off * 80, n)
+
+    def fb_tensor(self, torch, device):
+        """torch view of the framebuffer's device memory (un-clamped sums) for the composite reduce."""
+        cam = self.scene.camera
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (cam.height * cam.width * 4,), "typestr": "<f4",
+                                        "data": (self.fb.device_ptr(), False), "version": 2}
+
+        return torch.as_tensor(_View(), device=device)
+
+    def framebuffer(self, clamp=True):
+        return self.fb.download(clamp)
+
+    def sync(self):
+        capi.synchronize()
+
+
+def _pick_fullest(sizes, allowed=None):
+    """ImageTracer.h:159-173 / DomainTracer.h:235-241: first queue with the strictly largest size."""
+    target, cnt = -1, 0
+    for i, n in enumerate(sizes):
+        if (allowed is None or allowed[i]) and n > cnt:
+            cnt, target = n, i
+    return target
+
+
+class ImageTracer:
+    """Tracer<ImageScheduler>, one rank (ImageTracer.h:127-269)."""
+
+    def __init__(self, scene, normal_mode=NORMALS_FLAT, backend=None):
+        self.backend = backend or HipBackend(scene, normal_mode)
+        self.adapter_calls = 0
+
+    def __call__(self):
+        B = self.backend
+        B.begin_frame()  # clearBuffer
+        B.generate_and_filter(None)  # FilterRaysLocally
+        self.adapter_calls = 0
+        while True:
+            target = _pick_fullest(B.queue_sizes())
+            if target < 0:
+                break
+            B.trace_and_shuffle(target)  # adapter->trace + shuffleRays(moved_rays, instTarget)
+            self.adapter_calls += 1
+        return B
+
+    render = __call__
+
+
+class DomainTracer:
+    """Tracer<DomainScheduler> over torch.distributed (DomainTracer.h:185-496).
+
+    owner[i] = rank that holds instance i's data (mpiInstanceMap, DomainTracer.h:115-144).  Per round:
+    trace until the local queues are dry, then SendRays: one all-gather of the per-queue outgoing counts
+    (replaces the count exchange :409-415 and, because every rank then knows how many rays are in
+    flight, also the gather/scatter termination test :337-349) and one point-to-point payload exchange
+    (:433-463).  The frame ends with a sum-reduce of the float framebuffers to rank 0
+    (IceTComposite::composite, IceTComposite.cpp:84-101).
+    """
+
+    def __init__(self, scene, owner, dist, torch, comm_device, normal_mode=NORMALS_FLAT, backend=None):
+        self.scene = scene
+        self.owner = list(owner)
+        self.dist, self.torch, self.dev = dist, torch, comm_device
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.owned = [o == self.rank for o in self.owner]
+        self.backend = backend or HipBackend(scene, normal_mode, self.owned)
+        self.rounds = 0
+        self.rays_sent = 0
+        self.adapter_calls = 0
+
+    def __call__(self):
+        B, torch, dist = self.backend, self.torch, self.dist
+        n_inst = len(self.owner)
+        B.begin_frame()
+        B.generate_and_filter(np.array(self.owned, np.uint8))  # shuffleDropRays
+        self.rounds = self.rays_sent = self.adapter_calls = 0
+        while True:
+            while True:  # local work until dry (:228-326)
+                target = _pick_fullest(B.queue_sizes(), self.owned)
+                if target < 0:
+                    break
+                B.trace_and_shuffle(target)
+                self.adapter_calls += 1
+            self.rounds += 1
+            if self.world == 1:
+                break
+            # ---- SendRays (:370-496)
+            sizes = B.queue_sizes()
+            mine = torch.tensor([0 if self.owned[i] else sizes[i] for i in range(n_inst)], dtype=torch.int64, device=self.dev)
+            allc = torch.empty((self.world, n_inst), dtype=torch.int64, device=self.dev)
+            rows = [allc[r] for r in range(self.world)]
+            dist.all_gather(rows, mine)
+            counts = torch.stack(rows).cpu().numpy()
+            in_flight = int(counts.sum())
+            if in_flight == 0:  # all_done (:337-349)
+                break
+            ops, send_bufs, recv_bufs = [], {}, {}
+            for p in range(self.world):
+                if p == self.rank:
+                    continue
+                outq = [i for i in range(n_inst) if self.owner[i] == p and sizes[i] > 0]
+                if outq:
+                    send_bufs[p] = B.export_wire(outq, torch, self.dev)
+                    self.rays_sent += int(send_bufs[p].shape[0])
+                    ops.append(dist.P2POp(dist.isend, send_bufs[p], p))
+                n_in = int(sum(counts[p][i] for i in range(n_inst) if self.owned[i]))
+                if n_in:
+                    recv_bufs[p] = torch.empty((n_in, 20), dtype=torch.float32, device=self.dev)
+                    ops.append(dist.P2POp(dist.irecv, recv_bufs[p], p))
+            B.sync()  # wire buffers were filled on the adapter stream
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            if self.dev != "cpu":
+                torch.cuda.current_stream().synchronize()
+            for p, buf in recv_bufs.items():  # unpack into queue[q] (:466-481)
+                off = 0
+                for i in range(n_inst):
+                    if self.owned[i] and counts[p][i]:
+                        B.append_wire(i, buf, off, int(counts[p][i]))
+                        off += int(counts[p][i])
+        return B
+
+    render = __call__
+
+    def composite(self):
+        """Sum of the per-rank float framebuffers on rank 0, then the localAdd clamp.  Returns (H,W,4) on rank 0."""
+        B, torch, dist = self.backend, self.torch, self.dist
+        cam = self.scene.camera
+        if self.world == 1:
+            return B.framebuffer(True)
+        B.sync()
+        t = B.fb_tensor(torch, self.dev)
+        dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+        if self.dev != "cpu":
+            torch.cuda.current_stream().synchronize()
+        if self.rank != 0:
+            return None
+        return B.framebuffer(True).reshape(cam.height, cam.width, 4)

@@ -1,0 +1,190 @@
+/*
+ * gvt_hip.h -- C ABI of the MI355X (gfx950) engine adapter for GraviT: gvt::render::adapter::hip.
+ *
+ * This is the drop-in boundary.  Every entry point is what a GraviT-side binding for the
+ * adapter path would call; the reference interface each one replaces is cited as file:line
+ * relative to the GraviT source tree.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - Rays are the reference's 80-byte `gvt::render::actor::Ray` image (actor/Ray.h:68-96),
+ *     16-byte aligned, exactly what Ray::pack() puts on the wire (Ray.h:161-174).
+ *   - Materials are the reference's 92-byte `Material` POD (primitives/Material.h:59-90).
+ *   - Matrices are glm column-major: m[16], minv[16], normi[9] (api.cpp:303-308).
+ *   - Lights are 64-byte tagged PODs (the CPU reference uses virtual classes, scene/Light.h:46-104;
+ *     POD precedent adapter/optix/Light.cuh:44-112).
+ *   - Triangles are 0-based vertex triples (what the adapters read through std::get<>,
+ *     EmbreeMeshAdapter.cpp:152-155).
+ *   - Every function returning int returns 0 on success and a negative code on error; the
+ *     message is available from gvt_hip_last_error().  Nothing calls exit() (the reference's
+ *     Embree error handler does, EmbreeMeshAdapter.cpp:90-123).
+ *   - All work is issued on one HIP stream per process (gvt_hip_set_stream); calls on one
+ *     mesh/queue are serialised by the caller, as the reference's schedulers do
+ *     (ImageTracer.h:241-248).
+ */
+#ifndef GVT_HIP_H
+#define GVT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GVT_HIP_OK 0
+#define GVT_HIP_ERR_INVALID (-1)  /* bad argument */
+#define GVT_HIP_ERR_DEVICE (-2)   /* HIP runtime error */
+#define GVT_HIP_ERR_CAPACITY (-3) /* output buffer / queue too small; nothing lost, see call */
+#define GVT_HIP_ERR_NODEVICE (-4) /* no gfx950 device visible */
+
+#define GVT_HIP_NORMALS_FLAT 0   /* EmbreeMeshAdapter.cpp:75,520-522 (FLAT_SHADING) */
+#define GVT_HIP_NORMALS_SMOOTH 1 /* EmbreeMeshAdapter.cpp:505-518, EmbreeStreamMeshAdapter.cpp:708, OptixMeshAdapter.cu:298 */
+
+typedef struct gvt_hip_ray { /* actor/Ray.h:68-96 */
+  float origin[3];
+  float t_min;
+  float direction[3];
+  float t_max;
+  float color[3];
+  float t;
+  int32_t id;
+  int32_t depth;
+  float w;
+  int32_t type; /* 0 PRIMARY, 1 SHADOW, 2 SECONDARY */
+  float pad[4];
+} gvt_hip_ray;
+
+typedef struct gvt_hip_material { /* primitives/Material.h:59-90 */
+  int32_t type;                 /* 0 LAMBERT, 1 PHONG, 2 BLINN */
+  float ka[3], ks[3], kd[3];
+  float alpha;
+  float eta[3], k[3];
+  float roughness;
+  float horizonScatteringColor[3];
+  float backScattering, horizonScatteringFallOff;
+} gvt_hip_material;
+
+#define GVT_HIP_LIGHT_POINT 0
+#define GVT_HIP_LIGHT_AREA 1
+#define GVT_HIP_LIGHT_AMBIENT 2
+typedef struct gvt_hip_light { /* scene/Light.h:46-104 flattened */
+  int32_t type;
+  float position[3];
+  float color[3];
+  float normal[3];
+  float width, height;
+  float pad[4];
+} gvt_hip_light;
+
+typedef struct gvt_hip_hit {
+  float t;
+  int32_t prim; /* -1 = miss */
+  float u, v;
+} gvt_hip_hit;
+
+typedef struct gvt_hip_mesh gvt_hip_mesh;   /* one adapter instance: replaces EmbreeMeshAdapter */
+typedef struct gvt_hip_queue gvt_hip_queue; /* device-resident RayVector */
+typedef struct gvt_hip_top gvt_hip_top;     /* top-level instance set (accel/BVH.h) */
+typedef struct gvt_hip_fb gvt_hip_fb;       /* float RGBA framebuffer (IceTComposite) */
+
+/* ---- process / device ---- */
+int gvt_hip_init(int device);                 /* select device, create stream + workspace */
+int gvt_hip_set_stream(void *hip_stream);     /* issue all later work on this hipStream_t (NULL = own stream) */
+int gvt_hip_synchronize(void);
+const char *gvt_hip_last_error(void);
+
+/* ---- adapter construction: EmbreeMeshAdapter::EmbreeMeshAdapter (EmbreeMeshAdapter.cpp:125-162) ----
+ * Copies everything (no borrowed pointers), generates vertex normals when vnormals==NULL
+ * (Mesh::generateNormals, Mesh.cpp:116-154) and builds the LBVH on the device. */
+gvt_hip_mesh *gvt_hip_mesh_create(const float *verts, size_t nV, const int32_t *tris, size_t nT,
+                                  const float *vnormals /* nV*3 or NULL */, const float *vcolors /* nV*3 or NULL */,
+                                  const gvt_hip_material *materials, size_t nMat,
+                                  const int32_t *face_mat /* nT or NULL, -1 = none */,
+                                  const gvt_hip_material *mesh_mat /* Mesh::mat; NULL = Material() */);
+void gvt_hip_mesh_destroy(gvt_hip_mesh *);
+
+typedef struct gvt_hip_mesh_info {
+  uint64_t n_tris, n_verts, n_nodes, n_leaves;
+  float bbox_lo[3], bbox_hi[3];
+  float build_ms; /* device time of the LBVH build */
+  uint32_t max_leaf, pad;
+  uint64_t bytes_nodes, bytes_tris;
+} gvt_hip_mesh_info;
+int gvt_hip_mesh_get_info(const gvt_hip_mesh *, gvt_hip_mesh_info *);
+/* vertex normals in use (device -> host copy), nV*3 floats */
+int gvt_hip_mesh_get_normals(const gvt_hip_mesh *, float *out);
+
+/* ---- Adapter::trace (Adapter.h:82-84; EmbreeMeshAdapter.cpp:625-660) ----
+ * rays[begin,end) are traced (end==0 -> n_rays, EmbreeMeshAdapter.cpp:642) and updated in place like the
+ * reference's rayList (t, and origin/direction/w/depth/type on a bounce).  rays_out receives every
+ * PRIMARY/SECONDARY ray that missed and every un-occluded SHADOW ray (moved_rays); order unspecified.
+ * If cap is too small: returns GVT_HIP_ERR_CAPACITY, *n_out = needed count, rays_out untouched. */
+int gvt_hip_trace(gvt_hip_mesh *, gvt_hip_ray *rays, size_t n_rays, size_t begin, size_t end, gvt_hip_ray *rays_out,
+                  size_t cap, size_t *n_out, const float m[16], const float minv[16], const float normi[9],
+                  const gvt_hip_light *lights, size_t n_lights, int normal_mode, uint32_t seed);
+
+/* ---- the Embree queries the adapter is built on (rtcIntersect / rtcOccluded,
+ *      EmbreeMeshAdapter.cpp:474,375): object-space rays, t in (tnear, FLT_MAX) ---- */
+int gvt_hip_intersect(gvt_hip_mesh *, const float *org /* n*3 */, const float *dir /* n*3 */, size_t n, float tnear,
+                      gvt_hip_hit *hits_out);
+int gvt_hip_occluded(gvt_hip_mesh *, const float *org, const float *dir, size_t n, float tnear, int32_t *occluded_out);
+
+/* ---- device-resident RayVector (actor/Ray.h:189) ---- */
+gvt_hip_queue *gvt_hip_queue_create(size_t capacity);
+void gvt_hip_queue_destroy(gvt_hip_queue *);
+int gvt_hip_queue_reserve(gvt_hip_queue *, size_t capacity); /* grows, keeps contents */
+int gvt_hip_queue_clear(gvt_hip_queue *);
+int gvt_hip_queue_size(gvt_hip_queue *, size_t *n);          /* synchronises */
+/* append n 80-byte rays (host memory, or device memory when src_on_device) */
+int gvt_hip_queue_append(gvt_hip_queue *, const gvt_hip_ray *rays, size_t n, int src_on_device);
+/* copy the queue out as 80-byte rays (host or device destination) */
+int gvt_hip_queue_export(gvt_hip_queue *, gvt_hip_ray *dst, size_t cap, size_t *n, int dst_on_device);
+/* Adapter::trace on device queues: consumes q_in (left empty, like ImageTracer.h:248), appends to q_out */
+int gvt_hip_trace_queue(gvt_hip_mesh *, gvt_hip_queue *q_in, gvt_hip_queue *q_out, const float m[16], const float minv[16],
+                        const float normi[9], const gvt_hip_light *lights, size_t n_lights, int normal_mode, uint32_t seed);
+
+/* ---- gvtPerspectiveCamera::generateRays (gvtCamera.cpp:89-171, 233-312): fills q with W*H*samples^2 rays ---- */
+int gvt_hip_camera_generate(gvt_hip_queue *q, const float eye[3], const float focus[3], const float up[3], float fov,
+                            int width, int height, int samples, int depth, float jitter_window_size);
+
+/* ---- top-level instance set + shuffleRays (accel/BVH.h:61-135, actor/RayPacket.h:83-211,
+ *      algorithm/TracerBase.h:325-343,392-414) ----
+ * inst_lo/hi: world AABBs (api.cpp:309-312).  The instances are tested in the order the reference's
+ * BVH visits its leaves (BVH.cpp:77-171), so ties resolve identically. */
+gvt_hip_top *gvt_hip_top_create(const float *inst_lo, const float *inst_hi, size_t n_inst);
+void gvt_hip_top_destroy(gvt_hip_top *);
+int gvt_hip_top_order(const gvt_hip_top *, int32_t *order_out /* n_inst */);
+/* shuffleRays(rays, from): consumes q_in; a ray whose next instance is i is advanced
+ * (origin += dir * t * 0.95f) and appended to queues[i] -- unless keep_mask!=NULL and keep_mask[i]==0
+ * (Tracer<DomainScheduler>::shuffleDropRays, DomainTracer.h:148-183); SHADOW rays that hit no further
+ * instance deposit color*w into fb (fb may be NULL only if deposit is impossible, i.e. from<0 drop mode). */
+int gvt_hip_shuffle(gvt_hip_top *, gvt_hip_queue *q_in, int from, gvt_hip_queue *const *queues /* n_inst */,
+                    const uint8_t *keep_mask, gvt_hip_fb *fb);
+/* sizes of n queues in one round trip */
+int gvt_hip_queue_sizes(gvt_hip_queue *const *queues, size_t n, uint64_t *sizes_out);
+
+/* ---- framebuffer: IceTComposite (composite/IceTComposite.cpp:79-157) ---- */
+gvt_hip_fb *gvt_hip_fb_create(int width, int height);
+void gvt_hip_fb_destroy(gvt_hip_fb *);
+int gvt_hip_fb_clear(gvt_hip_fb *);                              /* reset(), :79-82 */
+int gvt_hip_fb_download(gvt_hip_fb *, float *rgba /* W*H*4 */, int clamp); /* clamp: c>1 -> 1 (localAdd :111-117) */
+void *gvt_hip_fb_device_ptr(gvt_hip_fb *);                       /* float[W*H*4], un-clamped sums: for the RCCL reduce */
+int gvt_hip_fb_write_ppm_bytes(gvt_hip_fb *, unsigned char *rgb /* W*H*3, rows flipped, (uchar)(c*255) :119-157 */);
+
+/* ---- measurement ---- */
+typedef struct gvt_hip_stats {
+  uint64_t rays_closest; /* rays pushed through the closest-hit kernel */
+  uint64_t rays_any;     /* rays pushed through the any-hit kernel */
+  uint64_t rays_shaded, rays_forwarded, trace_calls;
+  /* HIP-event time per kernel class, ms, accumulated while profiling is enabled */
+  double ms_closest, ms_any, ms_shade, ms_convert, ms_shuffle, ms_camera, ms_build;
+  uint64_t launches_closest, launches_any;
+} gvt_hip_stats;
+int gvt_hip_profile(int enable);           /* bracket every kernel with HIP events on the launch stream */
+int gvt_hip_stats_read(gvt_hip_stats *);   /* synchronises */
+int gvt_hip_stats_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
