@@ -110,8 +110,8 @@ struct BvhNode {
 #define GVT_LEAF_MAX 4
 __host__ __device__ inline int leaf_ref(uint32_t first, uint32_t count) { return ~(int)((first << 3) | count); }
 
-// Embree 2.x Moeller-Trumbore (kernels/geometry/triangle_intersector_moeller.h), restated like
-// oracle/gvt_oracle.c orc_tri_test; reached through rtcIntersect/rtcOccluded at
+// Embree 2.x Moeller-Trumbore (kernels/geometry/triangle_intersector_moeller.h), restated from its published
+// form (e1 = v0-v1, e2 = v2-v0, Ng = e1 x e2, inclusive edge tests); reached through rtcIntersect/rtcOccluded at
 // EmbreeMeshAdapter.cpp:474,375.  True division instead of rcp+Newton.
 __device__ inline bool tri_test(V3 O, V3 D, V3 v0, V3 e1, V3 e2, float tnear, float &t, float &u, float &v) {
   V3 Ng = cross3(e1, e2);
@@ -154,7 +154,8 @@ __host__ __device__ inline float gvt_fastrand_lcg(uint32_t &seed, float mn, floa
   seed = 214013u * seed + 2531011u;
   return mn + (seed >> 16) * ff * (mx - mn);
 }
-// one stream per ray, keyed on (call seed, index in rayList): see oracle ray_stream_seed
+// one stream per ray, keyed on (call seed, index in rayList): the reference seeds one engine per TBB chunk
+// (EmbreeMeshAdapter.cpp:446-447), which is schedule dependent; a per-ray stream is order independent
 __host__ __device__ inline uint32_t ray_stream_seed(uint32_t seed, uint64_t index) {
   uint32_t s = seed ^ (uint32_t)(index * 0x9E3779B9u) ^ (uint32_t)(index >> 32);
   s ^= s >> 16; s *= 0x85EBCA6Bu; s ^= s >> 13; s *= 0xC2B2AE35u; s ^= s >> 16;

@@ -288,3 +288,31 @@ def cathedral_scene(width=512, height=512, samples=2, depth=2, seed=7):
     mesh = MeshData(v, np.array(fs, np.int32), default_material(kd=(0.8, 0.8, 0.8)))
     cam = Camera((0.0, 1.5, 9.0), (0.0, 1.4, 0.0), (0.0, 1.0, 0.0), float(F(60.0 * np.pi / 180.0)), width, height, samples, depth, 0.0)
     return _assemble([mesh], [0], [mat_translate_scale((0, 0, 0), (1, 1, 1))], point_light((0.0, 2.5, 4.0)), cam, "cathedral")
+
+
+# ------------------------------------------------------------------ domain decomposition of the soup
+def domain_grid(n_domains):
+    """x-y tiling first (rays of the config-3 camera travel along -z), then z."""
+    return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (4, 2, 1), 16: (4, 4, 1)}.get(n_domains, (n_domains, 1, 1))
+
+
+def soup_domains_scene(n_tris=10_000_000, n_domains=8, width=1920, height=1080, seed=12345, half_extent=0.005):
+    """The config-3 soup cut into n_domains spatial domains (one Mesh + identity instance each, triangles assigned
+    by centroid cell), the layout GraviT's Domain scheduler distributes over ranks (DomainTracer.h:115-144)."""
+    v, t = triangle_soup(n_tris, seed, half_extent)
+    gx, gy, gz = domain_grid(n_domains)
+    c = v.reshape(-1, 3, 3).mean(axis=1)
+    ix = np.clip((c[:, 0] * gx).astype(np.int64), 0, gx - 1)
+    iy = np.clip((c[:, 1] * gy).astype(np.int64), 0, gy - 1)
+    iz = np.clip((c[:, 2] * gz).astype(np.int64), 0, gz - 1)
+    cell = (iz * gy + iy) * gx + ix
+    meshes, mats = [], []
+    tri_verts = v.reshape(-1, 3, 3)
+    for d in range(gx * gy * gz):
+        sel = np.nonzero(cell == d)[0]
+        dv = np.ascontiguousarray(tri_verts[sel].reshape(-1, 3))
+        dt = np.arange(len(sel) * 3, dtype=np.int32).reshape(-1, 3)
+        meshes.append(MeshData(dv, dt, default_material()))
+        mats.append(mat_translate_scale((0, 0, 0), (1, 1, 1)))
+    cam = Camera((0.5, 0.5, 3.0), (0.5, 0.5, 0.5), (0.0, 1.0, 0.0), float(F(30.0 * np.pi / 180.0)), width, height, 1, 1, 0.0)
+    return _assemble(meshes, list(range(len(meshes))), mats, point_light((0.5, 0.5, 3.0)), cam, "soup-%d-dom%d" % (n_tris, n_domains))

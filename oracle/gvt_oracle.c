@@ -381,14 +381,22 @@ static inline int orc_tri_test(v3 O, v3 D, v3 v0, v3 v1, v3 v2, float tnear, flo
 static inline v3 tri_vert(const orc_mesh *M, int32_t prim, int k) { return ld3(M->verts + 3 * M->tris[3 * prim + k]); }
 
 /* slab test of the oracle's own BVH: conservative (padded boxes, 1+3ulp on tfar a la Ize) */
-static inline int box_test(const orc_node *n, v3 O, v3 inv, float tbest) {
+static inline int box_test(const orc_node *n, v3 O, v3 inv, float tbest, float *tn_out) {
   float t0x = (n->lo[0] - O.x) * inv.x, t1x = (n->hi[0] - O.x) * inv.x;
   float t0y = (n->lo[1] - O.y) * inv.y, t1y = (n->hi[1] - O.y) * inv.y;
   float t0z = (n->lo[2] - O.z) * inv.z, t1z = (n->hi[2] - O.z) * inv.z;
   float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.f));
   float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
   tf *= 1.0000004f;
+  *tn_out = tn;
   return tn <= tf && tn <= tbest;
+}
+/* reciprocal direction for the slab test only; a zero component becomes +-1e-30 so that no NaN appears */
+static inline v3 safe_inv(v3 D) {
+  float dx = fabsf(D.x) < 1e-30f ? copysignf(1e-30f, D.x) : D.x;
+  float dy = fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y;
+  float dz = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;
+  return V3(1.0f / dx, 1.0f / dy, 1.0f / dz);
 }
 
 static orc_hit closest_hit(const orc_mesh *M, v3 O, v3 D, float tnear, int use_bvh) {
@@ -401,22 +409,27 @@ static orc_hit closest_hit(const orc_mesh *M, v3 O, v3 D, float tnear, int use_b
     return h;
   }
   if (!M->nT) return h;
-  v3 inv = V3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
-  int32_t stack[128];
+  v3 inv = safe_inv(D);
+  int32_t stack[256];
+  float tn0, tn1;
   int sp = 0;
+  if (!box_test(&M->nodes[0], O, inv, h.t, &tn0)) return h;
   stack[sp++] = 0;
   while (sp) {
     const orc_node *n = &M->nodes[stack[--sp]];
-    if (!box_test(n, O, inv, h.t)) continue;
     if (n->count) {
       for (int32_t i = 0; i < n->count; i++) {
         int32_t p = M->prim_idx[n->left + i];
         if (orc_tri_test(O, D, tri_vert(M, p, 0), tri_vert(M, p, 1), tri_vert(M, p, 2), tnear, &t, &u, &v))
           if (h.prim < 0 || t < h.t || (t == h.t && p < h.prim)) { h.t = t; h.prim = p; h.u = u; h.v = v; }
       }
-    } else {
-      stack[sp++] = n->left + 1;
-      stack[sp++] = n->left;
+    } else { /* near child first; a far child is re-tested against the current best when popped late */
+      int h0 = box_test(&M->nodes[n->left], O, inv, h.t, &tn0), h1 = box_test(&M->nodes[n->left + 1], O, inv, h.t, &tn1);
+      if (h0 && h1) {
+        if (tn1 < tn0) { stack[sp++] = n->left; stack[sp++] = n->left + 1; }
+        else { stack[sp++] = n->left + 1; stack[sp++] = n->left; }
+      } else if (h0) stack[sp++] = n->left;
+      else if (h1) stack[sp++] = n->left + 1;
     }
   }
   return h;
@@ -430,13 +443,14 @@ static int any_hit(const orc_mesh *M, v3 O, v3 D, float tnear, int use_bvh) {
     return 0;
   }
   if (!M->nT) return 0;
-  v3 inv = V3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
-  int32_t stack[128];
+  v3 inv = safe_inv(D);
+  int32_t stack[256];
+  float tn0;
   int sp = 0;
   stack[sp++] = 0;
   while (sp) {
     const orc_node *n = &M->nodes[stack[--sp]];
-    if (!box_test(n, O, inv, FLT_MAX)) continue;
+    if (!box_test(n, O, inv, FLT_MAX, &tn0)) continue;
     if (n->count) {
       for (int32_t i = 0; i < n->count; i++) {
         int32_t p = M->prim_idx[n->left + i];

@@ -1,0 +1,55 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def ref_vectors():
+    import json
+
+    return json.load(open(os.path.join(GOLDEN, "ref_vectors.json")))
+
+
+@pytest.fixture(scope="session")
+def oracle_vectors():
+    import json
+
+    import numpy as np
+
+    d = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    out = {k: d[k] for k in ("org", "dirs", "hits", "occluded")}
+    out["fb_hashes"] = json.loads(str(d["fb_hashes"]))
+    return out
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product library on a real device.  GPU tests FAIL (not skip) when it cannot be used."""
+    from gravit_amd import capi
+
+    capi.init(0)
+    return capi
+
+
+def read_ppm(path):
+    import numpy as np
+
+    b = open(path, "rb").read()
+    parts = b.split(b"\n", 3)
+    w, h = map(int, parts[1].split())
+    return np.frombuffer(parts[3], np.uint8).reshape(h, w, 3)

@@ -1,0 +1,79 @@
+"""BASELINE.json's full size (config 3: 10,000,000 random triangles, 1920x1080, primary + shadow) through
+size-independent properties, plus a bounded bit-exact sample against the oracle."""
+import numpy as np
+import pytest
+
+from gravit_amd import scenes
+from gravit_amd.adapter import HipMeshAdapter
+from gravit_amd.layouts import NORMALS_FLAT
+from gravit_amd.scheduler import ImageTracer
+from oracle import orc
+from tests.helpers import bits, oracle_camera_rays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def soup(hip):
+    sc = scenes.soup_scene(10_000_000)
+    tr = ImageTracer(sc, NORMALS_FLAT)
+    return sc, tr
+
+
+def test_frame_is_reproducible_and_counts_are_consistent(soup, hip):
+    sc, tr = soup
+    hip.stats_reset()
+    fb1 = tr().framebuffer(False).copy()
+    st = hip.stats()
+    fb2 = tr().framebuffer(False)
+    assert np.array_equal(fb1, fb2)  # idempotent: one writer per pixel, no order dependence
+    n_primary, n_shadow = st["rays_closest"], st["rays_any"]
+    assert n_primary == 1_040_400  # rays whose first domain is the soup's box (1020 x 1020 pixels)
+    assert 0.9 * n_primary < n_shadow <= n_primary  # one light: at most one shadow ray per hit
+    lit = fb1[..., 3] > 0
+    assert lit.sum() <= n_shadow and lit.sum() > 0.5 * n_shadow
+    assert fb1[..., :3].max() <= 1.0 and fb1[..., :3].min() >= 0.0
+    assert (fb1[..., 3][lit] == 1.0).all()  # exactly one deposit per lit pixel
+
+
+def test_light_colour_linearity(soup):
+    """Radiance is linear in the light colour: halving it halves every pixel exactly (power of two, no clamp)."""
+    sc, tr = soup
+    a = tr().framebuffer(False)[..., :3].copy()
+    old = sc.lights["color"].copy()
+    sc.lights["color"] = old * np.float32(0.5)
+    try:
+        b = tr().framebuffer(False)[..., :3]
+    finally:
+        sc.lights["color"] = old
+    assert np.array_equal(b, a * np.float32(0.5))
+
+
+def test_hit_records_reconstruct_the_hit_point_and_agree_with_any_hit(soup):
+    sc, tr = soup
+    ad = next(iter(tr.backend.adapter_cache.values()))
+    rays = oracle_camera_rays(sc)[::7]
+    h = ad.intersect(rays["origin"], rays["direction"])
+    occ = ad.occluded(rays["origin"], rays["direction"])
+    assert ((h["prim"] >= 0) == (occ == 1)).all()  # any-hit and closest-hit agree on hit/miss
+    hit = h["prim"] >= 0
+    assert hit.sum() > 100_000
+    m = sc.meshes[0]
+    tri = m.verts[m.tris[h["prim"][hit]]].astype(np.float64)
+    u, v = h["u"][hit].astype(np.float64)[:, None], h["v"][hit].astype(np.float64)[:, None]
+    p_bary = (1 - u - v) * tri[:, 0] + u * tri[:, 1] + v * tri[:, 2]
+    p_ray = rays["origin"][hit].astype(np.float64) + rays["direction"][hit].astype(np.float64) * h["t"][hit].astype(np.float64)[:, None]
+    assert np.abs(p_bary - p_ray).max() < 2e-5
+    assert (h["u"][hit] >= 0).all() and (h["v"][hit] >= 0).all() and (h["u"][hit] + h["v"][hit] <= 1.0 + 1e-6).all()
+
+
+def test_bounded_sample_bit_exact_against_oracle(soup):
+    """~30 K of the frame's rays against the CPU oracle's own BVH over the same 10 M triangles."""
+    sc, tr = soup
+    ad = next(iter(tr.backend.adapter_cache.values()))
+    om = orc.Mesh(sc.meshes[0].verts, sc.meshes[0].tris)
+    rays = oracle_camera_rays(sc)[3::67]
+    g, c = ad.intersect(rays["origin"], rays["direction"]), om.intersect(rays["origin"], rays["direction"])
+    assert (g["prim"] == c["prim"]).all() and (bits(g["t"]) == bits(c["t"])).all()
+    assert (bits(g["u"]) == bits(c["u"])).all() and (bits(g["v"]) == bits(c["v"])).all()
+    assert (g["prim"] >= 0).sum() > 10_000

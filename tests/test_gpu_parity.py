@@ -1,0 +1,381 @@
+"""Parity tests proper: the HIP adapter (through the C ABI) against the pinned CPU oracle on the same seeded
+inputs, against the committed golden fixtures, and -- at the full BASELINE sizes -- through size-independent
+properties.  Integer/index results (primID, hit/miss, ray counts, ids) and all Lambert-path floats must be
+BIT-EXACT; Phong/Blinn (powf) and the secondary-bounce path (sinf/cosf/acos) are held to 1e-5 absolute on
+radiance, the tolerance BASELINE.json's north_star states.
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from gravit_amd import layouts, scenes
+from gravit_amd.adapter import FrameBuffer, HipMeshAdapter, RayQueue, TopLevel, camera_generate
+from gravit_amd.layouts import NORMALS_FLAT, NORMALS_SMOOTH, RAY_DTYPE
+from gravit_amd.scheduler import ImageTracer
+from oracle import orc
+from tests.conftest import GOLDEN, read_ppm
+from tests.helpers import bits, oracle_camera_rays, oracle_meshes, oracle_render, rays_equal_bits, seeded_rays_at, sort_rays
+
+pytestmark = pytest.mark.gpu
+
+RADIANCE_TOL = 1e-5  # BASELINE.json north_star: "within 1e-5 on float radiance"
+
+
+def assert_hits_equal(g, c):
+    assert (g["prim"] == c["prim"]).all(), "%d primIDs differ" % (g["prim"] != c["prim"]).sum()
+    for f in ("t", "u", "v"):
+        assert (bits(g[f]) == bits(c[f])).all(), "%s differs in %d rays" % (f, (bits(g[f]) != bits(c[f])).sum())
+
+
+# ------------------------------------------------------------------ the two queries under the adapter
+def test_golden_hit_vectors_bunny(hip, oracle_vectors):
+    """Committed fixture: 4096 seeded rays on bunny.obj, (t, primID, u, v) and occlusion flags from the pinned oracle."""
+    sc = scenes.bunny_scene()
+    ad = HipMeshAdapter(sc.meshes[0])
+    g = ad.intersect(oracle_vectors["org"], oracle_vectors["dirs"])
+    assert_hits_equal(g, oracle_vectors["hits"])
+    assert (ad.occluded(oracle_vectors["org"], oracle_vectors["dirs"]) == oracle_vectors["occluded"]).all()
+    assert (g["prim"] >= 0).sum() > 1000
+
+
+@pytest.mark.parametrize("name", ["bunny", "bunny70k", "soup200k", "cone", "cube", "cathedral"])
+def test_closest_and_any_hit_match_oracle(hip, name):
+    mesh = {"bunny": lambda: scenes.bunny_scene().meshes[0], "bunny70k": lambda: scenes.bunny70k_scene().meshes[0],
+            "soup200k": lambda: scenes.soup_scene(200_000, 64, 36).meshes[0], "cone": lambda: scenes.simple_scene().meshes[0],
+            "cube": lambda: scenes.simple_scene().meshes[1], "cathedral": lambda: scenes.cathedral_scene(32, 32).meshes[0]}[name]()
+    ad = HipMeshAdapter(mesh)
+    om = orc.Mesh(mesh.verts, mesh.tris)
+    lo, hi = om.bbox()
+    org, d = seeded_rays_at(lo, hi, 20011, 3)  # ragged: not a multiple of 64
+    if name == "cathedral":  # rays from inside the hall
+        rng = np.random.default_rng(9)
+        org = np.tile(np.array([0.0, 1.5, 5.0], np.float32), (20011, 1))
+        d = rng.normal(size=(20011, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+    g, c = ad.intersect(org, d), om.intersect(org, d)
+    assert_hits_equal(g, c)
+    assert (ad.occluded(org, d) == om.occluded(org, d)).all()
+    info = ad.info()
+    assert info["n_tris"] == len(mesh.tris) and np.allclose(info["bbox_lo"], lo) and np.allclose(info["bbox_hi"], hi)
+
+
+def test_axis_aligned_faces_edges_and_vertices(hip):
+    """Rays through shared edges and vertices of the cube's flat, axis-aligned faces (zero-thickness boxes)."""
+    cube = scenes.simple_scene().meshes[1]
+    ad, om = HipMeshAdapter(cube), orc.Mesh(cube.verts, cube.tris)
+    g = np.linspace(-0.5, 0.5, 33, dtype=np.float32)
+    xx, yy = np.meshgrid(g, g)
+    for axis in range(3):
+        org = np.zeros((xx.size, 3), np.float32)
+        org[:, (axis + 1) % 3], org[:, (axis + 2) % 3], org[:, axis] = xx.ravel(), yy.ravel(), 2.0
+        d = np.zeros_like(org)
+        d[:, axis] = -1.0
+        a, b = ad.intersect(org, d), om.intersect(org, d)
+        assert_hits_equal(a, b)
+        assert (a["prim"] >= 0).all()
+
+
+def test_degenerate_inputs(hip):
+    """Empty ray lists, empty / tiny meshes, zero-area triangles, rays with zero direction components."""
+    tri = scenes.MeshData(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2]], np.int32))
+    ad = HipMeshAdapter(tri)
+    assert len(ad.intersect(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))) == 0
+    h = ad.intersect([[0.25, 0.25, 1.0], [2, 2, 1]], [[0, 0, -1], [0, 0, -1]])
+    assert h["prim"].tolist() == [0, -1] and h["t"][0] == 1.0 and np.allclose([h["u"][0], h["v"][0]], 0.25)
+    empty = HipMeshAdapter(scenes.MeshData(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32)))
+    assert empty.intersect([[0, 0, 1]], [[0, 0, -1]])["prim"].tolist() == [-1]
+    assert empty.occluded([[0, 0, 1]], [[0, 0, -1]]).tolist() == [0]
+    # 5 triangles (one more than a leaf), one of them zero-area, coincident duplicates -> lower primID wins the tie
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 0], [1, 0, 0], [0, 1, 0], [5, 5, 5], [5, 5, 5], [5, 5, 5], [0, 0, -1],
+                  [1, 0, -1], [0, 1, -1], [0, 0, -2], [1, 0, -2], [0, 1, -2]], np.float32)
+    t = np.arange(15, dtype=np.int32).reshape(5, 3)
+    m = scenes.MeshData(v, t)
+    a, b = HipMeshAdapter(m), orc.Mesh(v, t)
+    org, d = [[0.2, 0.2, 1.0]], [[0, 0, -1]]
+    assert a.intersect(org, d)["prim"].tolist() == [0] == b.intersect(org, d)["prim"].tolist()
+
+
+def test_mesh_create_rejects_bad_input(hip):
+    from gravit_amd import capi
+
+    bad = scenes.MeshData(np.zeros((3, 3), np.float32), np.array([[0, 1, 7]], np.int32))
+    with pytest.raises(capi.GvtHipError, match="references vertex"):
+        HipMeshAdapter(bad)
+
+
+def test_generated_normals_match_reference_hash(hip, ref_vectors):
+    sc = scenes.bunny_scene()
+    ad = HipMeshAdapter(sc.meshes[0])
+    assert hashlib.sha256(ad.normals().tobytes()).hexdigest() == ref_vectors["bunny_normals_sha256"]
+
+
+# ------------------------------------------------------------------ the adapter boundary: Adapter::trace
+@pytest.mark.parametrize("mode", [NORMALS_FLAT, NORMALS_SMOOTH])
+@pytest.mark.parametrize("name", ["bunny", "simple_cube", "soup"])
+def test_trace_matches_oracle_bit_exact(hip, name, mode):
+    if name == "bunny":
+        sc, inst = scenes.bunny_scene(200, 150), 0
+    elif name == "simple_cube":
+        sc, inst = scenes.simple_scene(160, 160), 13
+    else:
+        sc, inst = scenes.soup_scene(100_000, 192, 108), 0
+    mesh = sc.meshes[sc.inst_mesh[inst]]
+    ad, om = HipMeshAdapter(mesh, mode), orc.Mesh(mesh.verts, mesh.tris, mesh_mat=mesh.material)
+    rays = oracle_camera_rays(sc)
+    # what the scheduler does before the adapter sees the rays: advance to the instance box
+    nxt, t = orc.toplevel_intersect(sc.inst_lo, sc.inst_hi, orc.toplevel_order(sc.inst_lo, sc.inst_hi), rays)
+    sel = nxt == inst
+    rays = np.ascontiguousarray(rays[sel])
+    rays["origin"] += rays["direction"] * (t[sel] * np.float32(0.95))[:, None]
+    rg, rc = rays.copy(), rays.copy()
+    out_g = ad.trace(rg, sc.m[inst], sc.minv[inst], sc.normi[inst], sc.lights)
+    out_c = om.trace(rc, sc.m[inst], sc.minv[inst], sc.normi[inst], sc.lights, mode)
+    assert len(out_g) == len(out_c) and len(out_c) > 0
+    assert rays_equal_bits(sort_rays(out_g), sort_rays(out_c)), "moved_rays differ from the oracle"
+    assert rays_equal_bits(rg, rc), "rayList was not updated in place like the oracle's"
+    assert (out_g["type"] == 1).sum() > 0 and (out_g[out_g["type"] == 1]["t_max"] == np.float32(3.0)).all()
+
+
+def test_trace_ranges_capacity_and_errors(hip):
+    from gravit_amd import capi
+    import ctypes as C
+
+    sc = scenes.bunny_scene(96, 96)
+    mesh = sc.meshes[0]
+    ad, om = HipMeshAdapter(mesh), orc.Mesh(mesh.verts, mesh.tris, mesh_mat=mesh.material)
+    rays = oracle_camera_rays(sc)
+    # begin/end sub-range (ragged), everything outside untouched
+    rg, rc = rays.copy(), rays.copy()
+    og = ad.trace(rg, sc.m[0], sc.minv[0], sc.normi[0], sc.lights, begin=777, end=5001)
+    oc = om.trace(rc, sc.m[0], sc.minv[0], sc.normi[0], sc.lights, 0, begin=777, end=5001)
+    assert rays_equal_bits(sort_rays(og), sort_rays(oc)) and rays_equal_bits(rg, rc)
+    # empty list
+    assert len(ad.trace(rays.copy()[:0], sc.m[0], sc.minv[0], sc.normi[0], sc.lights)) == 0
+    # no lights: hits produce nothing, misses are forwarded
+    r0 = rays.copy()
+    o0 = ad.trace(r0, sc.m[0], sc.minv[0], sc.normi[0], sc.lights[:0])
+    assert (o0["type"] == 0).all() and len(o0) == (r0["t"] == layouts.FLT_MAX).sum()
+    # too small an output buffer is an error code + needed size, not a crash
+    lib = capi.load()
+    out = np.zeros(4, RAY_DTYPE)
+    n_out = C.c_size_t(0)
+    r1 = rays.copy()
+    rc_ = lib.gvt_hip_trace(ad.h, capi.ptr(r1), C.c_size_t(len(r1)), C.c_size_t(0), C.c_size_t(0), capi.ptr(out), C.c_size_t(4), C.byref(n_out),
+                            capi.ptr(capi.f32(sc.m[0])), capi.ptr(capi.f32(sc.minv[0])), capi.ptr(capi.f32(sc.normi[0])),
+                            capi.ptr(np.ascontiguousarray(sc.lights)), C.c_size_t(1), C.c_int(0), C.c_uint32(0))
+    assert rc_ == -3 and n_out.value == len(ad.trace(rays.copy(), sc.m[0], sc.minv[0], sc.normi[0], sc.lights))
+    # bad arguments
+    assert lib.gvt_hip_trace(ad.h, capi.ptr(r1), C.c_size_t(len(r1)), C.c_size_t(9), C.c_size_t(3), capi.ptr(out), C.c_size_t(4), C.byref(n_out),
+                             capi.ptr(capi.f32(sc.m[0])), capi.ptr(capi.f32(sc.minv[0])), capi.ptr(capi.f32(sc.normi[0])),
+                             capi.ptr(np.ascontiguousarray(sc.lights)), C.c_size_t(1), C.c_int(0), C.c_uint32(0)) == -1
+    assert b"range" in lib.gvt_hip_last_error()
+
+
+def test_shadow_rays_that_hit_are_dropped_and_secondary_weight(hip):
+    """Input lists with SHADOW and SECONDARY rays (EmbreeMeshAdapter.cpp:486-488, 572-575)."""
+    sc = scenes.bunny_scene(64, 64)
+    mesh = sc.meshes[0]
+    ad, om = HipMeshAdapter(mesh), orc.Mesh(mesh.verts, mesh.tris, mesh_mat=mesh.material)
+    rays = oracle_camera_rays(sc)
+    rays["type"] = np.arange(len(rays)) % 3
+    rg, rc = rays.copy(), rays.copy()
+    og = ad.trace(rg, sc.m[0], sc.minv[0], sc.normi[0], sc.lights)
+    oc = om.trace(rc, sc.m[0], sc.minv[0], sc.normi[0], sc.lights, 0)
+    assert rays_equal_bits(sort_rays(og), sort_rays(oc)) and rays_equal_bits(rg, rc)
+
+
+@pytest.mark.parametrize("mtype", [layouts.LAMBERT, layouts.PHONG, layouts.BLINN])
+def test_materials_lights_vertex_colors(hip, mtype):
+    """Phong/Blinn (powf), per-face materials, vertex colours, several lights incl. ambient and area."""
+    sc = scenes.bunny_scene(96, 96)
+    base = sc.meshes[0]
+    rng = np.random.default_rng(4)
+    mats = np.concatenate([layouts.default_material(kd=rng.random(3), mtype=mtype, ks=rng.random(3), alpha=1 + 4 * rng.random()) for _ in range(5)])
+    face_mat = (np.arange(len(base.tris)) % 6 - 1).astype(np.int32)  # -1 -> mesh material
+    lights = np.concatenate([layouts.point_light((0.0, 0.1, 0.5)), layouts.point_light((0.3, 0.4, 0.2), (0.2, 0.5, 0.9)),
+                             layouts.ambient_light((0.05, 0.05, 0.1)), layouts.area_light((0.1, 0.5, 0.3), (1, 1, 1), (0.0, -1.0, 0.2), 0.2, 0.1)])
+    for vcol in (None, rng.random(base.verts.shape).astype(np.float32)):
+        mesh = scenes.MeshData(base.verts, base.tris, layouts.default_material(mtype=mtype), None, vcol, mats, face_mat)
+        ad = HipMeshAdapter(mesh, NORMALS_SMOOTH)
+        om = orc.Mesh(mesh.verts, mesh.tris, vcolors=vcol, materials=mats, face_mat=face_mat, mesh_mat=mesh.material)
+        rays = oracle_camera_rays(sc)
+        rg, rc = rays.copy(), rays.copy()
+        og = sort_by_id_light(ad.trace(rg, sc.m[0], sc.minv[0], sc.normi[0], lights, seed=5))
+        oc = sort_by_id_light(om.trace(rc, sc.m[0], sc.minv[0], sc.normi[0], lights, 1, seed=5))
+        assert len(og) == len(oc)
+        assert (og["id"] == oc["id"]).all() and (og["type"] == oc["type"]).all()
+        assert (bits(og["origin"]) == bits(oc["origin"])).all() and (bits(og["direction"]) == bits(oc["direction"])).all()
+        if mtype == layouts.LAMBERT or vcol is not None:  # vertex colours force LAMBERT (:556-557): no powf anywhere
+            assert (bits(og["color"]) == bits(oc["color"])).all()
+        else:
+            assert np.abs(og["color"] - oc["color"]).max() <= RADIANCE_TOL
+        assert rays_equal_bits(rg, rc)
+
+
+def sort_by_id_light(r):
+    """Order by (type, id, origin, direction): stable across tiny colour differences."""
+    key = np.stack([r["type"], r["id"]] + [bits(r["origin"][:, k]).astype(np.int64) for k in range(3)] +
+                   [bits(r["direction"][:, k]).astype(np.int64) for k in range(3)], 0)
+    return r[np.lexsort(key[::-1])]
+
+
+def test_secondary_bounces_depth3(hip):
+    """depth > 1: Russian roulette + cosine-weighted bounce (EmbreeMeshAdapter.cpp:584-602, 289-318) on the per-ray RNG
+    streams; sinf/cosf/acos differ in ulps between libm and the device, so compare within tolerance and by count."""
+    sc = scenes.cathedral_scene(64, 64, samples=1, depth=3)
+    mesh = sc.meshes[0]
+    ad, om = HipMeshAdapter(mesh), orc.Mesh(mesh.verts, mesh.tris, mesh_mat=mesh.material)
+    rays = oracle_camera_rays(sc)
+    rg, rc = rays.copy(), rays.copy()
+    og = ad.trace(rg, sc.m[0], sc.minv[0], sc.normi[0], sc.lights, seed=11)
+    oc = om.trace(rc, sc.m[0], sc.minv[0], sc.normi[0], sc.lights, 0, seed=11)
+    assert (rc["type"] == 2).sum() > 100, "no bounces happened"
+    assert abs(len(og) - len(oc)) <= max(4, len(oc) // 500)
+    assert (rg["type"] == rc["type"]).mean() > 0.995 and (rg["depth"] == rc["depth"]).mean() > 0.995
+    same = (rg["type"] == rc["type"]) & (rg["depth"] == rc["depth"])
+    assert np.abs(rg["direction"][same] - rc["direction"][same]).max() < 1e-3
+    # radiance deposited per pixel agrees statistically
+    def img(o):
+        a = np.zeros((64 * 64, 3))
+        s = o[o["type"] == 1]
+        np.add.at(a, s["id"], s["color"] * s["w"][:, None])
+        return a
+    assert np.abs(img(og) - img(oc)).mean() < 2e-4
+
+
+# ------------------------------------------------------------------ device queues, camera, top level, framebuffer
+def test_queue_roundtrip_and_camera(hip):
+    sc = scenes.simple_scene(130, 70)  # ragged sizes
+    q = RayQueue()
+    camera_generate(q, sc.camera)
+    dev = q.to_numpy()
+    cpu = oracle_camera_rays(sc)
+    assert rays_equal_bits(dev, cpu), "camera rays differ from gvtPerspectiveCamera::generateRays restated"
+    q2 = RayQueue(16)
+    q2.append(cpu[:1000])
+    q2.append(cpu[1000:1003])
+    assert len(q2) == 1003 and rays_equal_bits(q2.to_numpy(), cpu[:1003])
+    q2.clear()
+    assert len(q2) == 0 and len(q2.to_numpy()) == 0
+    cam2 = scenes.Camera((1, 2, 3), (0, 0.5, 0), (0.1, 1, 0), 0.7, 33, 17, samples=2, depth=2, jitter=1.0)
+    camera_generate(q2, cam2)
+    assert rays_equal_bits(q2.to_numpy(), orc.camera_rays(cam2.eye, cam2.focus, cam2.up, cam2.fov, 33, 17, 2, 2, 1.0))
+
+
+def test_toplevel_shuffle_matches_oracle(hip):
+    sc = scenes.simple_scene(150, 150)
+    top = TopLevel(sc.inst_lo, sc.inst_hi)
+    order = orc.toplevel_order(sc.inst_lo, sc.inst_hi)
+    assert (top.order() == order).all()
+    cpu = oracle_camera_rays(sc)
+    q = RayQueue()
+    q.append(cpu)
+    queues = [RayQueue() for _ in range(sc.n_inst)]
+    fb = FrameBuffer(150, 150)
+    top.shuffle(q, -1, queues, fb)
+    assert len(q) == 0
+    nxt, t = orc.toplevel_intersect(sc.inst_lo, sc.inst_hi, order, cpu)
+    for i in range(sc.n_inst):
+        exp = cpu[nxt == i].copy()
+        exp["origin"] = exp["origin"] + exp["direction"] * (t[nxt == i] * np.float32(0.95))[:, None]
+        got = queues[i].to_numpy()
+        assert len(got) == len(exp) and rays_equal_bits(sort_rays(got), sort_rays(exp)), "queue %d" % i
+    # second shuffle from an instance, with SHADOW rays: t_max=3 bounds the test, free ones deposit color*w
+    shadow = cpu[:5000].copy()
+    shadow["type"] = 1
+    shadow["t_max"] = 3.0
+    shadow["color"] = (0.25, 0.5, 0.75)
+    shadow["w"] = 0.5
+    q.append(shadow)
+    for qq in queues:
+        qq.clear()
+    top.shuffle(q, 12, queues, fb)
+    nxt2, _ = orc.toplevel_intersect(sc.inst_lo, sc.inst_hi, order, shadow, 12)
+    assert [len(qq) for qq in queues] == [(nxt2 == i).sum() for i in range(sc.n_inst)]
+    exp_fb = np.zeros((150 * 150, 4), np.float32)
+    free = shadow[nxt2 < 0]
+    np.add.at(exp_fb[:, :3], free["id"], free["color"] * free["w"][:, None])
+    np.add.at(exp_fb[:, 3], free["id"], 1.0)
+    assert np.array_equal(fb.download(False).reshape(-1, 4), exp_fb)
+    # drop mode (shuffleDropRays): only kept queues receive rays
+    q.append(cpu)
+    for qq in queues:
+        qq.clear()
+    keep = np.array([i % 2 for i in range(sc.n_inst)], np.uint8)
+    top.shuffle(q, -1, queues, None, keep)
+    assert [len(qq) for qq in queues] == [int((nxt == i).sum()) if keep[i] else 0 for i in range(sc.n_inst)]
+
+
+def test_framebuffer_clamp_and_ppm(hip):
+    fb = FrameBuffer(8, 4)
+    top = TopLevel(np.array([[10, 10, 10]], np.float32), np.array([[11, 11, 11]], np.float32))
+    r = np.zeros(6, RAY_DTYPE)
+    r["origin"] = (0, 0, 0)
+    r["direction"] = (0, 0, 1)
+    r["type"] = 1
+    r["t_max"] = 3.0
+    r["w"] = 1.0
+    r["id"] = [0, 0, 0, 5, 31, 31]
+    r["color"] = [(0.5, 0.25, 0.1)] * 3 + [(0.2, 0.4, 0.6)] + [(0.9, 0.9, 0.9)] * 2
+    q = RayQueue()
+    q.append(r)
+    top.shuffle(q, -1, [RayQueue()], fb)
+    raw, cl = fb.download(False), fb.download(True)
+    assert np.allclose(raw[0, 0], (1.5, 0.75, 0.3, 3)) and np.allclose(cl[0, 0], (1.0, 0.75, 0.3, 3))
+    assert np.allclose(cl[3, 7], (1.0, 1.0, 1.0, 2))
+    assert (fb.ppm_bytes() == orc.fb_to_ppm_bytes(cl)).all()
+    fb.clear()
+    assert not fb.download(False).any()
+
+
+# ------------------------------------------------------------------ whole frames
+@pytest.mark.parametrize("name,builder", [("simple", scenes.simple_scene), ("bunny", scenes.bunny_scene)])
+def test_reference_golden_images_on_gpu(hip, name, builder, oracle_vectors):
+    """The reference's CTest on the HIP adapter: sum|byte diff| < 300 vs Test/CTESTtest/data/<name>.ppm (smooth mode),
+    and the float framebuffer bit-identical to the oracle's in both normal modes."""
+    sc = builder()
+    for mode in (NORMALS_SMOOTH, NORMALS_FLAT):
+        tr = ImageTracer(sc, mode)
+        B = tr()
+        fb = B.framebuffer(True)
+        rec = oracle_vectors["fb_hashes"]["%s_mode%d" % (name, mode)]
+        assert hashlib.sha256(np.ascontiguousarray(fb[..., :3]).tobytes()).hexdigest() == rec["rgb_sha256"]
+        assert tr.adapter_calls == rec["adapter_calls"]
+        if mode == NORMALS_SMOOTH:
+            img = B.fb.ppm_bytes().astype(np.int64)
+            gold = read_ppm(os.path.join(GOLDEN, "ref_%s.ppm" % name)).astype(np.int64)
+            assert np.abs(img - gold).sum() < 300
+
+
+def test_config2_bunny70k_1080p(hip):
+    """BASELINE config 2: bun_zipper (69,451 tris), 1920x1080, primary + shadow: integer framebuffer identical to the oracle."""
+    sc = scenes.bunny70k_scene()
+    B = ImageTracer(sc, NORMALS_FLAT)()
+    fb = B.framebuffer(True)
+    ref, st = oracle_render(sc, 0, nthreads=8)
+    assert np.array_equal(fb[..., :3], ref[..., :3])
+    assert (B.fb.ppm_bytes() == orc.fb_to_ppm_bytes(ref)).all()
+    assert st.rays_closest > 400_000 and st.rays_any > 300_000
+
+
+def test_config4_bunny_grid_image_scheduler(hip):
+    """BASELINE config 4 geometry on one GPU (8 instances of one mesh, one cached adapter): equals the oracle."""
+    sc = scenes.bunny_grid_scene(width=475, height=270)
+    tr = ImageTracer(sc, NORMALS_SMOOTH)
+    B = tr()
+    ref, st = oracle_render(sc, 1)
+    assert np.array_equal(B.framebuffer(True)[..., :3], ref[..., :3])
+    assert tr.adapter_calls == st.adapter_calls and len(B.adapter_cache) == 1
+
+
+def test_multisample_frame_within_tolerance(hip):
+    """samples=2: four contributions per pixel arrive through float atomics in arbitrary order -> 1e-5, not bit-exact."""
+    sc = scenes.bunny_scene(128, 128)
+    sc.camera.samples = 2
+    B = ImageTracer(sc, NORMALS_SMOOTH)()
+    ref, _ = oracle_render(sc, 1)
+    assert np.abs(B.framebuffer(True)[..., :3] - ref[..., :3]).max() <= RADIANCE_TOL

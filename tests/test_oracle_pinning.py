@@ -1,0 +1,205 @@
+"""Pins the CPU oracle: against the reference's golden images, against known answers produced by the
+reference's OWN code (tests/golden/ref_vectors.json, generated through oracle/_ref by
+tests/golden/make_fixtures.py) and -- when the reference build is present (build container) -- live.
+No GPU needed."""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from gravit_amd import scenes
+from oracle import orc
+from tests.conftest import GOLDEN, read_ppm
+from tests.helpers import oracle_meshes, oracle_render, oracle_render_domain
+
+REF_TOLERANCE = 300  # gvtImageDiff -tolerance 300 (reference CMakeLists.txt:666, ImageDiff.cpp:45-66,97)
+
+
+def test_struct_sizes_match_reference(ref_vectors):
+    assert ref_vectors["sizes"] == {"ray": 80, "material": 92, "box3d": 32}
+    assert orc.RAY_DTYPE.itemsize == 80 and orc.MATERIAL_DTYPE.itemsize == 92 and orc.LIGHT_DTYPE.itemsize == 64
+    assert np.float32(ref_vectors["ray_epsilon"]) == np.float32(1e-6)
+    # Material() initialises type..roughness (bytes 0-71); the velvet fields are left indeterminate (Material.h:62-77)
+    assert orc.default_material().tobytes().hex()[:144] == ref_vectors["default_material_hex"][:144]
+
+
+@pytest.mark.parametrize("name,builder", [("simple", scenes.simple_scene), ("bunny", scenes.bunny_scene)])
+def test_reference_golden_images_smooth(name, builder):
+    """The reference's CTest: render, diff against Test/CTESTtest/data/<name>.ppm, sum |byte diff| < 300.
+    The goldens pre-date FLAT_SHADING: smooth normals reproduce them."""
+    sc = builder()
+    fb, st = oracle_render(sc, 1)
+    img = orc.fb_to_ppm_bytes(fb).astype(np.int64)
+    gold = read_ppm(os.path.join(GOLDEN, "ref_%s.ppm" % name)).astype(np.int64)
+    d = np.abs(img - gold)
+    assert d.sum() < REF_TOLERANCE, "sum-abs %d (%d px)" % (d.sum(), (d.sum(axis=2) > 0).sum())
+    if name == "simple":
+        assert d.sum() == 0  # reproduced exactly
+        assert st.adapter_calls == 37  # 25 instances, queues drained in 37 adapter calls
+    else:
+        assert d.sum() <= 138 and (d.sum(axis=2) > 0).sum() <= 4
+
+
+@pytest.mark.parametrize("name,builder", [("simple", scenes.simple_scene), ("bunny", scenes.bunny_scene)])
+def test_flat_mode_is_not_the_golden(name, builder):
+    """Flat normals (the current EmbreeMeshAdapter.cpp, FLAT_SHADING) differ from the goldens by >1e6: both modes exist."""
+    fb, _ = oracle_render(builder(), 0)
+    img = orc.fb_to_ppm_bytes(fb).astype(np.int64)
+    gold = read_ppm(os.path.join(GOLDEN, "ref_%s.ppm" % name)).astype(np.int64)
+    assert np.abs(img - gold).sum() > 1_000_000
+
+
+def test_framebuffer_hashes_are_stable(oracle_vectors):
+    for name, builder in (("simple", scenes.simple_scene), ("bunny", scenes.bunny_scene)):
+        for mode in (0, 1):
+            fb, st = oracle_render(builder(), mode)
+            rec = oracle_vectors["fb_hashes"]["%s_mode%d" % (name, mode)]
+            assert hashlib.sha256(np.ascontiguousarray(fb[..., :3]).tobytes()).hexdigest() == rec["rgb_sha256"]
+            assert st.adapter_calls == rec["adapter_calls"] and st.rays_closest == rec["rays_closest"] and st.rays_any == rec["rays_any"]
+
+
+def test_domain_scheduler_two_ranks_matches_golden_and_image_scheduler():
+    """The reference runs the same goldens with -domain on 2 ranks (CMakeLists.txt:650-654, same tolerance)."""
+    sc = scenes.simple_scene()
+    owner = [(0 if sc.inst_mesh[i] == 0 else 1) for i in range(sc.n_inst)]  # SimpleApp.cpp:128-135: cones on even, cubes on odd ranks
+    fb, st = oracle_render_domain(sc, owner, 2, 1)
+    img = orc.fb_to_ppm_bytes(fb).astype(np.int64)
+    gold = read_ppm(os.path.join(GOLDEN, "ref_simple.ppm")).astype(np.int64)
+    assert np.abs(img - gold).sum() < REF_TOLERANCE
+    assert st.rays_sent > 0 and st.rounds >= 2
+    fb1, _ = oracle_render(sc, 1)
+    assert np.array_equal(fb[..., :3], fb1[..., :3])  # one writer per pixel: the composite is exact
+
+
+# ----------------------------------------------------------------- known answers from the reference's own code
+def test_shade_known_answers(ref_vectors):
+    n_ok = 0
+    for c in ref_vectors["shade_cases"]:
+        mat = np.frombuffer(bytes.fromhex(c["mat"]), orc.MATERIAL_DTYPE)
+        ray = np.frombuffer(bytes.fromhex(c["ray"]), orc.RAY_DTYPE)
+        light = np.zeros(1, orc.LIGHT_DTYPE)
+        light["type"] = c["light_type"]
+        light["position"] = c["lpos"]
+        light["color"] = c["lcolor"]
+        light["normal"] = c["lnormal"]
+        light["width"] = c["lwidth"]
+        light["height"] = c["lheight"]
+        ok, col = orc.shade(mat, ray, c["N"], light, c["sample"])
+        assert int(ok) == c["ok"]
+        if ok:
+            n_ok += 1
+            assert col.tobytes().hex() == c["color_hex"], "Shade differs from the reference (material %d, light %d)" % (mat["type"][0], c["light_type"])
+    assert n_ok > 30
+
+
+def test_shade_survey_probe():
+    """default material, N=(0,0,1), light (0,.1,.5), hit at t=.25 -> (0.5,0.5,0.5)."""
+    ray = np.zeros(1, orc.RAY_DTYPE)
+    ray["origin"] = (0, 0.1, 0.25)
+    ray["direction"] = (0, 0, -1)
+    ray["t"] = 0.25
+    ray["w"] = 1.0
+    ok, c = orc.shade(orc.default_material(), ray, (0, 0, 1), orc.point_light((0, 0.1, 0.5)), (0, 0.1, 0.5))
+    assert ok and np.allclose(c, 0.5)
+
+
+def test_randengine_streams(ref_vectors):
+    for rec in ref_vectors["rng"]:
+        s = rec["seed"]
+        for v in rec["values"]:
+            got, s = orc.rng(s)
+            assert np.float32(got) == np.float32(v)
+        assert s == rec["seed_after"]
+    for rec in ref_vectors["lcg"]:
+        s = rec["seed"]
+        for v in rec["values"]:
+            got, s = orc.fastrand_lcg(s)
+            assert np.float32(got) == np.float32(v)
+        assert s == rec["seed_after"]
+
+
+def test_generate_normals(ref_vectors):
+    v, t = scenes.read_obj(os.path.join(GOLDEN, "bunny.obj"))
+    assert v.shape == (2503, 3) and t.shape == (4968, 3)
+    assert hashlib.sha256(orc.generate_normals(v, t).tobytes()).hexdigest() == ref_vectors["bunny_normals_sha256"]
+    cone = scenes.simple_scene().meshes[0]
+    assert orc.generate_normals(cone.verts, cone.tris).tobytes().hex() == ref_vectors["cone_normals_hex"]
+
+
+def test_add_face_degenerate_filter(ref_vectors):
+    rec = ref_vectors["add_faces"]
+    kept = scenes.add_faces_1based(np.array(rec["verts"], np.float32), rec["faces1"])
+    assert kept.tolist() == rec["kept0"]
+    # the cone of SimpleApp.cpp has no degenerate faces, the cube neither
+    sc = scenes.simple_scene()
+    assert sc.meshes[0].tris.shape == (6, 3) and sc.meshes[1].tris.shape == (12, 3)
+
+
+def test_raypacket_box_test(ref_vectors):
+    """RayPacketIntersection::intersect(update=true) per ray == the oracle's top-level step."""
+    for rec in ref_vectors["raypacket"]:
+        ray = np.frombuffer(bytes.fromhex(rec["ray"]), orc.RAY_DTYPE).copy()
+        ray["t_max"] = np.float32(rec["t_in"])
+        nxt, t = orc.toplevel_intersect([rec["lo"]], [rec["hi"]], [0], ray)
+        # the packet test has no epsilon... it has: update=true applies tnear > RAY_EPSILON, same as the oracle
+        assert int(nxt[0] >= 0) == rec["hit"]
+        if rec["hit"]:
+            assert np.float32(t[0]).tobytes().hex() == rec["t_out_hex"]
+
+
+def test_box3d_helpers_and_toplevel_order(ref_vectors):
+    sc = scenes.simple_scene()
+    order = orc.toplevel_order(sc.inst_lo, sc.inst_hi)
+    assert sorted(order.tolist()) == list(range(25))
+    one = orc.toplevel_order(sc.inst_lo[:1], sc.inst_hi[:1])
+    assert one.tolist() == [0]
+
+
+def test_ray_constructor_image(ref_vectors):
+    """Ray(origin, dir, w, type): direction normalized, t_min = eps, t_max = t = FLT_MAX, id = -1 (Ray.h:106-116)."""
+    r = np.frombuffer(bytes.fromhex(ref_vectors["ray_ctor_hex"]), orc.RAY_DTYPE)[0]
+    assert np.allclose(r["direction"], (0, 0.6, 0.8)) and r["t_min"] == np.float32(1e-6)
+    assert r["t_max"] == np.finfo(np.float32).max and r["t"] == np.finfo(np.float32).max and r["id"] == -1 and r["type"] == 1
+
+
+def test_area_light_positions(ref_vectors):
+    """AreaLight::GetPosition through the oracle's trace path is exercised in test_oracle_consistency; here the LCG only."""
+    for rec in ref_vectors["area_light"]:
+        s = rec["seed"]
+        _, s = orc.fastrand_lcg(s)
+        _, s = orc.fastrand_lcg(s)
+        assert s == rec["seed_after"]
+
+
+# ----------------------------------------------------------------- live comparison when the reference build is present
+@pytest.mark.skipif(orc.ref() is None, reason="oracle/_ref not built (no /root/reference on this machine)")
+def test_live_against_reference_build():
+    ref = orc.ref()
+    assert ref.ref_sizeof_ray() == 80 and ref.ref_sizeof_material() == 92 and ref.ref_sizeof_box3d() == 32
+    rng = np.random.default_rng(5)
+    for k in range(200):
+        mat = orc.default_material()
+        mat["type"] = k % 3
+        mat["kd"] = rng.random(3, dtype=np.float32)
+        mat["alpha"] = np.float32(1 + 5 * rng.random())
+        ray = np.zeros(1, orc.RAY_DTYPE)
+        ray["origin"] = rng.random(3, dtype=np.float32)
+        d = rng.random(3, dtype=np.float32) - 0.5
+        ray["direction"] = d / np.linalg.norm(d)
+        ray["t"] = np.float32(rng.random() + 0.1)
+        ray["w"] = 1.0
+        N = rng.random(3, dtype=np.float32) - 0.5
+        N = (N / np.linalg.norm(N)).astype(np.float32)
+        lpos = (rng.random(3, dtype=np.float32) * 3).astype(np.float32)
+        lcol = rng.random(3, dtype=np.float32)
+        c = np.zeros(3, np.float32)
+        z = np.zeros(3, np.float32)
+        ok_ref = ref.ref_shade(mat.ctypes.data_as(C.c_void_p), ray.ctypes.data_as(C.c_void_p), N.ctypes.data_as(C.c_void_p), C.c_int(0),
+                               lpos.ctypes.data_as(C.c_void_p), lcol.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p),
+                               C.c_float(0), C.c_float(0), lpos.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p))
+        ok, col = orc.shade(mat, ray, N, orc.point_light(lpos, lcol), lpos)
+        assert int(ok) == ok_ref
+        if ok:
+            assert col.tobytes() == c.tobytes()
