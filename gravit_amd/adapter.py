@@ -139,6 +139,22 @@ class HipMeshAdapter:
                    "gvt_hip_intersect")
         return out
 
+    def visit_stats(self, org, dirs, tnear=1e-6):
+        """Diagnostic: per-ray (inner-node visits, leaf visits, triangle tests) of the closest-hit traversal, plus the
+        number of steps a 64-lane wave executes per batch (the slowest lane's inner + leaf steps)."""
+        org = capi.f32(org, (-1, 3))
+        dirs = capi.f32(dirs, (-1, 3))
+        n = len(org)
+        cnt = np.zeros((n, 3), np.uint32)
+        capi.check(self.lib.gvt_hip_visit_stats(self.h, capi.ptr(org), capi.ptr(dirs), C.c_size_t(n), C.c_float(tnear), capi.ptr(cnt)),
+                   "gvt_hip_visit_stats")
+        steps = (cnt[:, 0] + cnt[:, 1]).astype(np.int64)
+        pad = (-n) % 64
+        waves = np.concatenate([steps, np.zeros(pad, np.int64)]).reshape(-1, 64)
+        return {"inner_per_ray": float(cnt[:, 0].mean()), "leaf_per_ray": float(cnt[:, 1].mean()), "tri_tests_per_ray": float(cnt[:, 2].mean()),
+                "lane_steps_per_ray": float(steps.mean()), "wave_steps_per_batch": float(waves.max(axis=1).mean()),
+                "simd_efficiency": float(steps.sum() / max(1, waves.max(axis=1).sum() * 64)), "counts": cnt}
+
     def occluded(self, org, dirs, tnear=1e-6):
         org = capi.f32(org, (-1, 3))
         dirs = capi.f32(dirs, (-1, 3))

@@ -22,7 +22,7 @@ SYMBOLS = [
     "gvt_hip_top_create", "gvt_hip_top_destroy", "gvt_hip_top_order", "gvt_hip_shuffle", "gvt_hip_queue_sizes",
     "gvt_hip_fb_create", "gvt_hip_fb_destroy", "gvt_hip_fb_clear", "gvt_hip_fb_download", "gvt_hip_fb_device_ptr",
     "gvt_hip_fb_write_ppm_bytes",
-    "gvt_hip_profile", "gvt_hip_stats_read", "gvt_hip_stats_reset",
+    "gvt_hip_profile", "gvt_hip_stats_read", "gvt_hip_stats_reset", "gvt_hip_set_option", "gvt_hip_visit_stats",
 ]
 
 
@@ -41,7 +41,7 @@ class Stats(C.Structure):
                 ("rays_forwarded", C.c_uint64), ("trace_calls", C.c_uint64),
                 ("ms_closest", C.c_double), ("ms_any", C.c_double), ("ms_shade", C.c_double), ("ms_convert", C.c_double),
                 ("ms_shuffle", C.c_double), ("ms_camera", C.c_double), ("ms_build", C.c_double),
-                ("launches_closest", C.c_uint64), ("launches_any", C.c_uint64)]
+                ("launches_closest", C.c_uint64), ("launches_any", C.c_uint64), ("ms_sort", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -110,6 +110,10 @@ def stats(reset=False):
     if reset:
         check(load().gvt_hip_stats_reset(), "gvt_hip_stats_reset")
     return s.as_dict()
+
+
+def set_option(name, value):
+    check(load().gvt_hip_set_option(name.encode(), C.c_int(int(value))), "gvt_hip_set_option")
 
 
 def stats_reset():

@@ -106,7 +106,7 @@ static void drain_events() {
     float ms = 0.f;
     hipEventElapsedTime(&ms, p.a, p.b);
     double *slot[KC_COUNT] = { &C.stats.ms_closest, &C.stats.ms_any, &C.stats.ms_shade, &C.stats.ms_convert, &C.stats.ms_shuffle,
-                               &C.stats.ms_camera, &C.stats.ms_build };
+                               &C.stats.ms_camera, &C.stats.ms_build, &C.stats.ms_sort };
     *slot[p.cls] += ms;
     C.event_pool.push_back(p.a);
     C.event_pool.push_back(p.b);
@@ -132,6 +132,17 @@ extern "C" int gvt_hip_stats_reset(void) {
   drain_events();
   g_ctx.stats = gvt_hip_stats{};
   return 0;
+}
+
+extern "C" int gvt_hip_set_option(const char *name, int value) {
+  if (!name) { set_error("set_option: null name"); return GVT_HIP_ERR_INVALID; }
+  if (!std::strcmp(name, "sort_rays")) { g_ctx.sort_rays = value; return 0; }
+  if (!std::strcmp(name, "trav_kernel")) { g_ctx.trav_kernel = value; return 0; }
+  if (!std::strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 6) { set_error("blocks_per_cu must be 1..6"); return GVT_HIP_ERR_INVALID; } g_ctx.blocks_per_cu = value; return 0; }
+  if (!std::strcmp(name, "leaf_min")) { if (value < 1 || value > 64) { set_error("leaf_min must be 1..64"); return GVT_HIP_ERR_INVALID; } g_ctx.leaf_min = value; return 0; }
+  if (!std::strcmp(name, "refill_min")) { if (value < 1 || value > 64) { set_error("refill_min must be 1..64"); return GVT_HIP_ERR_INVALID; } g_ctx.refill_min = value; return 0; }
+  set_error("set_option: unknown option '%s'", name);
+  return GVT_HIP_ERR_INVALID;
 }
 
 // ---- meshes ----
@@ -426,6 +437,23 @@ extern "C" int gvt_hip_occluded(gvt_hip_mesh *M, const float *org, const float *
   Mat4 id{};
   if ((rc = launch_any_flags(M, pl, n, false, id, tnear, d_flags))) return rc;
   HIPCHK(hipMemcpyAsync(out, d_flags, sizeof(int) * n, hipMemcpyDeviceToHost, C.stream));
+  HIPCHK(hipStreamSynchronize(C.stream));
+  return 0;
+}
+
+// diagnostic: per-ray visit counts of the closest-hit traversal for object-space rays (see k_visit_stats)
+extern "C" int gvt_hip_visit_stats(gvt_hip_mesh *M, const float *org, const float *dir, size_t n, float tnear, uint32_t *counts /* n*3 */) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!M || (n && (!org || !dir || !counts))) { set_error("visit_stats: null argument"); return GVT_HIP_ERR_INVALID; }
+  if (!n) return 0;
+  Ctx &C = g_ctx;
+  RayPlanes pl;
+  int rc = stage_od(org, dir, n, pl);
+  if (rc) return rc;
+  unsigned *d_out = (unsigned *)scratch_get(0, 3 * n * sizeof(unsigned));
+  if (!d_out) return GVT_HIP_ERR_DEVICE;
+  if ((rc = launch_visit_stats(M, pl, n, tnear, d_out))) return rc;
+  HIPCHK(hipMemcpyAsync(counts, d_out, 3 * n * sizeof(unsigned), hipMemcpyDeviceToHost, C.stream));
   HIPCHK(hipStreamSynchronize(C.stream));
   return 0;
 }

@@ -10,7 +10,7 @@
 
 #include "gvt_device.h"
 
-enum KernelClass { KC_CLOSEST = 0, KC_ANY, KC_SHADE, KC_CONVERT, KC_SHUFFLE, KC_CAMERA, KC_BUILD, KC_COUNT };
+enum KernelClass { KC_CLOSEST = 0, KC_ANY, KC_SHADE, KC_CONVERT, KC_SHUFFLE, KC_CAMERA, KC_BUILD, KC_SORT, KC_COUNT };
 
 struct PendingEvent {
   hipEvent_t a, b;
@@ -23,6 +23,11 @@ struct Ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   bool profile = false;
+  int trav_kernel = 1;   // 1 = persistent waves with lane refill (k_trace), 0 = one 64-ray batch at a time (k_closest/k_any)
+  int blocks_per_cu = 4; // k_trace grid: resident 256-thread blocks per CU
+  int refill_min = 16;   // k_trace: idle lanes needed before a refill
+  int leaf_min = 24;     // k_trace: lanes waiting at a leaf that trigger a leaf phase
+  int sort_rays = 0; // Morton-sort rays before traversal (adapter-internal; results are order independent)
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;
   gvt_hip_stats stats{};
@@ -34,8 +39,8 @@ struct Ctx {
   // pinned host scratch for small read-backs
   unsigned *h_pinned = nullptr;
   // grow-only device scratch arenas (never freed inside hot calls)
-  void *scratch[8] = { nullptr };
-  size_t scratch_bytes[8] = { 0 };
+  void *scratch[16] = { nullptr };
+  size_t scratch_bytes[16] = { 0 };
 };
 Ctx &gctx();
 void set_error(const char *fmt, ...);
@@ -116,12 +121,14 @@ struct TraceParams {
 
 // lbvh.hip
 int build_lbvh(gvt_hip_mesh *M);
+int sort_pairs_u32(unsigned *keys_in, unsigned *keys_out, unsigned *vals_in, unsigned *vals_out, size_t n, int end_bit);
 // trace.hip
 int queue_reserve(gvt_hip_queue *q, size_t cap);
 int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt_hip_queue *out, const TraceParams &P,
                const gvt_hip_light *lights_host);
 int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, bool xform, const Mat4 &minv, float tnear,
                    gvt_hip_hit *d_hits);
+int launch_visit_stats(gvt_hip_mesh *M, RayPlanes q, size_t n, float tnear, unsigned *d_out);
 int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const Mat4 &minv, float tnear, int *d_flags);
 int convert_aos_to_planes(const gvt_hip_ray *d_src, size_t n, RayPlanes dst, size_t dst_off);
 int convert_planes_to_aos(RayPlanes src, size_t src_off, size_t n, gvt_hip_ray *d_dst);

@@ -329,3 +329,14 @@ done:
 #undef OK
 #undef HOK
 }
+
+// radix sort of (key, value) pairs on the adapter stream; temporary storage from the grow-only scratch arena
+int sort_pairs_u32(unsigned *keys_in, unsigned *keys_out, unsigned *vals_in, unsigned *vals_out, size_t n, int end_bit) {
+  Ctx &C = gctx();
+  size_t tb = 0;
+  HIPCHK(rocprim::radix_sort_pairs(nullptr, tb, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, C.stream));
+  void *tmp = scratch_get(12, tb ? tb : 16);
+  if (!tmp) return GVT_HIP_ERR_DEVICE;
+  HIPCHK(rocprim::radix_sort_pairs(tmp, tb, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, C.stream));
+  return 0;
+}

@@ -179,10 +179,16 @@ typedef struct gvt_hip_stats {
   /* HIP-event time per kernel class, ms, accumulated while profiling is enabled */
   double ms_closest, ms_any, ms_shade, ms_convert, ms_shuffle, ms_camera, ms_build;
   uint64_t launches_closest, launches_any;
+  double ms_sort; /* ray sorting inside the adapter */
 } gvt_hip_stats;
 int gvt_hip_profile(int enable);           /* bracket every kernel with HIP events on the launch stream */
 int gvt_hip_stats_read(gvt_hip_stats *);   /* synchronises */
 int gvt_hip_stats_reset(void);
+/* diagnostic, not on the hot path: per-ray visit counts of the closest-hit traversal over n object-space rays:
+ * counts[3*j + 0..2] = inner-node visits / leaf visits / triangle tests of ray j. */
+int gvt_hip_visit_stats(gvt_hip_mesh *, const float *org, const float *dir, size_t n, float tnear, uint32_t *counts);
+/* adapter-internal tuning knobs (results never depend on them): "sort_rays" = 0/1 */
+int gvt_hip_set_option(const char *name, int value);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/prof_<tag>/ (rocprofv3 csv output) into small, committed summaries under profiles/:
+  <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats per-kernel table (calls, total/avg/min/max ns)
+  <tag>_pmc.json           per-kernel PMC sums and per-launch means; HBM traffic with the gfx950 corrections of
+                           MI355X_MICROARCH.md (FETCH_SIZE counts 64-B units of 128-B requests for wide loads: reported raw
+                           and x2; WRITE_SIZE exact for 16-B stores; both in KiB units -> x1024)
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    """(anonymous namespace)::k_closest<true>(RayPlanes, ...) -> k_closest<true>"""
+    m = re.search(r"(k_[a-z_0-9]+(<[^>(]*>)?)", name)
+    return m.group(1) if m else name.split("(")[0]
+
+
+def find(pattern):
+    return sorted(glob.glob(pattern, recursive=True))
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    base = os.path.join(ROOT, "gpurun_out", "prof_%s" % tag)
+    out_stats = os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag)
+    stats = find(os.path.join(base, "trace", "**", "*kernel_stats.csv"))
+    if stats:
+        rows = list(csv.reader(open(stats[0])))
+        with open(out_stats, "w", newline="") as f:
+            csv.writer(f).writerows(rows)
+        print("kernel stats ->", out_stats)
+        for r in rows[:12]:
+            print("  ", ",".join(r[:8]))
+    # per-dispatch durations for our kernels
+    traces = find(os.path.join(base, "trace", "**", "*kernel_trace.csv"))
+    dur = {}
+    if traces:
+        for r in csv.DictReader(open(traces[0])):
+            k = short(r.get("Kernel_Name", ""))
+            d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            dur.setdefault(k, []).append(d)
+    pmc = {}
+    regs = {}
+    for d in find(os.path.join(base, "pmc_*")):
+        for f in find(os.path.join(d, "**", "*counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                k = short(r.get("Kernel_Name", ""))
+                e2 = regs.setdefault(k, {})
+                for col in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size"):
+                    if col in r:
+                        e2[col] = r[col]
+                c = r.get("Counter_Name", "")
+                v = float(r.get("Counter_Value", 0) or 0)
+                e = pmc.setdefault(k, {}).setdefault(c, [0.0, 0])
+                e[0] += v
+                e[1] += 1
+    summary = {}
+    for k, cs in pmc.items():
+        if not any(s in k for s in ("k_closest", "k_any", "k_shade", "k_top", "k_camera", "k_planes", "k_aos")):
+            continue
+        e = {c: {"sum": v[0], "launches": v[1], "per_launch": v[0] / max(1, v[1])} for c, v in cs.items()}
+        e["resources"] = regs.get(k, {})
+        if k in dur:
+            e["avg_duration_ns_trace_pass"] = sum(dur[k]) / len(dur[k])
+            e["launches_trace_pass"] = len(dur[k])
+        if "FETCH_SIZE" in e:
+            raw = e["FETCH_SIZE"]["per_launch"] * 1024.0
+            e["hbm_read_bytes_per_launch_raw"] = raw
+            e["hbm_read_bytes_per_launch_x2_wide_load_correction"] = raw * 2.0
+        if "WRITE_SIZE" in e:
+            e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE"]["per_launch"] * 1024.0
+        if "TCC_HIT_sum" in e and "TCC_MISS_sum" in e:
+            h, m = e["TCC_HIT_sum"]["sum"], e["TCC_MISS_sum"]["sum"]
+            e["l2_hit_rate"] = h / max(1.0, h + m)
+        summary[k] = e
+    out_pmc = os.path.join(ROOT, "profiles", "%s_pmc.json" % tag)
+    json.dump(summary, open(out_pmc, "w"), indent=1, sort_keys=True)
+    print("pmc ->", out_pmc)
+    for k, e in summary.items():
+        print(k)
+        for c in ("avg_duration_ns_trace_pass", "hbm_read_bytes_per_launch_raw", "hbm_write_bytes_per_launch", "l2_hit_rate"):
+            if c in e:
+                print("   %-45s %s" % (c, e[c]))
+    # bench lines of the passes
+    for f in find(os.path.join(base, "bench_*.log")):
+        for line in open(f, errors="replace"):
+            if line.startswith("{"):
+                j = json.loads(line)
+                print(os.path.basename(f), "value", round(j["value"], 1), "ms/step", round(j["ms_per_step"], 3), "closest avg ms",
+                      round(j["roofline"]["avg_launch_ms"], 4))
+
+
+if __name__ == "__main__":
+    main()

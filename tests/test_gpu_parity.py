@@ -63,6 +63,31 @@ def test_closest_and_any_hit_match_oracle(hip, name):
     assert info["n_tris"] == len(mesh.tris) and np.allclose(info["bbox_lo"], lo) and np.allclose(info["bbox_hi"], hi)
 
 
+@pytest.mark.parametrize("opts", [dict(trav_kernel=0), dict(trav_kernel=1, refill_min=1, leaf_min=1), dict(trav_kernel=1, refill_min=64, leaf_min=64),
+                                  dict(trav_kernel=1, blocks_per_cu=1, refill_min=8, leaf_min=16), dict(trav_kernel=1, sort_rays=1)])
+def test_results_do_not_depend_on_tuning_knobs(hip, opts):
+    """Both traversal kernels and every refill / phase / grid / sorting setting return the same bits."""
+    defaults = dict(trav_kernel=1, blocks_per_cu=4, refill_min=16, leaf_min=24, sort_rays=0)
+    sc = scenes.soup_scene(150_000, 160, 90)
+    mesh = sc.meshes[0]
+    ad, om = HipMeshAdapter(mesh), orc.Mesh(mesh.verts, mesh.tris, mesh_mat=mesh.material)
+    lo, hi = om.bbox()
+    org, d = seeded_rays_at(lo, hi, 30_001, 21)
+    rays = oracle_camera_rays(sc)
+    try:
+        for k, v in opts.items():
+            hip.set_option(k, v)
+        assert_hits_equal(ad.intersect(org, d), om.intersect(org, d))
+        assert (ad.occluded(org, d) == om.occluded(org, d)).all()
+        rg, rc = rays.copy(), rays.copy()
+        og = ad.trace(rg, sc.m[0], sc.minv[0], sc.normi[0], sc.lights)
+        oc = om.trace(rc, sc.m[0], sc.minv[0], sc.normi[0], sc.lights, 0)
+        assert rays_equal_bits(sort_rays(og), sort_rays(oc)) and rays_equal_bits(rg, rc)
+    finally:
+        for k, v in defaults.items():
+            hip.set_option(k, v)
+
+
 def test_axis_aligned_faces_edges_and_vertices(hip):
     """Rays through shared edges and vertices of the cube's flat, axis-aligned faces (zero-thickness boxes)."""
     cube = scenes.simple_scene().meshes[1]
