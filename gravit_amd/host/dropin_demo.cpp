@@ -1,0 +1,62 @@
+// dropin_demo.cpp -- drives HipMeshAdapter through a gvt::render::Adapter* with GraviT's OWN types
+// (Mesh, Ray, RayVector, PointLight, glm matrices), the way Tracer<ImageScheduler> does
+// (algorithm/ImageTracer.h:184-250).  Built only where the GraviT tree is available (oracle/Makefile target
+// `dropin`, output oracle/_ref/dropin_demo) and run on the GPU box by tests/test_gpu_dropin.py.
+//
+//   dropin_demo <mesh.obj> <rays.bin> <normal_mode> <out.bin>
+// rays.bin: n 80-byte gvt::render::actor::Ray images (the incoming queue).  Instance transform = identity, one
+// PointLight at (0,0.1,0.5) (SimpleFileLoadApp.cpp:223-225).
+// writes: uint64 n_moved, then n_moved 80-byte rays (moved_rays), then the n rays of rayList after the call.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+
+#include <glm/gtc/matrix_transform.hpp>
+
+#include "HipMeshAdapter.h"
+
+using namespace gvt::render;
+using gvt::render::actor::Ray;
+using gvt::render::actor::RayVector;
+
+int main(int argc, char **argv) {
+  if (argc < 5) { std::fprintf(stderr, "usage: %s mesh.obj rays.bin normal_mode out.bin\n", argv[0]); return 2; }
+  const int mode = std::atoi(argv[3]);
+  auto mesh = std::make_shared<data::primitives::Mesh>(new data::primitives::Material());
+  std::ifstream in(argv[1]);
+  std::string line;
+  while (std::getline(in, line)) { // ObjReader.cpp:122-135 pushes 0-based faces without the degenerate filter
+    std::istringstream ss(line);
+    std::string tag;
+    ss >> tag;
+    if (tag == "v") { float x, y, z; ss >> x >> y >> z; mesh->addVertex(glm::vec3(x, y, z)); }
+    else if (tag == "f") { int a, b, c; ss >> a >> b >> c; mesh->faces.push_back(data::primitives::Mesh::Face(a - 1, b - 1, c - 1)); }
+  }
+  std::shared_ptr<Adapter> adapter = std::make_shared<adapter::hip::data::HipMeshAdapter>(mesh, mode);
+
+  RayVector rays;
+  {
+    std::ifstream rf(argv[2], std::ios::binary | std::ios::ate);
+    const size_t bytes = (size_t)rf.tellg();
+    rf.seekg(0);
+    rays.resize(bytes / sizeof(Ray));
+    rf.read((char *)rays.data(), rays.size() * sizeof(Ray));
+  }
+  glm::mat4 m(1.f), minv = glm::inverse(m);
+  glm::mat3 normi = glm::transpose(glm::inverse(glm::mat3(m)));
+  std::vector<std::shared_ptr<data::scene::Light> > lights;
+  lights.push_back(std::make_shared<data::scene::PointLight>(glm::vec3(0.0, 0.1, 0.5), glm::vec3(1.0, 1.0, 1.0)));
+
+  RayVector moved;
+  moved.reserve(rays.size() * 10); // ImageTracer.h:240
+  adapter->trace(rays, moved, &m, &minv, &normi, lights);
+
+  std::ofstream out(argv[4], std::ios::binary);
+  const unsigned long long n = moved.size();
+  out.write((const char *)&n, 8);
+  out.write((const char *)moved.data(), n * sizeof(Ray));
+  out.write((const char *)rays.data(), rays.size() * sizeof(Ray));
+  std::printf("dropin_demo: %zu rays in, %llu moved\n", rays.size(), n);
+  return 0;
+}

@@ -1,0 +1,39 @@
+"""The GraviT-side binding itself: oracle/_ref/dropin_demo is gravit_amd/host/HipMeshAdapter.cpp compiled against the
+reference's OWN headers and sources (Adapter.h, Ray, Mesh, PointLight, glm) and linked with libgvt_hip.so.  It calls
+HipMeshAdapter::trace through a gvt::render::Adapter* with a std::vector<gvt::render::actor::Ray>; the result must be
+the oracle's.  The binary is built in the build container (make -C oracle dropin) and travels with the tree."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gravit_amd import scenes
+from oracle import orc
+from tests.conftest import GOLDEN, ROOT
+from tests.helpers import oracle_camera_rays, rays_equal_bits, sort_rays
+
+pytestmark = pytest.mark.gpu
+DEMO = os.path.join(ROOT, "oracle", "_ref", "dropin_demo")
+
+
+@pytest.mark.skipif(not os.path.exists(DEMO), reason="oracle/_ref/dropin_demo not built (needs the GraviT tree at build time)")
+@pytest.mark.parametrize("mode", [0, 1])
+def test_reference_types_through_the_virtual_interface(tmp_path, mode, hip):
+    out, rin = tmp_path / "out.bin", tmp_path / "rays.bin"
+    W, H = 160, 120
+    sc = scenes.bunny_scene(W, H)
+    rays = oracle_camera_rays(sc)
+    rays.tofile(rin)
+    r = subprocess.run([DEMO, os.path.join(GOLDEN, "bunny.obj"), str(rin), str(mode), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(out, np.uint8)
+    n = int(raw[:8].view(np.uint64)[0])
+    moved = raw[8:8 + 80 * n].view(orc.RAY_DTYPE)
+    ray_list = raw[8 + 80 * n:].view(orc.RAY_DTYPE)
+    assert len(ray_list) == W * H
+    om = orc.Mesh(sc.meshes[0].verts, sc.meshes[0].tris, mesh_mat=sc.meshes[0].material)
+    exp = om.trace(rays, sc.m[0], sc.minv[0], sc.normi[0], sc.lights, mode)
+    assert n == len(exp) and n > 1000
+    assert rays_equal_bits(sort_rays(moved.copy()), sort_rays(exp))
+    assert rays_equal_bits(ray_list.copy(), rays)
