@@ -226,7 +226,7 @@ def bunny_grid_scene(nx=4, ny=2, pitch=0.3, width=1900, height=1080, path=None):
         for i in range(nx):
             mats.append(mat_translate_scale(((i - (nx - 1) / 2) * pitch, (j - (ny - 1) / 2) * pitch, 0.0), (1, 1, 1)))
     cam = Camera((0.0, 0.1, 1.6), (0.0, 0.1, 0.0), (0.0, 1.0, 0.0), float(F(40.0 * np.pi / 180.0)), width, height, 1, 1, 0.0)
-    return _assemble([mesh], [0] * (nx * ny), mats, point_light((0.0, 0.3, 1.2)), cam, "bunny-grid-%dx%d" % (nx, ny))
+    return _assemble([mesh], [0] * (nx * ny), mats, point_light((0.9, 0.25, 0.25)), cam, "bunny-grid-%dx%d" % (nx, ny))  # light low and to the side: shadow rays cross neighbouring domains
 
 
 # ------------------------------------------------------------------ synthetic soups
