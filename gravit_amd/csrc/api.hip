@@ -137,9 +137,11 @@ extern "C" int gvt_hip_stats_reset(void) {
 extern "C" int gvt_hip_set_option(const char *name, int value) {
   if (!name) { set_error("set_option: null name"); return GVT_HIP_ERR_INVALID; }
   if (!std::strcmp(name, "sort_rays")) { g_ctx.sort_rays = value; return 0; }
+  if (!std::strcmp(name, "sort_bits")) { if (value < 8 || value > 32) { set_error("sort_bits must be 8..32"); return GVT_HIP_ERR_INVALID; } g_ctx.sort_bits = value; return 0; }
+  if (!std::strcmp(name, "top_lds")) { g_ctx.top_lds = value; return 0; }
   if (!std::strcmp(name, "trav_kernel")) { g_ctx.trav_kernel = value; return 0; }
   if (!std::strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 6) { set_error("blocks_per_cu must be 1..6"); return GVT_HIP_ERR_INVALID; } g_ctx.blocks_per_cu = value; return 0; }
-  if (!std::strcmp(name, "leaf_min")) { if (value < 1 || value > 64) { set_error("leaf_min must be 1..64"); return GVT_HIP_ERR_INVALID; } g_ctx.leaf_min = value; return 0; }
+  if (!std::strcmp(name, "inner_min")) { if (value < 1 || value > 64) { set_error("inner_min must be 1..64"); return GVT_HIP_ERR_INVALID; } g_ctx.inner_min = value; return 0; }
   if (!std::strcmp(name, "refill_min")) { if (value < 1 || value > 64) { set_error("refill_min must be 1..64"); return GVT_HIP_ERR_INVALID; } g_ctx.refill_min = value; return 0; }
   set_error("set_option: unknown option '%s'", name);
   return GVT_HIP_ERR_INVALID;
@@ -228,7 +230,7 @@ extern "C" int gvt_hip_mesh_get_info(const gvt_hip_mesh *M, gvt_hip_mesh_info *o
   o->n_tris = M->nT; o->n_verts = M->nV; o->n_nodes = M->nNodes; o->n_leaves = M->nLeaves;
   for (int k = 0; k < 3; k++) { o->bbox_lo[k] = M->lo[k]; o->bbox_hi[k] = M->hi[k]; }
   o->build_ms = M->build_ms; o->max_leaf = GVT_LEAF_MAX;
-  o->bytes_nodes = M->nNodes * sizeof(BvhNode); o->bytes_tris = M->nT * 48;
+  o->bytes_nodes = M->nNodes * sizeof(BvhNode); o->bytes_tris = M->nT * 64;
   return 0;
 }
 extern "C" int gvt_hip_mesh_get_normals(const gvt_hip_mesh *M, float *out) {
@@ -308,9 +310,8 @@ extern "C" int gvt_hip_queue_append(gvt_hip_queue *q, const gvt_hip_ray *rays, s
   rc = convert_aos_to_planes(d_src, n, make_planes(q->d_planes, q->cap), q->size);
   if (rc) return rc;
   q->size += n;
-  C.h_pinned[9] = (unsigned)q->size;
-  HIPCHK(hipMemcpyAsync(q->d_count, &C.h_pinned[9], sizeof(unsigned), hipMemcpyHostToDevice, C.stream));
-  HIPCHK(hipStreamSynchronize(C.stream));
+  if ((rc = set_device_u32(q->d_count, (unsigned)q->size))) return rc;
+  if (!src_on_device) HIPCHK(hipStreamSynchronize(C.stream)); // the staging copy reads the caller's host buffer
   return 0;
 }
 

@@ -102,7 +102,8 @@ __device__ inline void store_ray(const RayPlanes &q, size_t i, const RayRec &r) 
 //   n0 = (c0.lo.x, c0.hi.x, c0.lo.y, c0.hi.y)   n1 = (c1.lo.x, c1.hi.x, c1.lo.y, c1.hi.y)
 //   n2 = (c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z)   n3 = (child0, child1, -, -) bit-cast ints
 // child >= 0: inner node index.  child < 0: leaf, ~child = (first_tri_slot << 3) | count (count <= 4).
-// Triangle slot (48 B, leaf order): t0 = (v0.xyz, primID), t1 = (e1 = v0-v1, 0), t2 = (e2 = v2-v0, 0).
+// Triangle slot (64 B = one line, leaf order): t0 = (v0.xyz, primID), t1 = (e1 = v0-v1, 0), t2 = (e2 = v2-v0, 0),
+// t3 = (Ng = e1 x e2, 0) -- all precomputed with the very float operations the test would perform.
 // ---------------------------------------------------------------------------------------------
 struct BvhNode {
   float4 n0, n1, n2, n3;
@@ -129,6 +130,21 @@ __device__ inline bool tri_test(V3 O, V3 D, V3 v0, V3 e1, V3 e2, float tnear, fl
   if (!(tt <= GVT_FLT_MAX)) return false;
   t = tt; u = U / absDen; v = V / absDen;
   return true;
+}
+
+// The same test with the geometric normal taken from the slot and the divisions left to the caller: returns the
+// un-divided (T, U, V, |den|); t = T/|den| decides the order, u = U/|den| and v = V/|den| are needed for the winner only.
+__device__ inline bool tri_test_raw(V3 O, V3 D, V3 v0, V3 e1, V3 e2, V3 Ng, float tnear, float &T, float &U, float &V, float &absDen) {
+  V3 C = sub3(v0, O);
+  V3 R = cross3(D, C);
+  float den = dot3(Ng, D);
+  absDen = fabsf(den);
+  float sgn = (den < 0.f) ? -1.f : 1.f;
+  U = dot3(R, e2) * sgn;
+  V = dot3(R, e1) * sgn;
+  if (!(den != 0.f && U >= 0.f && V >= 0.f && U + V <= absDen)) return false;
+  T = dot3(Ng, C) * sgn;
+  return absDen * tnear < T;
 }
 
 // RandEngine::rng (core/math/RandEngine.h:43-56)
@@ -176,4 +192,21 @@ __device__ inline unsigned wave_alloc(unsigned *counter, bool want) {
   if ((int)lane_id() == leader) base = atomicAdd(counter, (unsigned)__popcll(mask));
   base = __shfl(base, leader);
   return base + lanes_below(mask);
+}
+
+// block-aggregated slot allocation: wave ballot -> LDS counter -> ONE global atomic per block and output list.
+// `sh` points at two LDS words reserved for this call site (count, base), zeroed before the first __syncthreads of the
+// kernel.  Must be reached by every thread of the block.
+__device__ inline unsigned block_alloc(unsigned *counter, bool want, unsigned *sh) {
+  const unsigned long long mask = __ballot(want);
+  unsigned woff = 0;
+  if (mask) {
+    const int leader = __ffsll((long long)mask) - 1;
+    if ((int)lane_id() == leader) woff = atomicAdd(&sh[0], (unsigned)__popcll(mask));
+    woff = __shfl(woff, leader);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && sh[0]) sh[1] = atomicAdd(counter, sh[0]);
+  __syncthreads();
+  return sh[1] + woff + lanes_below(mask);
 }

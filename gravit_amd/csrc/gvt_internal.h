@@ -25,9 +25,11 @@ struct Ctx {
   bool profile = false;
   int trav_kernel = 1;   // 1 = persistent waves with lane refill (k_trace), 0 = one 64-ray batch at a time (k_closest/k_any)
   int blocks_per_cu = 4; // k_trace grid: resident 256-thread blocks per CU
-  int refill_min = 16;   // k_trace: idle lanes needed before a refill
-  int leaf_min = 24;     // k_trace: lanes waiting at a leaf that trigger a leaf phase
-  int sort_rays = 0; // Morton-sort rays before traversal (adapter-internal; results are order independent)
+  int refill_min = 8;    // k_trace: idle lanes needed before a refill
+  int inner_min = 20;    // k_trace: the inner-node loop is left once fewer lanes than this still descend
+  int sort_rays = 1;
+  int sort_bits = 20;    // radix-sorted key width (8 bits per rocPRIM pass)
+  int top_lds = 1;       // shuffle kernels: aggregate destination counters in LDS per 1024-thread block // Morton-sort rays before traversal (adapter-internal; results are order independent)
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;
   gvt_hip_stats stats{};
@@ -130,6 +132,7 @@ int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, 
                    gvt_hip_hit *d_hits);
 int launch_visit_stats(gvt_hip_mesh *M, RayPlanes q, size_t n, float tnear, unsigned *d_out);
 int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const Mat4 &minv, float tnear, int *d_flags);
+int set_device_u32(unsigned *p, unsigned v); // stream-ordered store of a host-known value
 int convert_aos_to_planes(const gvt_hip_ray *d_src, size_t n, RayPlanes dst, size_t dst_off);
 int convert_planes_to_aos(RayPlanes src, size_t src_off, size_t n, gvt_hip_ray *d_dst);
 int convert_od_to_planes(const float *d_org, const float *d_dir, size_t n, RayPlanes dst);

@@ -5,7 +5,7 @@
 //   tri bounds + scene box  ->  63-bit Morton keys  ->  radix sort (rocPRIM)  ->  Karras 2012 topology
 //   ->  bottom-up box fit (agent-scope release/acquire per level, the per-XCD L2s are not coherent)
 //   ->  collapse subtrees of <= 4 triangles into leaves, compact live nodes (prefix scan)
-//   ->  emit 64-byte nodes (both child boxes in the parent) + 48-byte triangle slots in leaf order.
+//   ->  emit 64-byte nodes (both child boxes in the parent) + 64-byte triangle slots in leaf order.
 // Results of the closest/any-hit queries do not depend on the tree (conservative, padded boxes); only
 // speed does.
 #include <string.h>
@@ -192,9 +192,11 @@ __global__ __launch_bounds__(256) void k_emit_tris(const float *__restrict__ ver
   int a = tris[3 * p], b = tris[3 * p + 1], c = tris[3 * p + 2];
   V3 v0 = ld3(verts + 3 * a), v1 = ld3(verts + 3 * b), v2 = ld3(verts + 3 * c);
   V3 e1 = sub3(v0, v1), e2 = sub3(v2, v0);
-  out[3 * s + 0] = make_float4(v0.x, v0.y, v0.z, __int_as_float((int)p));
-  out[3 * s + 1] = make_float4(e1.x, e1.y, e1.z, 0.f);
-  out[3 * s + 2] = make_float4(e2.x, e2.y, e2.z, 0.f);
+  V3 Ng = cross3(e1, e2); // same float ops as evaluating it per test (no contraction): bit-identical
+  out[4 * s + 0] = make_float4(v0.x, v0.y, v0.z, __int_as_float((int)p));
+  out[4 * s + 1] = make_float4(e1.x, e1.y, e1.z, 0.f);
+  out[4 * s + 2] = make_float4(e2.x, e2.y, e2.z, 0.f);
+  out[4 * s + 3] = make_float4(Ng.x, Ng.y, Ng.z, 0.f);
 }
 
 // n <= GVT_LEAF_MAX: one node, child0 = the only leaf, child1 = empty leaf behind an inverted box
@@ -260,7 +262,7 @@ int build_lbvh(gvt_hip_mesh *M) {
     for (int k = 0; k < 3; k++) { ext = fmaxf(ext, fabsf(M->lo[k])); ext = fmaxf(ext, fabsf(M->hi[k])); }
     pad = ext * 1e-5f; // keeps the slab test conservative w.r.t. the triangle test's rounding
   }
-  OK(dalloc(&M->d_tri, (size_t)3 * n));
+  OK(dalloc(&M->d_tri, (size_t)4 * n));
 
   if (n <= GVT_LEAF_MAX) {
     OK(dalloc(&M->d_nodes, 1));

@@ -47,50 +47,80 @@ __device__ inline float fmax_ref(float a, float b) { return (a > b) ? a : b; }
 
 // per ray: nearest other instance box with tfar>tnear && tnear>eps && t>tnear; instances visited in the
 // reference BVH's leaf order so that equal entry distances resolve identically.
-__global__ __launch_bounds__(256) void k_top_classify(RayPlanes q, unsigned n, const float4 *__restrict__ blo, const float4 *__restrict__ bhi,
-                                                      int n_inst, int from, int *__restrict__ next_out, float *__restrict__ t_out,
-                                                      unsigned *__restrict__ hist) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ inline int top_nearest(const float4 a, const float4 b, const float4 *__restrict__ blo, const float4 *__restrict__ bhi, int n_inst,
+                                  int from, float &ret_t) {
+  const float ox = a.x, oy = a.y, oz = a.z;
+  const float dx = 1.f / b.x, dy = 1.f / b.y, dz = 1.f / b.z;
+  float t = b.w; // ray t_max
   int next = -1;
-  float ret_t = GVT_FLT_MAX;
-  if (i < n) {
-    const float4 a = q.p0[i], b = q.p1[i];
-    const float ox = a.x, oy = a.y, oz = a.z;
-    const float dx = 1.f / b.x, dy = 1.f / b.y, dz = 1.f / b.z;
-    float t = b.w; // ray t_max
-    for (int k = 0; k < n_inst; k++) {
-      const float4 lo = blo[k], hi = bhi[k];
-      const int inst = __float_as_int(lo.w);
-      if (from == inst) continue;
-      const float lx = (lo.x - ox) * dx, ly = (lo.y - oy) * dy, lz = (lo.z - oz) * dz;
-      const float ux = (hi.x - ox) * dx, uy = (hi.y - oy) * dy, uz = (hi.z - oz) * dz;
-      const float minx = fmin_ref(lx, ux), maxx = fmax_ref(lx, ux);
-      const float miny = fmin_ref(ly, uy), maxy = fmax_ref(ly, uy);
-      const float minz = fmin_ref(lz, uz), maxz = fmax_ref(lz, uz);
-      const float tnear = fmax_ref(fmax_ref(minx, miny), minz);
-      const float tfar = fmin_ref(fmin_ref(maxx, maxy), maxz);
-      if (tfar > tnear && tnear > GVT_RAY_EPSILON && t > tnear) {
-        t = tnear;
-        if (ret_t > t) { next = inst; ret_t = t; }
-      }
+  ret_t = GVT_FLT_MAX;
+  for (int k = 0; k < n_inst; k++) {
+    const float4 lo = blo[k], hi = bhi[k];
+    const int inst = __float_as_int(lo.w);
+    if (from == inst) continue;
+    const float lx = (lo.x - ox) * dx, ly = (lo.y - oy) * dy, lz = (lo.z - oz) * dz;
+    const float ux = (hi.x - ox) * dx, uy = (hi.y - oy) * dy, uz = (hi.z - oz) * dz;
+    const float minx = fmin_ref(lx, ux), maxx = fmax_ref(lx, ux);
+    const float miny = fmin_ref(ly, uy), maxy = fmax_ref(ly, uy);
+    const float minz = fmin_ref(lz, uz), maxz = fmax_ref(lz, uz);
+    const float tnear = fmax_ref(fmax_ref(minx, miny), minz);
+    const float tfar = fmin_ref(fmin_ref(maxx, maxy), maxz);
+    if (tfar > tnear && tnear > GVT_RAY_EPSILON && t > tnear) {
+      t = tnear;
+      if (ret_t > t) { next = inst; ret_t = t; }
     }
+  }
+  return next;
+}
+
+// Destination counting and slot allocation are aggregated twice before they reach a global counter: per wave
+// (__ballot over equal destinations) and per 1024-thread block (LDS counters), because one global counter word
+// sustains only ~90 atomics/us chip-wide (2 M rays: 32 K wave-level atomics on one word cost ~0.35 ms).
+#define TOP_BLOCK 1024
+
+__global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RayPlanes q, unsigned n, const float4 *__restrict__ blo, const float4 *__restrict__ bhi,
+                                                            int n_inst, int from, int *__restrict__ next_out, float *__restrict__ t_out,
+                                                            unsigned *__restrict__ hist, int use_lds) {
+  extern __shared__ unsigned sh_cnt[];
+  if (use_lds) {
+    for (int d = threadIdx.x; d < n_inst; d += TOP_BLOCK) sh_cnt[d] = 0u;
+    __syncthreads();
+  }
+  const unsigned i = blockIdx.x * TOP_BLOCK + threadIdx.x;
+  int next = -1;
+  if (i < n) {
+    float ret_t;
+    next = top_nearest(q.p0[i], q.p1[i], blo, bhi, n_inst, from, ret_t);
     next_out[i] = next;
     t_out[i] = ret_t;
   }
-  // histogram of destinations: one atomic per (wave, destination)
   unsigned long long todo = __ballot(next >= 0);
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;
     const int d = __shfl(next, leader);
     const unsigned long long m = __ballot(next == d);
-    if ((int)lane_id() == leader) atomicAdd(&hist[d], (unsigned)__popcll(m));
+    if ((int)lane_id() == leader) {
+      if (use_lds) atomicAdd(&sh_cnt[d], (unsigned)__popcll(m)); else atomicAdd(&hist[d], (unsigned)__popcll(m));
+    }
     todo &= ~m;
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int d = threadIdx.x; d < n_inst; d += TOP_BLOCK)
+      if (sh_cnt[d]) atomicAdd(&hist[d], sh_cnt[d]);
   }
 }
 
-__global__ __launch_bounds__(256) void k_top_scatter(RayPlanes q, unsigned n, const int *__restrict__ next_in, const float *__restrict__ t_in,
-                                                     const QueueDesc *__restrict__ queues, float *__restrict__ fb, unsigned n_pix) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(TOP_BLOCK) void k_top_scatter(RayPlanes q, unsigned n, const int *__restrict__ next_in, const float *__restrict__ t_in,
+                                                           const QueueDesc *__restrict__ queues, int n_inst, float *__restrict__ fb, unsigned n_pix,
+                                                           int use_lds) {
+  extern __shared__ unsigned sh[]; // [0,n_inst): rays of this block per destination, [n_inst,2n_inst): their base slot
+  unsigned *sh_cnt = sh, *sh_base = sh + n_inst;
+  if (use_lds) {
+    for (int d = threadIdx.x; d < n_inst; d += TOP_BLOCK) sh_cnt[d] = 0u;
+    __syncthreads();
+  }
+  const unsigned i = blockIdx.x * TOP_BLOCK + threadIdx.x;
   int next = -1;
   RayRec r;
   if (i < n) {
@@ -107,20 +137,28 @@ __global__ __launch_bounds__(256) void k_top_scatter(RayPlanes q, unsigned n, co
     }
     if (next >= 0 && !queues[next].keep) next = -1; // shuffleDropRays: not this rank's domain
   }
+  unsigned local = 0; // use_lds: offset inside the block's share of the destination; else: final slot
   unsigned long long todo = __ballot(next >= 0);
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;
     const int d = __shfl(next, leader);
     const unsigned long long m = __ballot(next == d);
     unsigned base = 0;
-    if ((int)lane_id() == leader) base = atomicAdd(queues[d].count, (unsigned)__popcll(m));
+    if ((int)lane_id() == leader) base = use_lds ? atomicAdd(&sh_cnt[d], (unsigned)__popcll(m)) : atomicAdd(queues[d].count, (unsigned)__popcll(m));
     base = __shfl(base, leader);
-    if (next == d) {
-      const QueueDesc Q = queues[d];
-      const unsigned slot = base + lanes_below(m);
-      if (slot < Q.cap) store_ray(make_planes(Q.planes, Q.cap), slot, r);
-    }
+    if (next == d) local = base + lanes_below(m);
     todo &= ~m;
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int d = threadIdx.x; d < n_inst; d += TOP_BLOCK)
+      if (sh_cnt[d]) sh_base[d] = atomicAdd(queues[d].count, sh_cnt[d]);
+    __syncthreads();
+    if (next >= 0) local += sh_base[next];
+  }
+  if (next >= 0) {
+    const QueueDesc Q = queues[next];
+    if (local < Q.cap) store_ray(make_planes(Q.planes, Q.cap), local, r);
   }
 }
 
@@ -175,10 +213,7 @@ extern "C" int gvt_hip_camera_generate(gvt_hip_queue *q, const float eye[3], con
   }
   HIPCHK(hipGetLastError());
   q->size = n;
-  unsigned sz = (unsigned)n;
-  HIPCHK(hipMemcpyAsync(q->d_count, &sz, sizeof sz, hipMemcpyHostToDevice, C.stream));
-  HIPCHK(hipStreamSynchronize(C.stream));
-  return 0;
+  return set_device_u32(q->d_count, (unsigned)n);
 }
 
 // ---- top-level BVH order: accel/BVH.cpp:77-216 restated on the host (tiny: <= #domains) ----
@@ -292,21 +327,37 @@ extern "C" int gvt_hip_shuffle(gvt_hip_top *T, gvt_hip_queue *q_in, int from, gv
   if (!d_next || !d_t) return GVT_HIP_ERR_DEVICE;
   RayPlanes in = make_planes(q_in->d_planes, q_in->cap);
   const size_t nI = T->n;
+  const int use_lds = (C.top_lds && nI > 0 && nI <= 4096) ? 1 : 0; // LDS counters per destination; beyond that straight to the global ones
   if (nI) HIPCHK(hipMemsetAsync(T->d_hist, 0, sizeof(unsigned) * nI, st));
   {
     ProfScope ps(KC_SHUFFLE);
-    k_top_classify<<<blocks_for(n), 256, 0, st>>>(in, (unsigned)n, T->d_lo, T->d_hi, (int)nI, from, d_next, d_t, T->d_hist);
+    k_top_classify<<<blocks_for(n, TOP_BLOCK), TOP_BLOCK, use_lds ? sizeof(unsigned) * nI : 0, st>>>(in, (unsigned)n, T->d_lo, T->d_hi, (int)nI, from, d_next,
+                                                                                                    d_t, T->d_hist, use_lds);
   }
   HIPCHK(hipGetLastError());
+  // Exact growth needs the histogram on the host before the scatter.  When every kept queue already has room for all n
+  // rays the scatter is launched right behind the classification and the histogram is read back once, at the end.
   std::vector<unsigned> hist(nI ? nI : 1, 0u);
-  if (nI) HIPCHK(hipMemcpyAsync(hist.data(), T->d_hist, sizeof(unsigned) * nI, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
   std::vector<QueueDesc> desc(nI ? nI : 1);
+  bool roomy = true;
+  for (size_t i = 0; i < nI; i++) {
+    const bool keep = !keep_mask || keep_mask[i];
+    if (!keep) continue;
+    if (nI <= 16 && queues[i]->cap < queues[i]->size + n) { // few domains: worst-case room is cheap next to 288 GB of HBM
+      int rc = queue_reserve(queues[i], queues[i]->size + n);
+      if (rc) return rc;
+    }
+    if (queues[i]->cap < queues[i]->size + n) roomy = false;
+  }
+  if (!roomy) {
+    if (nI) HIPCHK(hipMemcpyAsync(hist.data(), T->d_hist, sizeof(unsigned) * nI, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
   for (size_t i = 0; i < nI; i++) {
     const bool keep = !keep_mask || keep_mask[i];
     gvt_hip_queue *Q = queues[i];
-    if (keep && hist[i]) {
-      int rc = queue_reserve(Q, Q->size + hist[i]);
+    if (!roomy && keep && hist[i]) {
+      int rc = queue_reserve(Q, Q->size + hist[i] + (hist[i] >> 2)); // head-room: later frames take the single-sync path
       if (rc) return rc;
     }
     desc[i].planes = Q->d_planes; desc[i].cap = Q->cap; desc[i].count = Q->d_count; desc[i].keep = keep ? 1u : 0u;
@@ -314,10 +365,11 @@ extern "C" int gvt_hip_shuffle(gvt_hip_top *T, gvt_hip_queue *q_in, int from, gv
   if (nI) HIPCHK(hipMemcpyAsync(T->d_qdesc, desc.data(), sizeof(QueueDesc) * nI, hipMemcpyHostToDevice, st));
   {
     ProfScope ps(KC_SHUFFLE);
-    k_top_scatter<<<blocks_for(n), 256, 0, st>>>(in, (unsigned)n, d_next, d_t, (const QueueDesc *)T->d_qdesc, fb ? fb->d_rgba : nullptr,
-                                                 fb ? (unsigned)(fb->w * fb->h) : 0u);
+    k_top_scatter<<<blocks_for(n, TOP_BLOCK), TOP_BLOCK, use_lds ? 2 * sizeof(unsigned) * nI : 0, st>>>(
+        in, (unsigned)n, d_next, d_t, (const QueueDesc *)T->d_qdesc, (int)nI, fb ? fb->d_rgba : nullptr, fb ? (unsigned)(fb->w * fb->h) : 0u, use_lds);
   }
   HIPCHK(hipGetLastError());
+  if (roomy && nI) HIPCHK(hipMemcpyAsync(hist.data(), T->d_hist, sizeof(unsigned) * nI, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st)); // desc/hist are host vectors
   for (size_t i = 0; i < nI; i++)
     if (desc[i].keep) queues[i]->size += hist[i];

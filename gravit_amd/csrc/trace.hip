@@ -72,7 +72,7 @@ __device__ inline bool traverse(const Trav &T, V3 O, V3 D, float tnear, int *__r
       const unsigned first = code >> 3, ntri = code & 7u;
       if (COUNT) { cnt[1]++; cnt[2] += ntri; }
       for (unsigned k = 0; k < ntri; k++) {
-        const float4 t0 = T.tris[3 * (first + k)], t1 = T.tris[3 * (first + k) + 1], t2 = T.tris[3 * (first + k) + 2];
+        const float4 t0 = T.tris[4 * (first + k)], t1 = T.tris[4 * (first + k) + 1], t2 = T.tris[4 * (first + k) + 2];
         float t, u, v;
         if (tri_test(O, D, mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), tnear, t, u, v)) {
           if (ANY) return true;
@@ -147,7 +147,8 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
 template <bool ANY, bool XFORM, int MODE>
 __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, Trav T, float tnear,
                                                        gvt_hip_hit *__restrict__ hits, int *__restrict__ flags, RayPlanes out, unsigned *out_count,
-                                                       unsigned *counter, int *spill_base, int refill_min, int leaf_min) {
+                                                       unsigned *counter, int *spill_base, int refill_min, int inner_min, const unsigned *__restrict__ n_dev) {
+  if (n_dev) n = *n_dev; // ray count produced by the previous kernel on this stream (no host round trip)
   __shared__ int stack[TRAV_STACK * TRAV_BLOCK];
   int *lds = &stack[threadIdx.x];
   int *spill = spill_base + (size_t)(blockIdx.x * TRAV_BLOCK + threadIdx.x) * TRAV_SPILL;
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
   unsigned j = 0;
   V3 O = mk3(0, 0, 0), D = mk3(0, 0, 1);
   float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0;
-  float bt = GVT_FLT_MAX, bu = 0.f, bv = 0.f;
+  float bt = GVT_FLT_MAX, bu = 0.f, bv = 0.f, bden = 1.f; // bu, bv: un-divided U, V of the best hit; bden its |den|
   int bp = -1, sp = 0, cur = TRAV_DONE;
   for (;;) {
     // ---- refill idle lanes from the wave's private index range
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
           const float dz = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;
           ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
           ox = O.x * ix; oy = O.y * iy; oz = O.z * iz;
-          bt = GVT_FLT_MAX; bu = 0.f; bv = 0.f; bp = -1;
+          bt = GVT_FLT_MAX; bu = 0.f; bv = 0.f; bden = 1.f; bp = -1;
           sp = 0;
           cur = T.nodes ? 0 : TRAV_DONE;
           active = true;
@@ -200,16 +201,12 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
       }
     }
     if (nidle == 64) break; // nothing left in flight and nothing left to fetch
-    // ---- one phase per iteration, chosen for the wave: the leaf phase (several triangle tests, ~4x the cost of an
-    //      inner step) runs once leaf_min lanes wait at a leaf or no lane has an inner node left; otherwise the lanes
-    //      holding an inner node descend one level.  Both phases therefore run at high lane utilisation.
-    const bool at_inner = active && cur >= 0;
-    const bool at_leaf = active && cur < 0 && cur != TRAV_DONE;
-    const int n_leaf = __popcll(__ballot(at_leaf));
-    const bool any_inner = __ballot(at_inner) != 0ull;
-    bool occluded = false;
-    if (any_inner && n_leaf < leaf_min) {
-      if (at_inner) {
+    // ---- inner nodes: the lanes holding one descend level by level in a tight loop; the loop is left as soon as
+    //      fewer than inner_min lanes still descend (the others wait at a leaf, have finished, or are idle), so that
+    //      both this loop and the dearer leaf phase below run at high lane utilisation.
+    unsigned long long im = __ballot(active && cur >= 0);
+    while (im) {
+      if (active && cur >= 0) {
         const BvhNode *nd = T.nodes + cur;
         const float4 n0 = nd->n0, n1 = nd->n1, n2 = nd->n2, n3 = nd->n3;
         float a0 = __builtin_fmaf(n0.x, ix, -ox), a1 = __builtin_fmaf(n0.y, ix, -ox);
@@ -241,16 +238,25 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
           if (sp < TRAV_STACK) cur = lds[sp * TRAV_BLOCK]; else cur = spill[sp - TRAV_STACK];
         }
       }
-    } else if (at_leaf) {
+      im = __ballot(active && cur >= 0);
+      if (__popcll(im) < inner_min) break;
+    }
+    // ---- leaves: every lane waiting at one intersects its triangles (64-byte slots: v0|prim, e1, e2, Ng)
+    if (active && cur < 0 && cur != TRAV_DONE) {
       const unsigned code = (unsigned)~cur;
       const unsigned first = code >> 3, ntri = code & 7u;
+      bool occluded = false;
       for (unsigned k = 0; k < ntri; k++) {
-        const float4 t0 = T.tris[3 * (first + k)], t1 = T.tris[3 * (first + k) + 1], t2 = T.tris[3 * (first + k) + 2];
-        float t, u, v;
-        if (tri_test(O, D, mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), tnear, t, u, v)) {
-          if (ANY) { occluded = true; break; }
-          const int prim = __float_as_int(t0.w);
-          if (bp < 0 || t < bt || (t == bt && prim < bp)) { bt = t; bp = prim; bu = u; bv = v; }
+        const float4 *ts = T.tris + 4 * (size_t)(first + k);
+        const float4 t0 = ts[0], t1 = ts[1], t2 = ts[2], t3 = ts[3];
+        float TT, U, V, aden;
+        if (tri_test_raw(O, D, mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), mk3(t3.x, t3.y, t3.z), tnear, TT, U, V, aden)) {
+          const float t = TT / aden;
+          if (t <= GVT_FLT_MAX) {
+            if (ANY) { occluded = true; break; }
+            const int prim = __float_as_int(t0.w);
+            if (bp < 0 || t < bt || (t == bt && prim < bp)) { bt = t; bp = prim; bu = U; bv = V; bden = aden; }
+          }
         }
       }
       if (ANY && occluded) { cur = TRAV_DONE; bp = 0; }
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
     }
     if (fin) {
       if (ANY) { if (MODE == 0) flags[j] = (bp >= 0) ? 1 : 0; }
-      else { gvt_hip_hit h; h.t = bt; h.prim = bp; h.u = bu; h.v = bv; hits[j] = h; }
+      else { gvt_hip_hit h; h.t = bt; h.prim = bp; h.u = (bp >= 0) ? bu / bden : 0.f; h.v = (bp >= 0) ? bv / bden : 0.f; hits[j] = h; }
       active = false;
     }
   }
@@ -452,7 +458,12 @@ struct ShadeArgs {
   uint32_t seed;
 };
 
-__global__ __launch_bounds__(256) void k_shade(ShadeArgs A, MeshView M) {
+#define SHADE_BLOCK 512
+__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M) {
+  // one LDS (count, base) pair per output list use: moved_rays, next list, one per light
+  __shared__ unsigned sh_alloc[2 * (2 + 64)];
+  for (int k = threadIdx.x; k < 2 * (2 + 64); k += SHADE_BLOCK) sh_alloc[k] = 0u;
+  __syncthreads();
   const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in_range = j < A.n;
   const unsigned i = in_range ? (A.idx ? A.idx[j] : j) : 0u;
@@ -505,7 +516,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs A, MeshView M) {
   }
   // moved_rays: misses are forwarded as they are
   {
-    const unsigned slot = wave_alloc(A.out_count, miss);
+    const unsigned slot = block_alloc(A.out_count, miss, &sh_alloc[0]);
     if (miss) store_ray(A.out, slot, r);
   }
   // generateShadowRays :320-358 -- one pass per light so that the wave allocates slots together
@@ -529,7 +540,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs A, MeshView M) {
         s.id = r.id; s.depth = r.depth; s.w = r.w; s.type = 1;
       }
     }
-    const unsigned slot = wave_alloc(A.shadow_count, emit);
+    const unsigned slot = block_alloc(A.shadow_count, emit, &sh_alloc[2 * (2 + li)]);
     if (emit) store_ray(A.shadow, slot, s);
   }
   if (shaded) { // :584-602
@@ -550,7 +561,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs A, MeshView M) {
     A.rng[i] = g_seed;
   }
   {
-    const unsigned slot = wave_alloc(A.next_count, bounce);
+    const unsigned slot = block_alloc(A.next_count, bounce, &sh_alloc[2]);
     if (bounce) A.next_idx[slot] = i;
   }
 }
@@ -592,7 +603,7 @@ __device__ inline unsigned expand10(unsigned v) {
   return v;
 }
 __global__ __launch_bounds__(256) void k_ray_keys(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, float3 blo, float3 inv_ext,
-                                                   unsigned *__restrict__ keys, unsigned *__restrict__ vals) {
+                                                   unsigned *__restrict__ keys, unsigned *__restrict__ vals, int key_bits) {
   const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const unsigned i = idx ? idx[j] : j;
@@ -605,9 +616,11 @@ __global__ __launch_bounds__(256) void k_ray_keys(RayPlanes q, const unsigned *_
   const unsigned qz = (unsigned)fminf(fmaxf(pz * 1024.f, 0.f), 1023.f);
   const unsigned oct = (D.x < 0.f ? 4u : 0u) | (D.y < 0.f ? 2u : 0u) | (D.z < 0.f ? 1u : 0u);
   const unsigned morton = (expand10(qx) << 2) | (expand10(qy) << 1) | expand10(qz);
-  keys[j] = (oct << 29) | (morton >> 1);
+  keys[j] = ((oct << 29) | (morton >> 1)) >> (32 - key_bits); // top key_bits bits: octant, then the coarsest Morton levels
   vals[j] = i;
 }
+
+__global__ void k_set_u32(unsigned *p, unsigned v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
 
 inline unsigned blocks_for(size_t n, unsigned b = 256) { return (unsigned)((n + b - 1) / b); }
 
@@ -664,8 +677,8 @@ int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, 
     ProfScope ps(KC_CLOSEST);
     RayPlanes none{};
     if (C.trav_kernel == 1) {
-      if (xform) k_trace<false, true, 0><<<trav_grid2(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.leaf_min);
-      else k_trace<false, false, 0><<<trav_grid2(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.leaf_min);
+      if (xform) k_trace<false, true, 0><<<trav_grid2(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr);
+      else k_trace<false, false, 0><<<trav_grid2(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr);
     } else {
       if (xform) k_closest<true><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
       else k_closest<false><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
@@ -698,8 +711,8 @@ int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const M
   {
     ProfScope ps(KC_ANY);
     if (C.trav_kernel == 1) {
-      if (xform) k_trace<true, true, 0><<<trav_grid2(n), TRAV_BLOCK, 0, C.stream>>>(q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.leaf_min);
-      else k_trace<true, false, 0><<<trav_grid2(n), TRAV_BLOCK, 0, C.stream>>>(q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.leaf_min);
+      if (xform) k_trace<true, true, 0><<<trav_grid2(n), TRAV_BLOCK, 0, C.stream>>>(q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr);
+      else k_trace<true, false, 0><<<trav_grid2(n), TRAV_BLOCK, 0, C.stream>>>(q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr);
     } else {
       if (xform) k_any<true, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
       else k_any<false, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
@@ -733,11 +746,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
   RayPlanes shadow = make_planes(d_shadow, shadow_cap);
   RayPlanes outp = make_planes(out->d_planes, out->cap);
   unsigned *c_shadow = C.d_counters + 1, *c_next = C.d_counters + 2;
-  {
-    unsigned sz = (unsigned)out->size;
-    C.h_pinned[8] = sz;
-    HIPCHK(hipMemcpyAsync(out->d_count, &C.h_pinned[8], sizeof(unsigned), hipMemcpyHostToDevice, st));
-  }
+  k_set_u32<<<1, 64, 0, st>>>(out->d_count, (unsigned)out->size);
 
   MeshView mv;
   mv.verts = M->d_verts; mv.tris = M->d_tris; mv.normals = M->d_normals; mv.vcolors = M->d_vcolors;
@@ -760,8 +769,8 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
       const float3 inv = make_float3(ex > 0 ? 1.f / ex : 0.f, ey > 0 ? 1.f / ey : 0.f, ez > 0 ? 1.f / ez : 0.f);
       {
         ProfScope ps(KC_SORT);
-        k_ray_keys<<<blocks_for(n_active), 256, 0, st>>>(in, idx, (unsigned)n_active, P.minv, blo, inv, k_in, v_in);
-        if ((rc = sort_pairs_u32(k_in, k_out, v_in, v_out, n_active, 32))) return rc;
+        k_ray_keys<<<blocks_for(n_active), 256, 0, st>>>(in, idx, (unsigned)n_active, P.minv, blo, inv, k_in, v_in, C.sort_bits);
+        if ((rc = sort_pairs_u32(k_in, k_out, v_in, v_out, n_active, C.sort_bits))) return rc;
       }
       HIPCHK(hipGetLastError());
       idx = v_out;
@@ -776,39 +785,64 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
     A.n_lights = nL; A.seed = P.seed;
     {
       ProfScope ps(KC_SHADE);
-      k_shade<<<blocks_for(n_active), 256, 0, st>>>(A, mv);
+      k_shade<<<blocks_for(n_active, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, mv);
     }
     HIPCHK(hipGetLastError());
     C.stats.rays_shaded += n_active;
-    // counts of this pass: shadow rays to test, rays that bounce
-    HIPCHK(hipMemcpyAsync(C.h_pinned, c_shadow, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const unsigned n_shadow = C.h_pinned[0], n_next = C.h_pinned[1];
-    if (n_shadow) { // traceShadowRays :364-385
-      Trav T{ M->d_nodes, M->d_tri };
-      unsigned *counter = C.d_counters + 0;
-      HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
-      {
-        ProfScope ps(KC_ANY);
-        if (C.trav_kernel == 1)
-          k_trace<true, true, 1><<<trav_grid2(n_shadow), TRAV_BLOCK, 0, st>>>(shadow, nullptr, n_shadow, P.minv, T, GVT_RAY_EPSILON, nullptr, nullptr,
-                                                                               outp, out->d_count, counter, C.d_spill, C.refill_min, C.leaf_min);
-        else
-          k_any<true, 1><<<trav_grid(n_shadow), TRAV_BLOCK, 0, st>>>(shadow, n_shadow, P.minv, T, GVT_RAY_EPSILON, nullptr, outp,
-                                                                      out->d_count, counter, C.d_spill);
+    // traceShadowRays :364-385.  With the persistent kernel the shadow-ray count stays on the device (the kernel reads
+    // it, the grid does not depend on it); the host learns the counts of the pass in ONE read-back afterwards.
+    unsigned n_shadow = 0, n_next = 0;
+    const size_t shadow_ub = n_active * (size_t)nL;
+    if (C.trav_kernel == 1) {
+      if (shadow_ub) {
+        Trav T{ M->d_nodes, M->d_tri };
+        unsigned *counter = C.d_counters + 0;
+        HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
+        {
+          ProfScope ps(KC_ANY);
+          k_trace<true, true, 1><<<trav_grid2(shadow_ub), TRAV_BLOCK, 0, st>>>(shadow, nullptr, 0u, P.minv, T, GVT_RAY_EPSILON, nullptr, nullptr, outp,
+                                                                               out->d_count, counter, C.d_spill, C.refill_min, C.inner_min, c_shadow);
+        }
+        HIPCHK(hipGetLastError());
+        C.stats.launches_any++;
       }
-      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(C.h_pinned, c_shadow, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(C.h_pinned + 2, out->d_count, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      n_shadow = C.h_pinned[0]; n_next = C.h_pinned[1];
       C.stats.rays_any += n_shadow;
-      C.stats.launches_any++;
+    } else {
+      HIPCHK(hipMemcpyAsync(C.h_pinned, c_shadow, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      n_shadow = C.h_pinned[0]; n_next = C.h_pinned[1];
+      if (n_shadow) {
+        Trav T{ M->d_nodes, M->d_tri };
+        unsigned *counter = C.d_counters + 0;
+        HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
+        {
+          ProfScope ps(KC_ANY);
+          k_any<true, 1><<<trav_grid(n_shadow), TRAV_BLOCK, 0, st>>>(shadow, n_shadow, P.minv, T, GVT_RAY_EPSILON, nullptr, outp, out->d_count, counter,
+                                                                      C.d_spill);
+        }
+        HIPCHK(hipGetLastError());
+        C.stats.rays_any += n_shadow;
+        C.stats.launches_any++;
+      }
+      HIPCHK(hipMemcpyAsync(C.h_pinned + 2, out->d_count, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
     }
     n_active = n_next;
     idx = next;
     next = (next == d_idx_a) ? d_idx_b : d_idx_a;
     pass++;
   }
-  HIPCHK(hipMemcpyAsync(C.h_pinned, out->d_count, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  C.stats.rays_forwarded += C.h_pinned[0] - out->size;
-  out->size = C.h_pinned[0];
+  C.stats.rays_forwarded += C.h_pinned[2] - out->size; // read back with the last pass
+  out->size = C.h_pinned[2];
+  return 0;
+}
+
+int set_device_u32(unsigned *p, unsigned v) {
+  k_set_u32<<<1, 64, 0, gctx().stream>>>(p, v);
+  HIPCHK(hipGetLastError());
   return 0;
 }

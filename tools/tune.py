@@ -17,11 +17,12 @@ def run(opts, frames=4):
     capi.synchronize(); dt = (time.perf_counter() - t) / frames
     st = capi.stats(); capi.profile(False)
     return dt * 1e3, st['ms_closest'] / frames, st['ms_any'] / frames, (st['rays_closest'] + st['rays_any']) / frames / dt / 1e6
-configs = [dict(trav_kernel=0, blocks_per_cu=4, refill_min=16, leaf_min=24)]
-for b in (4, 6):
-    for r in (8, 24):
-        for l in (16, 24, 32):
-            configs.append(dict(trav_kernel=1, blocks_per_cu=b, refill_min=r, leaf_min=l))
+configs = []
+for sb in (32, 24, 20, 16, 12):
+    configs.append(dict(trav_kernel=1, blocks_per_cu=4, refill_min=8, inner_min=20, top_lds=1, sort_rays=1, sort_bits=sb))
+configs.append(dict(trav_kernel=1, blocks_per_cu=6, refill_min=8, inner_min=20, top_lds=1, sort_rays=1, sort_bits=24))
+configs.append(dict(trav_kernel=1, blocks_per_cu=4, refill_min=4, inner_min=12, top_lds=1, sort_rays=1, sort_bits=24))
+configs.append(dict(trav_kernel=1, blocks_per_cu=4, refill_min=16, inner_min=32, top_lds=1, sort_rays=1, sort_bits=24))
 res = {}
 for rnd in range(2):
     for c in configs:
@@ -29,6 +30,6 @@ for rnd in range(2):
         res.setdefault(key, []).append(run(c))
 for k, v in res.items():
     a = np.array(v)
-    print(k, 'frame %.3f ms closest %.3f any %.3f  Mrays/s %.0f' % (tuple(a.min(axis=0)[:3]) + (a.max(axis=0)[3],)), flush=True)
+    print(k, 'frame %.3f ms closest %.3f any %.3f  Mrays/s %.0f' % (tuple(a.min(axis=0)[:3]) + (a.max(axis=0)[3],)), 'sort %.3f' % capi.stats()['ms_sort'], flush=True)
 fb = tr().framebuffer(True)
 print('fb checksum', float(fb.sum()))
