@@ -137,7 +137,10 @@ extern "C" int gvt_hip_stats_reset(void) {
 extern "C" int gvt_hip_set_option(const char *name, int value) {
   if (!name) { set_error("set_option: null name"); return GVT_HIP_ERR_INVALID; }
   if (!std::strcmp(name, "sort_rays")) { g_ctx.sort_rays = value; return 0; }
+  if (!std::strcmp(name, "sort_gather")) { g_ctx.sort_gather = value; return 0; }
   if (!std::strcmp(name, "sort_bits")) { if (value < 8 || value > 32) { set_error("sort_bits must be 8..32"); return GVT_HIP_ERR_INVALID; } g_ctx.sort_bits = value; return 0; }
+  if (!std::strcmp(name, "wide4")) { g_ctx.wide4 = value; return 0; }
+  if (!std::strcmp(name, "coop_fetch")) { g_ctx.coop_fetch = value; return 0; }
   if (!std::strcmp(name, "top_lds")) { g_ctx.top_lds = value; return 0; }
   if (!std::strcmp(name, "trav_kernel")) { g_ctx.trav_kernel = value; return 0; }
   if (!std::strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 6) { set_error("blocks_per_cu must be 1..6"); return GVT_HIP_ERR_INVALID; } g_ctx.blocks_per_cu = value; return 0; }
@@ -220,7 +223,7 @@ extern "C" void gvt_hip_mesh_destroy(gvt_hip_mesh *M) {
   if (!M) return;
   if (g_ctx.ready) hipStreamSynchronize(g_ctx.stream);
   hipFree(M->d_verts); hipFree(M->d_tris); hipFree(M->d_normals); hipFree(M->d_vcolors); hipFree(M->d_materials);
-  hipFree(M->d_face_mat); hipFree(M->d_nodes); hipFree(M->d_tri);
+  hipFree(M->d_face_mat); hipFree(M->d_nodes); hipFree(M->d_tri); hipFree(M->d_nodes4);
   delete M;
 }
 
@@ -230,7 +233,7 @@ extern "C" int gvt_hip_mesh_get_info(const gvt_hip_mesh *M, gvt_hip_mesh_info *o
   o->n_tris = M->nT; o->n_verts = M->nV; o->n_nodes = M->nNodes; o->n_leaves = M->nLeaves;
   for (int k = 0; k < 3; k++) { o->bbox_lo[k] = M->lo[k]; o->bbox_hi[k] = M->hi[k]; }
   o->build_ms = M->build_ms; o->max_leaf = GVT_LEAF_MAX;
-  o->bytes_nodes = M->nNodes * sizeof(BvhNode); o->bytes_tris = M->nT * 64;
+  o->bytes_nodes = M->nNodes * sizeof(BvhNode) + M->nNodes4 * 128; o->bytes_tris = M->nT * 64;
   return 0;
 }
 extern "C" int gvt_hip_mesh_get_normals(const gvt_hip_mesh *M, float *out) {
@@ -458,3 +461,6 @@ extern "C" int gvt_hip_visit_stats(gvt_hip_mesh *M, const float *org, const floa
   HIPCHK(hipStreamSynchronize(C.stream));
   return 0;
 }
+
+int debug_stamps(unsigned long long *out, int reset);
+extern "C" int gvt_hip_debug_stamps(unsigned long long *out, int reset) { return debug_stamps(out, reset); }

@@ -27,7 +27,10 @@ struct Ctx {
   int blocks_per_cu = 4; // k_trace grid: resident 256-thread blocks per CU
   int refill_min = 8;    // k_trace: idle lanes needed before a refill
   int inner_min = 20;    // k_trace: the inner-node loop is left once fewer lanes than this still descend
+  int coop_fetch = 0;    // k_trace: quad-cooperative 64-byte fetches (DPP transpose) instead of 4 loads per lane
+  int wide4 = 0;         // k_trace: traverse the 4-wide collapse of the binary tree (half the dependent fetches per ray)
   int sort_rays = 1;
+  int sort_gather = 0;   // after sorting, traverse a contiguous object-space copy (o,d) of the rays
   int sort_bits = 20;    // radix-sorted key width (8 bits per rocPRIM pass)
   int top_lds = 1;       // shuffle kernels: aggregate destination counters in LDS per 1024-thread block // Morton-sort rays before traversal (adapter-internal; results are order independent)
   std::vector<PendingEvent> pending;
@@ -79,7 +82,9 @@ struct gvt_hip_mesh {
   // acceleration structure
   BvhNode *d_nodes = nullptr;
   size_t nNodes = 0;
-  float4 *d_tri = nullptr; // 3 float4 per slot, leaf order
+  float4 *d_tri = nullptr; // 4 float4 per slot, leaf order
+  float4 *d_nodes4 = nullptr; // 4-wide collapse: 8 float4 (128 B) per node
+  size_t nNodes4 = 0;
   size_t nLeaves = 0;
   float lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
   float build_ms = 0.f;
@@ -123,6 +128,7 @@ struct TraceParams {
 
 // lbvh.hip
 int build_lbvh(gvt_hip_mesh *M);
+int build_nodes4(gvt_hip_mesh *M); // lazily, when the wide4 option is on
 int sort_pairs_u32(unsigned *keys_in, unsigned *keys_out, unsigned *vals_in, unsigned *vals_out, size_t n, int end_bit);
 // trace.hip
 int queue_reserve(gvt_hip_queue *q, size_t cap);

@@ -215,6 +215,47 @@ __global__ void k_single_node(const float4 *__restrict__ plo, const float4 *__re
   nodes[0] = nd;
 }
 
+// 4-wide collapse, breadth first: every thread turns one binary node (and its two children) into one 4-wide node,
+// allocates indices for the grandchildren that are inner nodes and queues them for the next level.
+struct Frontier { int b; int idx4; };
+__device__ inline void put_child(float4 *w, int k, float4 lo_hi_xy /*lo.x,hi.x,lo.y,hi.y*/, float lz, float hz, int ref) {
+  ((float *)&w[0])[k] = lo_hi_xy.x; ((float *)&w[1])[k] = lo_hi_xy.y; ((float *)&w[2])[k] = lo_hi_xy.z; ((float *)&w[3])[k] = lo_hi_xy.w;
+  ((float *)&w[4])[k] = lz; ((float *)&w[5])[k] = hz; ((int *)&w[6])[k] = ref;
+}
+__global__ __launch_bounds__(256) void k_collapse4(const BvhNode *__restrict__ nodes, const Frontier *__restrict__ fin, unsigned n_in,
+                                                   Frontier *__restrict__ fout, unsigned *__restrict__ counters /*0: nodes4, 1: next frontier*/,
+                                                   float4 *__restrict__ nodes4) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_in) return;
+  const Frontier f = fin[i];
+  const BvhNode nb = nodes[f.b];
+  float4 w[GVT_NODE4_F4];
+  for (int k = 0; k < GVT_NODE4_F4; k++) w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < 4; k++) put_child(w, k, make_float4(GVT_FLT_MAX, -GVT_FLT_MAX, GVT_FLT_MAX, -GVT_FLT_MAX), GVT_FLT_MAX, -GVT_FLT_MAX, leaf_ref(0u, 0u));
+  int n = 0;
+  for (int side = 0; side < 2; side++) {
+    const int ref = __float_as_int(side ? nb.n3.y : nb.n3.x);
+    if (ref >= 0) { // inner binary child: adopt its two children
+      const BvhNode nc = nodes[ref];
+      for (int s2 = 0; s2 < 2; s2++) {
+        int r2 = __float_as_int(s2 ? nc.n3.y : nc.n3.x);
+        if (r2 >= 0) {
+          const int idx4 = (int)atomicAdd(&counters[0], 1u);
+          const unsigned slot = atomicAdd(&counters[1], 1u);
+          Frontier g; g.b = r2; g.idx4 = idx4;
+          fout[slot] = g;
+          r2 = idx4;
+        }
+        put_child(w, n++, s2 ? nc.n1 : nc.n0, s2 ? nc.n2.z : nc.n2.x, s2 ? nc.n2.w : nc.n2.y, r2);
+      }
+    } else {
+      put_child(w, n++, side ? nb.n1 : nb.n0, side ? nb.n2.z : nb.n2.x, side ? nb.n2.w : nb.n2.y, ref);
+    }
+  }
+  float4 *dst = nodes4 + (size_t)GVT_NODE4_F4 * f.idx4;
+  for (int k = 0; k < GVT_NODE4_F4; k++) dst[k] = w[k];
+}
+
 template <typename T> int dalloc(T **p, size_t n) {
   hipError_t e = hipMalloc((void **)p, sizeof(T) * (n ? n : 1));
   if (e != hipSuccess) { set_error("hipMalloc(%zu B) failed: %s", sizeof(T) * n, hipGetErrorString(e)); return GVT_HIP_ERR_DEVICE; }
@@ -341,4 +382,40 @@ int sort_pairs_u32(unsigned *keys_in, unsigned *keys_out, unsigned *vals_in, uns
   if (!tmp) return GVT_HIP_ERR_DEVICE;
   HIPCHK(rocprim::radix_sort_pairs(tmp, tb, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, C.stream));
   return 0;
+}
+
+// 4-wide collapse of the emitted binary tree (optional traversal layout, built on first use)
+int build_nodes4(gvt_hip_mesh *M) {
+  if (M->d_nodes4 || !M->nNodes) return 0;
+  Ctx &C = gctx();
+  hipStream_t st = C.stream;
+  Frontier *fa = nullptr, *fb = nullptr;
+  unsigned *cnt = nullptr;
+  int rc = dalloc(&M->d_nodes4, (size_t)GVT_NODE4_F4 * M->nNodes);
+  if (!rc) rc = dalloc(&fa, M->nNodes);
+  if (!rc) rc = dalloc(&fb, M->nNodes);
+  if (!rc) rc = dalloc(&cnt, 2);
+  if (!rc) {
+    Frontier root; root.b = 0; root.idx4 = 0;
+    unsigned h[2] = { 1u, 0u };
+    hipError_t e = hipMemcpyAsync(fa, &root, sizeof root, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(cnt, h, sizeof h, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    unsigned n_in = 1;
+    while (e == hipSuccess && n_in) {
+      k_collapse4<<<(n_in + 255) / 256, 256, 0, st>>>(M->d_nodes, fa, n_in, fb, cnt, M->d_nodes4);
+      e = hipMemcpyAsync(h, cnt, sizeof h, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      n_in = h[1];
+      unsigned zero = 0;
+      if (e == hipSuccess) e = hipMemcpyAsync(cnt + 1, &zero, sizeof zero, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      Frontier *t = fa; fa = fb; fb = t;
+    }
+    M->nNodes4 = h[0];
+    if (e != hipSuccess) { set_error("4-wide collapse: %s", hipGetErrorString(e)); rc = GVT_HIP_ERR_DEVICE; }
+  }
+  hipFree(fa); hipFree(fb); hipFree(cnt);
+  if (rc) { hipFree(M->d_nodes4); M->d_nodes4 = nullptr; }
+  return rc;
 }

@@ -20,6 +20,7 @@ namespace {
 struct Trav {
   const BvhNode *__restrict__ nodes;
   const float4 *__restrict__ tris;
+  const float4 *__restrict__ nodes4; // 4-wide collapse (8 float4 per node) or null
 };
 
 template <bool ANY, bool COUNT = false>
@@ -130,6 +131,15 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_closest(RayPlanes q, const unsig
 // all lanes that still have an inner node descend together, then the lanes that reached a leaf intersect
 // their triangles together.  Every wave exits once the counter has passed n and its lanes are empty.
 // ------------------------------------------------------------------------------------------------
+#ifndef GVT_TRI_NG_FROM_SLOT
+#define GVT_TRI_NG_FROM_SLOT 1 // measured: reading 48 of the 64 slot bytes and rebuilding Ng is not faster (same cache line either way)
+#endif
+#ifndef GVT_STAMP
+#define GVT_STAMP 0
+#endif
+#if GVT_STAMP
+__device__ unsigned long long g_stamp[16];
+#endif
 #define TRAV_CHUNK 256
 #define TRAV_DONE ((int)0x80000000) // ~code with count 7: never a valid leaf reference
 
@@ -144,7 +154,7 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
   }
 }
 
-template <bool ANY, bool XFORM, int MODE>
+template <bool ANY, bool XFORM, int MODE, bool COOP, bool W4>
 __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, Trav T, float tnear,
                                                        gvt_hip_hit *__restrict__ hits, int *__restrict__ flags, RayPlanes out, unsigned *out_count,
                                                        unsigned *counter, int *spill_base, int refill_min, int inner_min, const unsigned *__restrict__ n_dev) {
@@ -163,8 +173,14 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
   float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0;
   float bt = GVT_FLT_MAX, bu = 0.f, bv = 0.f, bden = 1.f; // bu, bv: un-divided U, V of the best hit; bden its |den|
   int bp = -1, sp = 0, cur = TRAV_DONE;
+#if GVT_STAMP
+  unsigned long long st_refill = 0, st_inner = 0, st_leaf = 0, st_retire = 0, n_inner_it = 0, n_outer_it = 0, t_mark = 0, t_begin = __builtin_amdgcn_s_memtime();
+#endif
   for (;;) {
     // ---- refill idle lanes from the wave's private index range
+#if GVT_STAMP
+    { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (n_outer_it) st_retire += t_ - t_mark; t_mark = t_; }
+#endif
     unsigned long long idle = __ballot(!active);
     int nidle = __popcll(idle);
     if (!exhausted && (nidle >= refill_min || nidle == 64)) {
@@ -201,14 +217,54 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
       }
     }
     if (nidle == 64) break; // nothing left in flight and nothing left to fetch
+#if GVT_STAMP
+    { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_refill += t_ - t_mark; t_mark = t_; n_outer_it++; }
+#endif
     // ---- inner nodes: the lanes holding one descend level by level in a tight loop; the loop is left as soon as
     //      fewer than inner_min lanes still descend (the others wait at a leaf, have finished, or are idle), so that
     //      both this loop and the dearer leaf phase below run at high lane utilisation.
     unsigned long long im = __ballot(active && cur >= 0);
     while (im) {
-      if (active && cur >= 0) {
-        const BvhNode *nd = T.nodes + cur;
-        const float4 n0 = nd->n0, n1 = nd->n1, n2 = nd->n2, n3 = nd->n3;
+      const bool at_inner = active && cur >= 0;
+      if (W4) {
+        if (at_inner) { // one fetch decides two levels of the binary tree: 4 child boxes, nearest first
+          const float4 *nd = T.nodes4 + (size_t)GVT_NODE4_F4 * cur;
+          const float4 lx = nd[0], hx = nd[1], ly = nd[2], hy = nd[3], lz = nd[4], hz = nd[5], rf = nd[6];
+          const float lim = ANY ? GVT_FLT_MAX : bt;
+          float tn[4];
+          int rr[4];
+#define GVT_SLAB4(C, LX, HX, LY, HY, LZ, HZ, RF)                                                                         \
+          {                                                                                                              \
+            const float a0 = __builtin_fmaf(LX, ix, -ox), a1 = __builtin_fmaf(HX, ix, -ox);                              \
+            const float b0 = __builtin_fmaf(LY, iy, -oy), b1 = __builtin_fmaf(HY, iy, -oy);                              \
+            const float c0 = __builtin_fmaf(LZ, iz, -oz), c1 = __builtin_fmaf(HZ, iz, -oz);                              \
+            const float n_ = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.f));                      \
+            const float f_ = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1)) * 1.0000004f;                     \
+            tn[C] = ((n_ <= f_) && (n_ <= lim)) ? n_ : GVT_FLT_MAX; /* a miss sorts last; entry distances are < FLT_MAX */ \
+            rr[C] = __float_as_int(RF);                                                                                  \
+          }
+          GVT_SLAB4(0, lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, rf.x)
+          GVT_SLAB4(1, lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, rf.y)
+          GVT_SLAB4(2, lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, rf.z)
+          GVT_SLAB4(3, lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, rf.w)
+#undef GVT_SLAB4
+#define GVT_CE(A, B) { const bool sw_ = tn[B] < tn[A]; const float ta_ = sw_ ? tn[B] : tn[A], tb_ = sw_ ? tn[A] : tn[B]; \
+                       const int ra_ = sw_ ? rr[B] : rr[A], rb_ = sw_ ? rr[A] : rr[B]; tn[A] = ta_; tn[B] = tb_; rr[A] = ra_; rr[B] = rb_; }
+          GVT_CE(0, 1) GVT_CE(2, 3) GVT_CE(0, 2) GVT_CE(1, 3) GVT_CE(1, 2)
+#undef GVT_CE
+          // hits are now tn[0] <= tn[1] <= ...; push the farther ones farthest first, continue with the nearest
+          if (tn[3] < GVT_FLT_MAX) { if (sp < TRAV_STACK) lds[sp * TRAV_BLOCK] = rr[3]; else spill[sp - TRAV_STACK] = rr[3]; sp++; }
+          if (tn[2] < GVT_FLT_MAX) { if (sp < TRAV_STACK) lds[sp * TRAV_BLOCK] = rr[2]; else spill[sp - TRAV_STACK] = rr[2]; sp++; }
+          if (tn[1] < GVT_FLT_MAX) { if (sp < TRAV_STACK) lds[sp * TRAV_BLOCK] = rr[1]; else spill[sp - TRAV_STACK] = rr[1]; sp++; }
+          if (tn[0] < GVT_FLT_MAX) cur = rr[0];
+          else if (sp == 0) cur = TRAV_DONE;
+          else { sp--; if (sp < TRAV_STACK) cur = lds[sp * TRAV_BLOCK]; else cur = spill[sp - TRAV_STACK]; }
+        }
+      } else {
+      float4 n0, n1, n2, n3;
+      if (COOP) quad_fetch64((const float4 *)T.nodes, (unsigned)cur, at_inner, n0, n1, n2, n3);
+      if (at_inner) {
+        if (!COOP) { const BvhNode *nd = T.nodes + cur; n0 = nd->n0; n1 = nd->n1; n2 = nd->n2; n3 = nd->n3; }
         float a0 = __builtin_fmaf(n0.x, ix, -ox), a1 = __builtin_fmaf(n0.y, ix, -ox);
         float b0 = __builtin_fmaf(n0.z, iy, -oy), b1 = __builtin_fmaf(n0.w, iy, -oy);
         float c0 = __builtin_fmaf(n2.x, iz, -oz), c1 = __builtin_fmaf(n2.y, iz, -oz);
@@ -238,34 +294,89 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
           if (sp < TRAV_STACK) cur = lds[sp * TRAV_BLOCK]; else cur = spill[sp - TRAV_STACK];
         }
       }
+      }
+#if GVT_STAMP
+      n_inner_it++;
+#endif
       im = __ballot(active && cur >= 0);
       if (__popcll(im) < inner_min) break;
     }
-    // ---- leaves: every lane waiting at one intersects its triangles (64-byte slots: v0|prim, e1, e2, Ng)
-    if (active && cur < 0 && cur != TRAV_DONE) {
-      const unsigned code = (unsigned)~cur;
-      const unsigned first = code >> 3, ntri = code & 7u;
-      bool occluded = false;
-      for (unsigned k = 0; k < ntri; k++) {
-        const float4 *ts = T.tris + 4 * (size_t)(first + k);
-        const float4 t0 = ts[0], t1 = ts[1], t2 = ts[2], t3 = ts[3];
-        float TT, U, V, aden;
-        if (tri_test_raw(O, D, mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), mk3(t3.x, t3.y, t3.z), tnear, TT, U, V, aden)) {
-          const float t = TT / aden;
-          if (t <= GVT_FLT_MAX) {
-            if (ANY) { occluded = true; break; }
-            const int prim = __float_as_int(t0.w);
-            if (bp < 0 || t < bt || (t == bt && prim < bp)) { bt = t; bp = prim; bu = U; bv = V; bden = aden; }
+#if GVT_STAMP
+    { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_inner += t_ - t_mark; t_mark = t_; }
+#endif
+    // ---- leaves: every lane waiting at one intersects its triangles (64-byte slots: v0|prim, e1, e2, Ng).
+    //      Measured with s_memtime stamps: a leaf phase that fetches and tests one triangle after the other costs ~6 K
+    //      cycles (four dependent round trips at the loaded memory latency), an inner step ~1.9 K.  So the triangles are
+    //      fetched two per round trip (48 of the 64 slot bytes each; fetching all four at once needs > 128 VGPRs and costs
+    //      a wave per SIMD).
+    {
+      const bool at_leaf = active && cur < 0 && cur != TRAV_DONE;
+      if (COOP) {
+        const unsigned code = at_leaf ? (unsigned)~cur : 0u;
+        const unsigned first = code >> 3, ntri = code & 7u;
+        bool occluded = false;
+        for (unsigned k = 0; k < GVT_LEAF_MAX; k++) {
+          const bool want = at_leaf && k < ntri && !occluded;
+          if (!__ballot(want)) break;
+          float4 t0, t1, t2, t3;
+          quad_fetch64(T.tris, first + k, want, t0, t1, t2, t3);
+          if (want) {
+            float TT, U, V, aden;
+            if (tri_test_raw(O, D, mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), mk3(t3.x, t3.y, t3.z), tnear, TT, U, V, aden)) {
+              const float t = TT / aden;
+              if (t <= GVT_FLT_MAX) {
+                if (ANY) occluded = true;
+                else {
+                  const int prim = __float_as_int(t0.w);
+                  if (bp < 0 || t < bt || (t == bt && prim < bp)) { bt = t; bp = prim; bu = U; bv = V; bden = aden; }
+                }
+              }
+            }
           }
         }
+        if (at_leaf && ANY && occluded) bp = 0;
+      } else if (at_leaf) {
+        const unsigned code = (unsigned)~cur;
+        const unsigned first = code >> 3, ntri = code & 7u;
+        const float4 *ts = T.tris + 4 * (size_t)first;
+        bool occluded = false;
+        for (unsigned kb = 0; kb < ntri && !(ANY && occluded); kb += 2) { // two triangles per round trip
+          float4 s0[2], s1[2], s2[2];
+#pragma unroll
+          for (unsigned k = 0; k < 2; k++)
+            if (kb + k < ntri) { s0[k] = ts[4 * (kb + k)]; s1[k] = ts[4 * (kb + k) + 1]; s2[k] = ts[4 * (kb + k) + 2]; }
+#pragma unroll
+          for (unsigned k = 0; k < 2; k++) {
+            if (kb + k < ntri && !(ANY && occluded)) {
+              const V3 e1 = mk3(s1[k].x, s1[k].y, s1[k].z), e2 = mk3(s2[k].x, s2[k].y, s2[k].z);
+              float TT, U, V, aden;
+              if (tri_test_raw(O, D, mk3(s0[k].x, s0[k].y, s0[k].z), e1, e2, cross3(e1, e2), tnear, TT, U, V, aden)) {
+                const float t = TT / aden;
+                if (t <= GVT_FLT_MAX) {
+                  if (ANY) occluded = true;
+                  else {
+                    const int prim = __float_as_int(s0[k].w);
+                    if (bp < 0 || t < bt || (t == bt && prim < bp)) { bt = t; bp = prim; bu = U; bv = V; bden = aden; }
+                  }
+                }
+              }
+            }
+          }
+        }
+        if (ANY && occluded) bp = 0;
       }
-      if (ANY && occluded) { cur = TRAV_DONE; bp = 0; }
-      else if (sp == 0) cur = TRAV_DONE;
-      else {
-        sp--;
-        if (sp < TRAV_STACK) cur = lds[sp * TRAV_BLOCK]; else cur = spill[sp - TRAV_STACK];
+      if (at_leaf) {
+        if (ANY && bp == 0) cur = TRAV_DONE;
+        else if (sp == 0) cur = TRAV_DONE;
+        else {
+          sp--;
+          if (sp < TRAV_STACK) cur = lds[sp * TRAV_BLOCK]; else cur = spill[sp - TRAV_STACK];
+        }
       }
     }
+#if GVT_STAMP
+    { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_leaf += t_ - t_mark; t_mark = t_; }
+#endif
     // ---- retire finished rays
     const bool fin = active && cur == TRAV_DONE;
     if (ANY && MODE == 1) {
@@ -286,6 +397,9 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
       active = false;
     }
   }
+#if GVT_STAMP
+  if (lane_id() == 0) { atomicAdd(&g_stamp[0], st_refill); atomicAdd(&g_stamp[1], st_inner); atomicAdd(&g_stamp[2], st_leaf); atomicAdd(&g_stamp[3], st_retire); atomicAdd(&g_stamp[4], n_inner_it); atomicAdd(&g_stamp[5], n_outer_it); atomicAdd(&g_stamp[6], 1ull); atomicAdd(&g_stamp[7], (unsigned long long)__builtin_amdgcn_s_memtime() - t_begin); }
+#endif
   if (ANY && MODE == 1) { if (n_pend) flush_pending(pend, n_pend, q, out, out_count); }
 }
 
@@ -622,12 +736,32 @@ __global__ __launch_bounds__(256) void k_ray_keys(RayPlanes q, const unsigned *_
 
 __global__ void k_set_u32(unsigned *p, unsigned v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
 
+// after the sort: object-space origin/direction of the rays in sorted order, as two contiguous planes, so that the
+// traversal kernel's lane refills read consecutive memory (the transform is the one k_trace<XFORM> would apply)
+__global__ __launch_bounds__(256) void k_gather_od(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, float4 *__restrict__ o_out,
+                                                    float4 *__restrict__ d_out) {
+  const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const unsigned i = idx[j];
+  const float4 a = q.p0[i], b = q.p1[i];
+  const V3 O = xfm_point(minv, mk3(a.x, a.y, a.z)), D = xfm_vector(minv, mk3(b.x, b.y, b.z));
+  o_out[j] = make_float4(O.x, O.y, O.z, a.w);
+  d_out[j] = make_float4(D.x, D.y, D.z, b.w);
+}
+
 inline unsigned blocks_for(size_t n, unsigned b = 256) { return (unsigned)((n + b - 1) / b); }
 
 int trav_grid(size_t n) {
   Ctx &C = gctx();
   size_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
   return (int)(need < (size_t)C.trav_blocks ? (need ? need : 1) : (size_t)C.trav_blocks);
+}
+
+static bool g_have_nodes4 = false; // set by the launchers from the mesh being traced
+template <bool ANY, bool XFORM, int MODE, typename... Args> void launch_trace(int grid, hipStream_t st, Args... args) {
+  if (gctx().wide4 && g_have_nodes4) k_trace<ANY, XFORM, MODE, false, true><<<grid, TRAV_BLOCK, 0, st>>>(args...);
+  else if (gctx().coop_fetch) k_trace<ANY, XFORM, MODE, true, false><<<grid, TRAV_BLOCK, 0, st>>>(args...);
+  else k_trace<ANY, XFORM, MODE, false, false><<<grid, TRAV_BLOCK, 0, st>>>(args...);
 }
 
 // persistent-wave kernel: fewer, longer-lived waves so that every lane is refilled several times
@@ -641,6 +775,17 @@ int trav_grid2(size_t n) {
 
 } // namespace
 
+int debug_stamps(unsigned long long *out, int reset) {
+#if GVT_STAMP
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = { 0 }; hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof z); }
+  return 0;
+#else
+  for (int i = 0; i < 16; i++) out[i] = 0;
+  return -1;
+#endif
+}
 size_t trav_spill_ints_per_thread() { return TRAV_SPILL; }
 int trav_block_threads() { return TRAV_BLOCK; }
 
@@ -670,15 +815,17 @@ int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, 
                    gvt_hip_hit *d_hits) {
   if (!n) return 0;
   Ctx &C = gctx();
-  Trav T{ M->d_nodes, M->d_tri };
+  if (gctx().wide4 && !M->d_nodes4) { int rc4 = build_nodes4(M); if (rc4) return rc4; }
+  g_have_nodes4 = M->d_nodes4 != nullptr;
+  Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
   unsigned *counter = C.d_counters + 0;
   HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), C.stream));
   {
     ProfScope ps(KC_CLOSEST);
     RayPlanes none{};
     if (C.trav_kernel == 1) {
-      if (xform) k_trace<false, true, 0><<<trav_grid2(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr);
-      else k_trace<false, false, 0><<<trav_grid2(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr);
+      if (xform) launch_trace<false, true, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr);
+      else launch_trace<false, false, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr);
     } else {
       if (xform) k_closest<true><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
       else k_closest<false><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
@@ -693,7 +840,9 @@ int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, 
 int launch_visit_stats(gvt_hip_mesh *M, RayPlanes q, size_t n, float tnear, unsigned *d_out) {
   if (!n) return 0;
   Ctx &C = gctx();
-  Trav T{ M->d_nodes, M->d_tri };
+  if (gctx().wide4 && !M->d_nodes4) { int rc4 = build_nodes4(M); if (rc4) return rc4; }
+  g_have_nodes4 = M->d_nodes4 != nullptr;
+  Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
   unsigned *counter = C.d_counters + 0;
   HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), C.stream));
   k_visit_stats<<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, T, tnear, d_out, counter, C.d_spill);
@@ -704,15 +853,17 @@ int launch_visit_stats(gvt_hip_mesh *M, RayPlanes q, size_t n, float tnear, unsi
 int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const Mat4 &minv, float tnear, int *d_flags) {
   if (!n) return 0;
   Ctx &C = gctx();
-  Trav T{ M->d_nodes, M->d_tri };
+  if (gctx().wide4 && !M->d_nodes4) { int rc4 = build_nodes4(M); if (rc4) return rc4; }
+  g_have_nodes4 = M->d_nodes4 != nullptr;
+  Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
   unsigned *counter = C.d_counters + 0;
   HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), C.stream));
   RayPlanes none{};
   {
     ProfScope ps(KC_ANY);
     if (C.trav_kernel == 1) {
-      if (xform) k_trace<true, true, 0><<<trav_grid2(n), TRAV_BLOCK, 0, C.stream>>>(q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr);
-      else k_trace<true, false, 0><<<trav_grid2(n), TRAV_BLOCK, 0, C.stream>>>(q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr);
+      if (xform) launch_trace<true, true, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr);
+      else launch_trace<true, false, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr);
     } else {
       if (xform) k_any<true, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
       else k_any<false, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
@@ -775,7 +926,18 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
       HIPCHK(hipGetLastError());
       idx = v_out;
     }
-    rc = launch_closest(M, in, idx, n_active, true, P.minv, GVT_RAY_EPSILON, d_hits);
+    if (idx && C.sort_rays && C.sort_gather && n_active >= 8192) {
+      float4 *od = (float4 *)scratch_get(13, sizeof(float4) * 2 * n);
+      if (!od) return GVT_HIP_ERR_DEVICE;
+      {
+        ProfScope ps(KC_SORT);
+        k_gather_od<<<blocks_for(n_active), 256, 0, st>>>(in, idx, (unsigned)n_active, P.minv, od, od + n);
+      }
+      HIPCHK(hipGetLastError());
+      RayPlanes sorted{ od, od + n, nullptr, nullptr };
+      rc = launch_closest(M, sorted, nullptr, n_active, false, P.minv, GVT_RAY_EPSILON, d_hits);
+    } else
+      rc = launch_closest(M, in, idx, n_active, true, P.minv, GVT_RAY_EPSILON, d_hits);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(c_shadow, 0, 2 * sizeof(unsigned), st)); // c_shadow, c_next adjacent
     ShadeArgs A;
@@ -795,12 +957,13 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
     const size_t shadow_ub = n_active * (size_t)nL;
     if (C.trav_kernel == 1) {
       if (shadow_ub) {
-        Trav T{ M->d_nodes, M->d_tri };
+  g_have_nodes4 = M->d_nodes4 != nullptr;
+  Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
         unsigned *counter = C.d_counters + 0;
         HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
         {
           ProfScope ps(KC_ANY);
-          k_trace<true, true, 1><<<trav_grid2(shadow_ub), TRAV_BLOCK, 0, st>>>(shadow, nullptr, 0u, P.minv, T, GVT_RAY_EPSILON, nullptr, nullptr, outp,
+          launch_trace<true, true, 1>(trav_grid2(shadow_ub), st, shadow, nullptr, 0u, P.minv, T, GVT_RAY_EPSILON, nullptr, nullptr, outp,
                                                                                out->d_count, counter, C.d_spill, C.refill_min, C.inner_min, c_shadow);
         }
         HIPCHK(hipGetLastError());
@@ -816,7 +979,8 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
       HIPCHK(hipStreamSynchronize(st));
       n_shadow = C.h_pinned[0]; n_next = C.h_pinned[1];
       if (n_shadow) {
-        Trav T{ M->d_nodes, M->d_tri };
+  g_have_nodes4 = M->d_nodes4 != nullptr;
+  Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
         unsigned *counter = C.d_counters + 0;
         HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
         {

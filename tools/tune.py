@@ -18,11 +18,9 @@ def run(opts, frames=4):
     st = capi.stats(); capi.profile(False)
     return dt * 1e3, st['ms_closest'] / frames, st['ms_any'] / frames, (st['rays_closest'] + st['rays_any']) / frames / dt / 1e6
 configs = []
-for sb in (32, 24, 20, 16, 12):
-    configs.append(dict(trav_kernel=1, blocks_per_cu=4, refill_min=8, inner_min=20, top_lds=1, sort_rays=1, sort_bits=sb))
-configs.append(dict(trav_kernel=1, blocks_per_cu=6, refill_min=8, inner_min=20, top_lds=1, sort_rays=1, sort_bits=24))
-configs.append(dict(trav_kernel=1, blocks_per_cu=4, refill_min=4, inner_min=12, top_lds=1, sort_rays=1, sort_bits=24))
-configs.append(dict(trav_kernel=1, blocks_per_cu=4, refill_min=16, inner_min=32, top_lds=1, sort_rays=1, sort_bits=24))
+for sg in (0, 1):
+    for (r, i) in ((8, 20), (16, 32), (24, 40)):
+        configs.append(dict(trav_kernel=1, blocks_per_cu=4, refill_min=r, inner_min=i, sort_gather=sg))
 res = {}
 for rnd in range(2):
     for c in configs:
