@@ -62,7 +62,7 @@ def main():
                 e[1] += 1
     summary = {}
     for k, cs in pmc.items():
-        if not any(s in k for s in ("k_closest", "k_any", "k_shade", "k_top", "k_camera", "k_planes", "k_aos")):
+        if not any(s in k for s in ("k_trace", "k_closest", "k_any", "k_shade", "k_top", "k_camera", "k_planes", "k_aos", "k_ray_keys")):
             continue
         e = {c: {"sum": v[0], "launches": v[1], "per_launch": v[0] / max(1, v[1])} for c, v in cs.items()}
         e["resources"] = regs.get(k, {})
@@ -79,6 +79,20 @@ def main():
             h, m = e["TCC_HIT_sum"]["sum"], e["TCC_MISS_sum"]["sum"]
             e["l2_hit_rate"] = h / max(1.0, h + m)
         summary[k] = e
+    # HBM traffic per launch of the two traversal kernels, for bench.py's roofline.traffic (PMC passes are separate runs
+    # of the same command; FETCH_SIZE/WRITE_SIZE are in KiB; the x2 wide-load correction of the guide does not apply to
+    # these 16-byte-per-lane gathers, so the raw value is used and flagged as uncalibrated for this access pattern)
+    traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE over `bench.py --steps 5 --warmup 2`, tag %s" % tag,
+               "note": "bytes = (FETCH_SIZE + WRITE_SIZE) * 1024 per launch; FETCH_SIZE uncorrected (gather pattern, uncalibrated)"}
+    for k, e in summary.items():
+        if k.startswith("k_trace<false") and "hbm_read_bytes_per_launch_raw" in e and "hbm_write_bytes_per_launch" in e:
+            traffic["k_closest_bytes_per_launch"] = e["hbm_read_bytes_per_launch_raw"] + e["hbm_write_bytes_per_launch"]
+            traffic["k_closest_kernel"] = k
+        if k.startswith("k_trace<true") and "hbm_read_bytes_per_launch_raw" in e and "hbm_write_bytes_per_launch" in e:
+            traffic["k_any_bytes_per_launch"] = e["hbm_read_bytes_per_launch_raw"] + e["hbm_write_bytes_per_launch"]
+            traffic["k_any_kernel"] = k
+    if len(traffic) > 2:
+        json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1, sort_keys=True)
     out_pmc = os.path.join(ROOT, "profiles", "%s_pmc.json" % tag)
     json.dump(summary, open(out_pmc, "w"), indent=1, sort_keys=True)
     print("pmc ->", out_pmc)
