@@ -140,7 +140,9 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_closest(RayPlanes q, const unsig
 #if GVT_STAMP
 __device__ unsigned long long g_stamp[16];
 #endif
+#ifndef TRAV_CHUNK
 #define TRAV_CHUNK 256
+#endif
 #define TRAV_DONE ((int)0x80000000) // ~code with count 7: never a valid leaf reference
 
 // copies the rays whose indices are parked in the wave's LDS list to consecutive slots of `out`
