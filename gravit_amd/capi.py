@@ -22,7 +22,7 @@ SYMBOLS = [
     "gvt_hip_top_create", "gvt_hip_top_destroy", "gvt_hip_top_order", "gvt_hip_shuffle", "gvt_hip_queue_sizes",
     "gvt_hip_fb_create", "gvt_hip_fb_destroy", "gvt_hip_fb_clear", "gvt_hip_fb_download", "gvt_hip_fb_device_ptr",
     "gvt_hip_fb_write_ppm_bytes",
-    "gvt_hip_profile", "gvt_hip_stats_read", "gvt_hip_stats_reset", "gvt_hip_set_option", "gvt_hip_visit_stats",
+    "gvt_hip_profile", "gvt_hip_stats_read", "gvt_hip_stats_reset", "gvt_hip_set_option", "gvt_hip_visit_stats", "gvt_hip_image_frame",
 ]
 
 
@@ -34,6 +34,11 @@ class MeshInfo(C.Structure):
     _fields_ = [("n_tris", C.c_uint64), ("n_verts", C.c_uint64), ("n_nodes", C.c_uint64), ("n_leaves", C.c_uint64),
                 ("bbox_lo", C.c_float * 3), ("bbox_hi", C.c_float * 3), ("build_ms", C.c_float), ("max_leaf", C.c_uint32),
                 ("pad", C.c_uint32), ("bytes_nodes", C.c_uint64), ("bytes_tris", C.c_uint64)]
+
+
+class CameraPod(C.Structure):
+    _fields_ = [("eye", C.c_float * 3), ("focus", C.c_float * 3), ("up", C.c_float * 3), ("fov", C.c_float), ("width", C.c_int32),
+                ("height", C.c_int32), ("samples", C.c_int32), ("depth", C.c_int32), ("jitter_window_size", C.c_float)]
 
 
 class Stats(C.Structure):

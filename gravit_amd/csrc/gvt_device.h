@@ -108,7 +108,9 @@ __device__ inline void store_ray(const RayPlanes &q, size_t i, const RayRec &r) 
 struct BvhNode {
   float4 n0, n1, n2, n3;
 };
-#define GVT_LEAF_MAX 4
+#ifndef GVT_LEAF_MAX
+#define GVT_LEAF_MAX 2 // measured 1..6 on the 10 M soup: 1-3 within noise (0.90-0.92 ms closest), 4: 0.96, 6: 1.05
+#endif
 // 4-wide node (128 B = 8 float4), the collapse of a binary node with its two children: child boxes as structure of arrays
 //   w[0] = lo.x[4]  w[1] = hi.x[4]  w[2] = lo.y[4]  w[3] = hi.y[4]  w[4] = lo.z[4]  w[5] = hi.z[4]  w[6] = refs[4] (bit-cast)  w[7] unused
 // refs as in the binary node (>= 0 inner 4-wide node, < 0 leaf); unused slots carry an inverted box and an empty leaf.

@@ -426,3 +426,35 @@ extern "C" int gvt_hip_fb_write_ppm_bytes(gvt_hip_fb *F, unsigned char *rgb) {
     }
   return 0;
 }
+
+// ---- Tracer<ImageScheduler>::operator() (algorithm/ImageTracer.h:127-269), one rank, native loop ----
+extern "C" int gvt_hip_image_frame(gvt_hip_top *T, gvt_hip_mesh *const *meshes, const float *m, const float *minv, const float *normi, size_t n_inst,
+                                   const gvt_hip_light *lights, size_t n_lights, int normal_mode, const gvt_hip_camera *cam,
+                                   gvt_hip_queue *const *queues, gvt_hip_queue *q_cam, gvt_hip_queue *q_moved, gvt_hip_fb *fb, uint64_t *adapter_calls) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!T || !cam || !q_cam || !q_moved || !fb || (n_inst && (!meshes || !m || !minv || !normi || !queues)) || T->n != n_inst) {
+    set_error("image_frame: null or inconsistent argument");
+    return GVT_HIP_ERR_INVALID;
+  }
+  int rc;
+  if ((rc = gvt_hip_fb_clear(fb))) return rc;                                              // clearBuffer :142
+  for (size_t i = 0; i < n_inst; i++) if ((rc = gvt_hip_queue_clear(queues[i]))) return rc;
+  if ((rc = gvt_hip_queue_clear(q_moved))) return rc;
+  if ((rc = gvt_hip_camera_generate(q_cam, cam->eye, cam->focus, cam->up, cam->fov, cam->width, cam->height, cam->samples, cam->depth,
+                                    cam->jitter_window_size))) return rc;
+  if ((rc = gvt_hip_shuffle(T, q_cam, -1, queues, nullptr, fb))) return rc;                // FilterRaysLocally :146
+  uint64_t calls = 0;
+  for (;;) {                                                                               // do { ... } while (instTarget != -1) :159-259
+    int target = -1;
+    size_t cnt = 0;
+    for (size_t i = 0; i < n_inst; i++)
+      if (queues[i]->size > cnt) { cnt = queues[i]->size; target = (int)i; }
+    if (target < 0) break;
+    if ((rc = gvt_hip_trace_queue(meshes[target], queues[target], q_moved, m + 16 * (size_t)target, minv + 16 * (size_t)target,
+                                  normi + 9 * (size_t)target, lights, n_lights, normal_mode, (uint32_t)calls))) return rc;
+    calls++;
+    if ((rc = gvt_hip_shuffle(T, q_moved, target, queues, nullptr, fb))) return rc;        // shuffleRays(moved_rays, instTarget) :252
+  }
+  if (adapter_calls) *adapter_calls = calls;
+  return 0;
+}

@@ -63,6 +63,24 @@ class HipBackend:
     def queue_sizes(self):
         return [len(q) for q in self.queues]
 
+    def image_frame(self):
+        """Tracer<ImageScheduler>::operator() run natively inside the library (gvt_hip_image_frame); returns the number of adapter calls."""
+        import ctypes as C
+
+        s = self.scene
+        cam = s.camera
+        pod = capi.CameraPod((C.c_float * 3)(*cam.eye), (C.c_float * 3)(*cam.focus), (C.c_float * 3)(*cam.up), cam.fov, cam.width, cam.height,
+                             cam.samples, cam.depth, cam.jitter)
+        meshes = (C.c_void_p * max(1, self.n_inst))(*[self.adapter(i).h for i in range(self.n_inst)])
+        queues = (C.c_void_p * max(1, self.n_inst))(*[q.h for q in self.queues])
+        lights = np.ascontiguousarray(s.lights)
+        calls = C.c_uint64(0)
+        capi.check(capi.load().gvt_hip_image_frame(
+            self.top.h, meshes, capi.ptr(capi.f32(s.m)), capi.ptr(capi.f32(s.minv)), capi.ptr(capi.f32(s.normi)), C.c_size_t(self.n_inst),
+            capi.ptr(lights), C.c_size_t(len(lights)), C.c_int(self.normal_mode), C.byref(pod), queues, self.q_cam.h, self.q_moved.h, self.fb.h,
+            C.byref(calls)), "gvt_hip_image_frame")
+        return calls.value
+
     def trace_and_shuffle(self, inst):
         s = self.scene
         self.adapter(inst).trace_queue(self.queues[inst], self.q_moved, s.m[inst], s.minv[inst], s.normi[inst], s.lights, seed=self.calls)
@@ -116,12 +134,16 @@ def _pick_fullest(sizes, allowed=None):
 class ImageTracer:
     """Tracer<ImageScheduler>, one rank (ImageTracer.h:127-269)."""
 
-    def __init__(self, scene, normal_mode=NORMALS_FLAT, backend=None):
+    def __init__(self, scene, normal_mode=NORMALS_FLAT, backend=None, native=True):
         self.backend = backend or HipBackend(scene, normal_mode)
         self.adapter_calls = 0
+        self.native = native  # run the loop natively (gvt_hip_image_frame) when the backend offers it
 
     def __call__(self):
         B = self.backend
+        if hasattr(B, "image_frame") and self.native:
+            self.adapter_calls = B.image_frame()  # the same loop, inside libgvt_hip.so
+            return B
         B.begin_frame()  # clearBuffer
         B.generate_and_filter(None)  # FilterRaysLocally
         self.adapter_calls = 0

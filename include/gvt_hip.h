@@ -163,6 +163,20 @@ int gvt_hip_shuffle(gvt_hip_top *, gvt_hip_queue *q_in, int from, gvt_hip_queue 
 /* sizes of n queues in one round trip */
 int gvt_hip_queue_sizes(gvt_hip_queue *const *queues, size_t n, uint64_t *sizes_out);
 
+/* ---- Tracer<ImageScheduler>::operator() (algorithm/ImageTracer.h:127-269) for one rank, natively: clearBuffer, generateRays,
+ *      FilterRaysLocally, then until every queue is empty: pick the fullest queue (first strictly largest, :159-173), adapter->trace,
+ *      shuffleRays.  meshes[i] / m / minv / normi are per instance (adapters may repeat: adapterCache, :184-233).  The caller
+ *      owns the queues (n_inst of them), q_cam, q_moved and fb; on return the queues are empty and fb holds the frame. ---- */
+typedef struct gvt_hip_camera {
+  float eye[3], focus[3], up[3];
+  float fov;
+  int32_t width, height, samples, depth;
+  float jitter_window_size;
+} gvt_hip_camera;
+int gvt_hip_image_frame(gvt_hip_top *, gvt_hip_mesh *const *meshes, const float *m /* n_inst*16 */, const float *minv, const float *normi /* n_inst*9 */,
+                        size_t n_inst, const gvt_hip_light *lights, size_t n_lights, int normal_mode, const gvt_hip_camera *cam,
+                        gvt_hip_queue *const *queues, gvt_hip_queue *q_cam, gvt_hip_queue *q_moved, gvt_hip_fb *fb, uint64_t *adapter_calls);
+
 /* ---- framebuffer: IceTComposite (composite/IceTComposite.cpp:79-157) ---- */
 gvt_hip_fb *gvt_hip_fb_create(int width, int height);
 void gvt_hip_fb_destroy(gvt_hip_fb *);

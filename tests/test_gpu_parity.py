@@ -377,6 +377,15 @@ def test_reference_golden_images_on_gpu(hip, name, builder, oracle_vectors):
             assert np.abs(img - gold).sum() < 300
 
 
+def test_native_and_python_image_loops_agree(hip):
+    """gvt_hip_image_frame (the loop inside the library) and the Python ImageTracer loop over the same entry points."""
+    sc = scenes.simple_scene(256, 256)
+    a = ImageTracer(sc, NORMALS_SMOOTH, native=True)
+    b = ImageTracer(sc, NORMALS_SMOOTH, native=False)
+    fa, fb_ = a().framebuffer(True).copy(), b().framebuffer(True)
+    assert np.array_equal(fa, fb_) and a.adapter_calls == b.adapter_calls and a.adapter_calls >= 25
+
+
 def test_config2_bunny70k_1080p(hip):
     """BASELINE config 2: bun_zipper (69,451 tris), 1920x1080, primary + shadow: integer framebuffer identical to the oracle."""
     sc = scenes.bunny70k_scene()
