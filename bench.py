@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--tris", type=int, default=10_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--domains", type=int, default=0, help="N=1 only: cut the soup into this many domains and use the Domain scheduler")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
     args = ap.parse_args()
@@ -104,7 +105,10 @@ def main():
     capi.init(local_rank)
     capi.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    if world == 1:
+    if world == 1 and args.domains > 1:
+        scene = scenes.soup_domains_scene(args.tris, args.domains, args.width, args.height)
+        tracer = DomainTracer(scene, [0] * scene.n_inst, dist, torch, dev, NORMALS_FLAT)
+    elif world == 1:
         scene = scenes.soup_scene(args.tris, args.width, args.height)
         tracer = ImageTracer(scene, NORMALS_FLAT)
     else:
@@ -122,7 +126,7 @@ def main():
     def frame():
         tracer()
         if world > 1:
-            tracer.composite()
+            tracer.composite(download=False)  # IceTComposite::composite: the reduce is part of the frame, the PPM download is not
 
     for _ in range(args.warmup):
         frame()
@@ -180,7 +184,7 @@ def main():
                 "workload": "soup-%d: %d random triangles (Philox seed 12345, half-extent 0.005), %dx%d, eye (.5,.5,3)->(.5,.5,.5), "
                             "fov 30deg, 1 point light at the eye, depth 1 (primary + 1 shadow ray), AO off"
                             % (args.tris, args.tris, args.width, args.height),
-                "scheduler": "image (1 domain)" if world == 1 else "domain (%d spatial domains, 1 per GPU, RCCL p2p ray exchange)" % world,
+                "scheduler": ("image (1 domain)" if args.domains <= 1 else "domain (%d spatial domains on 1 GPU)" % args.domains) if world == 1 else "domain (%d spatial domains, 1 per GPU, RCCL p2p ray exchange)" % world,
                 "rays_per_step": rays_total / args.steps,
                 "primary_traced_per_step": rays_closest / args.steps,
                 "shadow_traced_per_step": rays_any / args.steps,
@@ -194,7 +198,7 @@ def main():
                 "kernel_ms": {k: st[k] for k in ("ms_closest", "ms_any", "ms_shade", "ms_shuffle", "ms_camera", "ms_convert", "ms_sort")},
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and args.domains <= 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(scene, args.cpu_row_stride, os.cpu_count() or 1)
             except Exception as e:  # the checker is optional for the measurement itself

@@ -25,10 +25,12 @@ struct Ctx {
   bool profile = false;
   int trav_kernel = 1;   // 1 = persistent waves with lane refill (k_trace), 0 = one 64-ray batch at a time (k_closest/k_any)
   int blocks_per_cu = 4; // k_trace grid: resident 256-thread blocks per CU
-  int refill_min = 8;    // k_trace: idle lanes needed before a refill
-  int inner_min = 20;    // k_trace: the inner-node loop is left once fewer lanes than this still descend
+  int refill_min = 16;   // k_trace: idle lanes needed before a refill
+  int inner_min = 32;    // k_trace: the inner-node loop is left once fewer lanes than this still descend
   int coop_fetch = 0;    // k_trace: quad-cooperative 64-byte fetches (DPP transpose) instead of 4 loads per lane
   int wide4 = 0;         // k_trace: traverse the 4-wide collapse of the binary tree (half the dependent fetches per ray)
+  int share = 1;         // k_trace drain-phase work sharing, bit 0: any-hit launches (0.66 vs 0.80 ms per 1 M shadow rays), bit 1: closest-hit
+                         // launches (no gain: the pending subtrees of a closest-hit ray are mostly pruned by its eventual hit)
   int sort_rays = 1;
   int sort_gather = 0;   // after sorting, traverse a contiguous object-space copy (o,d) of the rays
   int sort_bits = 20;    // radix-sorted key width (8 bits per rocPRIM pass)

@@ -159,8 +159,12 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
 template <bool ANY, bool XFORM, int MODE, bool COOP, bool W4>
 __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, Trav T, float tnear,
                                                        gvt_hip_hit *__restrict__ hits, int *__restrict__ flags, RayPlanes out, unsigned *out_count,
-                                                       unsigned *counter, int *spill_base, int refill_min, int inner_min, const unsigned *__restrict__ n_dev) {
+                                                       unsigned *counter, int *spill_base, int refill_min, int inner_min, const unsigned *__restrict__ n_dev, int share) {
+  // rays per grab of the work counter: 256 for big launches (few atomics), down to 64 when there are fewer rays than lanes so
+  // that the rays spread over all resident waves instead of queueing four deep in a few of them
+  const unsigned n_lanes_total = gridDim.x * (unsigned)TRAV_BLOCK;
   if (n_dev) n = *n_dev; // ray count produced by the previous kernel on this stream (no host round trip)
+  const unsigned chunk = (n >= 4u * n_lanes_total) ? 256u : (n >= 2u * n_lanes_total) ? 128u : 64u;
   __shared__ int stack[TRAV_STACK * TRAV_BLOCK];
   int *lds = &stack[threadIdx.x];
   int *spill = spill_base + (size_t)(blockIdx.x * TRAV_BLOCK + threadIdx.x) * TRAV_SPILL;
@@ -175,8 +179,12 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
   float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0;
   float bt = GVT_FLT_MAX, bu = 0.f, bv = 0.f, bden = 1.f; // bu, bv: un-divided U, V of the best hit; bden its |den|
   int bp = -1, sp = 0, cur = TRAV_DONE;
+  int sb = 0;           // bottom of this lane's stack window [sb, sp): entries below sb were given away to helper lanes
+  bool sharing = false; // wave-uniform: some ray of this wave is being traversed by more than one lane
+  int donor_lane = -1;  // helper: the lane it took its subtree from (to follow that lane's best hit)
 #if GVT_STAMP
   unsigned long long st_refill = 0, st_inner = 0, st_leaf = 0, st_retire = 0, n_inner_it = 0, n_outer_it = 0, t_mark = 0, t_begin = __builtin_amdgcn_s_memtime();
+  unsigned long long t_exh = 0, it_exh = 0, out_exh = 0, act_exh = 0;
 #endif
   for (;;) {
     // ---- refill idle lanes from the wave's private index range
@@ -189,11 +197,17 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
       while (nidle > 0) {
         if (c_next == c_end) {
           unsigned base = 0;
-          if (lane_id() == 0) base = atomicAdd(counter, (unsigned)TRAV_CHUNK);
+          if (lane_id() == 0) base = atomicAdd(counter, chunk);
           base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-          if (base >= n) { exhausted = true; break; }
+          if (base >= n) {
+            exhausted = true;
+#if GVT_STAMP
+            if (!t_exh) { t_exh = __builtin_amdgcn_s_memtime(); it_exh = n_inner_it; out_exh = n_outer_it; act_exh = 64 - nidle; }
+#endif
+            break;
+          }
           c_next = base;
-          c_end = min(base + (unsigned)TRAV_CHUNK, n);
+          c_end = min(base + chunk, n);
         }
         const unsigned take = min(c_end - c_next, (unsigned)nidle);
         const unsigned rank = lanes_below(idle);
@@ -209,7 +223,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
           ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
           ox = O.x * ix; oy = O.y * iy; oz = O.z * iz;
           bt = GVT_FLT_MAX; bu = 0.f; bv = 0.f; bden = 1.f; bp = -1;
-          sp = 0;
+          sp = 0; sb = 0; donor_lane = -1;
           cur = T.nodes ? 0 : TRAV_DONE;
           active = true;
         }
@@ -219,9 +233,53 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
       }
     }
     if (nidle == 64) break; // nothing left in flight and nothing left to fetch
+    // ---- drain phase: work sharing inside the wave.  Once the work counter is exhausted, a wave used to finish at the pace of
+    //      its slowest ray (measured: up to 536 more inner steps at ~2.5 K cycles each while 63 lanes idle -- the fixed ~0.5 ms of
+    //      every launch).  Now an idle lane takes the BOTTOM entry (the largest pending subtree) of a busy lane's stack together with a
+    //      copy of its ray and best hit, and traverses that subtree as a helper; results are merged when lanes of a ray retire.
+    if ((ANY ? (share & 1) : (share & 2)) && exhausted && nidle > 0) {
+      unsigned long long idle_m = idle;
+      unsigned long long don_m = __ballot(active && cur != TRAV_DONE && (sp - sb) >= 2);
+      const unsigned wave_tid0 = threadIdx.x & ~63u;
+      for (int pairs = 0; idle_m && don_m && pairs < 16; pairs++) {
+        const int h = __ffsll((long long)idle_m) - 1, d = __ffsll((long long)don_m) - 1;
+        // the bottom entry = the largest pending subtree.  For the closest hit those are the far siblings near the root, which the
+        // owner's eventual hit usually prunes: helpers therefore keep pulling the donor's current best distance (below).
+        const int sbd = __shfl(sb, d);
+        const unsigned gj = (unsigned)__shfl((int)j, d);
+        const float gOx = __shfl(O.x, d), gOy = __shfl(O.y, d), gOz = __shfl(O.z, d);
+        const float gDx = __shfl(D.x, d), gDy = __shfl(D.y, d), gDz = __shfl(D.z, d);
+        const float gix = __shfl(ix, d), giy = __shfl(iy, d), giz = __shfl(iz, d);
+        const float gox = __shfl(ox, d), goy = __shfl(oy, d), goz = __shfl(oz, d);
+        const float gbt = __shfl(bt, d), gbu = __shfl(bu, d), gbv = __shfl(bv, d), gbden = __shfl(bden, d);
+        const int gbp = __shfl(bp, d);
+        if ((int)lane_id() == h) {
+          const unsigned tid_d = wave_tid0 + (unsigned)d;
+          cur = (sbd < TRAV_STACK) ? stack[sbd * TRAV_BLOCK + tid_d]
+                                   : spill_base[((size_t)blockIdx.x * TRAV_BLOCK + tid_d) * TRAV_SPILL + (sbd - TRAV_STACK)];
+          j = gj; O = mk3(gOx, gOy, gOz); D = mk3(gDx, gDy, gDz);
+          ix = gix; iy = giy; iz = giz; ox = gox; oy = goy; oz = goz;
+          bt = gbt; bu = gbu; bv = gbv; bden = gbden; bp = gbp; // the donor's best so far: a pruning bound, merged idempotently later
+          sp = 0; sb = 0;
+          donor_lane = d;
+          active = true;
+        }
+        if ((int)lane_id() == d) sb++;
+        idle_m &= idle_m - 1;
+        don_m &= don_m - 1; // one entry per donor and round: spread the helpers over the busy lanes
+        sharing = true;
+      }
+    }
 #if GVT_STAMP
     { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_refill += t_ - t_mark; t_mark = t_; n_outer_it++; }
 #endif
+    if (!ANY && sharing) { // helpers follow their donor's best hit: a closer hit found by the owner prunes the helper's subtree too
+      const int dl = donor_lane >= 0 ? donor_lane : (int)lane_id();
+      const unsigned dj = (unsigned)__shfl((int)j, dl);
+      const float dt = __shfl(bt, dl), du = __shfl(bu, dl), dv = __shfl(bv, dl), dd = __shfl(bden, dl);
+      const int dp = __shfl(bp, dl);
+      if (active && donor_lane >= 0 && dj == j && dp >= 0 && (bp < 0 || dt < bt || (dt == bt && dp < bp))) { bt = dt; bp = dp; bu = du; bv = dv; bden = dd; }
+    }
     // ---- inner nodes: the lanes holding one descend level by level in a tight loop; the loop is left as soon as
     //      fewer than inner_min lanes still descend (the others wait at a leaf, have finished, or are idle), so that
     //      both this loop and the dearer leaf phase below run at high lane utilisation.
@@ -259,7 +317,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
           if (tn[2] < GVT_FLT_MAX) { if (sp < TRAV_STACK) lds[sp * TRAV_BLOCK] = rr[2]; else spill[sp - TRAV_STACK] = rr[2]; sp++; }
           if (tn[1] < GVT_FLT_MAX) { if (sp < TRAV_STACK) lds[sp * TRAV_BLOCK] = rr[1]; else spill[sp - TRAV_STACK] = rr[1]; sp++; }
           if (tn[0] < GVT_FLT_MAX) cur = rr[0];
-          else if (sp == 0) cur = TRAV_DONE;
+          else if (sp == sb) cur = TRAV_DONE;
           else { sp--; if (sp < TRAV_STACK) cur = lds[sp * TRAV_BLOCK]; else cur = spill[sp - TRAV_STACK]; }
         }
       } else {
@@ -289,7 +347,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
           cur = swap ? r1 : r0;
         } else if (h0 || h1) {
           cur = h0 ? r0 : r1;
-        } else if (sp == 0) {
+        } else if (sp == sb) {
           cur = TRAV_DONE;
         } else {
           sp--;
@@ -369,7 +427,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
       }
       if (at_leaf) {
         if (ANY && bp == 0) cur = TRAV_DONE;
-        else if (sp == 0) cur = TRAV_DONE;
+        else if (sp == sb) cur = TRAV_DONE;
         else {
           sp--;
           if (sp < TRAV_STACK) cur = lds[sp * TRAV_BLOCK]; else cur = spill[sp - TRAV_STACK];
@@ -380,6 +438,30 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
     { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_leaf += t_ - t_mark; t_mark = t_; }
 #endif
     // ---- retire finished rays
+    if (sharing) { // lanes of one ray: the last one to finish carries the merged result, the others fold theirs into a partner
+      const unsigned long long FM = __ballot(active && cur == TRAV_DONE);
+      unsigned long long fm = FM;
+      while (fm) {
+        const int f = __ffsll((long long)fm) - 1;
+        const unsigned jf = (unsigned)__shfl((int)j, f);
+        const unsigned long long G = __ballot(active && j == jf);
+        const unsigned long long Gf = G & FM, A = G & ~FM;
+        const int tgt = A ? __ffsll((long long)A) - 1 : __ffsll((long long)Gf) - 1;
+        unsigned long long src = Gf & ~(1ull << tgt);
+        bool merged_occluded = false;
+        while (src) {
+          const int sidx = __ffsll((long long)src) - 1;
+          const float st = __shfl(bt, sidx), su = __shfl(bu, sidx), sv = __shfl(bv, sidx), sd = __shfl(bden, sidx);
+          const int spr = __shfl(bp, sidx);
+          if (ANY) { if (spr >= 0) merged_occluded = true; }
+          else if ((int)lane_id() == tgt && spr >= 0 && (bp < 0 || st < bt || (st == bt && spr < bp))) { bt = st; bp = spr; bu = su; bv = sv; bden = sd; }
+          if ((int)lane_id() == sidx) active = false; // folded into tgt: retires without writing
+          src &= src - 1;
+        }
+        if (ANY && merged_occluded && ((G >> lane_id()) & 1ull) && active) { bp = 0; cur = TRAV_DONE; } // one occluder ends the whole group
+        fm &= ~Gf;
+      }
+    }
     const bool fin = active && cur == TRAV_DONE;
     if (ANY && MODE == 1) {
       // un-occluded shadow rays go to moved_rays.  Their indices are parked in a per-wave LDS list and flushed 64+
@@ -400,7 +482,8 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
     }
   }
 #if GVT_STAMP
-  if (lane_id() == 0) { atomicAdd(&g_stamp[0], st_refill); atomicAdd(&g_stamp[1], st_inner); atomicAdd(&g_stamp[2], st_leaf); atomicAdd(&g_stamp[3], st_retire); atomicAdd(&g_stamp[4], n_inner_it); atomicAdd(&g_stamp[5], n_outer_it); atomicAdd(&g_stamp[6], 1ull); atomicAdd(&g_stamp[7], (unsigned long long)__builtin_amdgcn_s_memtime() - t_begin); }
+  if (lane_id() == 0) { atomicAdd(&g_stamp[0], st_refill); atomicAdd(&g_stamp[1], st_inner); atomicAdd(&g_stamp[2], st_leaf); atomicAdd(&g_stamp[3], st_retire); atomicAdd(&g_stamp[4], n_inner_it); atomicAdd(&g_stamp[5], n_outer_it); atomicAdd(&g_stamp[6], 1ull); atomicAdd(&g_stamp[7], (unsigned long long)__builtin_amdgcn_s_memtime() - t_begin);
+    if (t_exh) { atomicAdd(&g_stamp[8], (unsigned long long)__builtin_amdgcn_s_memtime() - t_exh); atomicAdd(&g_stamp[9], n_inner_it - it_exh); atomicAdd(&g_stamp[10], n_outer_it - out_exh); atomicAdd(&g_stamp[11], act_exh); atomicMax(&g_stamp[12], (unsigned long long)__builtin_amdgcn_s_memtime() - t_exh); atomicMax(&g_stamp[13], n_inner_it - it_exh); } }
 #endif
   if (ANY && MODE == 1) { if (n_pend) flush_pending(pend, n_pend, q, out, out_count); }
 }
@@ -826,8 +909,8 @@ int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, 
     ProfScope ps(KC_CLOSEST);
     RayPlanes none{};
     if (C.trav_kernel == 1) {
-      if (xform) launch_trace<false, true, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr);
-      else launch_trace<false, false, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr);
+      if (xform) launch_trace<false, true, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share);
+      else launch_trace<false, false, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share);
     } else {
       if (xform) k_closest<true><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
       else k_closest<false><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
@@ -864,8 +947,8 @@ int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const M
   {
     ProfScope ps(KC_ANY);
     if (C.trav_kernel == 1) {
-      if (xform) launch_trace<true, true, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr);
-      else launch_trace<true, false, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr);
+      if (xform) launch_trace<true, true, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share);
+      else launch_trace<true, false, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share);
     } else {
       if (xform) k_any<true, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
       else k_any<false, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
@@ -966,7 +1049,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
         {
           ProfScope ps(KC_ANY);
           launch_trace<true, true, 1>(trav_grid2(shadow_ub), st, shadow, nullptr, 0u, P.minv, T, GVT_RAY_EPSILON, nullptr, nullptr, outp,
-                                                                               out->d_count, counter, C.d_spill, C.refill_min, C.inner_min, c_shadow);
+                                                                               out->d_count, counter, C.d_spill, C.refill_min, C.inner_min, c_shadow, C.share);
         }
         HIPCHK(hipGetLastError());
         C.stats.launches_any++;

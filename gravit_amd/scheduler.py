@@ -236,17 +236,18 @@ class DomainTracer:
 
     render = __call__
 
-    def composite(self):
-        """Sum of the per-rank float framebuffers on rank 0, then the localAdd clamp.  Returns (H,W,4) on rank 0."""
+    def composite(self, download=True):
+        """Sum of the per-rank float framebuffers on rank 0 (in place, in HBM), then -- if download -- the localAdd clamp and the
+        copy to the host.  Returns (H,W,4) on rank 0, None elsewhere or when download is False."""
         B, torch, dist = self.backend, self.torch, self.dist
         cam = self.scene.camera
         if self.world == 1:
-            return B.framebuffer(True)
+            return B.framebuffer(True) if download else None
         B.sync()
         t = B.fb_tensor(torch, self.dev)
         dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
         if self.dev != "cpu":
             torch.cuda.current_stream().synchronize()
-        if self.rank != 0:
+        if self.rank != 0 or not download:
             return None
         return B.framebuffer(True).reshape(cam.height, cam.width, 4)

@@ -65,10 +65,10 @@ def test_closest_and_any_hit_match_oracle(hip, name):
 
 @pytest.mark.parametrize("opts", [dict(trav_kernel=0), dict(trav_kernel=1, refill_min=1, inner_min=1), dict(trav_kernel=1, refill_min=64, inner_min=64),
                                   dict(trav_kernel=1, blocks_per_cu=1, refill_min=8, inner_min=16), dict(trav_kernel=1, sort_rays=0, top_lds=0), dict(trav_kernel=1, sort_rays=1, sort_bits=32), dict(trav_kernel=1, wide4=0, coop_fetch=0), dict(trav_kernel=1, wide4=0, coop_fetch=1, refill_min=3, inner_min=5),
-                                  dict(trav_kernel=1, wide4=1, refill_min=2, inner_min=60)])
+                                  dict(trav_kernel=1, wide4=1, refill_min=2, inner_min=60), dict(trav_kernel=1, share=0), dict(trav_kernel=1, share=3, blocks_per_cu=6, refill_min=64), dict(trav_kernel=1, share=3)])
 def test_results_do_not_depend_on_tuning_knobs(hip, opts):
     """Both traversal kernels and every refill / phase / grid / sorting setting return the same bits."""
-    defaults = dict(trav_kernel=1, blocks_per_cu=4, refill_min=8, inner_min=20, sort_rays=1, sort_bits=20, top_lds=1, coop_fetch=0, wide4=1)
+    defaults = dict(trav_kernel=1, blocks_per_cu=4, refill_min=16, inner_min=32, sort_rays=1, sort_bits=20, top_lds=1, coop_fetch=0, wide4=0, share=1)
     sc = scenes.soup_scene(150_000, 160, 90)
     mesh = sc.meshes[0]
     ad, om = HipMeshAdapter(mesh), orc.Mesh(mesh.verts, mesh.tris, mesh_mat=mesh.material)

@@ -18,9 +18,9 @@ def run(opts, frames=4):
     st = capi.stats(); capi.profile(False)
     return dt * 1e3, st['ms_closest'] / frames, st['ms_any'] / frames, (st['rays_closest'] + st['rays_any']) / frames / dt / 1e6
 configs = []
-for sg in (0, 1):
-    for (r, i) in ((8, 20), (16, 32), (24, 40)):
-        configs.append(dict(trav_kernel=1, blocks_per_cu=4, refill_min=r, inner_min=i, sort_gather=sg))
+for bb in (3, 4, 5, 6):
+    for (r, i) in ((8, 20), (16, 32), (24, 40), (32, 48)):
+        configs.append(dict(trav_kernel=1, blocks_per_cu=bb, refill_min=r, inner_min=i, share=1))
 res = {}
 for rnd in range(2):
     for c in configs:
