@@ -316,3 +316,71 @@ def soup_domains_scene(n_tris=10_000_000, n_domains=8, width=1920, height=1080, 
         mats.append(mat_translate_scale((0, 0, 0), (1, 1, 1)))
     cam = Camera((0.5, 0.5, 3.0), (0.5, 0.5, 0.5), (0.0, 1.0, 0.0), float(F(30.0 * np.pi / 180.0)), width, height, 1, 1, 0.0)
     return _assemble(meshes, list(range(len(meshes))), mats, point_light((0.5, 0.5, 3.0)), cam, "soup-%d-dom%d" % (n_tris, n_domains))
+
+
+# ------------------------------------------------------------------ legacy .conf scenes (data/bunny.conf, data/README.conf)
+def load_conf(path, geom_dirs=None, width=None, height=None):
+    """Scene from one of the reference's legacy .conf files, as src/apps/render/ConfigFileLoader.cpp:70-285 reads them
+    (that loader is compiled out in the reference, `#if 0` at :31, so its quirks are restated from the source):
+      F w h                      film size                                         (:105-109)
+      C eye(3) look(3) up(3) fov camera; the fov field is parsed but 45 degrees is stored ("TODO", :111-129)
+      G file t(3) r(3) s(3)      one instance per line: translate, then scale; the rotation is computed into a temporary
+                                 and never applied (:171-186); a mesh file is loaded once and shared (:139-166)
+      LP pos(3) color(3)         point light (:225-238);  LA pos(3) normal(3) w h color(3)  area light (:240-262)
+      ST DOMAIN | ...            scheduler hint, returned as scene.name suffix
+    Mesh paths are resolved by base name in geom_dirs (default: tests/golden)."""
+    geom_dirs = list(geom_dirs or [GOLDEN_DIR])
+    meshes, mesh_index, inst_mesh, mats, lights = [], {}, [], [], []
+    cam = None
+    film = [512, 512]
+    sched = "image"
+    with open(path) as f:
+        for line in f:
+            if line.startswith("#"):
+                continue
+            e = line.split()
+            if not e:
+                continue
+            if e[0] == "F" and len(e) >= 3:
+                film = [int(e[1]), int(e[2])]
+            elif e[0] == "C" and len(e) >= 11:
+                v = [float(x) for x in e[1:10]]
+                cam = (tuple(v[0:3]), tuple(v[3:6]), tuple(v[6:9]))
+            elif e[0] == "G" and len(e) >= 11:
+                base = os.path.basename(e[1])
+                if base not in mesh_index:
+                    found = None
+                    for d in geom_dirs:
+                        for cand in (os.path.join(d, base), os.path.join(d, os.path.splitext(base)[0] + ".npz")):
+                            if os.path.exists(cand):
+                                found = cand
+                                break
+                        if found:
+                            break
+                    if not found:
+                        raise FileNotFoundError("%s: mesh %s not found in %s" % (path, e[1], geom_dirs))
+                    v, t = load_mesh_file(found)
+                    mesh_index[base] = len(meshes)
+                    meshes.append(MeshData(v, t, default_material()))
+                tr = [float(x) for x in e[2:5]]
+                sc = [float(x) for x in e[8:11]]
+                if not any(sc):
+                    sc = [1.0, 1.0, 1.0]  # glm::length(t) > 0 guard (:188-192)
+                mats.append(mat_translate_scale(tr, sc))
+                inst_mesh.append(mesh_index[base])
+            elif e[0] == "LP" and len(e) >= 7:
+                lights.append(point_light([float(x) for x in e[1:4]], [float(x) for x in e[4:7]]))
+            elif e[0] == "LA" and len(e) >= 12:
+                from .layouts import area_light
+
+                lights.append(area_light([float(x) for x in e[1:4]], [float(x) for x in e[9:12]], [float(x) for x in e[4:7]],
+                                         float(e[7]), float(e[8])))
+            elif e[0] == "ST" and len(e) >= 2 and e[1] in ("DOMAIN", "HYBRID"):
+                sched = e[1].lower()
+    if cam is None or not meshes:
+        raise ValueError("%s: no camera or no geometry" % path)
+    w, h = (width or film[0]), (height or film[1])
+    camera = Camera(cam[0], cam[1], cam[2], float(F(45.0 * np.pi / 180.0)), w, h, 1, 1, 0.0)
+    lights = np.concatenate(lights) if lights else np.zeros(0, LIGHT_DTYPE)
+    return _assemble(meshes, inst_mesh, mats, np.ascontiguousarray(lights, LIGHT_DTYPE), camera,
+                     "%s[%s]" % (os.path.basename(path), sched))

@@ -407,6 +407,16 @@ def test_config4_bunny_grid_image_scheduler(hip):
     assert tr.adapter_calls == st.adapter_calls and len(B.adapter_cache) == 1
 
 
+def test_legacy_conf_scene_three_bunnies(hip):
+    """BASELINE config 1/4 input: data/bunny.conf (3 instances of bunny.obj, Domain scheduler hint), reduced film."""
+    sc = scenes.load_conf(os.path.join(GOLDEN, "bunny.conf"), width=475, height=270)
+    tr = ImageTracer(sc, NORMALS_SMOOTH)
+    B = tr()
+    ref, st = oracle_render(sc, 1)
+    assert np.array_equal(B.framebuffer(True)[..., :3], ref[..., :3]) and tr.adapter_calls == st.adapter_calls
+    assert (ref[..., :3].sum(axis=2) > 0).sum() > 2000
+
+
 def test_multisample_frame_within_tolerance(hip):
     """samples=2: four contributions per pixel arrive through float atomics in arbitrary order -> 1e-5, not bit-exact."""
     sc = scenes.bunny_scene(128, 128)

@@ -62,6 +62,16 @@ def test_product_never_imports_the_oracle():
                 assert not pat.search(src), f
 
 
+def test_legacy_conf_loader():
+    """data/bunny.conf (copied to tests/golden as an input fixture): 3 bunny instances, one shared mesh, 1900x1080 film."""
+    sc = scenes.load_conf(os.path.join(GOLDEN, "bunny.conf"))
+    assert sc.n_inst == 3 and len(sc.meshes) == 1 and sc.inst_mesh == [0, 0, 0]
+    assert (sc.camera.width, sc.camera.height) == (1900, 1080) and sc.name.endswith("[domain]")
+    assert np.allclose(sc.m[0].reshape(4, 4)[3, :3], (-0.3, 0, 0)) and np.allclose(sc.m[2].reshape(4, 4)[3, :3], (0.3, 0, 0))
+    assert len(sc.lights) == 1 and np.allclose(sc.lights["position"][0], (0.0, 0.1, 0.25))
+    assert np.isclose(sc.camera.fov, 45.0 * np.pi / 180.0)  # the loader stores 45 degrees whatever the file says
+
+
 def test_scenes():
     s = scenes.simple_scene()
     assert s.n_inst == 25 and s.inst_mesh[:4] == [0, 1, 0, 1]
