@@ -234,7 +234,7 @@ extern "C" int gvt_hip_mesh_get_info(const gvt_hip_mesh *M, gvt_hip_mesh_info *o
   o->n_tris = M->nT; o->n_verts = M->nV; o->n_nodes = M->nNodes; o->n_leaves = M->nLeaves;
   for (int k = 0; k < 3; k++) { o->bbox_lo[k] = M->lo[k]; o->bbox_hi[k] = M->hi[k]; }
   o->build_ms = M->build_ms; o->max_leaf = GVT_LEAF_MAX;
-  o->bytes_nodes = M->nNodes * sizeof(BvhNode) + M->nNodes4 * 128; o->bytes_tris = M->nT * 64;
+  o->bytes_nodes = M->nNodes * sizeof(BvhNode) + M->nNodes4 * 64; o->bytes_tris = M->nT * 64;
   return 0;
 }
 extern "C" int gvt_hip_mesh_get_normals(const gvt_hip_mesh *M, float *out) {

@@ -111,10 +111,16 @@ struct BvhNode {
 #ifndef GVT_LEAF_MAX
 #define GVT_LEAF_MAX 2 // measured 1..6 on the 10 M soup: 1-3 within noise (0.90-0.92 ms closest), 4: 0.96, 6: 1.05
 #endif
-// 4-wide node (128 B = 8 float4), the collapse of a binary node with its two children: child boxes as structure of arrays
-//   w[0] = lo.x[4]  w[1] = hi.x[4]  w[2] = lo.y[4]  w[3] = hi.y[4]  w[4] = lo.z[4]  w[5] = hi.z[4]  w[6] = refs[4] (bit-cast)  w[7] unused
-// refs as in the binary node (>= 0 inner 4-wide node, < 0 leaf); unused slots carry an inverted box and an empty leaf.
-#define GVT_NODE4_F4 8
+// Compressed 4-wide node (64 B = one line, 4 float4), built by collapsing the binary tree (largest inner child first) until
+// four slots are filled.  Child boxes are quantised to 8 bits per plane on a per-node grid:
+//   plane = origin[a] + q * 2^(exp[a]-127),  q in 0..255, rounded outwards and verified in double at build time, so every
+//   decoded box CONTAINS the (already padded) binary box -- results cannot depend on the layout.
+//   w0 = (origin.x, origin.y, origin.z, exp.x | exp.y<<8 | exp.z<<16)
+//   w1 = (qlo.x[4], qhi.x[4], qlo.y[4], qhi.y[4])    one byte per child, child c in byte c
+//   w2 = (qlo.z[4], qhi.z[4], ref0, ref1)   w3 = (ref2, ref3, -, -)
+// refs as in the binary node (>= 0: 4-wide node index, < 0: leaf); an unused slot has ref = GVT_EMPTY_REF.
+#define GVT_NODE4_F4 4
+#define GVT_EMPTY_REF (-1) // == leaf_ref(0, 0)
 __host__ __device__ inline int leaf_ref(uint32_t first, uint32_t count) { return ~(int)((first << 3) | count); }
 
 // Embree 2.x Moeller-Trumbore (kernels/geometry/triangle_intersector_moeller.h), restated from its published

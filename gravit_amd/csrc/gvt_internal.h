@@ -28,7 +28,7 @@ struct Ctx {
   int refill_min = 16;   // k_trace: idle lanes needed before a refill
   int inner_min = 32;    // k_trace: the inner-node loop is left once fewer lanes than this still descend
   int coop_fetch = 0;    // k_trace: quad-cooperative 64-byte fetches (DPP transpose) instead of 4 loads per lane
-  int wide4 = 0;         // k_trace: traverse the 4-wide collapse of the binary tree (half the dependent fetches per ray)
+  int wide4 = 1;         // k_trace: traverse the compressed 4-wide collapse (64-B nodes, four 8-bit child boxes per fetch)
   int share = 1;         // k_trace drain-phase work sharing, bit 0: any-hit launches (0.66 vs 0.80 ms per 1 M shadow rays), bit 1: closest-hit
                          // launches (no gain: the pending subtrees of a closest-hit ray are mostly pruned by its eventual hit)
   int sort_rays = 1;
@@ -85,7 +85,7 @@ struct gvt_hip_mesh {
   BvhNode *d_nodes = nullptr;
   size_t nNodes = 0;
   float4 *d_tri = nullptr; // 4 float4 per slot, leaf order
-  float4 *d_nodes4 = nullptr; // 4-wide collapse: 8 float4 (128 B) per node
+  uint4 *d_nodes4 = nullptr;  // compressed 4-wide collapse: 4 x 16 B (64 B) per node
   size_t nNodes4 = 0;
   size_t nLeaves = 0;
   float lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };

@@ -238,45 +238,94 @@ __global__ void k_single_node(const float4 *__restrict__ plo, const float4 *__re
   nodes[0] = nd;
 }
 
-// 4-wide collapse, breadth first: every thread turns one binary node (and its two children) into one 4-wide node,
-// allocates indices for the grandchildren that are inner nodes and queues them for the next level.
-struct Frontier { int b; int idx4; };
-__device__ inline void put_child(float4 *w, int k, float4 lo_hi_xy /*lo.x,hi.x,lo.y,hi.y*/, float lz, float hz, int ref) {
-  ((float *)&w[0])[k] = lo_hi_xy.x; ((float *)&w[1])[k] = lo_hi_xy.y; ((float *)&w[2])[k] = lo_hi_xy.z; ((float *)&w[3])[k] = lo_hi_xy.w;
-  ((float *)&w[4])[k] = lz; ((float *)&w[5])[k] = hz; ((int *)&w[6])[k] = ref;
+// Compressed 4-wide collapse, breadth first.  Every thread turns one binary node into one 4-wide node: it starts from the
+// node's two children and replaces the inner child with the largest surface area by that child's two children until four
+// slots are filled (or only leaves remain).  Inner children get consecutive indices in the next level (one atomic per
+// wave), so the array ends up in breadth-first order.  Node index of frontier entry i = base_in + i.
+struct Slot4 { float lo[3], hi[3]; int ref; };
+__device__ inline void slot_from(const BvhNode &nd, int side, Slot4 &c) {
+  const float4 xy = side ? nd.n1 : nd.n0;
+  c.lo[0] = xy.x; c.hi[0] = xy.y; c.lo[1] = xy.z; c.hi[1] = xy.w;
+  c.lo[2] = side ? nd.n2.z : nd.n2.x; c.hi[2] = side ? nd.n2.w : nd.n2.y;
+  c.ref = __float_as_int(side ? nd.n3.y : nd.n3.x);
 }
-__global__ __launch_bounds__(256) void k_collapse4(const BvhNode *__restrict__ nodes, const Frontier *__restrict__ fin, unsigned n_in,
-                                                   Frontier *__restrict__ fout, unsigned *__restrict__ counters /*0: nodes4, 1: next frontier*/,
-                                                   float4 *__restrict__ nodes4) {
+__device__ inline float slot_area(const Slot4 &c) {
+  const float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+__global__ __launch_bounds__(256) void k_collapse4(const BvhNode *__restrict__ nodes, const int *__restrict__ fin, unsigned n_in, unsigned base_in,
+                                                   int *__restrict__ fout, unsigned *__restrict__ next_count, uint4 *__restrict__ nodes4) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_in) return;
-  const Frontier f = fin[i];
-  const BvhNode nb = nodes[f.b];
-  float4 w[GVT_NODE4_F4];
-  for (int k = 0; k < GVT_NODE4_F4; k++) w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = 0; k < 4; k++) put_child(w, k, make_float4(GVT_FLT_MAX, -GVT_FLT_MAX, GVT_FLT_MAX, -GVT_FLT_MAX), GVT_FLT_MAX, -GVT_FLT_MAX, leaf_ref(0u, 0u));
+  const bool live = i < n_in;
+  Slot4 c[4];
   int n = 0;
-  for (int side = 0; side < 2; side++) {
-    const int ref = __float_as_int(side ? nb.n3.y : nb.n3.x);
-    if (ref >= 0) { // inner binary child: adopt its two children
-      const BvhNode nc = nodes[ref];
-      for (int s2 = 0; s2 < 2; s2++) {
-        int r2 = __float_as_int(s2 ? nc.n3.y : nc.n3.x);
-        if (r2 >= 0) {
-          const int idx4 = (int)atomicAdd(&counters[0], 1u);
-          const unsigned slot = atomicAdd(&counters[1], 1u);
-          Frontier g; g.b = r2; g.idx4 = idx4;
-          fout[slot] = g;
-          r2 = idx4;
-        }
-        put_child(w, n++, s2 ? nc.n1 : nc.n0, s2 ? nc.n2.z : nc.n2.x, s2 ? nc.n2.w : nc.n2.y, r2);
-      }
-    } else {
-      put_child(w, n++, side ? nb.n1 : nb.n0, side ? nb.n2.z : nb.n2.x, side ? nb.n2.w : nb.n2.y, ref);
+  if (live) {
+    const BvhNode nb = nodes[fin[i]];
+    slot_from(nb, 0, c[0]); slot_from(nb, 1, c[1]);
+    n = 2;
+    if (c[1].ref == GVT_EMPTY_REF) n = 1; // single-leaf mesh (k_single_node)
+    for (int it = 0; it < 2 && n < 4; it++) {
+      int k = -1;
+      float best = -1.f;
+      for (int s = 0; s < n; s++)
+        if (c[s].ref >= 0) { const float a = slot_area(c[s]); if (a > best) { best = a; k = s; } }
+      if (k < 0) break;
+      const BvhNode nc = nodes[c[k].ref];
+      slot_from(nc, 0, c[k]); slot_from(nc, 1, c[n]);
+      n++;
     }
   }
-  float4 *dst = nodes4 + (size_t)GVT_NODE4_F4 * f.idx4;
-  for (int k = 0; k < GVT_NODE4_F4; k++) dst[k] = w[k];
+  // next-level indices for the inner children: wave-aggregated
+  int want = 0;
+  for (int s = 0; s < n; s++) want += (c[s].ref >= 0) ? 1 : 0;
+  int incl = want;
+  for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if ((int)lane_id() >= d) incl += v; }
+  const int total = __shfl(incl, 63);
+  unsigned base = 0;
+  if (lane_id() == 0 && total) base = atomicAdd(next_count, (unsigned)total);
+  base = (unsigned)__shfl((int)base, 0);
+  if (!live) return;
+  unsigned slot = base + (unsigned)(incl - want);
+  for (int s = 0; s < n; s++)
+    if (c[s].ref >= 0) { fout[slot] = c[s].ref; c[s].ref = (int)(base_in + n_in + slot); slot++; }
+  // quantise (outwards, verified in double against the very expression the traversal decodes with)
+  uint32_t w[16];
+  for (int k = 0; k < 16; k++) w[k] = 0u;
+  uint32_t exps = 0;
+  for (int a = 0; a < 3; a++) {
+    float o = c[0].lo[a], h = c[0].hi[a];
+    for (int s = 1; s < n; s++) { o = fminf(o, c[s].lo[a]); h = fmaxf(h, c[s].hi[a]); }
+    int k2 = 0;
+    (void)frexpf((h - o) * (1.0f / 255.0f), &k2);
+    int e = k2 + 127;
+    e = e < 1 ? 1 : (e > 254 ? 254 : e);
+    uint32_t ql = 0, qh = 0;
+    for (;;) {
+      const float scale = __int_as_float(e << 23);
+      bool ok = true;
+      ql = 0; qh = 0;
+      for (int s = 0; s < n && ok; s++) {
+        int l = (int)floorf((c[s].lo[a] - o) / scale);
+        l = l < 0 ? 0 : (l > 255 ? 255 : l);
+        while (l > 0 && (double)o + (double)l * (double)scale > (double)c[s].lo[a]) l--;
+        int u = (int)ceilf((c[s].hi[a] - o) / scale);
+        u = u < 0 ? 0 : u;
+        while (u <= 255 && (double)o + (double)u * (double)scale < (double)c[s].hi[a]) u++;
+        if (u > 255) { ok = false; break; }
+        ql |= (uint32_t)l << (8 * s); qh |= (uint32_t)u << (8 * s);
+      }
+      if (ok || e >= 254) break;
+      e++;
+    }
+    w[a] = __float_as_uint(o);
+    exps |= (uint32_t)e << (8 * a);
+    w[4 + 2 * a] = ql; w[5 + 2 * a] = qh;
+  }
+  w[3] = exps;
+  for (int s = 0; s < 4; s++) w[10 + s] = (uint32_t)(s < n ? c[s].ref : GVT_EMPTY_REF);
+  uint4 *dst = nodes4 + (size_t)GVT_NODE4_F4 * (base_in + i);
+  dst[0] = make_uint4(w[0], w[1], w[2], w[3]); dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  dst[2] = make_uint4(w[8], w[9], w[10], w[11]); dst[3] = make_uint4(w[12], w[13], w[14], w[15]);
 }
 
 template <typename T> int dalloc(T **p, size_t n) {
@@ -413,6 +462,7 @@ int build_lbvh(gvt_hip_mesh *M) {
     HOK(hipStreamSynchronize(st));
     M->nLeaves = nl;
   }
+  if (gctx().wide4) OK(build_nodes4(M)); // the traversal layout; counted in the build time
   HOK(hipEventRecord(e1, st));
   HOK(hipEventSynchronize(e1));
   HOK(hipEventElapsedTime(&M->build_ms, e0, e1));
@@ -440,35 +490,33 @@ int sort_pairs_u32(unsigned *keys_in, unsigned *keys_out, unsigned *vals_in, uns
   return 0;
 }
 
-// 4-wide collapse of the emitted binary tree (optional traversal layout, built on first use)
+// Compressed 4-wide collapse of the emitted binary tree (the traversal layout of k_trace's wide4 variant)
 int build_nodes4(gvt_hip_mesh *M) {
   if (M->d_nodes4 || !M->nNodes) return 0;
   Ctx &C = gctx();
   hipStream_t st = C.stream;
-  Frontier *fa = nullptr, *fb = nullptr;
+  int *fa = nullptr, *fb = nullptr;
   unsigned *cnt = nullptr;
   int rc = dalloc(&M->d_nodes4, (size_t)GVT_NODE4_F4 * M->nNodes);
   if (!rc) rc = dalloc(&fa, M->nNodes);
   if (!rc) rc = dalloc(&fb, M->nNodes);
-  if (!rc) rc = dalloc(&cnt, 2);
+  if (!rc) rc = dalloc(&cnt, 1);
   if (!rc) {
-    Frontier root; root.b = 0; root.idx4 = 0;
-    unsigned h[2] = { 1u, 0u };
+    const int root = 0;
     hipError_t e = hipMemcpyAsync(fa, &root, sizeof root, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(cnt, h, sizeof h, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    unsigned n_in = 1;
+    unsigned n_in = 1, base = 0;
     while (e == hipSuccess && n_in) {
-      k_collapse4<<<(n_in + 255) / 256, 256, 0, st>>>(M->d_nodes, fa, n_in, fb, cnt, M->d_nodes4);
-      e = hipMemcpyAsync(h, cnt, sizeof h, hipMemcpyDeviceToHost, st);
+      e = hipMemsetAsync(cnt, 0, sizeof(unsigned), st);
+      if (e != hipSuccess) break;
+      k_collapse4<<<(n_in + 255) / 256, 256, 0, st>>>(M->d_nodes, fa, n_in, base, fb, cnt, M->d_nodes4);
+      unsigned n_next = 0;
+      e = hipMemcpyAsync(&n_next, cnt, sizeof n_next, hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipStreamSynchronize(st);
-      n_in = h[1];
-      unsigned zero = 0;
-      if (e == hipSuccess) e = hipMemcpyAsync(cnt + 1, &zero, sizeof zero, hipMemcpyHostToDevice, st);
-      if (e == hipSuccess) e = hipStreamSynchronize(st);
-      Frontier *t = fa; fa = fb; fb = t;
+      base += n_in;
+      n_in = n_next;
+      int *t = fa; fa = fb; fb = t;
     }
-    M->nNodes4 = h[0];
+    M->nNodes4 = base;
     if (e != hipSuccess) { set_error("4-wide collapse: %s", hipGetErrorString(e)); rc = GVT_HIP_ERR_DEVICE; }
   }
   hipFree(fa); hipFree(fb); hipFree(cnt);

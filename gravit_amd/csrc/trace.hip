@@ -20,7 +20,7 @@ namespace {
 struct Trav {
   const BvhNode *__restrict__ nodes;
   const float4 *__restrict__ tris;
-  const float4 *__restrict__ nodes4; // 4-wide collapse (8 float4 per node) or null
+  const uint4 *__restrict__ nodes4;  // compressed 4-wide collapse (64 B per node) or null
 };
 
 template <bool ANY, bool COUNT = false>
@@ -287,36 +287,55 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
     while (im) {
       const bool at_inner = active && cur >= 0;
       if (W4) {
-        if (at_inner) { // one fetch decides two levels of the binary tree: 4 child boxes, nearest first
-          const float4 *nd = T.nodes4 + (size_t)GVT_NODE4_F4 * cur;
-          const float4 lx = nd[0], hx = nd[1], ly = nd[2], hy = nd[3], lz = nd[4], hz = nd[5], rf = nd[6];
+        if (at_inner) { // one 64-byte fetch decides four children (8-bit boxes on the node's own grid)
+          const uint4 *nd = T.nodes4 + (size_t)GVT_NODE4_F4 * cur;
+          const uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2];
+          const uint2 w3 = *(const uint2 *)(nd + 3);
+          // plane t = (origin + q*scale - O) / d = q * (scale*inv_d) + (origin*inv_d - O*inv_d); scale is a power of two, so
+          // scale*inv_d is exact.  The rounding of the two fused steps is covered by widening every slab by 2^-21 |O*inv_d|
+          // (about 5e-7 |O| in space, on top of the padded boxes).
+          const float sx = __uint_as_float((w0.w & 0xffu) << 23) * ix, sy = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * iy,
+                      sz = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * iz;
+          const float bx = __builtin_fmaf(__uint_as_float(w0.x), ix, -ox), by = __builtin_fmaf(__uint_as_float(w0.y), iy, -oy),
+                      bz = __builtin_fmaf(__uint_as_float(w0.z), iz, -oz);
+          const float ex = fabsf(ox) * 4.76837158e-7f, ey = fabsf(oy) * 4.76837158e-7f, ez = fabsf(oz) * 4.76837158e-7f;
+          const float bxn = bx - ex, bxf = bx + ex, byn = by - ey, byf = by + ey, bzn = bz - ez, bzf = bz + ez;
+          const unsigned qnx = ix >= 0.f ? w1.x : w1.y, qfx = ix >= 0.f ? w1.y : w1.x; // near / far planes by ray direction
+          const unsigned qny = iy >= 0.f ? w1.z : w1.w, qfy = iy >= 0.f ? w1.w : w1.z;
+          const unsigned qnz = iz >= 0.f ? w2.x : w2.y, qfz = iz >= 0.f ? w2.y : w2.x;
           const float lim = ANY ? GVT_FLT_MAX : bt;
           float tn[4];
           int rr[4];
-#define GVT_SLAB4(C, LX, HX, LY, HY, LZ, HZ, RF)                                                                         \
+          rr[0] = (int)w2.z; rr[1] = (int)w2.w; rr[2] = (int)w3.x; rr[3] = (int)w3.y;
+#define GVT_SLAB4(C)                                                                                                      \
           {                                                                                                              \
-            const float a0 = __builtin_fmaf(LX, ix, -ox), a1 = __builtin_fmaf(HX, ix, -ox);                              \
-            const float b0 = __builtin_fmaf(LY, iy, -oy), b1 = __builtin_fmaf(HY, iy, -oy);                              \
-            const float c0 = __builtin_fmaf(LZ, iz, -oz), c1 = __builtin_fmaf(HZ, iz, -oz);                              \
-            const float n_ = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.f));                      \
-            const float f_ = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1)) * 1.0000004f;                     \
-            tn[C] = ((n_ <= f_) && (n_ <= lim)) ? n_ : GVT_FLT_MAX; /* a miss sorts last; entry distances are < FLT_MAX */ \
-            rr[C] = __float_as_int(RF);                                                                                  \
+            const float n_ = fmaxf(fmaxf(__builtin_fmaf((float)((qnx >> (8 * C)) & 0xffu), sx, bxn),                     \
+                                         __builtin_fmaf((float)((qny >> (8 * C)) & 0xffu), sy, byn)),                    \
+                                   fmaxf(__builtin_fmaf((float)((qnz >> (8 * C)) & 0xffu), sz, bzn), 0.f));              \
+            const float f_ = fminf(fminf(__builtin_fmaf((float)((qfx >> (8 * C)) & 0xffu), sx, bxf),                     \
+                                         __builtin_fmaf((float)((qfy >> (8 * C)) & 0xffu), sy, byf)),                    \
+                                   __builtin_fmaf((float)((qfz >> (8 * C)) & 0xffu), sz, bzf)) * 1.0000004f;             \
+            tn[C] = ((n_ <= f_) && (n_ <= lim) && (rr[C] != GVT_EMPTY_REF)) ? n_ : GVT_FLT_MAX; /* a miss sorts last */  \
           }
-          GVT_SLAB4(0, lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, rf.x)
-          GVT_SLAB4(1, lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, rf.y)
-          GVT_SLAB4(2, lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, rf.z)
-          GVT_SLAB4(3, lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, rf.w)
+          GVT_SLAB4(0) GVT_SLAB4(1) GVT_SLAB4(2) GVT_SLAB4(3)
 #undef GVT_SLAB4
+          if (!ANY) { // nearest first; for any-hit the order does not matter
 #define GVT_CE(A, B) { const bool sw_ = tn[B] < tn[A]; const float ta_ = sw_ ? tn[B] : tn[A], tb_ = sw_ ? tn[A] : tn[B]; \
                        const int ra_ = sw_ ? rr[B] : rr[A], rb_ = sw_ ? rr[A] : rr[B]; tn[A] = ta_; tn[B] = tb_; rr[A] = ra_; rr[B] = rb_; }
-          GVT_CE(0, 1) GVT_CE(2, 3) GVT_CE(0, 2) GVT_CE(1, 3) GVT_CE(1, 2)
+            GVT_CE(0, 1) GVT_CE(2, 3) GVT_CE(0, 2) GVT_CE(1, 3) GVT_CE(1, 2)
 #undef GVT_CE
-          // hits are now tn[0] <= tn[1] <= ...; push the farther ones farthest first, continue with the nearest
-          if (tn[3] < GVT_FLT_MAX) { if (sp < TRAV_STACK) lds[sp * TRAV_BLOCK] = rr[3]; else spill[sp - TRAV_STACK] = rr[3]; sp++; }
-          if (tn[2] < GVT_FLT_MAX) { if (sp < TRAV_STACK) lds[sp * TRAV_BLOCK] = rr[2]; else spill[sp - TRAV_STACK] = rr[2]; sp++; }
-          if (tn[1] < GVT_FLT_MAX) { if (sp < TRAV_STACK) lds[sp * TRAV_BLOCK] = rr[1]; else spill[sp - TRAV_STACK] = rr[1]; sp++; }
-          if (tn[0] < GVT_FLT_MAX) cur = rr[0];
+          }
+          // push the hit children farthest first (closest hit: sorted), continue with the first hit one
+          int nxt = TRAV_DONE;
+          bool have = false;
+#pragma unroll
+          for (int c4 = 3; c4 >= 0; c4--) {
+            if (tn[c4] < GVT_FLT_MAX) {
+              if (have) { if (sp < TRAV_STACK) lds[sp * TRAV_BLOCK] = nxt; else spill[sp - TRAV_STACK] = nxt; sp++; }
+              nxt = rr[c4]; have = true;
+            }
+          }
+          if (have) cur = nxt;
           else if (sp == sb) cur = TRAV_DONE;
           else { sp--; if (sp < TRAV_STACK) cur = lds[sp * TRAV_BLOCK]; else cur = spill[sp - TRAV_STACK]; }
         }
@@ -808,8 +827,16 @@ __global__ __launch_bounds__(256) void k_ray_keys(RayPlanes q, const unsigned *_
   const unsigned i = idx ? idx[j] : j;
   const float4 a = q.p0[i], b = q.p1[i];
   const V3 O = xfm_point(minv, mk3(a.x, a.y, a.z)), D = xfm_vector(minv, mk3(b.x, b.y, b.z));
-  // a point a little inside along the ray: camera rays parked on a box face still get a 3-D code
-  const float px = (O.x - blo.x) * inv_ext.x, py = (O.y - blo.y) * inv_ext.y, pz = (O.z - blo.z) * inv_ext.z;
+  // the point where the ray enters the mesh's box (the origin itself for rays that start inside): camera rays, which all
+  // leave one eye point, are thereby keyed by where they hit the box face -- 2-D tiles of the image instead of scanlines
+  const float bhx = blo.x + (inv_ext.x > 0.f ? 1.f / inv_ext.x : 0.f), bhy = blo.y + (inv_ext.y > 0.f ? 1.f / inv_ext.y : 0.f),
+              bhz = blo.z + (inv_ext.z > 0.f ? 1.f / inv_ext.z : 0.f);
+  const float rx = 1.f / (fabsf(D.x) < 1e-30f ? copysignf(1e-30f, D.x) : D.x), ry = 1.f / (fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y),
+              rz = 1.f / (fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z);
+  const float t_in = fmaxf(fmaxf(fminf((blo.x - O.x) * rx, (bhx - O.x) * rx), fminf((blo.y - O.y) * ry, (bhy - O.y) * ry)),
+                           fmaxf(fminf((blo.z - O.z) * rz, (bhz - O.z) * rz), 0.f));
+  const float te = t_in < 1e30f ? t_in : 0.f;
+  const float px = (O.x + D.x * te - blo.x) * inv_ext.x, py = (O.y + D.y * te - blo.y) * inv_ext.y, pz = (O.z + D.z * te - blo.z) * inv_ext.z;
   const unsigned qx = (unsigned)fminf(fmaxf(px * 1024.f, 0.f), 1023.f);
   const unsigned qy = (unsigned)fminf(fmaxf(py * 1024.f, 0.f), 1023.f);
   const unsigned qz = (unsigned)fminf(fmaxf(pz * 1024.f, 0.f), 1023.f);

@@ -1,0 +1,25 @@
+import sys, time, json
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from gravit_amd import capi, scenes
+from gravit_amd.scheduler import ImageTracer
+capi.init(0)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+sc = scenes.soup_scene(N)
+tr = ImageTracer(sc, 0)
+def run(opts, frames=6):
+    for k, v in opts.items(): capi.set_option(k, v)
+    tr(); capi.synchronize()
+    capi.stats_reset(); capi.profile(True)
+    t = time.perf_counter()
+    for _ in range(frames): tr()
+    capi.synchronize(); dt = (time.perf_counter() - t) / frames
+    st = capi.stats(); capi.profile(False)
+    fb = tr().framebuffer(True).copy()
+    return (dt * 1e3, st['ms_closest'] / frames, st['ms_any'] / frames, (st['rays_closest'] + st['rays_any']) / frames / dt / 1e6), fb
+ref = None
+for opts in (dict(wide4=0), dict(wide4=1), dict(wide4=1, inner_min=24), dict(wide4=1, inner_min=40), dict(wide4=1, inner_min=48), dict(wide4=1, inner_min=32, refill_min=24), dict(wide4=1, refill_min=8), dict(wide4=1, refill_min=16, sort_rays=0)):
+    t0 = time.perf_counter()
+    r, fb = run(opts)
+    if ref is None: ref = fb
+    print(json.dumps(opts), 'frame %.3f ms closest %.3f any %.3f Mrays/s %.0f' % r, 'sort %.3f' % (capi.stats()['ms_sort'] / 6), 'fb equal:', bool(np.array_equal(fb, ref)), flush=True)
