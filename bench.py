@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--domains", type=int, default=0, help="N=1 only: cut the soup into this many domains and use the Domain scheduler")
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value (gvt_hip_set_option), for experiments")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
     args = ap.parse_args()
@@ -103,6 +104,9 @@ def main():
     from gravit_amd.scheduler import DomainTracer, ImageTracer
 
     capi.init(local_rank)
+    for o in args.opt:
+        k, v = o.split("=")
+        capi.set_option(k, int(v))
     capi.set_stream(torch.cuda.current_stream().cuda_stream)
 
     if world == 1 and args.domains > 1:

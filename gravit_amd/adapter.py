@@ -229,7 +229,9 @@ class FrameBuffer:
         return out
 
 
-def camera_generate(q, cam):
-    capi.check(capi.load().gvt_hip_camera_generate(
+def camera_generate(q, cam, tile=0):
+    """gvtPerspectiveCamera::generateRays into a device queue; tile=8 lists the same rays in 8x8-pixel tiles."""
+    capi.check(capi.load().gvt_hip_camera_generate_tiled(
         q.h, capi.ptr(capi.f32(cam.eye, 3)), capi.ptr(capi.f32(cam.focus, 3)), capi.ptr(capi.f32(cam.up, 3)), C.c_float(cam.fov),
-        C.c_int(cam.width), C.c_int(cam.height), C.c_int(cam.samples), C.c_int(cam.depth), C.c_float(cam.jitter)), "gvt_hip_camera_generate")
+        C.c_int(cam.width), C.c_int(cam.height), C.c_int(cam.samples), C.c_int(cam.depth), C.c_float(cam.jitter), C.c_int(tile)),
+        "gvt_hip_camera_generate_tiled")

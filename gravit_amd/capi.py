@@ -19,6 +19,7 @@ SYMBOLS = [
     "gvt_hip_queue_create", "gvt_hip_queue_destroy", "gvt_hip_queue_reserve", "gvt_hip_queue_clear", "gvt_hip_queue_size",
     "gvt_hip_queue_append", "gvt_hip_queue_export", "gvt_hip_trace_queue",
     "gvt_hip_camera_generate",
+    "gvt_hip_camera_generate_tiled",
     "gvt_hip_top_create", "gvt_hip_top_destroy", "gvt_hip_top_order", "gvt_hip_shuffle", "gvt_hip_queue_sizes",
     "gvt_hip_fb_create", "gvt_hip_fb_destroy", "gvt_hip_fb_clear", "gvt_hip_fb_download", "gvt_hip_fb_device_ptr",
     "gvt_hip_fb_write_ppm_bytes",

@@ -31,9 +31,11 @@ struct Ctx {
   int wide4 = 1;         // k_trace: traverse the compressed 4-wide collapse (64-B nodes, four 8-bit child boxes per fetch)
   int share = 1;         // k_trace drain-phase work sharing, bit 0: any-hit launches (0.66 vs 0.80 ms per 1 M shadow rays), bit 1: closest-hit
                          // launches (no gain: the pending subtrees of a closest-hit ray are mostly pruned by its eventual hit)
-  int sort_rays = 1;
+  int sort_rays = 0;     // Morton-sort the rays of a list before traversal (pays on incoherent lists; camera rays arrive in 8x8 tiles and the shuffle keeps list order)
   int sort_gather = 0;   // after sorting, traverse a contiguous object-space copy (o,d) of the rays
   int sort_bits = 20;    // radix-sorted key width (8 bits per rocPRIM pass)
+  int camera_tile = 8;   // gvt_hip_image_frame: camera rays listed in 8x8-pixel tiles (0: pixel-major like generateRays)
+  int top_ordered = 1;   // shuffle: order-preserving, deterministic slots (<= 64 destinations) instead of arrival-order atomics
   int top_lds = 1;       // shuffle kernels: aggregate destination counters in LDS per 1024-thread block // Morton-sort rays before traversal (adapter-internal; results are order independent)
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;

@@ -13,13 +13,30 @@ struct CamArgs {
   V3 eye, u, v, w;
   float vert, horz, wmult, hmult, half_sample, offset, contri;
   int W, H, samples, depth;
+  int tile; // 0: rays in the reference's order (pixel-major); 8: pixels enumerated in 8x8 tiles (one wave of rays = one tile)
 };
+
+// position in the generated list -> pixel.  tile == 8: the W8 x H8 part of the image that whole 8x8 tiles cover comes first, tile
+// by tile, then the right-hand strip and the bottom strip in scanline order -- a bijection on [0, W*H).
+__device__ inline unsigned camera_slot_pixel(unsigned slot, int W, int H, int tile) {
+  if (tile != 8) return slot;
+  const unsigned W8 = (unsigned)W & ~7u, H8 = (unsigned)H & ~7u, n_full = W8 * H8;
+  if (slot < n_full) {
+    const unsigned t = slot >> 6, k = slot & 63u, tpr = W8 >> 3;
+    return ((t / tpr) * 8u + (k >> 3)) * (unsigned)W + (t % tpr) * 8u + (k & 7u);
+  }
+  unsigned r = slot - n_full;
+  const unsigned Wr = (unsigned)W - W8;
+  if (r < Wr * H8) return (r / Wr) * (unsigned)W + W8 + r % Wr;
+  r -= Wr * H8;
+  return (H8 + r / (unsigned)W) * (unsigned)W + r % (unsigned)W;
+}
 
 __global__ __launch_bounds__(256) void k_camera(CamArgs A, RayPlanes q, unsigned long long n) {
   const unsigned long long ridx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (ridx >= n) return;
   const unsigned samples2 = (unsigned)(A.samples * A.samples);
-  const unsigned pix = (unsigned)(ridx / samples2);
+  const unsigned pix = camera_slot_pixel((unsigned)(ridx / samples2), A.W, A.H, A.tile);
   const unsigned sub = (unsigned)(ridx % samples2);
   const int k = (int)(sub / (unsigned)A.samples), ww = (int)(sub % (unsigned)A.samples);
   const int i = (int)(pix % (unsigned)A.W), j = (int)(pix / (unsigned)A.W);
@@ -80,7 +97,7 @@ __device__ inline int top_nearest(const float4 a, const float4 b, const float4 *
 
 __global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RayPlanes q, unsigned n, const float4 *__restrict__ blo, const float4 *__restrict__ bhi,
                                                             int n_inst, int from, int *__restrict__ next_out, float *__restrict__ t_out,
-                                                            unsigned *__restrict__ hist, int use_lds) {
+                                                            unsigned *__restrict__ hist, int use_lds, unsigned *__restrict__ blk_cnt) {
   extern __shared__ unsigned sh_cnt[];
   if (use_lds) {
     for (int d = threadIdx.x; d < n_inst; d += TOP_BLOCK) sh_cnt[d] = 0u;
@@ -106,17 +123,51 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RayPlanes q, unsigne
   }
   if (use_lds) {
     __syncthreads();
-    for (int d = threadIdx.x; d < n_inst; d += TOP_BLOCK)
+    for (int d = threadIdx.x; d < n_inst; d += TOP_BLOCK) {
       if (sh_cnt[d]) atomicAdd(&hist[d], sh_cnt[d]);
+      if (blk_cnt) blk_cnt[(size_t)d * gridDim.x + blockIdx.x] = sh_cnt[d]; // ordered mode: this block's rays per destination
+    }
   }
+}
+
+// Ordered mode (few destinations): exclusive scan of the per-block counts of one destination, offset by the queue's fill,
+// so that the scatter can place every ray at a slot that depends only on its index in the input list -- queues keep the order
+// of the list they were filled from (camera rays stay in pixel order; no sort is needed in front of the traversal) and the
+// result of a shuffle is deterministic.  One block per destination.
+__global__ __launch_bounds__(TOP_BLOCK) void k_top_scan(unsigned *__restrict__ blk_cnt, unsigned n_blk, const QueueDesc *__restrict__ queues) {
+  __shared__ unsigned sh_w[TOP_BLOCK / 64];
+  __shared__ unsigned sh_run;
+  const int d = blockIdx.x;
+  unsigned *row = blk_cnt + (size_t)d * n_blk;
+  if (threadIdx.x == 0) sh_run = *queues[d].count;
+  __syncthreads();
+  for (unsigned b0 = 0; b0 < n_blk; b0 += TOP_BLOCK) {
+    const unsigned b = b0 + threadIdx.x;
+    const unsigned v = b < n_blk ? row[b] : 0u;
+    unsigned incl = v;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o); if ((int)lane_id() >= o) incl += u; }
+    if (lane_id() == 63) sh_w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned woff = 0;
+    for (unsigned w = 0; w < (threadIdx.x >> 6); w++) woff += sh_w[w];
+    const unsigned run = sh_run;
+    if (b < n_blk) row[b] = run + woff + incl - v;
+    __syncthreads();
+    if (threadIdx.x == TOP_BLOCK - 1) sh_run = run + woff + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && queues[d].keep) *queues[d].count = sh_run;
 }
 
 __global__ __launch_bounds__(TOP_BLOCK) void k_top_scatter(RayPlanes q, unsigned n, const int *__restrict__ next_in, const float *__restrict__ t_in,
                                                            const QueueDesc *__restrict__ queues, int n_inst, float *__restrict__ fb, unsigned n_pix,
-                                                           int use_lds) {
+                                                           int use_lds, const unsigned *__restrict__ blk_base) {
   extern __shared__ unsigned sh[]; // [0,n_inst): rays of this block per destination, [n_inst,2n_inst): their base slot
-  unsigned *sh_cnt = sh, *sh_base = sh + n_inst;
-  if (use_lds) {
+  unsigned *sh_cnt = sh, *sh_base = sh + n_inst; // ordered mode: sh[w * n_inst + d] = rays of wave w for destination d
+  if (blk_base) {
+    for (int k = threadIdx.x; k < n_inst * (TOP_BLOCK / 64); k += TOP_BLOCK) sh[k] = 0u;
+    __syncthreads();
+  } else if (use_lds) {
     for (int d = threadIdx.x; d < n_inst; d += TOP_BLOCK) sh_cnt[d] = 0u;
     __syncthreads();
   }
@@ -144,12 +195,22 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_scatter(RayPlanes q, unsigned
     const int d = __shfl(next, leader);
     const unsigned long long m = __ballot(next == d);
     unsigned base = 0;
-    if ((int)lane_id() == leader) base = use_lds ? atomicAdd(&sh_cnt[d], (unsigned)__popcll(m)) : atomicAdd(queues[d].count, (unsigned)__popcll(m));
-    base = __shfl(base, leader);
+    if (blk_base) {
+      if ((int)lane_id() == leader) sh[(threadIdx.x >> 6) * n_inst + d] = (unsigned)__popcll(m);
+    } else {
+      if ((int)lane_id() == leader) base = use_lds ? atomicAdd(&sh_cnt[d], (unsigned)__popcll(m)) : atomicAdd(queues[d].count, (unsigned)__popcll(m));
+      base = __shfl(base, leader);
+    }
     if (next == d) local = base + lanes_below(m);
     todo &= ~m;
   }
-  if (use_lds) {
+  if (blk_base) {
+    __syncthreads();
+    if (next >= 0) {
+      for (unsigned w = 0; w < (threadIdx.x >> 6); w++) local += sh[w * n_inst + next];
+      local += blk_base[(size_t)next * gridDim.x + blockIdx.x];
+    }
+  } else if (use_lds) {
     __syncthreads();
     for (int d = threadIdx.x; d < n_inst; d += TOP_BLOCK)
       if (sh_cnt[d]) sh_base[d] = atomicAdd(queues[d].count, sh_cnt[d]);
@@ -178,8 +239,13 @@ inline unsigned blocks_for(size_t n, unsigned b = 256) { return (unsigned)((n + 
 
 extern "C" int gvt_hip_camera_generate(gvt_hip_queue *q, const float eye[3], const float focus[3], const float up[3], float fov, int W,
                                        int H, int samples, int depth, float jitterF) {
+  return gvt_hip_camera_generate_tiled(q, eye, focus, up, fov, W, H, samples, depth, jitterF, 0);
+}
+
+extern "C" int gvt_hip_camera_generate_tiled(gvt_hip_queue *q, const float eye[3], const float focus[3], const float up[3], float fov, int W,
+                                             int H, int samples, int depth, float jitterF, int tile) {
   if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
-  if (!q || W < 2 || H < 2 || samples < 1) { set_error("camera_generate: bad arguments"); return GVT_HIP_ERR_INVALID; }
+  if (!q || W < 2 || H < 2 || samples < 1 || (tile != 0 && tile != 8)) { set_error("camera_generate: bad arguments"); return GVT_HIP_ERR_INVALID; }
   const size_t n = (size_t)W * H * samples * samples;
   int rc = queue_reserve(q, n);
   if (rc) return rc;
@@ -205,7 +271,7 @@ extern "C" int gvt_hip_camera_generate(gvt_hip_queue *q, const float eye[3], con
   A.hmult = 2.f / (float)(H - 1);
   A.half_sample = samples * 0.5f;
   A.contri = 1.f / (samples * samples);
-  A.W = W; A.H = H; A.samples = samples; A.depth = depth;
+  A.W = W; A.H = H; A.samples = samples; A.depth = depth; A.tile = tile;
   Ctx &C = gctx();
   {
     ProfScope ps(KC_CAMERA);
@@ -328,11 +394,17 @@ extern "C" int gvt_hip_shuffle(gvt_hip_top *T, gvt_hip_queue *q_in, int from, gv
   RayPlanes in = make_planes(q_in->d_planes, q_in->cap);
   const size_t nI = T->n;
   const int use_lds = (C.top_lds && nI > 0 && nI <= 4096) ? 1 : 0; // LDS counters per destination; beyond that straight to the global ones
+  const unsigned n_blk = blocks_for(n, TOP_BLOCK);
+  unsigned *d_blk = nullptr; // ordered mode: [destination][block] counts, then base slots
+  if (C.top_ordered && use_lds && nI <= 64) {
+    d_blk = (unsigned *)scratch_get(14, sizeof(unsigned) * nI * n_blk);
+    if (!d_blk) return GVT_HIP_ERR_DEVICE;
+  }
   if (nI) HIPCHK(hipMemsetAsync(T->d_hist, 0, sizeof(unsigned) * nI, st));
   {
     ProfScope ps(KC_SHUFFLE);
-    k_top_classify<<<blocks_for(n, TOP_BLOCK), TOP_BLOCK, use_lds ? sizeof(unsigned) * nI : 0, st>>>(in, (unsigned)n, T->d_lo, T->d_hi, (int)nI, from, d_next,
-                                                                                                    d_t, T->d_hist, use_lds);
+    k_top_classify<<<n_blk, TOP_BLOCK, use_lds ? sizeof(unsigned) * nI : 0, st>>>(in, (unsigned)n, T->d_lo, T->d_hi, (int)nI, from, d_next, d_t, T->d_hist,
+                                                                                use_lds, d_blk);
   }
   HIPCHK(hipGetLastError());
   // Exact growth needs the histogram on the host before the scatter.  When every kept queue already has room for all n
@@ -365,8 +437,10 @@ extern "C" int gvt_hip_shuffle(gvt_hip_top *T, gvt_hip_queue *q_in, int from, gv
   if (nI) HIPCHK(hipMemcpyAsync(T->d_qdesc, desc.data(), sizeof(QueueDesc) * nI, hipMemcpyHostToDevice, st));
   {
     ProfScope ps(KC_SHUFFLE);
-    k_top_scatter<<<blocks_for(n, TOP_BLOCK), TOP_BLOCK, use_lds ? 2 * sizeof(unsigned) * nI : 0, st>>>(
-        in, (unsigned)n, d_next, d_t, (const QueueDesc *)T->d_qdesc, (int)nI, fb ? fb->d_rgba : nullptr, fb ? (unsigned)(fb->w * fb->h) : 0u, use_lds);
+    if (d_blk) k_top_scan<<<(unsigned)nI, TOP_BLOCK, 0, st>>>(d_blk, n_blk, (const QueueDesc *)T->d_qdesc);
+    const size_t lds = d_blk ? sizeof(unsigned) * nI * (TOP_BLOCK / 64) : (use_lds ? 2 * sizeof(unsigned) * nI : 0);
+    k_top_scatter<<<n_blk, TOP_BLOCK, lds, st>>>(in, (unsigned)n, d_next, d_t, (const QueueDesc *)T->d_qdesc, (int)nI, fb ? fb->d_rgba : nullptr,
+                                               fb ? (unsigned)(fb->w * fb->h) : 0u, use_lds, d_blk);
   }
   HIPCHK(hipGetLastError());
   if (roomy && nI) HIPCHK(hipMemcpyAsync(hist.data(), T->d_hist, sizeof(unsigned) * nI, hipMemcpyDeviceToHost, st));
@@ -440,8 +514,8 @@ extern "C" int gvt_hip_image_frame(gvt_hip_top *T, gvt_hip_mesh *const *meshes, 
   if ((rc = gvt_hip_fb_clear(fb))) return rc;                                              // clearBuffer :142
   for (size_t i = 0; i < n_inst; i++) if ((rc = gvt_hip_queue_clear(queues[i]))) return rc;
   if ((rc = gvt_hip_queue_clear(q_moved))) return rc;
-  if ((rc = gvt_hip_camera_generate(q_cam, cam->eye, cam->focus, cam->up, cam->fov, cam->width, cam->height, cam->samples, cam->depth,
-                                    cam->jitter_window_size))) return rc;
+  if ((rc = gvt_hip_camera_generate_tiled(q_cam, cam->eye, cam->focus, cam->up, cam->fov, cam->width, cam->height, cam->samples, cam->depth,
+                                          cam->jitter_window_size, gctx().camera_tile))) return rc;
   if ((rc = gvt_hip_shuffle(T, q_cam, -1, queues, nullptr, fb))) return rc;                // FilterRaysLocally :146
   uint64_t calls = 0;
   for (;;) {                                                                               // do { ... } while (instTarget != -1) :159-259

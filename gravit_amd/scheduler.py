@@ -57,7 +57,7 @@ class HipBackend:
     def generate_and_filter(self, keep_mask=None):
         """camera rays -> FilterRaysLocally: shuffleRays(rays,-1) (ImageTracer.h:111-125) or, with a keep mask,
         shuffleDropRays (DomainTracer.h:148-183)."""
-        camera_generate(self.q_cam, self.scene.camera)
+        camera_generate(self.q_cam, self.scene.camera, tile=8)
         self.top.shuffle(self.q_cam, -1, self.queues, self.fb, keep_mask)
 
     def queue_sizes(self):

@@ -146,6 +146,11 @@ int gvt_hip_trace_queue(gvt_hip_mesh *, gvt_hip_queue *q_in, gvt_hip_queue *q_ou
 /* ---- gvtPerspectiveCamera::generateRays (gvtCamera.cpp:89-171, 233-312): fills q with W*H*samples^2 rays ---- */
 int gvt_hip_camera_generate(gvt_hip_queue *q, const float eye[3], const float focus[3], const float up[3], float fov,
                             int width, int height, int samples, int depth, float jitter_window_size);
+/* The same rays, listed tile by tile (tile = 8: 8x8 pixels, i.e. one 64-wide wavefront per tile; 0 = the reference's
+ * pixel-major order).  A RayVector's order carries no meaning in the reference (TBB chunks, moved_rays under a mutex);
+ * the schedulers use the tiled list because the shuffle below keeps list order and coherent packets traverse faster. */
+int gvt_hip_camera_generate_tiled(gvt_hip_queue *q, const float eye[3], const float focus[3], const float up[3], float fov,
+                                  int width, int height, int samples, int depth, float jitter_window_size, int tile);
 
 /* ---- top-level instance set + shuffleRays (accel/BVH.h:61-135, actor/RayPacket.h:83-211,
  *      algorithm/TracerBase.h:325-343,392-414) ----

@@ -289,7 +289,16 @@ def test_queue_roundtrip_and_camera(hip):
     assert len(q2) == 0 and len(q2.to_numpy()) == 0
     cam2 = scenes.Camera((1, 2, 3), (0, 0.5, 0), (0.1, 1, 0), 0.7, 33, 17, samples=2, depth=2, jitter=1.0)
     camera_generate(q2, cam2)
-    assert rays_equal_bits(q2.to_numpy(), orc.camera_rays(cam2.eye, cam2.focus, cam2.up, cam2.fov, 33, 17, 2, 2, 1.0))
+    ref2 = orc.camera_rays(cam2.eye, cam2.focus, cam2.up, cam2.fov, 33, 17, 2, 2, 1.0)
+    assert rays_equal_bits(q2.to_numpy(), ref2)
+    # tiled listing (what the schedulers use): the same rays, 8x8 pixels at a time; ragged 33x17 exercises both edge strips
+    camera_generate(q2, cam2, tile=8)
+    t = q2.to_numpy()
+    assert not rays_equal_bits(t, ref2)
+    first_tile = t["id"][:64 * 4:4]  # samples=2 -> 4 rays per pixel
+    assert sorted(first_tile.tolist()) == sorted((j * 33 + i) for j in range(8) for i in range(8))
+    key = lambda r: np.lexsort((r["direction"][:, 2], r["direction"][:, 1], r["direction"][:, 0], r["id"]))
+    assert rays_equal_bits(t[key(t)], ref2[key(ref2)])
 
 
 def test_toplevel_shuffle_matches_oracle(hip):

@@ -18,8 +18,9 @@ def run(opts, frames=6):
     fb = tr().framebuffer(True).copy()
     return (dt * 1e3, st['ms_closest'] / frames, st['ms_any'] / frames, (st['rays_closest'] + st['rays_any']) / frames / dt / 1e6), fb
 ref = None
-for opts in (dict(wide4=0), dict(wide4=1), dict(wide4=1, inner_min=24), dict(wide4=1, inner_min=40), dict(wide4=1, inner_min=48), dict(wide4=1, inner_min=32, refill_min=24), dict(wide4=1, refill_min=8), dict(wide4=1, refill_min=16, sort_rays=0)):
+for opts in (dict(top_ordered=0, sort_rays=1), dict(top_ordered=1, sort_rays=1), dict(top_ordered=1, sort_rays=0), dict(top_ordered=0, sort_rays=0), dict(top_ordered=1, sort_rays=0, refill_min=8), dict(top_ordered=1, sort_rays=0, refill_min=24), dict(top_ordered=1, sort_rays=0, refill_min=16, inner_min=24)):
     t0 = time.perf_counter()
     r, fb = run(opts)
     if ref is None: ref = fb
-    print(json.dumps(opts), 'frame %.3f ms closest %.3f any %.3f Mrays/s %.0f' % r, 'sort %.3f' % (capi.stats()['ms_sort'] / 6), 'fb equal:', bool(np.array_equal(fb, ref)), flush=True)
+    st = capi.stats()
+    print(json.dumps(opts), 'frame %.3f ms closest %.3f any %.3f Mrays/s %.0f' % r, 'sort %.3f shuffle %.3f' % (st['ms_sort'] / 6, st['ms_shuffle'] / 6), 'fb equal:', bool(np.array_equal(fb, ref)), flush=True)
