@@ -427,8 +427,9 @@ extern "C" int gvt_hip_intersect(gvt_hip_mesh *M, const float *org, const float 
   Mat4 id{};
   if ((rc = launch_closest(M, pl, nullptr, n, false, id, tnear, d_hits))) return rc;
   HIPCHK(hipMemcpyAsync(hits, d_hits, sizeof(gvt_hip_hit) * n, hipMemcpyDeviceToHost, C.stream));
+  if ((rc = trav_overflow_fetch_async())) return rc;
   HIPCHK(hipStreamSynchronize(C.stream));
-  return 0;
+  return trav_overflow_result();
 }
 
 extern "C" int gvt_hip_occluded(gvt_hip_mesh *M, const float *org, const float *dir, size_t n, float tnear, int32_t *out) {
@@ -444,8 +445,9 @@ extern "C" int gvt_hip_occluded(gvt_hip_mesh *M, const float *org, const float *
   Mat4 id{};
   if ((rc = launch_any_flags(M, pl, n, false, id, tnear, d_flags))) return rc;
   HIPCHK(hipMemcpyAsync(out, d_flags, sizeof(int) * n, hipMemcpyDeviceToHost, C.stream));
+  if ((rc = trav_overflow_fetch_async())) return rc;
   HIPCHK(hipStreamSynchronize(C.stream));
-  return 0;
+  return trav_overflow_result();
 }
 
 // diagnostic: per-ray visit counts of the closest-hit traversal for object-space rays (see k_visit_stats)

@@ -132,6 +132,8 @@ struct TraceParams {
 
 // lbvh.hip
 int build_lbvh(gvt_hip_mesh *M);
+int trav_overflow_fetch_async();
+int trav_overflow_result();
 int build_nodes4(gvt_hip_mesh *M); // lazily, when the wide4 option is on
 int sort_pairs_u32(unsigned *keys_in, unsigned *keys_out, unsigned *vals_in, unsigned *vals_out, size_t n, int end_bit);
 // trace.hip

@@ -13,7 +13,8 @@
 
 #define TRAV_BLOCK 256
 #define TRAV_STACK 24   // LDS entries per lane; deeper levels spill to a per-thread global area
-#define TRAV_SPILL 104  // 24 + 104 = 128 >= 63 + 32 + margin levels of a 63-bit Karras tree
+#define TRAV_SPILL 128  // 24 + 128 = 152 pending entries: > 63 + 24 levels of a 63-bit Karras tree with index tie-breaks, and > 3 x 44, the
+                        // worst case of its 4-wide collapse; k_trace reports an error beyond that instead of losing entries
 
 namespace {
 
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_closest(RayPlanes q, const unsig
 #if GVT_STAMP
 __device__ unsigned long long g_stamp[16];
 #endif
+__device__ unsigned g_trav_overflow; // set by k_trace when a traversal stack would have exceeded LDS levels + spill entries
 #ifndef TRAV_CHUNK
 #define TRAV_CHUNK 256
 #endif
@@ -168,6 +170,18 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
   __shared__ int stack[TRAV_STACK * TRAV_BLOCK];
   int *lds = &stack[threadIdx.x];
   int *spill = spill_base + (size_t)(blockIdx.x * TRAV_BLOCK + threadIdx.x) * TRAV_SPILL;
+  bool overflow = false;
+#define KT_PUSH(REF)                                                                  \
+  {                                                                                   \
+    if (sp < TRAV_STACK) { lds[sp * TRAV_BLOCK] = (REF); sp++; }                      \
+    else if (sp - TRAV_STACK < TRAV_SPILL) { spill[sp - TRAV_STACK] = (REF); sp++; }  \
+    else overflow = true;                                                             \
+  }
+#define KT_POP()                                                                      \
+  {                                                                                   \
+    if (sp == sb) cur = TRAV_DONE;                                                    \
+    else { sp--; if (sp < TRAV_STACK) cur = lds[sp * TRAV_BLOCK]; else cur = spill[sp - TRAV_STACK]; } \
+  }
   __shared__ unsigned pend_all[(TRAV_BLOCK / 64) * 128];
   volatile unsigned *pend = &pend_all[(threadIdx.x >> 6) * 128];
   int n_pend = 0;                 // wave-uniform
@@ -331,13 +345,12 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
 #pragma unroll
           for (int c4 = 3; c4 >= 0; c4--) {
             if (tn[c4] < GVT_FLT_MAX) {
-              if (have) { if (sp < TRAV_STACK) lds[sp * TRAV_BLOCK] = nxt; else spill[sp - TRAV_STACK] = nxt; sp++; }
+              if (have) KT_PUSH(nxt)
               nxt = rr[c4]; have = true;
             }
           }
           if (have) cur = nxt;
-          else if (sp == sb) cur = TRAV_DONE;
-          else { sp--; if (sp < TRAV_STACK) cur = lds[sp * TRAV_BLOCK]; else cur = spill[sp - TRAV_STACK]; }
+          else KT_POP()
         }
       } else {
       float4 n0, n1, n2, n3;
@@ -361,17 +374,11 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
         if (h0 && h1) {
           const bool swap = tn1 < tn0;
           const int farc = swap ? r0 : r1;
-          if (sp < TRAV_STACK) lds[sp * TRAV_BLOCK] = farc; else spill[sp - TRAV_STACK] = farc;
-          sp++;
+          KT_PUSH(farc)
           cur = swap ? r1 : r0;
         } else if (h0 || h1) {
           cur = h0 ? r0 : r1;
-        } else if (sp == sb) {
-          cur = TRAV_DONE;
-        } else {
-          sp--;
-          if (sp < TRAV_STACK) cur = lds[sp * TRAV_BLOCK]; else cur = spill[sp - TRAV_STACK];
-        }
+        } else KT_POP()
       }
       }
 #if GVT_STAMP
@@ -446,11 +453,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
       }
       if (at_leaf) {
         if (ANY && bp == 0) cur = TRAV_DONE;
-        else if (sp == sb) cur = TRAV_DONE;
-        else {
-          sp--;
-          if (sp < TRAV_STACK) cur = lds[sp * TRAV_BLOCK]; else cur = spill[sp - TRAV_STACK];
-        }
+        else KT_POP()
       }
     }
 #if GVT_STAMP
@@ -505,6 +508,9 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
     if (t_exh) { atomicAdd(&g_stamp[8], (unsigned long long)__builtin_amdgcn_s_memtime() - t_exh); atomicAdd(&g_stamp[9], n_inner_it - it_exh); atomicAdd(&g_stamp[10], n_outer_it - out_exh); atomicAdd(&g_stamp[11], act_exh); atomicMax(&g_stamp[12], (unsigned long long)__builtin_amdgcn_s_memtime() - t_exh); atomicMax(&g_stamp[13], n_inner_it - it_exh); } }
 #endif
   if (ANY && MODE == 1) { if (n_pend) flush_pending(pend, n_pend, q, out, out_count); }
+  if (overflow) atomicOr(&g_trav_overflow, 1u);
+#undef KT_PUSH
+#undef KT_POP
 }
 
 // diagnostic (not on the hot path): per-ray visit counts of the closest-hit traversal.
@@ -898,6 +904,21 @@ int debug_stamps(unsigned long long *out, int reset) {
   return -1;
 #endif
 }
+// queued behind the traversal launches on the stream; read after the caller's next synchronisation through trav_overflow_result()
+int trav_overflow_fetch_async() {
+  Ctx &C = gctx();
+  HIPCHK(hipMemcpyFromSymbolAsync(C.h_pinned + 8, HIP_SYMBOL(g_trav_overflow), sizeof(unsigned), 0, hipMemcpyDeviceToHost, C.stream));
+  return 0;
+}
+int trav_overflow_result() {
+  Ctx &C = gctx();
+  if (!C.h_pinned[8]) return 0;
+  C.h_pinned[8] = 0;
+  const unsigned zero = 0;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_trav_overflow), &zero, sizeof zero);
+  set_error("BVH traversal stack overflow (more than %d pending entries for one ray): results of this call are incomplete", TRAV_STACK + TRAV_SPILL);
+  return GVT_HIP_ERR_DEVICE;
+}
 size_t trav_spill_ints_per_thread() { return TRAV_SPILL; }
 int trav_block_threads() { return TRAV_BLOCK; }
 
@@ -1083,7 +1104,9 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
       }
       HIPCHK(hipMemcpyAsync(C.h_pinned, c_shadow, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
       HIPCHK(hipMemcpyAsync(C.h_pinned + 2, out->d_count, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+      if ((rc = trav_overflow_fetch_async())) return rc;
       HIPCHK(hipStreamSynchronize(st));
+      if ((rc = trav_overflow_result())) return rc;
       n_shadow = C.h_pinned[0]; n_next = C.h_pinned[1];
       C.stats.rays_any += n_shadow;
     } else {

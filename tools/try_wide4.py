@@ -18,7 +18,7 @@ def run(opts, frames=6):
     fb = tr().framebuffer(True).copy()
     return (dt * 1e3, st['ms_closest'] / frames, st['ms_any'] / frames, (st['rays_closest'] + st['rays_any']) / frames / dt / 1e6), fb
 ref = None
-for opts in (dict(top_ordered=0, sort_rays=1), dict(top_ordered=1, sort_rays=1), dict(top_ordered=1, sort_rays=0), dict(top_ordered=0, sort_rays=0), dict(top_ordered=1, sort_rays=0, refill_min=8), dict(top_ordered=1, sort_rays=0, refill_min=24), dict(top_ordered=1, sort_rays=0, refill_min=16, inner_min=24)):
+for opts in (dict(share=1), dict(share=3), dict(share=1), dict(share=3), dict(share=0)):
     t0 = time.perf_counter()
     r, fb = run(opts)
     if ref is None: ref = fb
