@@ -9,7 +9,7 @@ import numpy as np
 from .layouts import HIT_DTYPE, LIGHT_DTYPE, MATERIAL_DTYPE, RAY_DTYPE
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgvt_hip.so")
+LIB_PATH = os.environ.get("GVT_HIP_LIB") or os.path.join(HERE, "libgvt_hip.so")  # GVT_HIP_LIB: an alternative build (A/B measurements)
 
 # every symbol include/gvt_hip.h declares
 SYMBOLS = [
@@ -20,6 +20,7 @@ SYMBOLS = [
     "gvt_hip_queue_append", "gvt_hip_queue_export", "gvt_hip_trace_queue",
     "gvt_hip_camera_generate",
     "gvt_hip_camera_generate_tiled",
+    "gvt_hip_camera_filter",
     "gvt_hip_top_create", "gvt_hip_top_destroy", "gvt_hip_top_order", "gvt_hip_shuffle", "gvt_hip_queue_sizes",
     "gvt_hip_fb_create", "gvt_hip_fb_destroy", "gvt_hip_fb_clear", "gvt_hip_fb_download", "gvt_hip_fb_device_ptr",
     "gvt_hip_fb_write_ppm_bytes",

@@ -32,9 +32,7 @@ __device__ inline unsigned camera_slot_pixel(unsigned slot, int W, int H, int ti
   return (H8 + r / (unsigned)W) * (unsigned)W + r % (unsigned)W;
 }
 
-__global__ __launch_bounds__(256) void k_camera(CamArgs A, RayPlanes q, unsigned long long n) {
-  const unsigned long long ridx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (ridx >= n) return;
+__device__ inline RayRec camera_ray(const CamArgs &A, unsigned long long ridx) {
   const unsigned samples2 = (unsigned)(A.samples * A.samples);
   const unsigned pix = camera_slot_pixel((unsigned)(ridx / samples2), A.W, A.H, A.tile);
   const unsigned sub = (unsigned)(ridx % samples2);
@@ -55,8 +53,22 @@ __global__ __launch_bounds__(256) void k_camera(CamArgs A, RayPlanes q, unsigned
   r.d = norm3(d); r.t_max = GVT_FLT_MAX;
   r.c = mk3(0.f, 0.f, 0.f); r.t = GVT_FLT_MAX;
   r.id = (int)pix; r.depth = A.depth; r.w = A.contri; r.type = 0;
-  store_ray(q, ridx, r);
+  return r;
 }
+
+__global__ __launch_bounds__(256) void k_camera(CamArgs A, RayPlanes q, unsigned long long n) {
+  const unsigned long long ridx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ridx >= n) return;
+  store_ray(q, ridx, camera_ray(A, ridx));
+}
+
+// where the shuffle kernels take their rays from: a queue, or the camera itself (generateRays fused into FilterRaysLocally:
+// the W*H*samples^2 list is never written to memory, each kernel regenerates ray i from its index)
+struct RaySrc {
+  RayPlanes q;
+  CamArgs cam;
+  int from_cam;
+};
 
 // RayPacket.h fastmin/fastmax: (a<b)?a:b / (a>b)?a:b
 __device__ inline float fmin_ref(float a, float b) { return (a < b) ? a : b; }
@@ -95,7 +107,7 @@ __device__ inline int top_nearest(const float4 a, const float4 b, const float4 *
 // sustains only ~90 atomics/us chip-wide (2 M rays: 32 K wave-level atomics on one word cost ~0.35 ms).
 #define TOP_BLOCK 1024
 
-__global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RayPlanes q, unsigned n, const float4 *__restrict__ blo, const float4 *__restrict__ bhi,
+__global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RaySrc S, unsigned n, const float4 *__restrict__ blo, const float4 *__restrict__ bhi,
                                                             int n_inst, int from, int *__restrict__ next_out, float *__restrict__ t_out,
                                                             unsigned *__restrict__ hist, int use_lds, unsigned *__restrict__ blk_cnt) {
   extern __shared__ unsigned sh_cnt[];
@@ -107,7 +119,10 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RayPlanes q, unsigne
   int next = -1;
   if (i < n) {
     float ret_t;
-    next = top_nearest(q.p0[i], q.p1[i], blo, bhi, n_inst, from, ret_t);
+    float4 a, b;
+    if (S.from_cam) { const RayRec r = camera_ray(S.cam, i); a = make_float4(r.o.x, r.o.y, r.o.z, r.t_min); b = make_float4(r.d.x, r.d.y, r.d.z, r.t_max); }
+    else { a = S.q.p0[i]; b = S.q.p1[i]; }
+    next = top_nearest(a, b, blo, bhi, n_inst, from, ret_t);
     next_out[i] = next;
     t_out[i] = ret_t;
   }
@@ -159,7 +174,7 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_scan(unsigned *__restrict__ b
   if (threadIdx.x == 0 && queues[d].keep) *queues[d].count = sh_run;
 }
 
-__global__ __launch_bounds__(TOP_BLOCK) void k_top_scatter(RayPlanes q, unsigned n, const int *__restrict__ next_in, const float *__restrict__ t_in,
+__global__ __launch_bounds__(TOP_BLOCK) void k_top_scatter(RaySrc S, unsigned n, const int *__restrict__ next_in, const float *__restrict__ t_in,
                                                            const QueueDesc *__restrict__ queues, int n_inst, float *__restrict__ fb, unsigned n_pix,
                                                            int use_lds, const unsigned *__restrict__ blk_base) {
   extern __shared__ unsigned sh[]; // [0,n_inst): rays of this block per destination, [n_inst,2n_inst): their base slot
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_scatter(RayPlanes q, unsigned
   RayRec r;
   if (i < n) {
     next = next_in[i];
-    r = load_ray(q, i);
+    r = S.from_cam ? camera_ray(S.cam, i) : load_ray(S.q, i);
     if (next >= 0) {
       r.o = add3(r.o, scl3(r.d, t_in[i] * 0.95f)); // TracerBase.h:393
     } else if (fb && r.type == 1 && len3(r.c) > 0.f) { // TracerBase.h:396-400 -> localAdd
@@ -242,14 +257,9 @@ extern "C" int gvt_hip_camera_generate(gvt_hip_queue *q, const float eye[3], con
   return gvt_hip_camera_generate_tiled(q, eye, focus, up, fov, W, H, samples, depth, jitterF, 0);
 }
 
-extern "C" int gvt_hip_camera_generate_tiled(gvt_hip_queue *q, const float eye[3], const float focus[3], const float up[3], float fov, int W,
-                                             int H, int samples, int depth, float jitterF, int tile) {
-  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
-  if (!q || W < 2 || H < 2 || samples < 1 || (tile != 0 && tile != 8)) { set_error("camera_generate: bad arguments"); return GVT_HIP_ERR_INVALID; }
-  const size_t n = (size_t)W * H * samples * samples;
-  int rc = queue_reserve(q, n);
-  if (rc) return rc;
-  // buildTransform, RIGHT_HAND_CAMERA (gvtCamera.cpp:89-139); host float arithmetic, same order as the reference
+// buildTransform, RIGHT_HAND_CAMERA (gvtCamera.cpp:89-139); host float arithmetic, same order as the reference
+static CamArgs make_cam_args(const float eye[3], const float focus[3], const float up[3], float fov, int W, int H, int samples, int depth, float jitterF,
+                             int tile) {
   CamArgs A;
   V3 e = ld3(eye), f = ld3(focus), upv = ld3(up);
   V3 w = norm3(sub3(f, e));
@@ -272,6 +282,17 @@ extern "C" int gvt_hip_camera_generate_tiled(gvt_hip_queue *q, const float eye[3
   A.half_sample = samples * 0.5f;
   A.contri = 1.f / (samples * samples);
   A.W = W; A.H = H; A.samples = samples; A.depth = depth; A.tile = tile;
+  return A;
+}
+
+extern "C" int gvt_hip_camera_generate_tiled(gvt_hip_queue *q, const float eye[3], const float focus[3], const float up[3], float fov, int W,
+                                             int H, int samples, int depth, float jitterF, int tile) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!q || W < 2 || H < 2 || samples < 1 || (tile != 0 && tile != 8)) { set_error("camera_generate: bad arguments"); return GVT_HIP_ERR_INVALID; }
+  const size_t n = (size_t)W * H * samples * samples;
+  int rc = queue_reserve(q, n);
+  if (rc) return rc;
+  const CamArgs A = make_cam_args(eye, focus, up, fov, W, H, samples, depth, jitterF, tile);
   Ctx &C = gctx();
   {
     ProfScope ps(KC_CAMERA);
@@ -378,20 +399,14 @@ extern "C" int gvt_hip_top_order(const gvt_hip_top *T, int32_t *out) {
   return 0;
 }
 
-extern "C" int gvt_hip_shuffle(gvt_hip_top *T, gvt_hip_queue *q_in, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
-                               gvt_hip_fb *fb) {
-  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
-  if (!T || !q_in || (T->n && !queues)) { set_error("shuffle: null argument"); return GVT_HIP_ERR_INVALID; }
-  for (size_t i = 0; i < T->n; i++)
-    if (!queues[i] || queues[i] == q_in) { set_error("shuffle: queue %zu is null or aliases q_in", i); return GVT_HIP_ERR_INVALID; }
+// shuffleRays over n rays taken from S (a queue's planes or the camera)
+static int shuffle_impl(gvt_hip_top *T, const RaySrc &in, size_t n, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask, gvt_hip_fb *fb) {
   Ctx &C = gctx();
-  const size_t n = q_in->size;
   if (!n) return 0;
   hipStream_t st = C.stream;
   int *d_next = (int *)scratch_get(6, sizeof(int) * n);
   float *d_t = (float *)scratch_get(7, sizeof(float) * n);
   if (!d_next || !d_t) return GVT_HIP_ERR_DEVICE;
-  RayPlanes in = make_planes(q_in->d_planes, q_in->cap);
   const size_t nI = T->n;
   const int use_lds = (C.top_lds && nI > 0 && nI <= 4096) ? 1 : 0; // LDS counters per destination; beyond that straight to the global ones
   const unsigned n_blk = blocks_for(n, TOP_BLOCK);
@@ -447,9 +462,39 @@ extern "C" int gvt_hip_shuffle(gvt_hip_top *T, gvt_hip_queue *q_in, int from, gv
   HIPCHK(hipStreamSynchronize(st)); // desc/hist are host vectors
   for (size_t i = 0; i < nI; i++)
     if (desc[i].keep) queues[i]->size += hist[i];
-  q_in->size = 0; // rays.clear(), TracerBase.h:411
-  HIPCHK(hipMemsetAsync(q_in->d_count, 0, sizeof(unsigned), st));
   return 0;
+}
+
+extern "C" int gvt_hip_shuffle(gvt_hip_top *T, gvt_hip_queue *q_in, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
+                               gvt_hip_fb *fb) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!T || !q_in || (T->n && !queues)) { set_error("shuffle: null argument"); return GVT_HIP_ERR_INVALID; }
+  for (size_t i = 0; i < T->n; i++)
+    if (!queues[i] || queues[i] == q_in) { set_error("shuffle: queue %zu is null or aliases q_in", i); return GVT_HIP_ERR_INVALID; }
+  if (!q_in->size) return 0;
+  RaySrc S{};
+  S.q = make_planes(q_in->d_planes, q_in->cap);
+  S.from_cam = 0;
+  int rc = shuffle_impl(T, S, q_in->size, from, queues, keep_mask, fb);
+  if (rc) return rc;
+  q_in->size = 0; // rays.clear(), TracerBase.h:411
+  HIPCHK(hipMemsetAsync(q_in->d_count, 0, sizeof(unsigned), gctx().stream));
+  return 0;
+}
+
+// generateRays + FilterRaysLocally in one step: the camera's rays go straight to the queues of the instances they enter first
+extern "C" int gvt_hip_camera_filter(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *const *queues, const uint8_t *keep_mask) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!T || !cam || (T->n && !queues)) { set_error("camera_filter: null argument"); return GVT_HIP_ERR_INVALID; }
+  if (cam->width < 2 || cam->height < 2 || cam->samples < 1 || (tile != 0 && tile != 8)) { set_error("camera_filter: bad arguments"); return GVT_HIP_ERR_INVALID; }
+  for (size_t i = 0; i < T->n; i++)
+    if (!queues[i]) { set_error("camera_filter: queue %zu is null", i); return GVT_HIP_ERR_INVALID; }
+  const size_t n = (size_t)cam->width * cam->height * cam->samples * cam->samples;
+  if (n > 0xffffffffull) { set_error("camera_filter: more than 2^32 rays"); return GVT_HIP_ERR_INVALID; }
+  RaySrc S{};
+  S.cam = make_cam_args(cam->eye, cam->focus, cam->up, cam->fov, cam->width, cam->height, cam->samples, cam->depth, cam->jitter_window_size, tile);
+  S.from_cam = 1;
+  return shuffle_impl(T, S, n, -1, queues, keep_mask, nullptr);
 }
 
 // ---- framebuffer ----
@@ -514,9 +559,7 @@ extern "C" int gvt_hip_image_frame(gvt_hip_top *T, gvt_hip_mesh *const *meshes, 
   if ((rc = gvt_hip_fb_clear(fb))) return rc;                                              // clearBuffer :142
   for (size_t i = 0; i < n_inst; i++) if ((rc = gvt_hip_queue_clear(queues[i]))) return rc;
   if ((rc = gvt_hip_queue_clear(q_moved))) return rc;
-  if ((rc = gvt_hip_camera_generate_tiled(q_cam, cam->eye, cam->focus, cam->up, cam->fov, cam->width, cam->height, cam->samples, cam->depth,
-                                          cam->jitter_window_size, gctx().camera_tile))) return rc;
-  if ((rc = gvt_hip_shuffle(T, q_cam, -1, queues, nullptr, fb))) return rc;                // FilterRaysLocally :146
+  if ((rc = gvt_hip_camera_filter(T, cam, gctx().camera_tile, queues, nullptr))) return rc; // generateRays :137 + FilterRaysLocally :146
   uint64_t calls = 0;
   for (;;) {                                                                               // do { ... } while (instTarget != -1) :159-259
     int target = -1;

@@ -57,8 +57,14 @@ class HipBackend:
     def generate_and_filter(self, keep_mask=None):
         """camera rays -> FilterRaysLocally: shuffleRays(rays,-1) (ImageTracer.h:111-125) or, with a keep mask,
         shuffleDropRays (DomainTracer.h:148-183)."""
-        camera_generate(self.q_cam, self.scene.camera, tile=8)
-        self.top.shuffle(self.q_cam, -1, self.queues, self.fb, keep_mask)
+        import ctypes as C
+
+        cam = self.scene.camera
+        pod = capi.CameraPod((C.c_float * 3)(*cam.eye), (C.c_float * 3)(*cam.focus), (C.c_float * 3)(*cam.up), cam.fov, cam.width, cam.height,
+                             cam.samples, cam.depth, cam.jitter)
+        queues = (C.c_void_p * max(1, self.n_inst))(*[q.h for q in self.queues])
+        km = None if keep_mask is None else np.ascontiguousarray(keep_mask, dtype=np.uint8)
+        capi.check(capi.load().gvt_hip_camera_filter(self.top.h, C.byref(pod), C.c_int(8), queues, capi.ptr(km)), "gvt_hip_camera_filter")
 
     def queue_sizes(self):
         return [len(q) for q in self.queues]

@@ -178,6 +178,10 @@ typedef struct gvt_hip_camera {
   int32_t width, height, samples, depth;
   float jitter_window_size;
 } gvt_hip_camera;
+/* generateRays (gvtCamera.cpp:233-312) + FilterRaysLocally (ImageTracer.h:111-125 / shuffleDropRays, DomainTracer.h:148-183) in one
+ * step: every camera ray is appended to the queue of the instance it enters first (advanced like gvt_hip_shuffle does), without the
+ * W*H*samples^2 list ever being written to memory.  tile as in gvt_hip_camera_generate_tiled. */
+int gvt_hip_camera_filter(gvt_hip_top *, const gvt_hip_camera *cam, int tile, gvt_hip_queue *const *queues, const uint8_t *keep_mask);
 int gvt_hip_image_frame(gvt_hip_top *, gvt_hip_mesh *const *meshes, const float *m /* n_inst*16 */, const float *minv, const float *normi /* n_inst*9 */,
                         size_t n_inst, const gvt_hip_light *lights, size_t n_lights, int normal_mode, const gvt_hip_camera *cam,
                         gvt_hip_queue *const *queues, gvt_hip_queue *q_cam, gvt_hip_queue *q_moved, gvt_hip_fb *fb, uint64_t *adapter_calls);

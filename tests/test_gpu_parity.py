@@ -345,6 +345,40 @@ def test_toplevel_shuffle_matches_oracle(hip):
     assert [len(qq) for qq in queues] == [int((nxt == i).sum()) if keep[i] else 0 for i in range(sc.n_inst)]
 
 
+def test_shuffle_keeps_list_order_and_fused_camera_filter(hip):
+    """The shuffle is order preserving and deterministic (<= 64 destinations): queue i holds exactly the rays of the input list whose
+    next instance is i, in list order.  gvt_hip_camera_filter (generateRays fused into FilterRaysLocally) must produce the same queues
+    as camera_generate + shuffle, for the pixel-major and the tiled listing, with and without a keep mask."""
+    import ctypes as C
+    from gravit_amd import capi
+
+    sc = scenes.simple_scene(150, 130)
+    top = TopLevel(sc.inst_lo, sc.inst_hi)
+    order = orc.toplevel_order(sc.inst_lo, sc.inst_hi)
+    cam = sc.camera
+    pod = capi.CameraPod((C.c_float * 3)(*cam.eye), (C.c_float * 3)(*cam.focus), (C.c_float * 3)(*cam.up), cam.fov, cam.width, cam.height,
+                         cam.samples, cam.depth, cam.jitter)
+    for tile in (0, 8):
+        for keep in (None, np.array([i % 3 != 0 for i in range(sc.n_inst)], np.uint8)):
+            q = RayQueue()
+            camera_generate(q, cam, tile=tile)
+            lst = q.to_numpy()
+            nxt, t = orc.toplevel_intersect(sc.inst_lo, sc.inst_hi, order, lst)
+            qa = [RayQueue() for _ in range(sc.n_inst)]
+            top.shuffle(q, -1, qa, None, keep)
+            qb = [RayQueue() for _ in range(sc.n_inst)]
+            arr = (C.c_void_p * sc.n_inst)(*[x.h for x in qb])
+            capi.check(capi.load().gvt_hip_camera_filter(top.h, C.byref(pod), C.c_int(tile), arr, capi.ptr(keep)), "gvt_hip_camera_filter")
+            for i in range(sc.n_inst):
+                exp = lst[nxt == i].copy()  # list order
+                exp["origin"] = exp["origin"] + exp["direction"] * (t[nxt == i] * np.float32(0.95))[:, None]
+                if keep is not None and not keep[i]:
+                    exp = exp[:0]
+                a, b = qa[i].to_numpy(), qb[i].to_numpy()
+                assert len(a) == len(exp) and rays_equal_bits(a, exp), "shuffle: queue %d not in list order" % i
+                assert len(b) == len(exp) and rays_equal_bits(b, exp), "camera_filter: queue %d" % i
+
+
 def test_framebuffer_clamp_and_ppm(hip):
     fb = FrameBuffer(8, 4)
     top = TopLevel(np.array([[10, 10, 10]], np.float32), np.array([[11, 11, 11]], np.float32))
