@@ -123,12 +123,15 @@ class HipMeshAdapter:
             C.c_size_t(len(lights)), C.c_int(self.normal_mode), C.c_uint32(seed)), "gvt_hip_trace")
         return out[: n_out.value]
 
-    def trace_queue(self, q_in, q_out, m, minv, normi, lights, seed=0):
-        """Adapter::trace on device-resident queues: q_in is consumed, moved rays are appended to q_out."""
+    def trace_queue(self, q_in, q_out, m, minv, normi, lights, seed=0, sink=None):
+        """Adapter::trace on device-resident queues: q_in is consumed, moved rays are appended to q_out.  sink=(top, from_inst, fb):
+        un-occluded shadow rays that meet no other instance deposit into fb inside the adapter (gvt_hip_trace_queue_sink)."""
         lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
-        capi.check(self.lib.gvt_hip_trace_queue(
+        top, from_inst, fb = sink if sink is not None else (None, -1, None)
+        capi.check(self.lib.gvt_hip_trace_queue_sink(
             self.h, q_in.h, q_out.h, capi.ptr(capi.f32(m, 16)), capi.ptr(capi.f32(minv, 16)), capi.ptr(capi.f32(normi, 9)),
-            capi.ptr(lights), C.c_size_t(len(lights)), C.c_int(self.normal_mode), C.c_uint32(seed)), "gvt_hip_trace_queue")
+            capi.ptr(lights), C.c_size_t(len(lights)), C.c_int(self.normal_mode), C.c_uint32(seed),
+            top.h if top is not None else None, C.c_int(from_inst), fb.h if fb is not None else None), "gvt_hip_trace_queue_sink")
 
     # -- the two Embree queries underneath (EmbreeMeshAdapter.cpp:474,375) -------------------------------
     def intersect(self, org, dirs, tnear=1e-6):

@@ -17,7 +17,7 @@ SYMBOLS = [
     "gvt_hip_mesh_create", "gvt_hip_mesh_destroy", "gvt_hip_mesh_get_info", "gvt_hip_mesh_get_normals",
     "gvt_hip_trace", "gvt_hip_intersect", "gvt_hip_occluded",
     "gvt_hip_queue_create", "gvt_hip_queue_destroy", "gvt_hip_queue_reserve", "gvt_hip_queue_clear", "gvt_hip_queue_size",
-    "gvt_hip_queue_append", "gvt_hip_queue_export", "gvt_hip_trace_queue",
+    "gvt_hip_queue_append", "gvt_hip_queue_export", "gvt_hip_trace_queue", "gvt_hip_trace_queue_sink",
     "gvt_hip_camera_generate",
     "gvt_hip_camera_generate_tiled",
     "gvt_hip_camera_filter",

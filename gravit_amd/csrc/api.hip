@@ -140,6 +140,7 @@ extern "C" int gvt_hip_set_option(const char *name, int value) {
   if (!std::strcmp(name, "sort_gather")) { g_ctx.sort_gather = value; return 0; }
   if (!std::strcmp(name, "sort_bits")) { if (value < 8 || value > 32) { set_error("sort_bits must be 8..32"); return GVT_HIP_ERR_INVALID; } g_ctx.sort_bits = value; return 0; }
   if (!std::strcmp(name, "share")) { g_ctx.share = value; return 0; }
+  if (!std::strcmp(name, "term_sink")) { g_ctx.term_sink = value; return 0; }
   if (!std::strcmp(name, "camera_tile")) { if (value != 0 && value != 8) { set_error("camera_tile: 0 or 8"); return GVT_HIP_ERR_INVALID; } g_ctx.camera_tile = value; return 0; }
   if (!std::strcmp(name, "top_ordered")) { g_ctx.top_ordered = value; return 0; }
   if (!std::strcmp(name, "wide4")) { g_ctx.wide4 = value; return 0; }
@@ -349,16 +350,27 @@ static int fill_params(TraceParams &P, const float m[16], const float minv[16], 
   if (normal_mode != GVT_HIP_NORMALS_FLAT && normal_mode != GVT_HIP_NORMALS_SMOOTH) { set_error("trace: bad normal_mode %d", normal_mode); return GVT_HIP_ERR_INVALID; }
   std::memcpy(P.m.m, m, 64); std::memcpy(P.minv.m, minv, 64); std::memcpy(P.normi.n, normi, 36);
   P.normal_mode = normal_mode; P.seed = seed; P.n_lights = (int)n_lights;
+  P.sink = TermSink{};
   return 0;
 }
 
 extern "C" int gvt_hip_trace_queue(gvt_hip_mesh *M, gvt_hip_queue *q_in, gvt_hip_queue *q_out, const float m[16], const float minv[16],
                                    const float normi[9], const gvt_hip_light *lights, size_t n_lights, int normal_mode, uint32_t seed) {
+  return gvt_hip_trace_queue_sink(M, q_in, q_out, m, minv, normi, lights, n_lights, normal_mode, seed, nullptr, -1, nullptr);
+}
+
+extern "C" int gvt_hip_trace_queue_sink(gvt_hip_mesh *M, gvt_hip_queue *q_in, gvt_hip_queue *q_out, const float m[16], const float minv[16],
+                                        const float normi[9], const gvt_hip_light *lights, size_t n_lights, int normal_mode, uint32_t seed,
+                                        gvt_hip_top *top, int from_inst, gvt_hip_fb *fb) {
   if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
   if (!M || !q_in || !q_out || q_in == q_out) { set_error("trace_queue: null or aliased queue"); return GVT_HIP_ERR_INVALID; }
   TraceParams P;
   int rc = fill_params(P, m, minv, normi, n_lights, normal_mode, seed, lights);
   if (rc) return rc;
+  if (top && fb && g_ctx.term_sink) {
+    P.sink.blo = top->d_lo; P.sink.bhi = top->d_hi; P.sink.n_inst = (int)top->n; P.sink.from = from_inst;
+    P.sink.fb = fb->d_rgba; P.sink.n_pix = (unsigned)(fb->w * fb->h);
+  }
   const size_t n = q_in->size;
   rc = queue_reserve(q_out, q_out->size + n * (1 + n_lights));
   if (rc) return rc;

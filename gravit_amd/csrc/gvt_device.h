@@ -260,3 +260,37 @@ __device__ inline void quad_fetch64(const float4 *__restrict__ base, unsigned re
   quad_xchg4<0x4E>(p0, p2, hi);  quad_xchg4<0x4E>(p1, p3, hi);  // quad_perm [2,3,0,1]
   r0 = p0; r1 = p1; r2 = p2; r3 = p3;
 }
+
+// ---- top-level instance test (BVH::intersect + RayPacketIntersection), shared by the shuffle kernels and k_trace's sink ----
+// RayPacket.h fastmin/fastmax: (a<b)?a:b / (a>b)?a:b
+__device__ inline float fmin_ref(float a, float b) { return (a < b) ? a : b; }
+__device__ inline float fmax_ref(float a, float b) { return (a > b) ? a : b; }
+
+// per ray: nearest other instance box with tfar>tnear && tnear>eps && t>tnear; instances visited in the
+// reference BVH's leaf order so that equal entry distances resolve identically.
+__device__ inline int top_nearest(const float4 a, const float4 b, const float4 *__restrict__ blo, const float4 *__restrict__ bhi, int n_inst,
+                                  int from, float &ret_t) {
+  const float ox = a.x, oy = a.y, oz = a.z;
+  const float dx = 1.f / b.x, dy = 1.f / b.y, dz = 1.f / b.z;
+  float t = b.w; // ray t_max
+  int next = -1;
+  ret_t = GVT_FLT_MAX;
+  for (int k = 0; k < n_inst; k++) {
+    const float4 lo = blo[k], hi = bhi[k];
+    const int inst = __float_as_int(lo.w);
+    if (from == inst) continue;
+    const float lx = (lo.x - ox) * dx, ly = (lo.y - oy) * dy, lz = (lo.z - oz) * dz;
+    const float ux = (hi.x - ox) * dx, uy = (hi.y - oy) * dy, uz = (hi.z - oz) * dz;
+    const float minx = fmin_ref(lx, ux), maxx = fmax_ref(lx, ux);
+    const float miny = fmin_ref(ly, uy), maxy = fmax_ref(ly, uy);
+    const float minz = fmin_ref(lz, uz), maxz = fmax_ref(lz, uz);
+    const float tnear = fmax_ref(fmax_ref(minx, miny), minz);
+    const float tfar = fmin_ref(fmin_ref(maxx, maxy), maxz);
+    if (tfar > tnear && tnear > GVT_RAY_EPSILON && t > tnear) {
+      t = tnear;
+      if (ret_t > t) { next = inst; ret_t = t; }
+    }
+  }
+  return next;
+}
+

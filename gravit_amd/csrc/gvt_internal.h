@@ -34,6 +34,7 @@ struct Ctx {
   int sort_rays = 0;     // Morton-sort the rays of a list before traversal (pays on incoherent lists; camera rays arrive in 8x8 tiles and the shuffle keeps list order)
   int sort_gather = 0;   // after sorting, traverse a contiguous object-space copy (o,d) of the rays
   int sort_bits = 20;    // radix-sorted key width (8 bits per rocPRIM pass)
+  int term_sink = 1;     // gvt_hip_trace_queue_sink: deposit terminal shadow rays from the any-hit kernel (0: always through moved_rays)
   int camera_tile = 8;   // gvt_hip_image_frame: camera rays listed in 8x8-pixel tiles (0: pixel-major like generateRays)
   int top_ordered = 1;   // shuffle: order-preserving, deterministic slots (<= 64 destinations) instead of arrival-order atomics
   int top_lds = 1;       // shuffle kernels: aggregate destination counters in LDS per 1024-thread block // Morton-sort rays before traversal (adapter-internal; results are order independent)
@@ -122,12 +123,21 @@ struct QueueDesc { // device-visible view of one destination queue
   unsigned keep;
 };
 
+// Terminal rule of shuffleRays (TracerBase.h:396-400) applied where the any-hit kernel retires an un-occluded shadow ray: a ray that
+// meets no other instance is not appended to moved_rays but deposits color*w in the framebuffer at once (fb == nullptr: disabled).
+struct TermSink {
+  const float4 *blo, *bhi; // instance boxes in the reference BVH's leaf order (gvt_hip_top)
+  int n_inst, from;
+  float *fb;
+  unsigned n_pix;
+};
 struct TraceParams {
   Mat4 m, minv;
   Mat3 normi;
   int normal_mode;
   uint32_t seed;
   int n_lights;
+  TermSink sink;
 };
 
 // lbvh.hip

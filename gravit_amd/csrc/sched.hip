@@ -70,38 +70,6 @@ struct RaySrc {
   int from_cam;
 };
 
-// RayPacket.h fastmin/fastmax: (a<b)?a:b / (a>b)?a:b
-__device__ inline float fmin_ref(float a, float b) { return (a < b) ? a : b; }
-__device__ inline float fmax_ref(float a, float b) { return (a > b) ? a : b; }
-
-// per ray: nearest other instance box with tfar>tnear && tnear>eps && t>tnear; instances visited in the
-// reference BVH's leaf order so that equal entry distances resolve identically.
-__device__ inline int top_nearest(const float4 a, const float4 b, const float4 *__restrict__ blo, const float4 *__restrict__ bhi, int n_inst,
-                                  int from, float &ret_t) {
-  const float ox = a.x, oy = a.y, oz = a.z;
-  const float dx = 1.f / b.x, dy = 1.f / b.y, dz = 1.f / b.z;
-  float t = b.w; // ray t_max
-  int next = -1;
-  ret_t = GVT_FLT_MAX;
-  for (int k = 0; k < n_inst; k++) {
-    const float4 lo = blo[k], hi = bhi[k];
-    const int inst = __float_as_int(lo.w);
-    if (from == inst) continue;
-    const float lx = (lo.x - ox) * dx, ly = (lo.y - oy) * dy, lz = (lo.z - oz) * dz;
-    const float ux = (hi.x - ox) * dx, uy = (hi.y - oy) * dy, uz = (hi.z - oz) * dz;
-    const float minx = fmin_ref(lx, ux), maxx = fmax_ref(lx, ux);
-    const float miny = fmin_ref(ly, uy), maxy = fmax_ref(ly, uy);
-    const float minz = fmin_ref(lz, uz), maxz = fmax_ref(lz, uz);
-    const float tnear = fmax_ref(fmax_ref(minx, miny), minz);
-    const float tfar = fmin_ref(fmin_ref(maxx, maxy), maxz);
-    if (tfar > tnear && tnear > GVT_RAY_EPSILON && t > tnear) {
-      t = tnear;
-      if (ret_t > t) { next = inst; ret_t = t; }
-    }
-  }
-  return next;
-}
-
 // Destination counting and slot allocation are aggregated twice before they reach a global counter: per wave
 // (__ballot over equal destinations) and per 1024-thread block (LDS counters), because one global counter word
 // sustains only ~90 atomics/us chip-wide (2 M rays: 32 K wave-level atomics on one word cost ~0.35 ms).
@@ -567,8 +535,8 @@ extern "C" int gvt_hip_image_frame(gvt_hip_top *T, gvt_hip_mesh *const *meshes, 
     for (size_t i = 0; i < n_inst; i++)
       if (queues[i]->size > cnt) { cnt = queues[i]->size; target = (int)i; }
     if (target < 0) break;
-    if ((rc = gvt_hip_trace_queue(meshes[target], queues[target], q_moved, m + 16 * (size_t)target, minv + 16 * (size_t)target,
-                                  normi + 9 * (size_t)target, lights, n_lights, normal_mode, (uint32_t)calls))) return rc;
+    if ((rc = gvt_hip_trace_queue_sink(meshes[target], queues[target], q_moved, m + 16 * (size_t)target, minv + 16 * (size_t)target,
+                                       normi + 9 * (size_t)target, lights, n_lights, normal_mode, (uint32_t)calls, T, target, fb))) return rc;
     calls++;
     if ((rc = gvt_hip_shuffle(T, q_moved, target, queues, nullptr, fb))) return rc;        // shuffleRays(moved_rays, instTarget) :252
   }

@@ -147,21 +147,52 @@ __device__ unsigned g_trav_overflow; // set by k_trace when a traversal stack wo
 #endif
 #define TRAV_DONE ((int)0x80000000) // ~code with count 7: never a valid leaf reference
 
-// copies the rays whose indices are parked in the wave's LDS list to consecutive slots of `out`
-__device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const RayPlanes &q, const RayPlanes &out, unsigned *out_count) {
-  unsigned base = 0;
-  if (lane_id() == 0) base = atomicAdd(out_count, (unsigned)n_pend);
-  base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-  for (int k = (int)lane_id(); k < n_pend; k += 64) {
-    const unsigned src = pend[k];
-    out.p0[base + k] = q.p0[src]; out.p1[base + k] = q.p1[src]; out.p2[base + k] = q.p2[src]; out.p3[base + k] = q.p3[src];
+// copies the rays whose indices are parked in the wave's LDS list to consecutive slots of `out`; with a sink, rays that meet no
+// other instance end here (shuffleRays' terminal rule) and only the others are copied
+__device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const RayPlanes &q, const RayPlanes &out, unsigned *out_count, const TermSink &K) {
+  if (!K.fb) {
+    unsigned base = 0;
+    if (lane_id() == 0) base = atomicAdd(out_count, (unsigned)n_pend);
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    for (int k = (int)lane_id(); k < n_pend; k += 64) {
+      const unsigned src = pend[k];
+      out.p0[base + k] = q.p0[src]; out.p1[base + k] = q.p1[src]; out.p2[base + k] = q.p2[src]; out.p3[base + k] = q.p3[src];
+    }
+    return;
+  }
+  for (int k0 = 0; k0 < n_pend; k0 += 64) {
+    const int k = k0 + (int)lane_id();
+    bool go_on = false;
+    float4 a, b, c, d;
+    if (k < n_pend) {
+      const unsigned src = pend[k];
+      a = q.p0[src]; b = q.p1[src]; c = q.p2[src]; d = q.p3[src];
+      float ret_t;
+      go_on = top_nearest(a, b, K.blo, K.bhi, K.n_inst, K.from, ret_t) >= 0;
+      if (!go_on) {
+        const V3 col = mk3(c.x, c.y, c.z);
+        const unsigned id = (unsigned)__float_as_int(d.x);
+        if (__float_as_int(d.w) == 1 && len3(col) > 0.f && id < K.n_pix) { // TracerBase.h:396-400 -> IceTComposite::localAdd
+          const V3 cw = scl3(col, d.z);
+          float *px = K.fb + (size_t)4 * id;
+          atomicAdd(px + 0, cw.x); atomicAdd(px + 1, cw.y); atomicAdd(px + 2, cw.z); atomicAdd(px + 3, 1.f);
+        }
+      }
+    }
+    const unsigned long long m = __ballot(go_on);
+    if (m) {
+      unsigned base = 0;
+      if (lane_id() == 0) base = atomicAdd(out_count, (unsigned)__popcll(m));
+      base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+      if (go_on) { const unsigned slot = base + lanes_below(m); out.p0[slot] = a; out.p1[slot] = b; out.p2[slot] = c; out.p3[slot] = d; }
+    }
   }
 }
 
 template <bool ANY, bool XFORM, int MODE, bool COOP, bool W4>
 __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, Trav T, float tnear,
                                                        gvt_hip_hit *__restrict__ hits, int *__restrict__ flags, RayPlanes out, unsigned *out_count,
-                                                       unsigned *counter, int *spill_base, int refill_min, int inner_min, const unsigned *__restrict__ n_dev, int share) {
+                                                       unsigned *counter, int *spill_base, int refill_min, int inner_min, const unsigned *__restrict__ n_dev, int share, TermSink sink) {
   // rays per grab of the work counter: 256 for big launches (few atomics), down to 64 when there are fewer rays than lanes so
   // that the rays spread over all resident waves instead of queueing four deep in a few of them
   const unsigned n_lanes_total = gridDim.x * (unsigned)TRAV_BLOCK;
@@ -495,7 +526,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
         if (survive) pend[n_pend + lanes_below(sm)] = j;
         n_pend += __popcll(sm);
       }
-      if (n_pend >= 64) { flush_pending(pend, n_pend, q, out, out_count); n_pend = 0; }
+      if (n_pend >= 64) { flush_pending(pend, n_pend, q, out, out_count, sink); n_pend = 0; }
     }
     if (fin) {
       if (ANY) { if (MODE == 0) flags[j] = (bp >= 0) ? 1 : 0; }
@@ -507,7 +538,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
   if (lane_id() == 0) { atomicAdd(&g_stamp[0], st_refill); atomicAdd(&g_stamp[1], st_inner); atomicAdd(&g_stamp[2], st_leaf); atomicAdd(&g_stamp[3], st_retire); atomicAdd(&g_stamp[4], n_inner_it); atomicAdd(&g_stamp[5], n_outer_it); atomicAdd(&g_stamp[6], 1ull); atomicAdd(&g_stamp[7], (unsigned long long)__builtin_amdgcn_s_memtime() - t_begin);
     if (t_exh) { atomicAdd(&g_stamp[8], (unsigned long long)__builtin_amdgcn_s_memtime() - t_exh); atomicAdd(&g_stamp[9], n_inner_it - it_exh); atomicAdd(&g_stamp[10], n_outer_it - out_exh); atomicAdd(&g_stamp[11], act_exh); atomicMax(&g_stamp[12], (unsigned long long)__builtin_amdgcn_s_memtime() - t_exh); atomicMax(&g_stamp[13], n_inner_it - it_exh); } }
 #endif
-  if (ANY && MODE == 1) { if (n_pend) flush_pending(pend, n_pend, q, out, out_count); }
+  if (ANY && MODE == 1) { if (n_pend) flush_pending(pend, n_pend, q, out, out_count, sink); }
   if (overflow) atomicOr(&g_trav_overflow, 1u);
 #undef KT_PUSH
 #undef KT_POP
@@ -957,8 +988,8 @@ int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, 
     ProfScope ps(KC_CLOSEST);
     RayPlanes none{};
     if (C.trav_kernel == 1) {
-      if (xform) launch_trace<false, true, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share);
-      else launch_trace<false, false, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share);
+      if (xform) launch_trace<false, true, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{});
+      else launch_trace<false, false, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{});
     } else {
       if (xform) k_closest<true><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
       else k_closest<false><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
@@ -995,8 +1026,8 @@ int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const M
   {
     ProfScope ps(KC_ANY);
     if (C.trav_kernel == 1) {
-      if (xform) launch_trace<true, true, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share);
-      else launch_trace<true, false, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share);
+      if (xform) launch_trace<true, true, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{});
+      else launch_trace<true, false, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{});
     } else {
       if (xform) k_any<true, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
       else k_any<false, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
@@ -1097,7 +1128,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
         {
           ProfScope ps(KC_ANY);
           launch_trace<true, true, 1>(trav_grid2(shadow_ub), st, shadow, nullptr, 0u, P.minv, T, GVT_RAY_EPSILON, nullptr, nullptr, outp,
-                                                                               out->d_count, counter, C.d_spill, C.refill_min, C.inner_min, c_shadow, C.share);
+                                                                               out->d_count, counter, C.d_spill, C.refill_min, C.inner_min, c_shadow, C.share, P.sink);
         }
         HIPCHK(hipGetLastError());
         C.stats.launches_any++;

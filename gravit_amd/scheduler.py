@@ -89,7 +89,8 @@ class HipBackend:
 
     def trace_and_shuffle(self, inst):
         s = self.scene
-        self.adapter(inst).trace_queue(self.queues[inst], self.q_moved, s.m[inst], s.minv[inst], s.normi[inst], s.lights, seed=self.calls)
+        self.adapter(inst).trace_queue(self.queues[inst], self.q_moved, s.m[inst], s.minv[inst], s.normi[inst], s.lights, seed=self.calls,
+                                       sink=(self.top, inst, self.fb))
         self.calls += 1
         self.top.shuffle(self.q_moved, inst, self.queues, self.fb, None)
 

@@ -379,6 +379,25 @@ def test_shuffle_keeps_list_order_and_fused_camera_filter(hip):
                 assert len(b) == len(exp) and rays_equal_bits(b, exp), "camera_filter: queue %d" % i
 
 
+def test_terminal_sink_equals_shuffle(hip):
+    """gvt_hip_trace_queue_sink deposits terminal shadow rays inside the adapter; the frame must equal the one where every moved ray
+    goes through shuffleRays (term_sink=0), on a scene where shadow rays do cross other instances."""
+    from gravit_amd import capi
+
+    sc = scenes.bunny_grid_scene(width=190, height=108)
+    frames = {}
+    for sink in (0, 1):
+        capi.set_option("term_sink", sink)
+        for native in (True, False):
+            tr = ImageTracer(sc, NORMALS_SMOOTH, native=native)
+            frames[(sink, native)] = (tr().framebuffer(False).copy(), tr.adapter_calls)
+    capi.set_option("term_sink", 1)
+    ref_fb, ref_calls = frames[(0, True)]
+    assert ref_fb[..., :3].sum() > 0
+    for k, (fb, calls) in frames.items():
+        assert calls == ref_calls and np.array_equal(fb, ref_fb), k
+
+
 def test_framebuffer_clamp_and_ppm(hip):
     fb = FrameBuffer(8, 4)
     top = TopLevel(np.array([[10, 10, 10]], np.float32), np.array([[11, 11, 11]], np.float32))

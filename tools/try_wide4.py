@@ -18,9 +18,8 @@ def run(opts, frames=6):
     fb = tr().framebuffer(True).copy()
     return (dt * 1e3, st['ms_closest'] / frames, st['ms_any'] / frames, (st['rays_closest'] + st['rays_any']) / frames / dt / 1e6), fb
 ref = None
-for opts in (dict(share=1), dict(share=3), dict(share=1), dict(share=3), dict(share=0)):
-    t0 = time.perf_counter()
+for opts in (dict(term_sink=1), dict(term_sink=0), dict(term_sink=1), dict(term_sink=0)):
     r, fb = run(opts)
     if ref is None: ref = fb
     st = capi.stats()
-    print(json.dumps(opts), 'frame %.3f ms closest %.3f any %.3f Mrays/s %.0f' % r, 'sort %.3f shuffle %.3f' % (st['ms_sort'] / 6, st['ms_shuffle'] / 6), 'fb equal:', bool(np.array_equal(fb, ref)), flush=True)
+    print(json.dumps(opts), 'frame %.3f ms closest %.3f any %.3f Mrays/s %.0f' % r, 'shuffle %.3f shade %.3f' % (st['ms_shuffle'] / 6, st['ms_shade'] / 6), 'fb equal:', bool(np.array_equal(fb, ref)), flush=True)
