@@ -109,6 +109,8 @@ struct gvt_hip_top {
   float4 *d_hi = nullptr;
   unsigned *d_hist = nullptr; // n counters
   void **d_qdesc = nullptr;   // device array of queue descriptors
+  unsigned *h_hist = nullptr; // pinned staging for the two (asynchronous copies, no pageable bounce)
+  void *h_qdesc = nullptr;
 };
 
 struct gvt_hip_fb {
@@ -151,7 +153,7 @@ int queue_reserve(gvt_hip_queue *q, size_t cap);
 int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt_hip_queue *out, const TraceParams &P,
                const gvt_hip_light *lights_host);
 int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, bool xform, const Mat4 &minv, float tnear,
-                   gvt_hip_hit *d_hits);
+                   gvt_hip_hit *d_hits, bool counter_is_zero = false);
 int launch_visit_stats(gvt_hip_mesh *M, RayPlanes q, size_t n, float tnear, unsigned *d_out);
 int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const Mat4 &minv, float tnear, int *d_flags);
 int set_device_u32(unsigned *p, unsigned v); // stream-ordered store of a host-known value

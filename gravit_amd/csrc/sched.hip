@@ -107,7 +107,7 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RaySrc S, unsigned n
   if (use_lds) {
     __syncthreads();
     for (int d = threadIdx.x; d < n_inst; d += TOP_BLOCK) {
-      if (sh_cnt[d]) atomicAdd(&hist[d], sh_cnt[d]);
+      if (hist && sh_cnt[d]) atomicAdd(&hist[d], sh_cnt[d]);
       if (blk_cnt) blk_cnt[(size_t)d * gridDim.x + blockIdx.x] = sh_cnt[d]; // ordered mode: this block's rays per destination
     }
   }
@@ -117,12 +117,14 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RaySrc S, unsigned n
 // so that the scatter can place every ray at a slot that depends only on its index in the input list -- queues keep the order
 // of the list they were filled from (camera rays stay in pixel order; no sort is needed in front of the traversal) and the
 // result of a shuffle is deterministic.  One block per destination.
-__global__ __launch_bounds__(TOP_BLOCK) void k_top_scan(unsigned *__restrict__ blk_cnt, unsigned n_blk, const QueueDesc *__restrict__ queues) {
+__global__ __launch_bounds__(TOP_BLOCK) void k_top_scan(unsigned *__restrict__ blk_cnt, unsigned n_blk, const QueueDesc *__restrict__ queues,
+                                                        unsigned *__restrict__ totals) {
   __shared__ unsigned sh_w[TOP_BLOCK / 64];
   __shared__ unsigned sh_run;
   const int d = blockIdx.x;
   unsigned *row = blk_cnt + (size_t)d * n_blk;
-  if (threadIdx.x == 0) sh_run = *queues[d].count;
+  __shared__ unsigned sh_start;
+  if (threadIdx.x == 0) { sh_run = *queues[d].count; sh_start = sh_run; }
   __syncthreads();
   for (unsigned b0 = 0; b0 < n_blk; b0 += TOP_BLOCK) {
     const unsigned b = b0 + threadIdx.x;
@@ -139,7 +141,10 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_scan(unsigned *__restrict__ b
     if (threadIdx.x == TOP_BLOCK - 1) sh_run = run + woff + incl;
     __syncthreads();
   }
-  if (threadIdx.x == 0 && queues[d].keep) *queues[d].count = sh_run;
+  if (threadIdx.x == 0) {
+    if (queues[d].keep) *queues[d].count = sh_run;
+    if (totals) totals[d] = sh_run - sh_start;
+  }
 }
 
 __global__ __launch_bounds__(TOP_BLOCK) void k_top_scatter(RaySrc S, unsigned n, const int *__restrict__ next_in, const float *__restrict__ t_in,
@@ -348,7 +353,9 @@ extern "C" gvt_hip_top *gvt_hip_top_create(const float *inst_lo, const float *in
   bool ok = hipMalloc((void **)&T->d_lo, sizeof(float4) * (n ? n : 1)) == hipSuccess &&
             hipMalloc((void **)&T->d_hi, sizeof(float4) * (n ? n : 1)) == hipSuccess &&
             hipMalloc((void **)&T->d_hist, sizeof(unsigned) * (n ? n : 1)) == hipSuccess &&
-            hipMalloc((void **)&T->d_qdesc, sizeof(QueueDesc) * (n ? n : 1)) == hipSuccess;
+            hipMalloc((void **)&T->d_qdesc, sizeof(QueueDesc) * (n ? n : 1)) == hipSuccess &&
+            hipHostMalloc((void **)&T->h_hist, sizeof(unsigned) * (n ? n : 1), hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc((void **)&T->h_qdesc, sizeof(QueueDesc) * (n ? n : 1), hipHostMallocDefault) == hipSuccess;
   if (ok && n) {
     ok = hipMemcpy(T->d_lo, lo.data(), sizeof(float4) * n, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(T->d_hi, hi.data(), sizeof(float4) * n, hipMemcpyHostToDevice) == hipSuccess;
@@ -358,7 +365,7 @@ extern "C" gvt_hip_top *gvt_hip_top_create(const float *inst_lo, const float *in
 }
 extern "C" void gvt_hip_top_destroy(gvt_hip_top *T) {
   if (!T) return;
-  hipFree(T->d_lo); hipFree(T->d_hi); hipFree(T->d_hist); hipFree(T->d_qdesc);
+  hipFree(T->d_lo); hipFree(T->d_hi); hipFree(T->d_hist); hipFree(T->d_qdesc); hipHostFree(T->h_hist); hipHostFree(T->h_qdesc);
   delete T;
 }
 extern "C" int gvt_hip_top_order(const gvt_hip_top *T, int32_t *out) {
@@ -383,17 +390,10 @@ static int shuffle_impl(gvt_hip_top *T, const RaySrc &in, size_t n, int from, gv
     d_blk = (unsigned *)scratch_get(14, sizeof(unsigned) * nI * n_blk);
     if (!d_blk) return GVT_HIP_ERR_DEVICE;
   }
-  if (nI) HIPCHK(hipMemsetAsync(T->d_hist, 0, sizeof(unsigned) * nI, st));
-  {
-    ProfScope ps(KC_SHUFFLE);
-    k_top_classify<<<n_blk, TOP_BLOCK, use_lds ? sizeof(unsigned) * nI : 0, st>>>(in, (unsigned)n, T->d_lo, T->d_hi, (int)nI, from, d_next, d_t, T->d_hist,
-                                                                                use_lds, d_blk);
-  }
-  HIPCHK(hipGetLastError());
-  // Exact growth needs the histogram on the host before the scatter.  When every kept queue already has room for all n
-  // rays the scatter is launched right behind the classification and the histogram is read back once, at the end.
-  std::vector<unsigned> hist(nI ? nI : 1, 0u);
-  std::vector<QueueDesc> desc(nI ? nI : 1);
+  // When every kept queue already has room for all n rays the scatter is launched right behind the classification and the
+  // per-destination totals are read back once, at the end; exact growth needs them on the host before the scatter.
+  unsigned *hist = T->h_hist;
+  QueueDesc *desc = (QueueDesc *)T->h_qdesc;
   bool roomy = true;
   for (size_t i = 0; i < nI; i++) {
     const bool keep = !keep_mask || keep_mask[i];
@@ -404,8 +404,16 @@ static int shuffle_impl(gvt_hip_top *T, const RaySrc &in, size_t n, int from, gv
     }
     if (queues[i]->cap < queues[i]->size + n) roomy = false;
   }
+  const bool scan_totals = d_blk && roomy; // ordered mode: k_top_scan leaves the totals in d_hist, no atomics and no memset needed
+  if (nI && !scan_totals) HIPCHK(hipMemsetAsync(T->d_hist, 0, sizeof(unsigned) * nI, st));
+  {
+    ProfScope ps(KC_SHUFFLE);
+    k_top_classify<<<n_blk, TOP_BLOCK, use_lds ? sizeof(unsigned) * nI : 0, st>>>(in, (unsigned)n, T->d_lo, T->d_hi, (int)nI, from, d_next, d_t,
+                                                                                scan_totals ? nullptr : T->d_hist, use_lds, d_blk);
+  }
+  HIPCHK(hipGetLastError());
   if (!roomy) {
-    if (nI) HIPCHK(hipMemcpyAsync(hist.data(), T->d_hist, sizeof(unsigned) * nI, hipMemcpyDeviceToHost, st));
+    if (nI) HIPCHK(hipMemcpyAsync(hist, T->d_hist, sizeof(unsigned) * nI, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
   }
   for (size_t i = 0; i < nI; i++) {
@@ -417,17 +425,17 @@ static int shuffle_impl(gvt_hip_top *T, const RaySrc &in, size_t n, int from, gv
     }
     desc[i].planes = Q->d_planes; desc[i].cap = Q->cap; desc[i].count = Q->d_count; desc[i].keep = keep ? 1u : 0u;
   }
-  if (nI) HIPCHK(hipMemcpyAsync(T->d_qdesc, desc.data(), sizeof(QueueDesc) * nI, hipMemcpyHostToDevice, st));
+  if (nI) HIPCHK(hipMemcpyAsync(T->d_qdesc, desc, sizeof(QueueDesc) * nI, hipMemcpyHostToDevice, st));
   {
     ProfScope ps(KC_SHUFFLE);
-    if (d_blk) k_top_scan<<<(unsigned)nI, TOP_BLOCK, 0, st>>>(d_blk, n_blk, (const QueueDesc *)T->d_qdesc);
+    if (d_blk) k_top_scan<<<(unsigned)nI, TOP_BLOCK, 0, st>>>(d_blk, n_blk, (const QueueDesc *)T->d_qdesc, scan_totals ? T->d_hist : nullptr);
     const size_t lds = d_blk ? sizeof(unsigned) * nI * (TOP_BLOCK / 64) : (use_lds ? 2 * sizeof(unsigned) * nI : 0);
     k_top_scatter<<<n_blk, TOP_BLOCK, lds, st>>>(in, (unsigned)n, d_next, d_t, (const QueueDesc *)T->d_qdesc, (int)nI, fb ? fb->d_rgba : nullptr,
                                                fb ? (unsigned)(fb->w * fb->h) : 0u, use_lds, d_blk);
   }
   HIPCHK(hipGetLastError());
-  if (roomy && nI) HIPCHK(hipMemcpyAsync(hist.data(), T->d_hist, sizeof(unsigned) * nI, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st)); // desc/hist are host vectors
+  if (roomy && nI) HIPCHK(hipMemcpyAsync(hist, T->d_hist, sizeof(unsigned) * nI, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st)); // desc/hist are read by the copies above
   for (size_t i = 0; i < nI; i++)
     if (desc[i].keep) queues[i]->size += hist[i];
   return 0;

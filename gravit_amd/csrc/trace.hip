@@ -711,6 +711,7 @@ struct ShadeArgs {
   Mat3 normi;
   int normal_mode, n_lights;
   uint32_t seed;
+  unsigned *zero_word;     // reset for the launch that follows (the any-hit kernel's work counter)
 };
 
 #define SHADE_BLOCK 512
@@ -720,6 +721,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M) 
   for (int k = threadIdx.x; k < 2 * (2 + 64); k += SHADE_BLOCK) sh_alloc[k] = 0u;
   __syncthreads();
   const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0 && A.zero_word) *A.zero_word = 0u;
   const bool in_range = j < A.n;
   const unsigned i = in_range ? (A.idx ? A.idx[j] : j) : 0u;
   RayRec r;
@@ -884,6 +886,11 @@ __global__ __launch_bounds__(256) void k_ray_keys(RayPlanes q, const unsigned *_
 }
 
 __global__ void k_set_u32(unsigned *p, unsigned v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
+// start of a trace call: moved_rays count := its current size, work counter / shadow count / next count := 0 (one launch, not three memsets)
+__global__ void k_trace_begin(unsigned *out_count, unsigned out_size, unsigned *counters) {
+  if (blockIdx.x == 0 && threadIdx.x < 3) counters[threadIdx.x] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 3) *out_count = out_size;
+}
 
 // after the sort: object-space origin/direction of the rays in sorted order, as two contiguous planes, so that the
 // traversal kernel's lane refills read consecutive memory (the transform is the one k_trace<XFORM> would apply)
@@ -976,14 +983,14 @@ int convert_od_to_planes(const float *d_org, const float *d_dir, size_t n, RayPl
 }
 
 int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, bool xform, const Mat4 &minv, float tnear,
-                   gvt_hip_hit *d_hits) {
+                   gvt_hip_hit *d_hits, bool counter_is_zero) {
   if (!n) return 0;
   Ctx &C = gctx();
   if (gctx().wide4 && !M->d_nodes4) { int rc4 = build_nodes4(M); if (rc4) return rc4; }
   g_have_nodes4 = M->d_nodes4 != nullptr;
   Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
   unsigned *counter = C.d_counters + 0;
-  HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), C.stream));
+  if (!counter_is_zero) HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), C.stream));
   {
     ProfScope ps(KC_CLOSEST);
     RayPlanes none{};
@@ -1057,11 +1064,21 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
   unsigned *d_idx_b = (unsigned *)scratch_get(4, sizeof(unsigned) * n);
   gvt_hip_light *d_lights = (gvt_hip_light *)scratch_get(5, sizeof(gvt_hip_light) * (nL > 0 ? nL : 1));
   if (!d_hits || !d_rng || !d_shadow || !d_idx_a || !d_idx_b || !d_lights) return GVT_HIP_ERR_DEVICE;
-  if (nL) HIPCHK(hipMemcpyAsync(d_lights, lights_host, sizeof(gvt_hip_light) * nL, hipMemcpyHostToDevice, st));
+  { // the light list rarely changes between calls: upload only when it (or its scratch buffer) did
+    static std::vector<unsigned char> cached;
+    static const void *cached_dst = nullptr;
+    const size_t bytes = sizeof(gvt_hip_light) * (size_t)nL;
+    if (nL && (cached_dst != d_lights || cached.size() != bytes || std::memcmp(cached.data(), lights_host, bytes) != 0)) {
+      cached.assign((const unsigned char *)lights_host, (const unsigned char *)lights_host + bytes);
+      cached_dst = d_lights;
+      HIPCHK(hipMemcpyAsync(d_lights, cached.data(), bytes, hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st)); // pageable source: finish the copy before `cached` can change
+    }
+  }
   RayPlanes shadow = make_planes(d_shadow, shadow_cap);
   RayPlanes outp = make_planes(out->d_planes, out->cap);
   unsigned *c_shadow = C.d_counters + 1, *c_next = C.d_counters + 2;
-  k_set_u32<<<1, 64, 0, st>>>(out->d_count, (unsigned)out->size);
+  k_trace_begin<<<1, 64, 0, st>>>(out->d_count, (unsigned)out->size, C.d_counters); // c_shadow, c_next, work counter
 
   MeshView mv;
   mv.verts = M->d_verts; mv.tris = M->d_tris; mv.normals = M->d_normals; mv.vcolors = M->d_vcolors;
@@ -1099,16 +1116,16 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
       }
       HIPCHK(hipGetLastError());
       RayPlanes sorted{ od, od + n, nullptr, nullptr };
-      rc = launch_closest(M, sorted, nullptr, n_active, false, P.minv, GVT_RAY_EPSILON, d_hits);
+      rc = launch_closest(M, sorted, nullptr, n_active, false, P.minv, GVT_RAY_EPSILON, d_hits, pass == 0);
     } else
-      rc = launch_closest(M, in, idx, n_active, true, P.minv, GVT_RAY_EPSILON, d_hits);
+      rc = launch_closest(M, in, idx, n_active, true, P.minv, GVT_RAY_EPSILON, d_hits, pass == 0);
     if (rc) return rc;
-    HIPCHK(hipMemsetAsync(c_shadow, 0, 2 * sizeof(unsigned), st)); // c_shadow, c_next adjacent
+    if (pass > 0) HIPCHK(hipMemsetAsync(c_shadow, 0, 2 * sizeof(unsigned), st)); // c_shadow, c_next adjacent (pass 0: k_trace_begin)
     ShadeArgs A;
     A.in = in; A.idx = idx; A.n = (unsigned)n_active; A.index_base = index_base; A.hits = d_hits; A.rng = d_rng;
     A.first_pass = (pass == 0); A.out = outp; A.out_count = out->d_count; A.shadow = shadow; A.shadow_count = c_shadow;
     A.next_idx = next; A.next_count = c_next; A.lights = d_lights; A.normi = P.normi; A.normal_mode = P.normal_mode;
-    A.n_lights = nL; A.seed = P.seed;
+    A.n_lights = nL; A.seed = P.seed; A.zero_word = (C.trav_kernel == 1) ? C.d_counters + 0 : nullptr;
     {
       ProfScope ps(KC_SHADE);
       k_shade<<<blocks_for(n_active, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, mv);
@@ -1123,8 +1140,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
       if (shadow_ub) {
   g_have_nodes4 = M->d_nodes4 != nullptr;
   Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
-        unsigned *counter = C.d_counters + 0;
-        HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
+        unsigned *counter = C.d_counters + 0; // zeroed by k_shade
         {
           ProfScope ps(KC_ANY);
           launch_trace<true, true, 1>(trav_grid2(shadow_ub), st, shadow, nullptr, 0u, P.minv, T, GVT_RAY_EPSILON, nullptr, nullptr, outp,
