@@ -34,6 +34,8 @@ struct Ctx {
   int sort_rays = 0;     // Morton-sort the rays of a list before traversal (pays on incoherent lists; camera rays arrive in 8x8 tiles and the shuffle keeps list order)
   int sort_gather = 0;   // after sorting, traverse a contiguous object-space copy (o,d) of the rays
   int sort_bits = 20;    // radix-sorted key width (8 bits per rocPRIM pass)
+  int long_steps = 96;   // closest hit: a ray that exceeds this many 4-wide node steps is parked and finished by a whole wave (0: off)
+  int long_min_rays = 65536; // ... only in launches of at least this many rays (small launches have no tail to speak of)
   int term_sink = 1;     // gvt_hip_trace_queue_sink: deposit terminal shadow rays from the any-hit kernel (0: always through moved_rays)
   int camera_tile = 8;   // gvt_hip_image_frame: camera rays listed in 8x8-pixel tiles (0: pixel-major like generateRays)
   int top_ordered = 1;   // shuffle: order-preserving, deterministic slots (<= 64 destinations) instead of arrival-order atomics

@@ -147,6 +147,51 @@ __device__ unsigned g_trav_overflow; // set by k_trace when a traversal stack wo
 #endif
 #define TRAV_DONE ((int)0x80000000) // ~code with count 7: never a valid leaf reference
 
+// Long rays.  Per-ray cost is heavy-tailed (10 M soup, binary visits: mean 53, p99 130, p99.9 206, max 711) and one traversal step is
+// a dependent memory access of ~1.5 us, so a handful of rays used to set the duration of a whole closest-hit launch (capping
+// rays at 100 steps -- 0.1 % of them -- shortened it by 18 %).  k_trace therefore parks a ray that exceeds `steps` inner steps,
+// with its best hit so far, in `recs`; k_long_closest then traverses each parked ray with a whole wave: 64 pending nodes per step
+// instead of one.  The result is the same minimum over (t, primID) -- it does not depend on the order in which boxes are opened.
+struct LongRec { unsigned j, i; float bt; int bp; float bu, bv, bden; unsigned pad; };
+struct LongQ {
+  LongRec *recs;
+  unsigned *count;
+  int steps; // 0: off
+};
+
+// One compressed 4-wide node against one ray: entry distances of the children the ray enters within [0, lim], GVT_FLT_MAX for the
+// others (misses and unused slots), and their references.
+//   plane t = (origin + q*scale - O) / d = q * (scale*inv_d) + (origin*inv_d - O*inv_d); scale is a power of two, so scale*inv_d is
+//   exact.  The rounding of the two fused steps is covered by widening every slab by 2^-21 |O*inv_d| (about 5e-7 |O| in space, on
+//   top of the padded boxes).
+__device__ __forceinline__ void node4_test(const uint4 *__restrict__ nd, float ix, float iy, float iz, float ox, float oy, float oz, float lim,
+                                           float tn[4], int rr[4]) {
+  const uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2];
+  const uint2 w3 = *(const uint2 *)(nd + 3);
+  const float sx = __uint_as_float((w0.w & 0xffu) << 23) * ix, sy = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * iy,
+              sz = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * iz;
+  const float bx = __builtin_fmaf(__uint_as_float(w0.x), ix, -ox), by = __builtin_fmaf(__uint_as_float(w0.y), iy, -oy),
+              bz = __builtin_fmaf(__uint_as_float(w0.z), iz, -oz);
+  const float ex = fabsf(ox) * 4.76837158e-7f, ey = fabsf(oy) * 4.76837158e-7f, ez = fabsf(oz) * 4.76837158e-7f;
+  const float bxn = bx - ex, bxf = bx + ex, byn = by - ey, byf = by + ey, bzn = bz - ez, bzf = bz + ez;
+  const unsigned qnx = ix >= 0.f ? w1.x : w1.y, qfx = ix >= 0.f ? w1.y : w1.x; // near / far planes by ray direction
+  const unsigned qny = iy >= 0.f ? w1.z : w1.w, qfy = iy >= 0.f ? w1.w : w1.z;
+  const unsigned qnz = iz >= 0.f ? w2.x : w2.y, qfz = iz >= 0.f ? w2.y : w2.x;
+  rr[0] = (int)w2.z; rr[1] = (int)w2.w; rr[2] = (int)w3.x; rr[3] = (int)w3.y;
+#define GVT_SLAB4(C)                                                                                              \
+  {                                                                                                              \
+    const float n_ = fmaxf(fmaxf(__builtin_fmaf((float)((qnx >> (8 * C)) & 0xffu), sx, bxn),                     \
+                                 __builtin_fmaf((float)((qny >> (8 * C)) & 0xffu), sy, byn)),                    \
+                           fmaxf(__builtin_fmaf((float)((qnz >> (8 * C)) & 0xffu), sz, bzn), 0.f));              \
+    const float f_ = fminf(fminf(__builtin_fmaf((float)((qfx >> (8 * C)) & 0xffu), sx, bxf),                     \
+                                 __builtin_fmaf((float)((qfy >> (8 * C)) & 0xffu), sy, byf)),                    \
+                           __builtin_fmaf((float)((qfz >> (8 * C)) & 0xffu), sz, bzf)) * 1.0000004f;             \
+    tn[C] = ((n_ <= f_) && (n_ <= lim) && (rr[C] != GVT_EMPTY_REF)) ? n_ : GVT_FLT_MAX; /* a miss sorts last */  \
+  }
+  GVT_SLAB4(0) GVT_SLAB4(1) GVT_SLAB4(2) GVT_SLAB4(3)
+#undef GVT_SLAB4
+}
+
 // copies the rays whose indices are parked in the wave's LDS list to consecutive slots of `out`; with a sink, rays that meet no
 // other instance end here (shuffleRays' terminal rule) and only the others are copied
 __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const RayPlanes &q, const RayPlanes &out, unsigned *out_count, const TermSink &K) {
@@ -192,7 +237,7 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
 template <bool ANY, bool XFORM, int MODE, bool COOP, bool W4>
 __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, Trav T, float tnear,
                                                        gvt_hip_hit *__restrict__ hits, int *__restrict__ flags, RayPlanes out, unsigned *out_count,
-                                                       unsigned *counter, int *spill_base, int refill_min, int inner_min, const unsigned *__restrict__ n_dev, int share, TermSink sink) {
+                                                       unsigned *counter, int *spill_base, int refill_min, int inner_min, const unsigned *__restrict__ n_dev, int share, TermSink sink, LongQ LQ) {
   // rays per grab of the work counter: 256 for big launches (few atomics), down to 64 when there are fewer rays than lanes so
   // that the rays spread over all resident waves instead of queueing four deep in a few of them
   const unsigned n_lanes_total = gridDim.x * (unsigned)TRAV_BLOCK;
@@ -227,6 +272,8 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
   int sb = 0;           // bottom of this lane's stack window [sb, sp): entries below sb were given away to helper lanes
   bool sharing = false; // wave-uniform: some ray of this wave is being traversed by more than one lane
   int donor_lane = -1;  // helper: the lane it took its subtree from (to follow that lane's best hit)
+  int nsteps = 0;       // closest hit: inner steps of this lane's ray; beyond LQ.steps the ray is parked for k_long_closest
+  bool parked = false;
 #if GVT_STAMP
   unsigned long long st_refill = 0, st_inner = 0, st_leaf = 0, st_retire = 0, n_inner_it = 0, n_outer_it = 0, t_mark = 0, t_begin = __builtin_amdgcn_s_memtime();
   unsigned long long t_exh = 0, it_exh = 0, out_exh = 0, act_exh = 0;
@@ -268,7 +315,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
           ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
           ox = O.x * ix; oy = O.y * iy; oz = O.z * iz;
           bt = GVT_FLT_MAX; bu = 0.f; bv = 0.f; bden = 1.f; bp = -1;
-          sp = 0; sb = 0; donor_lane = -1;
+          sp = 0; sb = 0; donor_lane = -1; nsteps = 0; parked = false;
           cur = T.nodes ? 0 : TRAV_DONE;
           active = true;
         }
@@ -333,37 +380,9 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
       const bool at_inner = active && cur >= 0;
       if (W4) {
         if (at_inner) { // one 64-byte fetch decides four children (8-bit boxes on the node's own grid)
-          const uint4 *nd = T.nodes4 + (size_t)GVT_NODE4_F4 * cur;
-          const uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2];
-          const uint2 w3 = *(const uint2 *)(nd + 3);
-          // plane t = (origin + q*scale - O) / d = q * (scale*inv_d) + (origin*inv_d - O*inv_d); scale is a power of two, so
-          // scale*inv_d is exact.  The rounding of the two fused steps is covered by widening every slab by 2^-21 |O*inv_d|
-          // (about 5e-7 |O| in space, on top of the padded boxes).
-          const float sx = __uint_as_float((w0.w & 0xffu) << 23) * ix, sy = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * iy,
-                      sz = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * iz;
-          const float bx = __builtin_fmaf(__uint_as_float(w0.x), ix, -ox), by = __builtin_fmaf(__uint_as_float(w0.y), iy, -oy),
-                      bz = __builtin_fmaf(__uint_as_float(w0.z), iz, -oz);
-          const float ex = fabsf(ox) * 4.76837158e-7f, ey = fabsf(oy) * 4.76837158e-7f, ez = fabsf(oz) * 4.76837158e-7f;
-          const float bxn = bx - ex, bxf = bx + ex, byn = by - ey, byf = by + ey, bzn = bz - ez, bzf = bz + ez;
-          const unsigned qnx = ix >= 0.f ? w1.x : w1.y, qfx = ix >= 0.f ? w1.y : w1.x; // near / far planes by ray direction
-          const unsigned qny = iy >= 0.f ? w1.z : w1.w, qfy = iy >= 0.f ? w1.w : w1.z;
-          const unsigned qnz = iz >= 0.f ? w2.x : w2.y, qfz = iz >= 0.f ? w2.y : w2.x;
-          const float lim = ANY ? GVT_FLT_MAX : bt;
           float tn[4];
           int rr[4];
-          rr[0] = (int)w2.z; rr[1] = (int)w2.w; rr[2] = (int)w3.x; rr[3] = (int)w3.y;
-#define GVT_SLAB4(C)                                                                                                      \
-          {                                                                                                              \
-            const float n_ = fmaxf(fmaxf(__builtin_fmaf((float)((qnx >> (8 * C)) & 0xffu), sx, bxn),                     \
-                                         __builtin_fmaf((float)((qny >> (8 * C)) & 0xffu), sy, byn)),                    \
-                                   fmaxf(__builtin_fmaf((float)((qnz >> (8 * C)) & 0xffu), sz, bzn), 0.f));              \
-            const float f_ = fminf(fminf(__builtin_fmaf((float)((qfx >> (8 * C)) & 0xffu), sx, bxf),                     \
-                                         __builtin_fmaf((float)((qfy >> (8 * C)) & 0xffu), sy, byf)),                    \
-                                   __builtin_fmaf((float)((qfz >> (8 * C)) & 0xffu), sz, bzf)) * 1.0000004f;             \
-            tn[C] = ((n_ <= f_) && (n_ <= lim) && (rr[C] != GVT_EMPTY_REF)) ? n_ : GVT_FLT_MAX; /* a miss sorts last */  \
-          }
-          GVT_SLAB4(0) GVT_SLAB4(1) GVT_SLAB4(2) GVT_SLAB4(3)
-#undef GVT_SLAB4
+          node4_test(T.nodes4 + (size_t)GVT_NODE4_F4 * cur, ix, iy, iz, ox, oy, oz, ANY ? GVT_FLT_MAX : bt, tn, rr);
           if (!ANY) { // nearest first; for any-hit the order does not matter
 #define GVT_CE(A, B) { const bool sw_ = tn[B] < tn[A]; const float ta_ = sw_ ? tn[B] : tn[A], tb_ = sw_ ? tn[A] : tn[B]; \
                        const int ra_ = sw_ ? rr[B] : rr[A], rb_ = sw_ ? rr[A] : rr[B]; tn[A] = ta_; tn[B] = tb_; rr[A] = ra_; rr[B] = rb_; }
@@ -415,6 +434,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
 #if GVT_STAMP
       n_inner_it++;
 #endif
+      if (!ANY && at_inner && LQ.steps && ++nsteps > LQ.steps && cur != TRAV_DONE) { cur = TRAV_DONE; parked = true; }
       im = __ballot(active && cur >= 0);
       if (__popcll(im) < inner_min) break;
     }
@@ -528,9 +548,21 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
       }
       if (n_pend >= 64) { flush_pending(pend, n_pend, q, out, out_count, sink); n_pend = 0; }
     }
+    if (!ANY && LQ.steps) {
+      const unsigned long long pm = __ballot(fin && parked);
+      if (pm) {
+        unsigned base = 0;
+        if ((int)lane_id() == __ffsll((long long)pm) - 1) base = atomicAdd(LQ.count, (unsigned)__popcll(pm));
+        base = __shfl(base, __ffsll((long long)pm) - 1);
+        if (fin && parked) {
+          LongRec R; R.j = j; R.i = idx ? idx[j] : j; R.bt = bt; R.bp = bp; R.bu = bu; R.bv = bv; R.bden = bden; R.pad = 0u;
+          LQ.recs[base + lanes_below(pm)] = R;
+        }
+      }
+    }
     if (fin) {
       if (ANY) { if (MODE == 0) flags[j] = (bp >= 0) ? 1 : 0; }
-      else { gvt_hip_hit h; h.t = bt; h.prim = bp; h.u = (bp >= 0) ? bu / bden : 0.f; h.v = (bp >= 0) ? bv / bden : 0.f; hits[j] = h; }
+      else if (!parked) { gvt_hip_hit h; h.t = bt; h.prim = bp; h.u = (bp >= 0) ? bu / bden : 0.f; h.v = (bp >= 0) ? bv / bden : 0.f; hits[j] = h; }
       active = false;
     }
   }
@@ -542,6 +574,121 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
   if (overflow) atomicOr(&g_trav_overflow, 1u);
 #undef KT_PUSH
 #undef KT_POP
+}
+
+// A whole wave per parked ray.  The pending nodes live in a per-wave LDS list; each step the 64 lanes open up to 64 of them (newest
+// first), append the children the ray enters to the node list or the leaf list, and when enough leaves have gathered (or no node is
+// left) every lane intersects one leaf and the wave reduces to the best (t, primID).  Entries farther than the best hit are dropped
+// when they are taken.  LONG_CAP throttles the number of nodes opened per step so that the lists cannot outgrow LONG_PHYS.
+#define LONG_CAP 512
+#define LONG_PHYS (LONG_CAP + 256)
+template <bool XFORM>
+__global__ __launch_bounds__(256) void k_long_closest(RayPlanes q, const LongRec *__restrict__ recs, const unsigned *__restrict__ n_recs, Mat4 minv,
+                                                       Trav T, float tnear, gvt_hip_hit *__restrict__ hits, unsigned *counter) {
+  __shared__ int s_ref_all[4][LONG_PHYS];
+  __shared__ float s_tn_all[4][LONG_PHYS];
+  __shared__ int l_ref_all[4][LONG_PHYS];
+  __shared__ float l_tn_all[4][LONG_PHYS];
+  const int wv = threadIdx.x >> 6;
+  const int lane = (int)lane_id();
+  volatile int *s_ref = s_ref_all[wv];
+  volatile float *s_tn = s_tn_all[wv];
+  volatile int *l_ref = l_ref_all[wv];
+  volatile float *l_tn = l_tn_all[wv];
+  const unsigned n = *n_recs;
+  bool overflow = false;
+  for (;;) {
+    unsigned r = 0;
+    if (lane == 0) r = atomicAdd(counter, 1u);
+    r = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+    if (r >= n) break;
+    const LongRec R = recs[r];
+    const float4 a = q.p0[R.i], b = q.p1[R.i];
+    V3 O = mk3(a.x, a.y, a.z), D = mk3(b.x, b.y, b.z);
+    if (XFORM) { O = xfm_point(minv, O); D = xfm_vector(minv, D); }
+    const float dx = fabsf(D.x) < 1e-30f ? copysignf(1e-30f, D.x) : D.x;
+    const float dy = fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y;
+    const float dz = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    const float ox = O.x * ix, oy = O.y * iy, oz = O.z * iz;
+    float bt = R.bt, bu = R.bu, bv = R.bv, bden = R.bden; // the same in every lane
+    int bp = R.bp;
+    int ns = 1, nl = 0;                                   // wave-uniform
+    if (lane == 0) { s_ref[0] = 0; s_tn[0] = 0.f; }
+    __builtin_amdgcn_wave_barrier();
+    while (ns > 0 || nl > 0) {
+      const bool do_leaf = nl > 0 && (ns == 0 || nl >= 64 || nl > LONG_CAP - 256);
+      if (!do_leaf) {
+        int take = min(min(ns, 64), min((LONG_CAP - ns) / 3, (LONG_CAP - nl) / 4));
+        take = max(take, 1);
+        const bool mine = lane < take;
+        int ref = 0;
+        float etn = 0.f;
+        if (mine) { ref = s_ref[ns - 1 - lane]; etn = s_tn[ns - 1 - lane]; }
+        __builtin_amdgcn_wave_barrier();
+        ns -= take;
+        float tn[4];
+        int rr[4];
+        const bool open = mine && etn <= bt;
+        if (open) {
+          node4_test(T.nodes4 + (size_t)GVT_NODE4_F4 * ref, ix, iy, iz, ox, oy, oz, bt, tn, rr);
+          // nearest child last: the lists are taken from their end, so the wave keeps descending along the nearest pending nodes
+#define GVT_CE(A, B) { const bool sw_ = tn[B] < tn[A]; const float ta_ = sw_ ? tn[B] : tn[A], tb_ = sw_ ? tn[A] : tn[B]; \
+                       const int ra_ = sw_ ? rr[B] : rr[A], rb_ = sw_ ? rr[A] : rr[B]; tn[A] = ta_; tn[B] = tb_; rr[A] = ra_; rr[B] = rb_; }
+          GVT_CE(0, 1) GVT_CE(2, 3) GVT_CE(0, 2) GVT_CE(1, 3) GVT_CE(1, 2)
+#undef GVT_CE
+        }
+#pragma unroll
+        for (int c = 3; c >= 0; c--) {
+          const bool hit = open && tn[c] < GVT_FLT_MAX;
+          const unsigned long long mi = __ballot(hit && rr[c] >= 0), ml = __ballot(hit && rr[c] < 0);
+          if (hit && rr[c] >= 0) { const int pos = ns + (int)lanes_below(mi); if (pos < LONG_PHYS) { s_ref[pos] = rr[c]; s_tn[pos] = tn[c]; } else overflow = true; }
+          if (hit && rr[c] < 0) { const int pos = nl + (int)lanes_below(ml); if (pos < LONG_PHYS) { l_ref[pos] = rr[c]; l_tn[pos] = tn[c]; } else overflow = true; }
+          ns = min(ns + __popcll(mi), LONG_PHYS);
+          nl = min(nl + __popcll(ml), LONG_PHYS);
+        }
+        __builtin_amdgcn_wave_barrier();
+      } else {
+        const int take = min(nl, 64);
+        const bool mine = lane < take;
+        int ref = -1;
+        float etn = 0.f;
+        if (mine) { ref = l_ref[nl - 1 - lane]; etn = l_tn[nl - 1 - lane]; }
+        __builtin_amdgcn_wave_barrier();
+        nl -= take;
+        float lt = GVT_FLT_MAX, lu = 0.f, lv = 0.f, ld = 1.f;
+        int lp = -1;
+        if (mine && etn <= bt) {
+          const unsigned code = (unsigned)~ref;
+          const unsigned first = code >> 3, ntri = code & 7u;
+          const float4 *ts = T.tris + 4 * (size_t)first;
+          for (unsigned k = 0; k < ntri; k++) {
+            const float4 s0 = ts[4 * k], s1 = ts[4 * k + 1], s2 = ts[4 * k + 2];
+            const V3 e1 = mk3(s1.x, s1.y, s1.z), e2 = mk3(s2.x, s2.y, s2.z);
+            float TT, U, V, aden;
+            if (tri_test_raw(O, D, mk3(s0.x, s0.y, s0.z), e1, e2, cross3(e1, e2), tnear, TT, U, V, aden)) {
+              const float t = TT / aden;
+              if (t <= GVT_FLT_MAX) {
+                const int prim = __float_as_int(s0.w);
+                if (lp < 0 || t < lt || (t == lt && prim < lp)) { lt = t; lp = prim; lu = U; lv = V; ld = aden; }
+              }
+            }
+          }
+        }
+        if (__ballot(lp >= 0)) { // the wave's best candidate, then against the ray's best so far
+#pragma unroll
+          for (int off = 32; off >= 1; off >>= 1) {
+            const float ot = __shfl_xor(lt, off), ou = __shfl_xor(lu, off), ov = __shfl_xor(lv, off), od = __shfl_xor(ld, off);
+            const int op = __shfl_xor(lp, off);
+            if (op >= 0 && (lp < 0 || ot < lt || (ot == lt && op < lp))) { lt = ot; lp = op; lu = ou; lv = ov; ld = od; }
+          }
+          if (lp >= 0 && (bp < 0 || lt < bt || (lt == bt && lp < bp))) { bt = lt; bp = lp; bu = lu; bv = lv; bden = ld; }
+        }
+      }
+    }
+    if (lane == 0) { gvt_hip_hit h; h.t = bt; h.prim = bp; h.u = (bp >= 0) ? bu / bden : 0.f; h.v = (bp >= 0) ? bv / bden : 0.f; hits[R.j] = h; }
+  }
+  if (overflow) atomicOr(&g_trav_overflow, 1u);
 }
 
 // diagnostic (not on the hot path): per-ray visit counts of the closest-hit traversal.
@@ -888,8 +1035,8 @@ __global__ __launch_bounds__(256) void k_ray_keys(RayPlanes q, const unsigned *_
 __global__ void k_set_u32(unsigned *p, unsigned v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
 // start of a trace call: moved_rays count := its current size, work counter / shadow count / next count := 0 (one launch, not three memsets)
 __global__ void k_trace_begin(unsigned *out_count, unsigned out_size, unsigned *counters) {
-  if (blockIdx.x == 0 && threadIdx.x < 3) counters[threadIdx.x] = 0u;
-  if (blockIdx.x == 0 && threadIdx.x == 3) *out_count = out_size;
+  if (blockIdx.x == 0 && threadIdx.x < 5) counters[threadIdx.x] = 0u; // work counter, shadow count, next count, parked rays, their work counter
+  if (blockIdx.x == 0 && threadIdx.x == 5) *out_count = out_size;
 }
 
 // after the sort: object-space origin/direction of the rays in sorted order, as two contiguous planes, so that the
@@ -990,13 +1137,25 @@ int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, 
   g_have_nodes4 = M->d_nodes4 != nullptr;
   Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
   unsigned *counter = C.d_counters + 0;
-  if (!counter_is_zero) HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), C.stream));
+  if (!counter_is_zero) HIPCHK(hipMemsetAsync(C.d_counters, 0, 5 * sizeof(unsigned), C.stream));
+  LongQ LQ{};
+  if (C.trav_kernel == 1 && C.wide4 && g_have_nodes4 && C.long_steps > 0 && n >= (size_t)C.long_min_rays) { // long rays are parked and traversed a wave per ray
+    LQ.recs = (LongRec *)scratch_get(15, sizeof(LongRec) * n);
+    if (!LQ.recs) return GVT_HIP_ERR_DEVICE;
+    LQ.count = C.d_counters + 3;
+    LQ.steps = C.long_steps;
+  }
   {
     ProfScope ps(KC_CLOSEST);
     RayPlanes none{};
     if (C.trav_kernel == 1) {
-      if (xform) launch_trace<false, true, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{});
-      else launch_trace<false, false, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{});
+      if (xform) launch_trace<false, true, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{}, LQ);
+      else launch_trace<false, false, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{}, LQ);
+      if (LQ.steps) {
+        const int grid = C.n_cu * 3; // 48 KiB of LDS per block
+        if (xform) k_long_closest<true><<<grid, 256, 0, C.stream>>>(q, LQ.recs, LQ.count, minv, T, tnear, d_hits, C.d_counters + 4);
+        else k_long_closest<false><<<grid, 256, 0, C.stream>>>(q, LQ.recs, LQ.count, minv, T, tnear, d_hits, C.d_counters + 4);
+      }
     } else {
       if (xform) k_closest<true><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
       else k_closest<false><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
@@ -1033,8 +1192,8 @@ int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const M
   {
     ProfScope ps(KC_ANY);
     if (C.trav_kernel == 1) {
-      if (xform) launch_trace<true, true, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{});
-      else launch_trace<true, false, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{});
+      if (xform) launch_trace<true, true, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{}, LongQ{});
+      else launch_trace<true, false, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{}, LongQ{});
     } else {
       if (xform) k_any<true, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
       else k_any<false, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
@@ -1144,7 +1303,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
         {
           ProfScope ps(KC_ANY);
           launch_trace<true, true, 1>(trav_grid2(shadow_ub), st, shadow, nullptr, 0u, P.minv, T, GVT_RAY_EPSILON, nullptr, nullptr, outp,
-                                                                               out->d_count, counter, C.d_spill, C.refill_min, C.inner_min, c_shadow, C.share, P.sink);
+                                                                               out->d_count, counter, C.d_spill, C.refill_min, C.inner_min, c_shadow, C.share, P.sink, LongQ{});
         }
         HIPCHK(hipGetLastError());
         C.stats.launches_any++;

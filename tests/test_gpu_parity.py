@@ -379,6 +379,39 @@ def test_shuffle_keeps_list_order_and_fused_camera_filter(hip):
                 assert len(b) == len(exp) and rays_equal_bits(b, exp), "camera_filter: queue %d" % i
 
 
+def test_long_ray_path_is_bit_exact(hip):
+    """Rays that exceed `long_steps` node steps are parked by k_trace and finished by k_long_closest, a wave per ray.  Forced onto
+    (nearly) every ray here -- threshold 1..8 steps, no minimum launch size -- hits and whole frames must not change by a bit."""
+    from gravit_amd import capi
+
+    v, t = scenes.load_mesh_file(os.path.join(GOLDEN, "bun_zipper.npz"))
+    mesh = scenes.MeshData(v, t, scenes.default_material())
+    ad = HipMeshAdapter(mesh, NORMALS_SMOOTH)
+    rng = np.random.default_rng(5)
+    n = 30000
+    lo, hi = v.min(0), v.max(0)
+    org = (rng.uniform(-1, 2, (n, 3)) * (hi - lo) + lo).astype(np.float32)
+    tgt = (rng.uniform(0, 1, (n, 3)) * (hi - lo) + lo).astype(np.float32)
+    d = tgt - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    sc = scenes.bunny_grid_scene(width=190, height=108)
+    try:
+        capi.set_option("long_steps", 0)
+        ref_hits = ad.intersect(org, d.astype(np.float32))
+        ref_fb = ImageTracer(sc, NORMALS_SMOOTH)().framebuffer(False).copy()
+        assert (ref_hits["prim"] >= 0).sum() > 1000
+        capi.set_option("long_min_rays", 0)
+        for steps in (1, 3, 8):
+            capi.set_option("long_steps", steps)
+            h = ad.intersect(org, d.astype(np.float32))
+            assert h.tobytes() == ref_hits.tobytes(), "hits differ with long_steps=%d" % steps
+            fb = ImageTracer(sc, NORMALS_SMOOTH)().framebuffer(False)
+            assert np.array_equal(fb, ref_fb), "frame differs with long_steps=%d" % steps
+    finally:
+        capi.set_option("long_steps", 96)
+        capi.set_option("long_min_rays", 65536)
+
+
 def test_terminal_sink_equals_shuffle(hip):
     """gvt_hip_trace_queue_sink deposits terminal shadow rays inside the adapter; the frame must equal the one where every moved ray
     goes through shuffleRays (term_sink=0), on a scene where shadow rays do cross other instances."""
