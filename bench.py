@@ -199,7 +199,7 @@ def main():
                 "bound": "hbm", "kernel": "k_%s" % dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_ray": b_ray, "rays_per_launch": rays_dom / n_launch, "avg_launch_ms": ms_dom / n_launch,
-                "kernel_ms": {k: st[k] for k in ("ms_closest", "ms_any", "ms_shade", "ms_shuffle", "ms_camera", "ms_convert", "ms_sort")},
+                "kernel_ms": {k: st[k] for k in ("ms_closest", "ms_any", "ms_shade", "ms_shuffle", "ms_camera", "ms_convert", "ms_sort", "ms_long")},
             },
         }
         if world == 1 and args.domains <= 1 and not args.no_cpu_baseline:

@@ -48,7 +48,7 @@ class Stats(C.Structure):
                 ("rays_forwarded", C.c_uint64), ("trace_calls", C.c_uint64),
                 ("ms_closest", C.c_double), ("ms_any", C.c_double), ("ms_shade", C.c_double), ("ms_convert", C.c_double),
                 ("ms_shuffle", C.c_double), ("ms_camera", C.c_double), ("ms_build", C.c_double),
-                ("launches_closest", C.c_uint64), ("launches_any", C.c_uint64), ("ms_sort", C.c_double)]
+                ("launches_closest", C.c_uint64), ("launches_any", C.c_uint64), ("ms_sort", C.c_double), ("ms_long", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -106,7 +106,7 @@ static void drain_events() {
     float ms = 0.f;
     hipEventElapsedTime(&ms, p.a, p.b);
     double *slot[KC_COUNT] = { &C.stats.ms_closest, &C.stats.ms_any, &C.stats.ms_shade, &C.stats.ms_convert, &C.stats.ms_shuffle,
-                               &C.stats.ms_camera, &C.stats.ms_build, &C.stats.ms_sort };
+                               &C.stats.ms_camera, &C.stats.ms_build, &C.stats.ms_sort, &C.stats.ms_long };
     *slot[p.cls] += ms;
     C.event_pool.push_back(p.a);
     C.event_pool.push_back(p.b);

@@ -10,7 +10,7 @@
 
 #include "gvt_device.h"
 
-enum KernelClass { KC_CLOSEST = 0, KC_ANY, KC_SHADE, KC_CONVERT, KC_SHUFFLE, KC_CAMERA, KC_BUILD, KC_SORT, KC_COUNT };
+enum KernelClass { KC_CLOSEST = 0, KC_ANY, KC_SHADE, KC_CONVERT, KC_SHUFFLE, KC_CAMERA, KC_BUILD, KC_SORT, KC_LONG, KC_COUNT };
 
 struct PendingEvent {
   hipEvent_t a, b;

@@ -1151,14 +1151,19 @@ int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, 
     if (C.trav_kernel == 1) {
       if (xform) launch_trace<false, true, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{}, LQ);
       else launch_trace<false, false, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{}, LQ);
-      if (LQ.steps) {
+    } else {
+      if (xform) k_closest<true><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
+      else k_closest<false><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
+    }
+  }
+  if (LQ.steps) {
+    {
+      ProfScope ps(KC_LONG);
+      {
         const int grid = C.n_cu * 3; // 48 KiB of LDS per block
         if (xform) k_long_closest<true><<<grid, 256, 0, C.stream>>>(q, LQ.recs, LQ.count, minv, T, tnear, d_hits, C.d_counters + 4);
         else k_long_closest<false><<<grid, 256, 0, C.stream>>>(q, LQ.recs, LQ.count, minv, T, tnear, d_hits, C.d_counters + 4);
       }
-    } else {
-      if (xform) k_closest<true><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
-      else k_closest<false><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
     }
   }
   HIPCHK(hipGetLastError());

@@ -210,6 +210,7 @@ typedef struct gvt_hip_stats {
   double ms_closest, ms_any, ms_shade, ms_convert, ms_shuffle, ms_camera, ms_build;
   uint64_t launches_closest, launches_any;
   double ms_sort; /* ray sorting inside the adapter */
+  double ms_long; /* k_long_closest: parked long rays, a wave per ray (not part of ms_closest) */
 } gvt_hip_stats;
 int gvt_hip_profile(int enable);           /* bracket every kernel with HIP events on the launch stream */
 int gvt_hip_stats_read(gvt_hip_stats *);   /* synchronises */
