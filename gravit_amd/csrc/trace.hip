@@ -859,6 +859,7 @@ struct ShadeArgs {
   int normal_mode, n_lights;
   uint32_t seed;
   unsigned *zero_word;     // reset for the launch that follows (the any-hit kernel's work counter)
+  TermSink sink;           // terminal rule of the shuffle for rays that leave this instance without a hit (fb == nullptr: off)
 };
 
 #define SHADE_BLOCK 512
@@ -918,10 +919,24 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M) 
       }
     }
   }
-  // moved_rays: misses are forwarded as they are
+  // moved_rays: misses are forwarded as they are -- unless the sink is on and no other instance lies ahead: then shuffleRays would
+  // only drop the ray (or, for a SHADOW ray that carries colour, deposit it: TracerBase.h:396-400), which is done here at once
   {
-    const unsigned slot = block_alloc(A.out_count, miss, &sh_alloc[0]);
-    if (miss) store_ray(A.out, slot, r);
+    bool forward = miss;
+    if (miss && A.sink.fb) {
+      float ret_t;
+      const float4 a = make_float4(r.o.x, r.o.y, r.o.z, r.t_min), b = make_float4(r.d.x, r.d.y, r.d.z, r.t_max);
+      if (top_nearest(a, b, A.sink.blo, A.sink.bhi, A.sink.n_inst, A.sink.from, ret_t) < 0) {
+        forward = false;
+        if (r.type == 1 && len3(r.c) > 0.f && (unsigned)r.id < A.sink.n_pix) {
+          const V3 cw = scl3(r.c, r.w);
+          float *px = A.sink.fb + (size_t)4 * (unsigned)r.id;
+          atomicAdd(px + 0, cw.x); atomicAdd(px + 1, cw.y); atomicAdd(px + 2, cw.z); atomicAdd(px + 3, 1.f);
+        }
+      }
+    }
+    const unsigned slot = block_alloc(A.out_count, forward, &sh_alloc[0]);
+    if (forward) store_ray(A.out, slot, r);
   }
   // generateShadowRays :320-358 -- one pass per light so that the wave allocates slots together
   for (int li = 0; li < A.n_lights; li++) {
@@ -1290,6 +1305,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
     A.first_pass = (pass == 0); A.out = outp; A.out_count = out->d_count; A.shadow = shadow; A.shadow_count = c_shadow;
     A.next_idx = next; A.next_count = c_next; A.lights = d_lights; A.normi = P.normi; A.normal_mode = P.normal_mode;
     A.n_lights = nL; A.seed = P.seed; A.zero_word = (C.trav_kernel == 1) ? C.d_counters + 0 : nullptr;
+    A.sink = P.sink;
     {
       ProfScope ps(KC_SHADE);
       k_shade<<<blocks_for(n_active, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, mv);

@@ -142,10 +142,11 @@ int gvt_hip_queue_export(gvt_hip_queue *, gvt_hip_ray *dst, size_t cap, size_t *
 /* Adapter::trace on device queues: consumes q_in (left empty, like ImageTracer.h:248), appends to q_out */
 int gvt_hip_trace_queue(gvt_hip_mesh *, gvt_hip_queue *q_in, gvt_hip_queue *q_out, const float m[16], const float minv[16],
                         const float normi[9], const gvt_hip_light *lights, size_t n_lights, int normal_mode, uint32_t seed);
-/* The same call, with the terminal rule of the shuffleRays that would follow (TracerBase.h:396-400) applied inside the adapter: an
- * un-occluded shadow ray that meets no instance other than from_inst deposits color*w into fb right where the any-hit kernel
- * retires it and is not appended to q_out; all other rays reach q_out as before, so gvt_hip_shuffle(top, q_out, from_inst, ...)
- * afterwards completes exactly what it would have done.  top == NULL or fb == NULL: plain gvt_hip_trace_queue. */
+/* The same call, with the terminal rule of the shuffleRays that would follow (TracerBase.h:396-400) applied inside the adapter: a
+ * ray the adapter would append to q_out (an un-occluded shadow ray, or a ray that leaves the mesh without a hit) but that meets no
+ * instance other than from_inst is not appended: a SHADOW ray that carries colour deposits color*w into fb on the spot, any other
+ * such ray is dropped -- exactly what the shuffle would have done with it.  All other rays reach q_out as before, so
+ * gvt_hip_shuffle(top, q_out, from_inst, ...) afterwards completes the step.  top == NULL or fb == NULL: plain gvt_hip_trace_queue. */
 int gvt_hip_trace_queue_sink(gvt_hip_mesh *, gvt_hip_queue *q, gvt_hip_queue *moved, const float m[16], const float minv[16],
                              const float normi[9], const gvt_hip_light *lights, size_t n_lights, int normal_mode, uint32_t seed,
                              gvt_hip_top *top, int from_inst, gvt_hip_fb *fb);

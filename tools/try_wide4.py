@@ -18,8 +18,8 @@ def run(opts, frames=6):
     fb = tr().framebuffer(True).copy()
     return (dt * 1e3, st['ms_closest'] / frames, st['ms_any'] / frames, (st['rays_closest'] + st['rays_any']) / frames / dt / 1e6), fb
 ref = None
-for opts in (dict(long_steps=0), dict(long_steps=80), dict(long_steps=96), dict(long_steps=112), dict(long_steps=128), dict(long_steps=160), dict(long_steps=200), dict(long_steps=0)):
+for opts in (dict(term_sink=1), dict(term_sink=0), dict(term_sink=1), dict(term_sink=0)):
     r, fb = run(opts, frames=12)
     if ref is None: ref = fb
     st = capi.stats()
-    print(json.dumps(opts), 'frame %.3f ms closest %.3f any %.3f Mrays/s %.0f' % r, 'fb equal:', bool(np.array_equal(fb, ref)), flush=True)
+    print(json.dumps(opts), 'frame %.3f ms closest %.3f long %.3f any %.3f Mrays/s %.0f' % (r[0], r[1], st['ms_long'] / 12, r[2], r[3]), 'shuffle %.3f' % (st['ms_shuffle'] / 12), 'fb equal:', bool(np.array_equal(fb, ref)), flush=True)
