@@ -140,6 +140,7 @@ extern "C" int gvt_hip_set_option(const char *name, int value) {
   if (!std::strcmp(name, "sort_gather")) { g_ctx.sort_gather = value; return 0; }
   if (!std::strcmp(name, "sort_bits")) { if (value < 8 || value > 32) { set_error("sort_bits must be 8..32"); return GVT_HIP_ERR_INVALID; } g_ctx.sort_bits = value; return 0; }
   if (!std::strcmp(name, "share")) { g_ctx.share = value; return 0; }
+  if (!std::strcmp(name, "defaults")) { static_cast<Knobs &>(g_ctx) = Knobs{}; return 0; }
   if (!std::strcmp(name, "long_steps")) { g_ctx.long_steps = value < 0 ? 0 : value; return 0; }
   if (!std::strcmp(name, "long_min_rays")) { g_ctx.long_min_rays = value < 0 ? 0 : value; return 0; }
   if (!std::strcmp(name, "term_sink")) { g_ctx.term_sink = value; return 0; }

@@ -17,12 +17,8 @@ struct PendingEvent {
   int cls;
 };
 
-struct Ctx {
-  bool ready = false;
-  int device = -1;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
-  bool profile = false;
+// tuning knobs (gvt_hip_set_option); results never depend on them.  "defaults" restores this initial state.
+struct Knobs {
   int trav_kernel = 1;   // 1 = persistent waves with lane refill (k_trace), 0 = one 64-ray batch at a time (k_closest/k_any)
   int blocks_per_cu = 4; // k_trace grid: resident 256-thread blocks per CU
   int refill_min = 16;   // k_trace: idle lanes needed before a refill
@@ -39,7 +35,15 @@ struct Ctx {
   int term_sink = 1;     // gvt_hip_trace_queue_sink: deposit terminal shadow rays from the any-hit kernel (0: always through moved_rays)
   int camera_tile = 8;   // gvt_hip_image_frame: camera rays listed in 8x8-pixel tiles (0: pixel-major like generateRays)
   int top_ordered = 1;   // shuffle: order-preserving, deterministic slots (<= 64 destinations) instead of arrival-order atomics
-  int top_lds = 1;       // shuffle kernels: aggregate destination counters in LDS per 1024-thread block // Morton-sort rays before traversal (adapter-internal; results are order independent)
+  int top_lds = 1;       // shuffle kernels: aggregate destination counters in LDS per 1024-thread block
+};
+
+struct Ctx : Knobs {
+  bool ready = false;
+  int device = -1;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  bool profile = false;
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;
   gvt_hip_stats stats{};

@@ -219,7 +219,9 @@ int gvt_hip_stats_reset(void);
 /* diagnostic, not on the hot path: per-ray visit counts of the closest-hit traversal over n object-space rays:
  * counts[3*j + 0..2] = inner-node visits / leaf visits / triangle tests of ray j. */
 int gvt_hip_visit_stats(gvt_hip_mesh *, const float *org, const float *dir, size_t n, float tnear, uint32_t *counts);
-/* adapter-internal tuning knobs (results never depend on them): "sort_rays" = 0/1 */
+/* adapter-internal tuning knobs (results never depend on them; gvt_internal.h `struct Knobs` lists them with their defaults):
+ * "wide4", "blocks_per_cu", "refill_min", "inner_min", "share", "long_steps", "long_min_rays", "sort_rays", "sort_bits",
+ * "top_ordered", "top_lds", "term_sink", "camera_tile", "trav_kernel", "coop_fetch"; ("defaults", 0) restores all of them. */
 int gvt_hip_set_option(const char *name, int value);
 
 #ifdef __cplusplus

@@ -46,6 +46,19 @@ def hip():
     return capi
 
 
+@pytest.fixture(autouse=True)
+def _default_knobs(request):
+    """Tuning knobs are process-wide state of the library: every GPU test starts from (and leaves) the defaults."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    from gravit_amd import capi
+
+    capi.set_option("defaults", 0)
+    yield
+    capi.set_option("defaults", 0)
+
+
 def read_ppm(path):
     import numpy as np
 

@@ -63,12 +63,13 @@ def test_closest_and_any_hit_match_oracle(hip, name):
     assert info["n_tris"] == len(mesh.tris) and np.allclose(info["bbox_lo"], lo) and np.allclose(info["bbox_hi"], hi)
 
 
-@pytest.mark.parametrize("opts", [dict(trav_kernel=0), dict(trav_kernel=1, refill_min=1, inner_min=1), dict(trav_kernel=1, refill_min=64, inner_min=64),
-                                  dict(trav_kernel=1, blocks_per_cu=1, refill_min=8, inner_min=16), dict(trav_kernel=1, sort_rays=0, top_lds=0), dict(trav_kernel=1, sort_rays=1, sort_bits=32), dict(trav_kernel=1, wide4=0, coop_fetch=0), dict(trav_kernel=1, wide4=0, coop_fetch=1, refill_min=3, inner_min=5),
-                                  dict(trav_kernel=1, wide4=1, refill_min=2, inner_min=60), dict(trav_kernel=1, share=0), dict(trav_kernel=1, share=3, blocks_per_cu=6, refill_min=64), dict(trav_kernel=1, share=3)])
+@pytest.mark.parametrize("opts", [dict(trav_kernel=0), dict(refill_min=1, inner_min=1), dict(refill_min=64, inner_min=64),
+                                  dict(blocks_per_cu=1, refill_min=8, inner_min=16), dict(sort_rays=0, top_lds=0), dict(sort_rays=1, sort_bits=32),
+                                  dict(wide4=0, coop_fetch=0), dict(wide4=0, coop_fetch=1, refill_min=3, inner_min=5), dict(wide4=0, sort_rays=1),
+                                  dict(wide4=1, refill_min=2, inner_min=60), dict(share=0), dict(share=3, blocks_per_cu=6, refill_min=64), dict(share=3),
+                                  dict(long_steps=2, long_min_rays=0), dict(long_steps=0), dict(top_ordered=0), dict(term_sink=0, camera_tile=0)])
 def test_results_do_not_depend_on_tuning_knobs(hip, opts):
     """Both traversal kernels and every refill / phase / grid / sorting setting return the same bits."""
-    defaults = dict(trav_kernel=1, blocks_per_cu=4, refill_min=16, inner_min=32, sort_rays=1, sort_bits=20, top_lds=1, coop_fetch=0, wide4=0, share=1)
     sc = scenes.soup_scene(150_000, 160, 90)
     mesh = sc.meshes[0]
     ad, om = HipMeshAdapter(mesh), orc.Mesh(mesh.verts, mesh.tris, mesh_mat=mesh.material)
@@ -85,8 +86,7 @@ def test_results_do_not_depend_on_tuning_knobs(hip, opts):
         oc = om.trace(rc, sc.m[0], sc.minv[0], sc.normi[0], sc.lights, 0)
         assert rays_equal_bits(sort_rays(og), sort_rays(oc)) and rays_equal_bits(rg, rc)
     finally:
-        for k, v in defaults.items():
-            hip.set_option(k, v)
+        hip.set_option("defaults", 0)
 
 
 def test_axis_aligned_faces_edges_and_vertices(hip):
@@ -408,8 +408,7 @@ def test_long_ray_path_is_bit_exact(hip):
             fb = ImageTracer(sc, NORMALS_SMOOTH)().framebuffer(False)
             assert np.array_equal(fb, ref_fb), "frame differs with long_steps=%d" % steps
     finally:
-        capi.set_option("long_steps", 96)
-        capi.set_option("long_min_rays", 65536)
+        capi.set_option("defaults", 0)
 
 
 def test_terminal_sink_equals_shuffle(hip):
@@ -424,7 +423,7 @@ def test_terminal_sink_equals_shuffle(hip):
         for native in (True, False):
             tr = ImageTracer(sc, NORMALS_SMOOTH, native=native)
             frames[(sink, native)] = (tr().framebuffer(False).copy(), tr.adapter_calls)
-    capi.set_option("term_sink", 1)
+    capi.set_option("defaults", 0)
     ref_fb, ref_calls = frames[(0, True)]
     assert ref_fb[..., :3].sum() > 0
     for k, (fb, calls) in frames.items():
