@@ -774,7 +774,28 @@ __device__ inline V3 area_light_position(const gvt_hip_light &L, uint32_t &seed)
 }
 
 // primitives::Shade (Material.cpp:90-139)
-__device__ inline bool shade(int mtype, V3 kd, V3 ks, float alpha, const RayRec &ray, V3 N, const gvt_hip_light &L, V3 lightPos, V3 &out) {
+// the material as Shade() sees it (per-face material, Mesh::mat, or the vertex-colour Lambert of EmbreeMeshAdapter.cpp:534-569)
+struct MatEval {
+  int type;
+  V3 kd, ks;
+  float alpha;
+  V3 eta, k;
+  float roughness;
+  V3 hsc;
+  float back, falloff;
+};
+__device__ inline MatEval mat_eval(const gvt_hip_material &m) {
+  MatEval e;
+  e.type = m.type; e.kd = ld3(m.kd); e.ks = ld3(m.ks); e.alpha = m.alpha; e.eta = ld3(m.eta); e.k = ld3(m.k); e.roughness = m.roughness;
+  e.hsc = ld3(m.horizonScatteringColor); e.back = m.backScattering; e.falloff = m.horizonScatteringFallOff;
+  return e;
+}
+__device__ inline float clamp01(float x) { const float a = (x < 0.f) ? 0.f : x; return (1.f < a) ? 1.f : a; } // embree clamp(x)
+
+__device__ inline bool shade(const MatEval &m, const RayRec &ray, V3 N, const gvt_hip_light &L, V3 lightPos, V3 &out) {
+  const int mtype = m.type;
+  const V3 kd = m.kd, ks = m.ks;
+  const float alpha = m.alpha;
   V3 hitPoint = add3(ray.o, scl3(ray.d, ray.t));
   V3 wi = norm3(sub3(lightPos, hitPoint));
   float dNw = dot3(N, wi);
@@ -799,6 +820,49 @@ __device__ inline bool shade(int mtype, V3 kd, V3 ks, float alpha, const RayRec 
     V3 diffuse = scl3(kd, NdotL * ray.w);
     V3 specular = scl3(ks, power * ray.w);
     color = add3(diffuse, specular);
+  } else if (mtype >= 3 && mtype <= 5) {
+    // EMBREE_MATERIAL_METAL / VELVET / MATTE: Material.cpp:106-122 -> Material__eval (adapter/embree/EmbreeMaterial.h:289-314), the
+    // Embree tutorials' BRDFs; dg.Ns = N, wo = -ray.direction.  Embree's rcp/rsqrt (SSE estimate + Newton step) are 1/x, 1/sqrt(x)
+    // here: parity with the reference is ~1e-6 relative for these types (checked against its own build through the oracle).
+    const V3 wo = neg3(ray.d);
+    const float one_over_pi = 0.31830988618379069122f;
+    V3 r = mk3(0, 0, 0);
+    if (mtype == 5) { // MatteMaterial__eval :168-172
+      r = scl3(kd, clamp01(dot3(wi, N)));
+    } else if (mtype == 4) { // VelvetMaterial__eval :246-253 = Minneart :188-192 + Velvety :222-228
+      const float cosThetaI = clamp01(dot3(wi, N));
+      const float backScatter = powf(clamp01(dot3(wo, wi)), m.back);
+      const V3 a = scl3(ks, backScatter * cosThetaI * one_over_pi);
+      const float cosThetaO = clamp01(dot3(wo, N));
+      const float sinThetaO = sqrtf(1.0f - cosThetaO * cosThetaO);
+      const float horizonScatter = powf(sinThetaO, m.falloff);
+      const V3 b = scl3(m.hsc, horizonScatter * cosThetaI * one_over_pi);
+      r = add3(a, b);
+    } else { // MetalMaterial__eval :259-277; optics.h:75-83 fresnelConductor, :131-137 PowerCosineDistribution
+      const float expo = 1.0f / m.roughness;
+      const float cosThetaO = dot3(wo, N), cosThetaI = dot3(wi, N);
+      if (!(cosThetaI <= 0.0f || cosThetaO <= 0.0f)) {
+        const V3 s_ = add3(wi, wo);
+        const V3 wh = scl3(s_, 1.0f / sqrtf(dot3(s_, s_)));
+        const float cosThetaH = dot3(wh, N);
+        const float cosTheta = dot3(wi, wh);
+        const float cosi = cosTheta, c2 = cosi * cosi;
+        const V3 tmp = add3(mul3(m.eta, m.eta), mul3(m.k, m.k));
+        const V3 two_eta_c = scl3(scl3(m.eta, 2.0f), cosi);
+        const V3 one = mk3(1.0f, 1.0f, 1.0f), vc2 = mk3(c2, c2, c2);
+        const V3 num1 = add3(sub3(scl3(tmp, c2), two_eta_c), one), den1 = add3(add3(scl3(tmp, c2), two_eta_c), one);
+        const V3 num2 = add3(sub3(tmp, two_eta_c), vc2), den2 = add3(add3(tmp, two_eta_c), vc2);
+        const V3 Rpar = mk3(num1.x / den1.x, num1.y / den1.y, num1.z / den1.z);
+        const V3 Rper = mk3(num2.x / den2.x, num2.y / den2.y, num2.z / den2.z);
+        const V3 F = scl3(add3(Rpar, Rper), 0.5f);
+        const float D = (expo + 2) * (1.0f / (2.0f * 3.14159265358979323846f)) * powf(fabsf(cosThetaH), expo);
+        const float g1 = 2.0f * cosThetaH * cosThetaO / cosTheta, g2 = 2.0f * cosThetaH * cosThetaI / cosTheta;
+        const float gm = (g1 < g2) ? g1 : g2;
+        const float G = (1.0f < gm) ? 1.0f : gm;
+        r = scl3(scl3(scl3(mul3(ks, F), D), G), 1.0f / (4.0f * cosThetaO));
+      }
+    }
+    color = scl3(scl3(r, 2.f), ray.w); // 2.f * glm::vec3(r) * ray.w :120
   } else {
     color = mk3(0, 0, 0);
   }
@@ -839,8 +903,7 @@ struct MeshView {
   const gvt_hip_material *materials;
   unsigned n_mat;
   const int *face_mat;
-  int mtype;
-  float kd[3], ks[3], alpha; // Mesh::mat
+  gvt_hip_material mat; // Mesh::mat
 };
 
 struct ShadeArgs {
@@ -878,9 +941,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M) 
   bool miss = false, shaded = false, bounce = false;
   uint32_t g_seed = 0;
   V3 N = mk3(0, 0, 0);
-  int mtype = 0;
-  V3 kd = mk3(0, 0, 0), ks = mk3(0, 0, 0);
-  float alpha = 1.f;
+  MatEval me = mat_eval(M.mat);
   if (in_range) {
     r = load_ray(A.in, i);
     h = A.hits[j];
@@ -904,14 +965,12 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M) 
       }
       if (dot3(neg3(r.d), normalflat) <= 0.f) N = neg3(N); // :527-529
       // material pick :534-569
-      mtype = M.mtype; kd = ld3(M.kd); ks = ld3(M.ks); alpha = M.alpha;
       if (M.vcolors) {
         const V3 c0 = ld3(M.vcolors + 3 * ia), c1 = ld3(M.vcolors + 3 * ib), c2 = ld3(M.vcolors + 3 * ic);
-        kd = add3(add3(scl3(c0, 1.f - h.u - h.v), scl3(c1, h.u)), scl3(c2, h.v));
-        mtype = 0; ks = mk3(.5f, .5f, .5f); alpha = 1.f;
+        me.kd = add3(add3(scl3(c0, 1.f - h.u - h.v), scl3(c1, h.u)), scl3(c2, h.v));
+        me.type = 0; me.ks = mk3(.5f, .5f, .5f); me.alpha = 1.f;
       } else if (M.face_mat && M.face_mat[h.prim] >= 0 && (unsigned)M.face_mat[h.prim] < M.n_mat) {
-        const gvt_hip_material &fm = M.materials[M.face_mat[h.prim]];
-        mtype = fm.type; kd = ld3(fm.kd); ks = ld3(fm.ks); alpha = fm.alpha;
+        me = mat_eval(M.materials[M.face_mat[h.prim]]);
       }
       if (r.type == 2) { // SECONDARY :572-575
         t = (t > 1) ? 1.f / t : t;
@@ -946,7 +1005,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M) 
       const gvt_hip_light L = A.lights[li];
       const V3 lightPos = (L.type == GVT_HIP_LIGHT_AREA) ? area_light_position(L, g_seed) : ld3(L.position);
       V3 c;
-      if (shade(mtype, kd, ks, alpha, r, N, L, lightPos, c)) {
+      if (shade(me, r, N, L, lightPos, c)) {
         emit = true;
         const float multiplier = 1.0f - GVT_RAY_EPSILON * 16;
         const float t_shadow = multiplier * r.t;
@@ -1262,8 +1321,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
   MeshView mv;
   mv.verts = M->d_verts; mv.tris = M->d_tris; mv.normals = M->d_normals; mv.vcolors = M->d_vcolors;
   mv.materials = M->d_materials; mv.n_mat = (unsigned)M->nMat; mv.face_mat = M->d_face_mat;
-  mv.mtype = M->mesh_mat.type; mv.alpha = M->mesh_mat.alpha;
-  for (int k = 0; k < 3; k++) { mv.kd[k] = M->mesh_mat.kd[k]; mv.ks[k] = M->mesh_mat.ks[k]; }
+  mv.mat = M->mesh_mat;
 
   size_t n_active = n;
   const unsigned *idx = nullptr;

@@ -10,7 +10,7 @@ import numpy as np
 
 RAY_PRIMARY, RAY_SHADOW, RAY_SECONDARY = 0, 1, 2  # Ray.h:50-55
 LIGHT_POINT, LIGHT_AREA, LIGHT_AMBIENT = 0, 1, 2
-LAMBERT, PHONG, BLINN = 0, 1, 2  # Material.h:49-56
+LAMBERT, PHONG, BLINN, EMBREE_METAL, EMBREE_VELVET, EMBREE_MATTE = 0, 1, 2, 3, 4, 5  # Material.h:49-57
 NORMALS_FLAT, NORMALS_SMOOTH = 0, 1  # EmbreeMeshAdapter.cpp:75 (FLAT_SHADING) vs goldens / EmbreeStream / OptiX
 RAY_EPSILON = np.float32(1.0e-6)  # Ray.cpp:33
 FLT_MAX = np.float32(np.finfo(np.float32).max)

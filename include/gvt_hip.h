@@ -55,7 +55,7 @@ typedef struct gvt_hip_ray { /* actor/Ray.h:68-96 */
 } gvt_hip_ray;
 
 typedef struct gvt_hip_material { /* primitives/Material.h:59-90 */
-  int32_t type;                 /* 0 LAMBERT, 1 PHONG, 2 BLINN */
+  int32_t type;                 /* 0 LAMBERT, 1 PHONG, 2 BLINN, 3 EMBREE_MATERIAL_METAL, 4 _VELVET, 5 _MATTE (Material.h:50-57) */
   float ka[3], ks[3], kd[3];
   float alpha;
   float eta[3], k[3];

@@ -129,6 +129,7 @@ static v3 area_light_position(const orc_light *L, uint32_t *seed) {
 /* ------------------------------------------------------------------------- */
 /* Shade (data/primitives/Material.cpp:50-139)                                */
 /* ------------------------------------------------------------------------- */
+static float clamp01(float x) { const float a = (x < 0.f) ? 0.f : x; return (1.f < a) ? 1.f : a; } /* embree clamp(x) = min(max(x,0),1) */
 int orc_shade(const orc_material *mat, const orc_ray *ray, const float Nf[3], const orc_light *light,
               const float lightPos[3], float color_out[3]) {
   v3 N = ld3(Nf), o = ld3(ray->origin), d = ld3(ray->direction);
@@ -162,6 +163,54 @@ int orc_shade(const orc_material *mat, const orc_ray *ray, const float Nf[3], co
     v3 diffuse = scl3(kd, NdotL * ray->w);
     v3 specular = scl3(ks, power * ray->w);
     color = add3(diffuse, specular);
+  } break;
+  case 3:   /* EMBREE_MATERIAL_METAL  */
+  case 4:   /* EMBREE_MATERIAL_VELVET */
+  case 5: { /* EMBREE_MATERIAL_MATTE  -- Material.cpp:106-122 -> Material__eval (adapter/embree/EmbreeMaterial.h:289-314) */
+    /* dg.Ns = surfaceNormal, wo = -ray.direction; Embree's rcp()/rsqrt() (SSE estimate + one Newton step,
+       embree-shaders/common/math/math.h:59-85, vec3fa.h:124-144) are restated as 1/x and 1/sqrt(x): parity with the reference build
+       is to ~1e-6 relative for these three types, not to the bit */
+    v3 wo = neg3(d), r = V3(0, 0, 0);
+    const float one_over_pi = 0.31830988618379069122f;
+    if (mat->type == 5) { /* MatteMaterial__eval :168-172: Lambertian R * clamp(dot(wi, Ns)) */
+      r = scl3(kd, clamp01(dot3(wi, N)));
+    } else if (mat->type == 4) { /* VelvetMaterial__eval :246-253 = Minneart (:188-192) + Velvety (:222-228) */
+      const float cosThetaI = clamp01(dot3(wi, N));
+      const float backScatter = powf(clamp01(dot3(wo, wi)), mat->backScattering);
+      v3 a = scl3(ks, backScatter * cosThetaI * one_over_pi);
+      const float cosThetaO = clamp01(dot3(wo, N));
+      const float sinThetaO = sqrtf(1.0f - cosThetaO * cosThetaO);
+      const float horizonScatter = powf(sinThetaO, mat->horizonScatteringFallOff);
+      v3 b = scl3(ld3(mat->horizonScatteringColor), horizonScatter * cosThetaI * one_over_pi);
+      r = add3(a, b);
+    } else { /* MetalMaterial__eval :259-277, optics.h:75-83 (fresnelConductor), :131-137 (PowerCosineDistribution) */
+      const float expo = 1.0f / mat->roughness;
+      const float cosThetaO = dot3(wo, N), cosThetaI = dot3(wi, N);
+      if (!(cosThetaI <= 0.0f || cosThetaO <= 0.0f)) {
+        v3 s_ = add3(wi, wo);
+        v3 wh = scl3(s_, 1.0f / sqrtf(dot3(s_, s_)));
+        const float cosThetaH = dot3(wh, N);
+        const float cosTheta = dot3(wi, wh);
+        v3 eta = ld3(mat->eta), k = ld3(mat->k), F;
+        {
+          const float cosi = cosTheta, c2 = cosi * cosi;
+          v3 tmp = add3(mul3(eta, eta), mul3(k, k));
+          v3 two_eta_c = scl3(scl3(eta, 2.0f), cosi);
+          v3 one = V3(1.0f, 1.0f, 1.0f), vc2 = V3(c2, c2, c2);
+          v3 num1 = add3(sub3(scl3(tmp, c2), two_eta_c), one), den1 = add3(add3(scl3(tmp, c2), two_eta_c), one);
+          v3 num2 = add3(sub3(tmp, two_eta_c), vc2), den2 = add3(add3(tmp, two_eta_c), vc2);
+          v3 Rpar = V3(num1.x / den1.x, num1.y / den1.y, num1.z / den1.z);
+          v3 Rper = V3(num2.x / den2.x, num2.y / den2.y, num2.z / den2.z);
+          F = scl3(add3(Rpar, Rper), 0.5f);
+        }
+        const float D = (expo + 2) * (1.0f / (2.0f * 3.14159265358979323846f)) * powf(fabsf(cosThetaH), expo);
+        const float g1 = 2.0f * cosThetaH * cosThetaO / cosTheta, g2 = 2.0f * cosThetaH * cosThetaI / cosTheta;
+        const float gm = (g1 < g2) ? g1 : g2;
+        const float G = (1.0f < gm) ? 1.0f : gm;
+        r = scl3(scl3(scl3(mul3(ks, F), D), G), 1.0f / (4.0f * cosThetaO));
+      }
+    }
+    color = scl3(scl3(r, 2.f), ray->w); /* 2.f * glm::vec3(r) * ray.w :120 */
   } break;
   default: /* :128-131: prints and leaves `color` untouched; restated as black */
     color = V3(0, 0, 0);

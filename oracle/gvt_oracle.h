@@ -44,7 +44,7 @@ typedef struct {
 
 /* gvt::render::data::primitives::Material (Material.h:59-90): 92 B */
 typedef struct {
-  int32_t type; /* 0 LAMBERT, 1 PHONG, 2 BLINN */
+  int32_t type; /* 0 LAMBERT, 1 PHONG, 2 BLINN, 3 EMBREE_MATERIAL_METAL, 4 _VELVET, 5 _MATTE (Material.h:50-57) */
   float ka[3];
   float ks[3];
   float kd[3];

@@ -88,6 +88,46 @@ def main():
     # SURVEY probe: default material, N=(0,0,1), light (0,.1,.5), hit at t=.25 -> (0.5,0.5,0.5)
     out["shade_cases"] = cases
 
+    # ---- Shade, Embree-tutorial BRDFs (EMBREE_MATERIAL_METAL / VELVET / MATTE, Material.cpp:106-122 under GVT_RENDER_ADAPTER_EMBREE,
+    #      the Embree adapter's build): float answers -- Embree's rcp/rsqrt are SSE estimates, so the restatement matches to ~1e-6
+    rng = np.random.default_rng(4321)
+    ecases = []
+    for k in range(120):
+        m = mat.copy()
+        m["type"] = 3 + k % 3
+        m["kd"] = rng.random(3, dtype=np.float32)
+        m["ks"] = rng.random(3, dtype=np.float32)
+        m["eta"] = (0.2 + 2.5 * rng.random(3)).astype(np.float32)
+        m["k"] = (1.0 + 5.0 * rng.random(3)).astype(np.float32)
+        m["roughness"] = np.float32(0.02 + 0.5 * rng.random())
+        m["hsc"] = rng.random(3, dtype=np.float32)
+        m["backScattering"] = np.float32(0.2 + 1.5 * rng.random())
+        m["hsFallOff"] = np.float32(1 + 9 * rng.random())
+        ray = np.zeros(1, orc.RAY_DTYPE)
+        ray["origin"] = rng.random(3, dtype=np.float32) * 2 - 1
+        N = rng.random(3, dtype=np.float32) * 2 - 1
+        N = (N / np.linalg.norm(N)).astype(np.float32)
+        d = rng.random(3, dtype=np.float32) * 2 - 1
+        if k % 4:  # mostly front-facing geometry so that the lobes are exercised
+            d = d - N * (np.dot(d, N) + abs(np.dot(d, N)) + 0.2)
+        ray["direction"] = d / np.linalg.norm(d)
+        ray["t"] = np.float32(0.2 + rng.random())
+        ray["w"] = np.float32(0.25 + 0.75 * rng.random())
+        hit = ray["origin"][0] + ray["direction"][0] * ray["t"][0]
+        lt = (k // 3) % 3
+        lpos = (hit + N * np.float32(0.5 + rng.random()) + (rng.random(3, dtype=np.float32) - 0.5)).astype(np.float32) if k % 5 else \
+            (rng.random(3, dtype=np.float32) * 4 - 2).astype(np.float32)
+        lcol = rng.random(3, dtype=np.float32)
+        lnorm = f3(0, -1, 0)
+        lw, lh = np.float32(0.5), np.float32(0.25)
+        sample = lpos + f3(0.01, 0.02, -0.03) if lt == 1 else lpos
+        c = np.zeros(3, np.float32)
+        ok = ref.ref_shade(p(m), p(ray), p(N), C.c_int(lt), p(lpos), p(lcol), p(lnorm), C.c_float(lw), C.c_float(lh), p(sample), p(c))
+        ecases.append({"mat": m.tobytes().hex(), "ray": ray.tobytes().hex(), "N": N.tolist(), "light_type": lt, "lpos": lpos.tolist(),
+                       "lcolor": lcol.tolist(), "lnormal": lnorm.tolist(), "lwidth": float(lw), "lheight": float(lh),
+                       "sample": sample.tolist(), "ok": int(ok), "color": [float(x) for x in c]})
+    out["shade_cases_embree"] = ecases
+
     # ---- area light sample positions (LCG stream)
     al = []
     for seed in (0, 1, 12345, 0xDEADBEEF):

@@ -242,6 +242,43 @@ def test_materials_lights_vertex_colors(hip, mtype):
         assert rays_equal_bits(rg, rc)
 
 
+@pytest.mark.parametrize("mtype", [layouts.EMBREE_METAL, layouts.EMBREE_VELVET, layouts.EMBREE_MATTE])
+def test_embree_tutorial_brdfs(hip, mtype):
+    """EMBREE_MATERIAL_METAL / VELVET / MATTE (Material.cpp:106-122, adapter/embree/EmbreeMaterial.h) through the adapter, as mesh
+    material and as per-face materials: same shadow rays as the oracle (bit-exact origins / directions / ids), radiance to 1e-5
+    (powf); the oracle itself is pinned on the reference's own build of these BRDFs (tests/test_oracle_pinning.py)."""
+    sc = scenes.bunny_scene(96, 96)
+    base = sc.meshes[0]
+    rng = np.random.default_rng(40 + mtype)
+
+    def mat():
+        m = layouts.default_material(kd=rng.random(3), mtype=mtype, ks=rng.random(3))
+        m["eta"] = 0.2 + 2.5 * rng.random(3)
+        m["k"] = 1.0 + 5.0 * rng.random(3)
+        m["roughness"] = 0.05 + 0.5 * rng.random()
+        m["hsc"] = rng.random(3)
+        m["backScattering"] = 0.2 + 1.5 * rng.random()
+        m["hsFallOff"] = 1 + 9 * rng.random()
+        return m
+
+    mats = np.concatenate([mat() for _ in range(4)])
+    face_mat = (np.arange(len(base.tris)) % 5 - 1).astype(np.int32)
+    lights = np.concatenate([layouts.point_light((0.0, 0.1, 0.5)), layouts.point_light((0.3, 0.4, 0.2), (0.2, 0.5, 0.9))])
+    mesh = scenes.MeshData(base.verts, base.tris, mat(), None, None, mats, face_mat)
+    ad = HipMeshAdapter(mesh, NORMALS_SMOOTH)
+    om = orc.Mesh(mesh.verts, mesh.tris, materials=mats, face_mat=face_mat, mesh_mat=mesh.material)
+    rays = oracle_camera_rays(sc)
+    rg, rc = rays.copy(), rays.copy()
+    og = sort_by_id_light(ad.trace(rg, sc.m[0], sc.minv[0], sc.normi[0], lights, seed=5))
+    oc = sort_by_id_light(om.trace(rc, sc.m[0], sc.minv[0], sc.normi[0], lights, 1, seed=5))
+    assert len(og) == len(oc) and (og["type"] == 1).sum() > 1000
+    assert (og["id"] == oc["id"]).all() and (og["type"] == oc["type"]).all()
+    assert (bits(og["origin"]) == bits(oc["origin"])).all() and (bits(og["direction"]) == bits(oc["direction"])).all()
+    assert np.abs(og["color"] - oc["color"]).max() <= RADIANCE_TOL
+    assert og["color"][og["type"] == 1].max() > 0.05, "the lobes were never lit"
+    assert rays_equal_bits(rg, rc)
+
+
 def sort_by_id_light(r):
     """Order by (type, id, origin, direction): stable across tiny colour differences."""
     key = np.stack([r["type"], r["id"]] + [bits(r["origin"][:, k]).astype(np.int64) for k in range(3)] +

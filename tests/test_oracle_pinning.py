@@ -94,6 +94,31 @@ def test_shade_known_answers(ref_vectors):
     assert n_ok > 30
 
 
+def test_shade_embree_brdfs_known_answers(ref_vectors):
+    """EMBREE_MATERIAL_METAL / VELVET / MATTE (Material.cpp:106-122 -> adapter/embree/EmbreeMaterial.h, the Embree adapter's build of
+    Shade): answers of the reference's own code (vendored embree-shaders math).  Embree's rcp/rsqrt are SSE estimates + a Newton step,
+    so the restatement is compared to 1e-5 on [0,1] radiance (north_star's float tolerance), not to the bit."""
+    n_ok, lit = 0, {3: 0, 4: 0, 5: 0}
+    for c in ref_vectors["shade_cases_embree"]:
+        mat = np.frombuffer(bytes.fromhex(c["mat"]), orc.MATERIAL_DTYPE)
+        ray = np.frombuffer(bytes.fromhex(c["ray"]), orc.RAY_DTYPE)
+        light = np.zeros(1, orc.LIGHT_DTYPE)
+        light["type"] = c["light_type"]
+        light["position"] = c["lpos"]
+        light["color"] = c["lcolor"]
+        light["normal"] = c["lnormal"]
+        light["width"] = c["lwidth"]
+        light["height"] = c["lheight"]
+        ok, col = orc.shade(mat, ray, c["N"], light, c["sample"])
+        assert int(ok) == c["ok"]
+        if ok:
+            n_ok += 1
+            assert np.allclose(col, np.array(c["color"], np.float32), rtol=1e-5, atol=1e-5), (int(mat["type"][0]), col, c["color"])
+            if max(c["color"]) > 1e-3:
+                lit[int(mat["type"][0])] += 1
+    assert n_ok > 60 and min(lit.values()) >= 8, lit
+
+
 def test_shade_survey_probe():
     """default material, N=(0,0,1), light (0,.1,.5), hit at t=.25 -> (0.5,0.5,0.5)."""
     ray = np.zeros(1, orc.RAY_DTYPE)
