@@ -4,8 +4,10 @@
 // Pipeline (all on the adapter stream, one pass over HBM each):
 //   tri bounds + scene box  ->  63-bit Morton keys  ->  radix sort (rocPRIM)  ->  Karras 2012 topology
 //   ->  node boxes from a base-32 range-union table over the sorted triangle boxes (no inter-workgroup hand-off)
-//   ->  collapse subtrees of <= 4 triangles into leaves, compact live nodes (prefix scan)
-//   ->  emit 64-byte nodes (both child boxes in the parent) + 64-byte triangle slots in leaf order.
+//   ->  collapse subtrees of <= GVT_LEAF_MAX triangles into leaves, compact live nodes (prefix scan)
+//   ->  emit 64-byte binary nodes (both child boxes in the parent) + 64-byte triangle slots in leaf order
+//   ->  collapse to 4-wide nodes, breadth first, child boxes quantised to 8 bits on a per-node grid (build_nodes4): the layout
+//       k_trace traverses.
 // Results of the closest/any-hit queries do not depend on the tree (conservative, padded boxes); only
 // speed does.
 #include <string.h>

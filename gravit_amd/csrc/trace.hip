@@ -1,14 +1,20 @@
 // trace.hip -- the adapter hot path on gfx950: Adapter::trace
 // (src/gvt/render/Adapter.h:82-84, adapter/embree/EmbreeMeshAdapter.cpp:436-660).
 //
-//   k_closest   rtcIntersect   (EmbreeMeshAdapter.cpp:474): ray -> object space, nearest hit in (1e-6, inf)
-//   k_shade     per-lane block (:483-609): miss forward / shadow drop / normal / material / Shade /
-//               shadow-ray generation (:320-358) / Russian-roulette bounce (:584-602)
-//   k_any       rtcOccluded    (:364-385): un-occluded shadow rays are appended to moved_rays
+//   k_trace<false,..>  rtcIntersect (EmbreeMeshAdapter.cpp:474): ray -> object space, nearest hit in (1e-6, inf)
+//   k_long_closest     the few rays k_trace parks after `long_steps` node steps, finished a wave per ray
+//   k_shade            per-lane block (:483-609): miss forward / shadow drop / normal / material / Shade /
+//                      shadow-ray generation (:320-358) / Russian-roulette bounce (:584-602)
+//   k_trace<true,..>   rtcOccluded  (:364-385): un-occluded shadow rays are appended to moved_rays -- or, with a sink, end
+//                      right there by the terminal rule of the shuffleRays that would follow (TracerBase.h:396-400)
+//   trace_core         the host side of one Adapter::trace call: closest -> shade -> any, one read-back per pass
 //
-// One lane per ray.  Waves fetch 64-ray batches from a device counter (work queue with an exit every
-// wave reaches), keep their traversal stacks in LDS (stack[level][lane]: lane-contiguous, bank
-// conflict free) and compact survivors with one atomic per wave (__ballot + mbcnt).
+// One lane per ray.  k_trace runs persistent waves: a wave pulls index ranges from a device counter (an exit every wave
+// reaches), refills lanes whose ray has finished while the others go on, alternates a tight loop over the compressed 4-wide
+// nodes with a leaf phase, keeps its traversal stacks in LDS (stack[level][lane]: lane-contiguous, bank conflict free) and
+// compacts survivors per wave (__ballot + mbcnt, one atomic per >= 64 rays).  k_closest / k_any / traverse() further down are
+// the first version (one 64-ray batch per wave over the binary tree), kept as the trav_kernel=0 baseline and for the
+// visit-count diagnostic; DESIGN.md 4.1 lists what was measured on the way.
 #include "gvt_internal.h"
 
 #define TRAV_BLOCK 256
