@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--domains", type=int, default=0, help="N=1 only: cut the soup into this many domains and use the Domain scheduler")
+    ap.add_argument("--bsp", action="store_true", help="N>1: bulk-synchronous exchange rounds instead of the overlapped exchange")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (gvt_hip_set_option), for experiments")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
@@ -118,7 +119,7 @@ def main():
     else:
         scene = scenes.soup_domains_scene(args.tris, world, args.width, args.height)
         owner = [i % world for i in range(scene.n_inst)]
-        tracer = DomainTracer(scene, owner, dist, torch, dev, NORMALS_FLAT)
+        tracer = DomainTracer(scene, owner, dist, torch, dev, NORMALS_FLAT, overlap=not args.bsp)
     build_ms = sum(a.info()["build_ms"] for a in tracer.backend.adapter_cache.values())
 
     def barrier():

@@ -176,7 +176,8 @@ class DomainTracer:
     (IceTComposite::composite, IceTComposite.cpp:84-101).
     """
 
-    def __init__(self, scene, owner, dist, torch, comm_device, normal_mode=NORMALS_FLAT, backend=None):
+    def __init__(self, scene, owner, dist, torch, comm_device, normal_mode=NORMALS_FLAT, backend=None, overlap=False):
+        self.overlap = overlap  # post each exchange before the next local adapter call and complete it afterwards
         self.scene = scene
         self.owner = list(owner)
         self.dist, self.torch, self.dev = dist, torch, comm_device
@@ -188,7 +189,81 @@ class DomainTracer:
         self.rays_sent = 0
         self.adapter_calls = 0
 
+    def _post_exchange(self, counts, sizes):
+        """SendRays payload (:433-463) as non-blocking point-to-point operations; returns (requests, receive buffers, send buffers)."""
+        B, torch, dist = self.backend, self.torch, self.dist
+        n_inst = len(self.owner)
+        ops, send_bufs, recv_bufs = [], {}, {}
+        for p in range(self.world):
+            if p == self.rank:
+                continue
+            outq = [i for i in range(n_inst) if self.owner[i] == p and sizes[i] > 0]
+            if outq:
+                send_bufs[p] = B.export_wire(outq, torch, self.dev)
+                self.rays_sent += int(send_bufs[p].shape[0])
+                ops.append(dist.P2POp(dist.isend, send_bufs[p], p))
+            n_in = int(sum(counts[p][i] for i in range(n_inst) if self.owned[i]))
+            if n_in:
+                recv_bufs[p] = torch.empty((n_in, 20), dtype=torch.float32, device=self.dev)
+                ops.append(dist.P2POp(dist.irecv, recv_bufs[p], p))
+        B.sync()  # wire buffers were filled on the adapter stream
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        return reqs, recv_bufs, send_bufs
+
+    def _complete_exchange(self, posted, counts):
+        reqs, recv_bufs, _send_bufs = posted
+        B = self.backend
+        n_inst = len(self.owner)
+        for req in reqs:
+            req.wait()
+        if self.dev != "cpu":
+            self.torch.cuda.current_stream().synchronize()
+        for p, buf in recv_bufs.items():  # unpack into queue[q] (:466-481)
+            off = 0
+            for i in range(n_inst):
+                if self.owned[i] and counts[p][i]:
+                    B.append_wire(i, buf, off, int(counts[p][i]))
+                    off += int(counts[p][i])
+
+    def _frame_overlapped(self):
+        """The same frame with the ray exchange overlapped with traversal: every iteration all ranks exchange the outgoing counts (and
+        whether they still hold local work), post the payload transfers of what has accumulated so far, run ONE local adapter call
+        while those move (RCCL on its own stream), then complete the transfers.  Ends when no rank has local work and nothing is in
+        flight -- the vote of the reference's asynchronous tracer (tracer/Domain/DomainTracer.cpp:109-192) folded into the count
+        exchange.  Same rays, same image; only the interleaving differs."""
+        B, torch, dist = self.backend, self.torch, self.dist
+        n_inst = len(self.owner)
+        B.begin_frame()
+        B.generate_and_filter(np.array(self.owned, np.uint8))  # shuffleDropRays
+        self.rounds = self.rays_sent = self.adapter_calls = 0
+        while True:
+            sizes = B.queue_sizes()
+            target = _pick_fullest(sizes, self.owned)
+            if self.world == 1:
+                if target < 0:
+                    break
+                B.trace_and_shuffle(target)
+                self.adapter_calls += 1
+                continue
+            mine = torch.tensor([0 if self.owned[i] else sizes[i] for i in range(n_inst)] + [1 if target >= 0 else 0], dtype=torch.int64,
+                                device=self.dev)
+            allc = torch.empty((self.world, n_inst + 1), dtype=torch.int64, device=self.dev)
+            rows = [allc[r] for r in range(self.world)]
+            dist.all_gather(rows, mine)
+            counts = torch.stack(rows).cpu().numpy()
+            if int(counts[:, :n_inst].sum()) == 0 and int(counts[:, n_inst].sum()) == 0:
+                break
+            posted = self._post_exchange(counts, sizes)
+            if target >= 0:  # one local adapter call while the payload moves
+                B.trace_and_shuffle(target)
+                self.adapter_calls += 1
+            self._complete_exchange(posted, counts)
+            self.rounds += 1
+        return B
+
     def __call__(self):
+        if self.overlap:
+            return self._frame_overlapped()
         B, torch, dist = self.backend, self.torch, self.dist
         n_inst = len(self.owner)
         B.begin_frame()

@@ -37,7 +37,7 @@ def _build(name):
     return sc, owner
 
 
-def _worker(rank, world, port, name, outdir):
+def _worker(rank, world, port, name, outdir, overlap=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -45,7 +45,7 @@ def _worker(rank, world, port, name, outdir):
         sc, owner_fn = _build(name)
         owner = owner_fn(world)
         owned = [o == rank for o in owner]
-        tr = DomainTracer(sc, owner, dist, torch, "cpu", 1, backend=OracleBackend(sc, 1, owned))
+        tr = DomainTracer(sc, owner, dist, torch, "cpu", 1, backend=OracleBackend(sc, 1, owned), overlap=overlap)
         tr()
         fb = tr.composite()
         stats = torch.tensor([tr.rays_sent, tr.rounds, tr.adapter_calls], dtype=torch.int64)
@@ -71,6 +71,19 @@ def test_domain_tracer_over_gloo(tmp_path, name, world):
     if name == "simple":  # and it is the 1-rank image (one writer per pixel)
         img_fb, _ = oracle_render(sc, 1)
         assert np.array_equal(fb[..., :3], img_fb[..., :3])
+
+
+@pytest.mark.parametrize("name,world", [("simple", 2), ("soup", 3)])
+def test_overlapped_domain_tracer_over_gloo(tmp_path, name, world):
+    """overlap=True: exchanges posted before each local adapter call and completed after it, termination folded into the count
+    exchange.  Same rays cross the same boundaries and the image is the BSP one."""
+    mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path), True), nprocs=world, join=True)
+    fb = np.load(tmp_path / "fb.npy")
+    stats = np.load(tmp_path / "stats.npy")
+    sc, owner_fn = _build(name)
+    ref_fb, st = oracle_render_domain(sc, owner_fn(world), world, 1)
+    assert stats[0] == st.rays_sent and stats[0] > 0
+    assert np.array_equal(fb[..., :3], ref_fb[..., :3])
 
 
 def test_image_tracer_with_checker_backend_matches_restated_loop():

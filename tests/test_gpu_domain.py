@@ -36,7 +36,7 @@ class LockedBackend:
         return call
 
 
-def run_ranks(scene, owner, world, mode):
+def run_ranks(scene, owner, world, mode, overlap=False):
     fw = FakeWorld(world)
     out = {}
     errs = []
@@ -47,7 +47,7 @@ def run_ranks(scene, owner, world, mode):
             owned = [o == rank for o in owner]
             with LockedBackend.lock:
                 backend = HipBackend(scene, mode, owned)
-            tr = DomainTracer(scene, owner, dist, torch, torch.device("cuda", 0), mode, backend=LockedBackend(backend))
+            tr = DomainTracer(scene, owner, dist, torch, torch.device("cuda", 0), mode, backend=LockedBackend(backend), overlap=overlap)
             tr()
             fb = tr.composite()
             out[rank] = (fb, tr.rays_sent, tr.rounds, tr.adapter_calls)
@@ -66,12 +66,13 @@ def run_ranks(scene, owner, world, mode):
     return out
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_bunny_grid_domains_equal_the_single_rank_image(hip, world):
-    """BASELINE config 4 (reduced film): 8 bunny instances, one domain per virtual rank round-robin."""
+@pytest.mark.parametrize("world,overlap", [(2, False), (4, False), (2, True), (4, True)])
+def test_bunny_grid_domains_equal_the_single_rank_image(hip, world, overlap):
+    """BASELINE config 4 (reduced film): 8 bunny instances, one domain per virtual rank round-robin; BSP rounds and the overlapped
+    exchange (several local domains per rank: transfers are in flight during adapter calls)."""
     sc = scenes.bunny_grid_scene(width=380, height=216)
     owner = [i % world for i in range(sc.n_inst)]
-    res = run_ranks(sc, owner, world, NORMALS_SMOOTH)
+    res = run_ranks(sc, owner, world, NORMALS_SMOOTH, overlap)
     fb = res[0][0]
     ref, st = oracle_render_domain(sc, owner, world, 1)
     assert np.array_equal(fb[..., :3], ref[..., :3])
