@@ -269,6 +269,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
   int n_pend = 0;                 // wave-uniform
   unsigned c_next = 0, c_end = 0; // wave-uniform
   bool exhausted = false;         // wave-uniform
+  bool first_chunk = true;        // wave-uniform
   bool active = false;
   unsigned j = 0;
   V3 O = mk3(0, 0, 0), D = mk3(0, 0, 1);
@@ -294,9 +295,16 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
     if (!exhausted && (nidle >= refill_min || nidle == 64)) {
       while (nidle > 0) {
         if (c_next == c_end) {
+          // the first chunk of every wave is assigned statically (chunk number = wave number): 4096 waves hitting one counter word at
+          // launch would queue for ~45 us (a single word sustains ~90 atomics/us); the dynamic chunks start behind those
           unsigned base = 0;
-          if (lane_id() == 0) base = atomicAdd(counter, chunk);
-          base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+          if (first_chunk) {
+            first_chunk = false;
+            base = (blockIdx.x * (unsigned)(TRAV_BLOCK / 64) + (threadIdx.x >> 6)) * chunk;
+          } else {
+            if (lane_id() == 0) base = atomicAdd(counter, chunk);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + gridDim.x * (unsigned)(TRAV_BLOCK / 64) * chunk;
+          }
           if (base >= n) {
             exhausted = true;
 #if GVT_STAMP
@@ -602,11 +610,16 @@ __global__ __launch_bounds__(256) void k_long_closest(RayPlanes q, const LongRec
   volatile int *l_ref = l_ref_all[wv];
   volatile float *l_tn = l_tn_all[wv];
   const unsigned n = *n_recs;
-  bool overflow = false;
+  bool overflow = false, first = true;
   for (;;) {
     unsigned r = 0;
-    if (lane == 0) r = atomicAdd(counter, 1u);
-    r = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+    if (first) { // first ray of a wave: its own number; later ones through the counter, behind those
+      first = false;
+      r = blockIdx.x * 4u + (unsigned)wv;
+    } else {
+      if (lane == 0) r = atomicAdd(counter, 1u);
+      r = (unsigned)__builtin_amdgcn_readfirstlane((int)r) + gridDim.x * 4u;
+    }
     if (r >= n) break;
     const LongRec R = recs[r];
     const float4 a = q.p0[R.i], b = q.p1[R.i];
