@@ -298,12 +298,15 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
           // the first chunk of every wave is assigned statically (chunk number = wave number): 4096 waves hitting one counter word at
           // launch would queue for ~45 us (a single word sustains ~90 atomics/us); the dynamic chunks start behind those
           unsigned base = 0;
+          // ... and are one wave wide (64 rays): finer balance at the end of the launch (128: +3 % time; 32: the counter word saturates)
+          unsigned this_chunk = chunk;
           if (first_chunk) {
             first_chunk = false;
             base = (blockIdx.x * (unsigned)(TRAV_BLOCK / 64) + (threadIdx.x >> 6)) * chunk;
           } else {
-            if (lane_id() == 0) base = atomicAdd(counter, chunk);
+            if (lane_id() == 0) base = atomicAdd(counter, 64u);
             base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + gridDim.x * (unsigned)(TRAV_BLOCK / 64) * chunk;
+            this_chunk = 64u;
           }
           if (base >= n) {
             exhausted = true;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
             break;
           }
           c_next = base;
-          c_end = min(base + chunk, n);
+          c_end = min(base + this_chunk, n);
         }
         const unsigned take = min(c_end - c_next, (unsigned)nidle);
         const unsigned rank = lanes_below(idle);
