@@ -244,11 +244,15 @@ template <bool ANY, bool XFORM, int MODE, bool COOP, bool W4>
 __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, Trav T, float tnear,
                                                        gvt_hip_hit *__restrict__ hits, int *__restrict__ flags, RayPlanes out, unsigned *out_count,
                                                        unsigned *counter, int *spill_base, int refill_min, int inner_min, const unsigned *__restrict__ n_dev, int share, TermSink sink, LongQ LQ) {
-  // rays per grab of the work counter: 256 for big launches (few atomics), down to 64 when there are fewer rays than lanes so
-  // that the rays spread over all resident waves instead of queueing four deep in a few of them
-  const unsigned n_lanes_total = gridDim.x * (unsigned)TRAV_BLOCK;
+  // Work distribution: wave w first takes the static range [w*chunk, (w+1)*chunk) -- no atomic, see the refill below -- and after that
+  // dynamic ranges of `dyn` rays from the counter.  chunk is a fraction of a wave's fair share (3/8 for closest-hit launches, whose
+  // per-ray cost varies most, 5/8 for any-hit; measured at 1 M rays: 96/128/160 rays -> 0.542/0.549/0.579 ms closest, 0.400/0.400/0.384
+  // any), never less than one wave's width; dyn is 1/16 of the share, at least 64 (32: the counter word saturates).
+  const unsigned n_waves_total = gridDim.x * (unsigned)(TRAV_BLOCK / 64);
   if (n_dev) n = *n_dev; // ray count produced by the previous kernel on this stream (no host round trip)
-  const unsigned chunk = (n >= 4u * n_lanes_total) ? 256u : (n >= 2u * n_lanes_total) ? 128u : 64u;
+  const unsigned share_w = n / n_waves_total;
+  const unsigned chunk = max(64u, ((share_w * (ANY ? 5u : 3u) / 8u) + 16u) & ~31u);
+  const unsigned dyn = max(64u, (share_w / 16u) & ~63u);
   __shared__ int stack[TRAV_STACK * TRAV_BLOCK];
   int *lds = &stack[threadIdx.x];
   int *spill = spill_base + (size_t)(blockIdx.x * TRAV_BLOCK + threadIdx.x) * TRAV_SPILL;
@@ -298,15 +302,14 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
           // the first chunk of every wave is assigned statically (chunk number = wave number): 4096 waves hitting one counter word at
           // launch would queue for ~45 us (a single word sustains ~90 atomics/us); the dynamic chunks start behind those
           unsigned base = 0;
-          // ... and are one wave wide (64 rays): finer balance at the end of the launch (128: +3 % time; 32: the counter word saturates)
           unsigned this_chunk = chunk;
           if (first_chunk) {
             first_chunk = false;
             base = (blockIdx.x * (unsigned)(TRAV_BLOCK / 64) + (threadIdx.x >> 6)) * chunk;
           } else {
-            if (lane_id() == 0) base = atomicAdd(counter, 64u);
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + gridDim.x * (unsigned)(TRAV_BLOCK / 64) * chunk;
-            this_chunk = 64u;
+            if (lane_id() == 0) base = atomicAdd(counter, dyn);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + n_waves_total * chunk;
+            this_chunk = dyn;
           }
           if (base >= n) {
             exhausted = true;
