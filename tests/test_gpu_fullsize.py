@@ -77,3 +77,30 @@ def test_bounded_sample_bit_exact_against_oracle(soup):
     assert (g["prim"] == c["prim"]).all() and (bits(g["t"]) == bits(c["t"])).all()
     assert (bits(g["u"]) == bits(c["u"])).all() and (bits(g["v"]) == bits(c["v"])).all()
     assert (g["prim"] >= 0).sum() > 10_000
+
+
+def test_traversal_layouts_agree_at_full_size(soup, hip):
+    """The default path (compressed 4-wide nodes, long rays parked and finished a wave per ray), the same without parking, and the
+    first-version kernel over the binary tree return the same hit records for every primary ray of the frame, bit for bit --
+    and the default launch really parked rays."""
+    sc, tr = soup
+    ad = next(iter(tr.backend.adapter_cache.values()))
+    rays = oracle_camera_rays(sc)
+    o, d = rays["origin"], rays["direction"]
+    hip.stats_reset()
+    hip.profile(True)
+    try:
+        a = ad.intersect(o, d)
+        parked_ms = hip.stats()["ms_long"]
+    finally:
+        hip.profile(False)
+    hip.set_option("long_steps", 0)
+    b = ad.intersect(o, d)
+    hip.set_option("defaults", 0)
+    hip.set_option("wide4", 0)
+    hip.set_option("trav_kernel", 0)
+    c = ad.intersect(o, d)
+    hip.set_option("defaults", 0)
+    assert a.tobytes() == b.tobytes(), "parking long rays changed a hit record"
+    assert a.tobytes() == c.tobytes(), "4-wide compressed layout and binary tree disagree"
+    assert parked_ms > 0.0 and (a["prim"] >= 0).sum() > 900_000
