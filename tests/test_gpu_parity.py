@@ -538,6 +538,18 @@ def test_config4_bunny_grid_image_scheduler(hip):
     assert tr.adapter_calls == st.adapter_calls and len(B.adapter_cache) == 1
 
 
+def test_many_instances_take_the_unordered_shuffle(hip):
+    """More than 64 destinations: the shuffle falls back from the scan-ordered slots to per-block atomics (queue order then is
+    arrival order, which the reference does not define either).  96 bunny instances, image and adapter-call count equal the oracle."""
+    sc = scenes.bunny_grid_scene(nx=12, ny=8, pitch=0.22, width=240, height=160)
+    assert sc.n_inst == 96
+    tr = ImageTracer(sc, NORMALS_SMOOTH)
+    B = tr()
+    ref, st = oracle_render(sc, 1)
+    assert np.array_equal(B.framebuffer(True)[..., :3], ref[..., :3])
+    assert tr.adapter_calls == st.adapter_calls and (ref[..., :3].sum(axis=2) > 0).sum() > 1000
+
+
 def test_legacy_conf_scene_three_bunnies(hip):
     """BASELINE config 1/4 input: data/bunny.conf (3 instances of bunny.obj, Domain scheduler hint), reduced film."""
     sc = scenes.load_conf(os.path.join(GOLDEN, "bunny.conf"), width=475, height=270)
