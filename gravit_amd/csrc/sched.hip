@@ -527,7 +527,8 @@ extern "C" int gvt_hip_image_frame(gvt_hip_top *T, gvt_hip_mesh *const *meshes, 
                                    const gvt_hip_light *lights, size_t n_lights, int normal_mode, const gvt_hip_camera *cam,
                                    gvt_hip_queue *const *queues, gvt_hip_queue *q_cam, gvt_hip_queue *q_moved, gvt_hip_fb *fb, uint64_t *adapter_calls) {
   if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
-  if (!T || !cam || !q_cam || !q_moved || !fb || (n_inst && (!meshes || !m || !minv || !normi || !queues)) || T->n != n_inst) {
+  (void)q_cam; // the camera list is no longer materialised
+  if (!T || !cam || !q_moved || !fb || (n_inst && (!meshes || !m || !minv || !normi || !queues)) || T->n != n_inst) {
     set_error("image_frame: null or inconsistent argument");
     return GVT_HIP_ERR_INVALID;
   }

@@ -179,7 +179,8 @@ int gvt_hip_queue_sizes(gvt_hip_queue *const *queues, size_t n, uint64_t *sizes_
 /* ---- Tracer<ImageScheduler>::operator() (algorithm/ImageTracer.h:127-269) for one rank, natively: clearBuffer, generateRays,
  *      FilterRaysLocally, then until every queue is empty: pick the fullest queue (first strictly largest, :159-173), adapter->trace,
  *      shuffleRays.  meshes[i] / m / minv / normi are per instance (adapters may repeat: adapterCache, :184-233).  The caller
- *      owns the queues (n_inst of them), q_cam, q_moved and fb; on return the queues are empty and fb holds the frame. ---- */
+ *      owns the queues (n_inst of them), q_moved and fb; on return the queues are empty and fb holds the frame.  q_cam is not used
+ *      any more (generateRays is fused into FilterRaysLocally, gvt_hip_camera_filter) and may be NULL. ---- */
 typedef struct gvt_hip_camera {
   float eye[3], focus[3], up[3];
   float fov;
