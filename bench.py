@@ -120,7 +120,10 @@ def main():
     for o in args.opt:
         k, v = o.split("=")
         capi.set_option(k, int(v))
-    capi.set_stream(torch.cuda.current_stream().cuda_stream)
+    if world == 1:
+        capi.set_stream(torch.cuda.current_stream().cuda_stream)
+    # world > 1: the adapter keeps its own non-blocking stream, so that RCCL transfers posted on torch's side really run beside the
+    # traversal kernels; the scheduler synchronises explicitly where the two meet (DomainTracer._post_exchange / _complete_exchange)
 
     if world == 1 and args.domains > 1:
         scene = scenes.soup_domains_scene(args.tris, args.domains, args.width, args.height)
