@@ -354,6 +354,7 @@ static int fill_params(TraceParams &P, const float m[16], const float minv[16], 
   std::memcpy(P.m.m, m, 64); std::memcpy(P.minv.m, minv, 64); std::memcpy(P.normi.n, normi, 36);
   P.normal_mode = normal_mode; P.seed = seed; P.n_lights = (int)n_lights;
   P.sink = TermSink{};
+  P.update_in_place = 1;
   return 0;
 }
 
@@ -377,6 +378,7 @@ extern "C" int gvt_hip_trace_queue_sink(gvt_hip_mesh *M, gvt_hip_queue *q_in, gv
   const size_t n = q_in->size;
   rc = queue_reserve(q_out, q_out->size + n * (1 + n_lights));
   if (rc) return rc;
+  P.update_in_place = 0; // q_in is cleared below: nobody reads the updated rays
   rc = trace_core(M, make_planes(q_in->d_planes, q_in->cap), n, 0, q_out, P, lights);
   if (rc) return rc;
   return gvt_hip_queue_clear(q_in); // the caller's queue[instTarget].clear(), ImageTracer.h:248

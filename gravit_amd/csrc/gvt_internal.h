@@ -146,6 +146,7 @@ struct TraceParams {
   uint32_t seed;
   int n_lights;
   TermSink sink;
+  int update_in_place; // Adapter::trace updates rayList in place; device-queue callers clear the list afterwards and skip that write
 };
 
 // lbvh.hip

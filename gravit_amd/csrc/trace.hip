@@ -948,6 +948,7 @@ struct ShadeArgs {
   uint32_t seed;
   unsigned *zero_word;     // reset for the launch that follows (the any-hit kernel's work counter)
   TermSink sink;           // terminal rule of the shuffle for rays that leave this instance without a hit (fb == nullptr: off)
+  int update_in_place;     // 1: every shaded ray is written back (gvt_hip_trace: the caller reads rayList); 0: only rays that bounce
 };
 
 #define SHADE_BLOCK 512
@@ -1060,8 +1061,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M) 
       r.depth = ndepth;
       bounce = true;
     }
-    store_ray(A.in, i, r); // rayList is updated in place
-    A.rng[i] = g_seed;
+    if (bounce || A.update_in_place) { // rayList is updated in place; a list the caller discards anyway (device queues) only needs it for the next pass
+      store_ray(A.in, i, r);
+      A.rng[i] = g_seed;
+    }
   }
   {
     const unsigned slot = block_alloc(A.next_count, bounce, &sh_alloc[2]);
@@ -1388,7 +1391,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
     A.first_pass = (pass == 0); A.out = outp; A.out_count = out->d_count; A.shadow = shadow; A.shadow_count = c_shadow;
     A.next_idx = next; A.next_count = c_next; A.lights = d_lights; A.normi = P.normi; A.normal_mode = P.normal_mode;
     A.n_lights = nL; A.seed = P.seed; A.zero_word = (C.trav_kernel == 1) ? C.d_counters + 0 : nullptr;
-    A.sink = P.sink;
+    A.sink = P.sink; A.update_in_place = P.update_in_place;
     {
       ProfScope ps(KC_SHADE);
       k_shade<<<blocks_for(n_active, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, mv);
