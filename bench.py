@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--domains", type=int, default=0, help="N=1 only: cut the soup into this many domains and use the Domain scheduler")
+    ap.add_argument("--full-reduce", action="store_true", help="N>1: composite by a sum-reduce of whole frames instead of each rank's written rectangle")
     ap.add_argument("--bsp", action="store_true", help="N>1: bulk-synchronous exchange rounds instead of the overlapped exchange")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (gvt_hip_set_option), for experiments")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -146,7 +147,7 @@ def main():
     def frame():
         tracer()
         if world > 1:
-            tracer.composite(download=False)  # IceTComposite::composite: the reduce is part of the frame, the PPM download is not
+            tracer.composite(download=False, rows_only=not args.full_reduce)  # IceTComposite::composite is part of the frame, the PPM download is not
 
     for _ in range(args.warmup):
         frame()

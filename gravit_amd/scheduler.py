@@ -318,16 +318,49 @@ class DomainTracer:
 
     render = __call__
 
-    def composite(self, download=True):
+    def composite(self, download=True, rows_only=True):
         """Sum of the per-rank float framebuffers on rank 0 (in place, in HBM), then -- if download -- the localAdd clamp and the
-        copy to the host.  Returns (H,W,4) on rank 0, None elsewhere or when download is False."""
+        copy to the host.  Returns (H,W,4) on rank 0, None elsewhere or when download is False.
+
+        rows_only: a rank's deposits lie where its domains project, so instead of a sum-reduce of whole frames (IceT's job in the
+        reference, IceTComposite.cpp:84-101) every rank sends rank 0 just the bounding rectangle of the pixels it wrote to: one
+        all-gather of the rectangles, point-to-point transfers, an add per rectangle.  Same sums, rank order instead of tree order."""
         B, torch, dist = self.backend, self.torch, self.dist
         cam = self.scene.camera
         if self.world == 1:
             return B.framebuffer(True) if download else None
         B.sync()
         t = B.fb_tensor(torch, self.dev)
-        dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+        if not rows_only:
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+        else:
+            img = t.view(cam.height, cam.width, 4)
+            lit = img[..., 3] > 0  # every deposit counts in the fourth component (localAdd adds 1.0)
+            ys = torch.nonzero(lit.any(dim=1)).flatten()
+            xs = torch.nonzero(lit.any(dim=0)).flatten()
+            box = [int(ys[0].item()), int(ys[-1].item()) + 1, int(xs[0].item()), int(xs[-1].item()) + 1] if ys.numel() else [0, 0, 0, 0]
+            mine = torch.tensor(box, dtype=torch.int64, device=self.dev)
+            allr = torch.empty((self.world, 4), dtype=torch.int64, device=self.dev)
+            parts = [allr[r] for r in range(self.world)]
+            dist.all_gather(parts, mine)
+            boxes = torch.stack(parts).cpu().numpy()
+            ops, bufs = [], {}
+            if self.rank == 0:
+                for p in range(1, self.world):
+                    y0, y1, x0, x1 = (int(v) for v in boxes[p])
+                    if y1 > y0:
+                        bufs[p] = torch.empty((y1 - y0, x1 - x0, 4), dtype=torch.float32, device=self.dev)
+                        ops.append(dist.P2POp(dist.irecv, bufs[p], p))
+            elif box[1] > box[0]:
+                bufs[0] = img[box[0]:box[1], box[2]:box[3]].contiguous()
+                ops.append(dist.P2POp(dist.isend, bufs[0], 0))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            if self.rank == 0:
+                for p, buf in bufs.items():
+                    y0, y1, x0, x1 = (int(v) for v in boxes[p])
+                    img[y0:y1, x0:x1] += buf
         if self.dev != "cpu":
             torch.cuda.current_stream().synchronize()
         if self.rank != 0 or not download:
