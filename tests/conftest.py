@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_product_library():
+    """A fresh checkout has no libgvt_hip.so (build artefacts are not tracked): cross-compile it once (hipcc needs no GPU) so that the
+    ABI tests have a library to load.  No-op when the library is up to date; building is not a fallback -- nothing computes without a GPU."""
+    from gravit_amd import _build
+
+    try:
+        _build.build()
+    except Exception as e:  # no hipcc on this machine: the tests that need the library report it
+        print("libgvt_hip.so could not be built here:", e, file=sys.stderr)
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
