@@ -25,6 +25,7 @@ SYMBOLS = [
     "gvt_hip_fb_create", "gvt_hip_fb_destroy", "gvt_hip_fb_clear", "gvt_hip_fb_download", "gvt_hip_fb_device_ptr",
     "gvt_hip_fb_write_ppm_bytes",
     "gvt_hip_profile", "gvt_hip_stats_read", "gvt_hip_stats_reset", "gvt_hip_set_option", "gvt_hip_visit_stats", "gvt_hip_image_frame",
+    "gvt_hip_math_probe",
 ]
 
 
@@ -121,6 +122,14 @@ def stats(reset=False):
 
 def set_option(name, value):
     check(load().gvt_hip_set_option(name.encode(), C.c_int(int(value))), "gvt_hip_set_option")
+
+
+def math_probe(kind, x):
+    """include/gvt_math.h evaluated on the device (diagnostic): kind 0 gvt_sinf, 1 gvt_cosf, 2 (float)gvt_acos(sqrt(1 - x))."""
+    x = f32(x, -1)
+    out = np.zeros_like(x)
+    check(load().gvt_hip_math_probe(C.c_int(kind), ptr(x), C.c_size_t(len(x)), ptr(out)), "gvt_hip_math_probe")
+    return out
 
 
 def stats_reset():

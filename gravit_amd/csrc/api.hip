@@ -140,6 +140,7 @@ extern "C" int gvt_hip_set_option(const char *name, int value) {
   if (!std::strcmp(name, "sort_gather")) { g_ctx.sort_gather = value; return 0; }
   if (!std::strcmp(name, "sort_bits")) { if (value < 8 || value > 32) { set_error("sort_bits must be 8..32"); return GVT_HIP_ERR_INVALID; } g_ctx.sort_bits = value; return 0; }
   if (!std::strcmp(name, "share")) { g_ctx.share = value; return 0; }
+  if (!std::strcmp(name, "share_min_rays")) { g_ctx.share_min_rays = value < 0 ? 0 : value; return 0; }
   if (!std::strcmp(name, "defaults")) { static_cast<Knobs &>(g_ctx) = Knobs{}; return 0; }
   if (!std::strcmp(name, "long_steps")) { g_ctx.long_steps = value < 0 ? 0 : value; return 0; }
   if (!std::strcmp(name, "long_min_rays")) { g_ctx.long_min_rays = value < 0 ? 0 : value; return 0; }
@@ -256,10 +257,11 @@ int queue_reserve(gvt_hip_queue *q, size_t cap) {
   size_t ncap = cap + cap / 8 + 1024;
   if (ncap >= 0xffffffffull) { set_error("queue_reserve: %zu rays exceed the 32-bit slot counter", ncap); return GVT_HIP_ERR_INVALID; }
   float4 *np = nullptr;
-  HIPCHK(hipMalloc((void **)&np, sizeof(float4) * 4 * ncap));
+  HIPCHK(hipMalloc((void **)&np, GVT_QUEUE_BYTES_PER_RAY * ncap));
   if (q->size) {
     for (int k = 0; k < 4; k++)
       HIPCHK(hipMemcpyAsync(np + (size_t)k * ncap, q->d_planes + (size_t)k * q->cap, sizeof(float4) * q->size, hipMemcpyDeviceToDevice, C.stream));
+    HIPCHK(hipMemcpyAsync(np + 4 * ncap, q->d_planes + 4 * q->cap, sizeof(uint32_t) * q->size, hipMemcpyDeviceToDevice, C.stream));
   }
   HIPCHK(hipStreamSynchronize(C.stream));
   if (q->d_planes) HIPCHK(hipFree(q->d_planes));
@@ -355,6 +357,7 @@ static int fill_params(TraceParams &P, const float m[16], const float minv[16], 
   P.normal_mode = normal_mode; P.seed = seed; P.n_lights = (int)n_lights;
   P.sink = TermSink{};
   P.update_in_place = 1;
+  P.carried_rng = 0;
   return 0;
 }
 
@@ -379,6 +382,7 @@ extern "C" int gvt_hip_trace_queue_sink(gvt_hip_mesh *M, gvt_hip_queue *q_in, gv
   rc = queue_reserve(q_out, q_out->size + n * (1 + n_lights));
   if (rc) return rc;
   P.update_in_place = 0; // q_in is cleared below: nobody reads the updated rays
+  P.carried_rng = 1;     // device-resident rays own their RNG stream
   rc = trace_core(M, make_planes(q_in->d_planes, q_in->cap), n, 0, q_out, P, lights);
   if (rc) return rc;
   return gvt_hip_queue_clear(q_in); // the caller's queue[instTarget].clear(), ImageTracer.h:248
@@ -427,7 +431,7 @@ static int stage_od(const float *org, const float *dir, size_t n, RayPlanes &pla
   float *d_dir = d_org + 3 * n;
   HIPCHK(hipMemcpyAsync(d_org, org, sizeof(float) * 3 * n, hipMemcpyHostToDevice, C.stream));
   HIPCHK(hipMemcpyAsync(d_dir, dir, sizeof(float) * 3 * n, hipMemcpyHostToDevice, C.stream));
-  planes.p0 = d_pl; planes.p1 = d_pl + n; planes.p2 = nullptr; planes.p3 = nullptr;
+  planes.p0 = d_pl; planes.p1 = d_pl + n; planes.p2 = nullptr; planes.p3 = nullptr; planes.p4 = nullptr;
   return convert_od_to_planes(d_org, d_dir, n, planes);
 }
 

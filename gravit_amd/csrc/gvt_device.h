@@ -11,6 +11,8 @@
 #include <stdint.h>
 
 #include "../../include/gvt_hip.h"
+#define GVT_MATH_FN __host__ __device__ static inline
+#include "../../include/gvt_math.h"
 
 #define GVT_RAY_EPSILON 1.e-6f   // actor/Ray.cpp:33
 #define GVT_FLT_MAX 3.402823466e+38f
@@ -64,14 +66,21 @@ __host__ __device__ inline V3 mat3_mul(const Mat3 &N, V3 v) {
 // float4 per plane, 1 KiB contiguous per wave-instruction.
 //   plane0 = (origin.xyz, t_min)   plane1 = (direction.xyz, t_max)
 //   plane2 = (color.rgb, t)        plane3 = (id, depth, w, type) bit-cast
+//   plane4 = one uint32 per ray: the ray's RNG stream word = bytes 64..67 of the 80-byte Ray image (inside Ray::data[68], copied by
+//            every Ray copy / pack of the reference and never read by it, actor/Ray.h:95,128-151).  The reference seeds one RandEngine
+//            per TBB chunk (EmbreeMeshAdapter.cpp:446-447: schedule dependent); here the stream belongs to the ray and travels with
+//            it -- through queues, shuffles and the wire -- so a frame does not depend on list order, rank count or scheduling.
+//            p4 may be null (lists that never shade: object-space query rays, shadow-ray scratch): loads read 0, stores skip it.
 // The traversal kernels touch planes 0 and 1 only (32 B/ray).
 // ---------------------------------------------------------------------------------------------
 struct RayPlanes {
   float4 *p0, *p1, *p2, *p3;
+  uint32_t *p4;
 };
-__host__ __device__ inline RayPlanes make_planes(float4 *base, size_t cap) {
+#define GVT_QUEUE_BYTES_PER_RAY (4 * sizeof(float4) + sizeof(uint32_t))
+__host__ __device__ inline RayPlanes make_planes(float4 *base, size_t cap) { // a queue allocation: GVT_QUEUE_BYTES_PER_RAY * cap
   RayPlanes r;
-  r.p0 = base; r.p1 = base + cap; r.p2 = base + 2 * cap; r.p3 = base + 3 * cap;
+  r.p0 = base; r.p1 = base + cap; r.p2 = base + 2 * cap; r.p3 = base + 3 * cap; r.p4 = (uint32_t *)(base + 4 * cap);
   return r;
 }
 
@@ -80,6 +89,7 @@ struct RayRec { // unpacked ray in registers
   V3 d; float t_max;
   V3 c; float t;
   int id, depth; float w; int type;
+  uint32_t rng; // stream word (plane 4)
 };
 __device__ inline RayRec load_ray(const RayPlanes &q, size_t i) {
   float4 a = q.p0[i], b = q.p1[i], c = q.p2[i], d = q.p3[i];
@@ -88,6 +98,7 @@ __device__ inline RayRec load_ray(const RayPlanes &q, size_t i) {
   r.d = mk3(b.x, b.y, b.z); r.t_max = b.w;
   r.c = mk3(c.x, c.y, c.z); r.t = c.w;
   r.id = __float_as_int(d.x); r.depth = __float_as_int(d.y); r.w = d.z; r.type = __float_as_int(d.w);
+  r.rng = q.p4 ? q.p4[i] : 0u;
   return r;
 }
 __device__ inline void store_ray(const RayPlanes &q, size_t i, const RayRec &r) {
@@ -95,6 +106,7 @@ __device__ inline void store_ray(const RayPlanes &q, size_t i, const RayRec &r) 
   q.p1[i] = make_float4(r.d.x, r.d.y, r.d.z, r.t_max);
   q.p2[i] = make_float4(r.c.x, r.c.y, r.c.z, r.t);
   q.p3[i] = make_float4(__int_as_float(r.id), __int_as_float(r.depth), r.w, __int_as_float(r.type));
+  if (q.p4) q.p4[i] = r.rng;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -182,12 +194,22 @@ __host__ __device__ inline float gvt_fastrand_lcg(uint32_t &seed, float mn, floa
   seed = 214013u * seed + 2531011u;
   return mn + (seed >> 16) * ff * (mx - mn);
 }
-// one stream per ray, keyed on (call seed, index in rayList): the reference seeds one engine per TBB chunk
-// (EmbreeMeshAdapter.cpp:446-447), which is schedule dependent; a per-ray stream is order independent
+// One RNG stream per ray.  The reference seeds one engine per TBB chunk (EmbreeMeshAdapter.cpp:446-447), which is schedule
+// dependent; a per-ray stream is order independent.  Two ways a stream starts:
+//  - Adapter::trace on a host RayVector (gvt_hip_trace): keyed on (call seed, index in rayList); bytes 64..67 of the incoming
+//    rays are ignored (a GraviT host leaves them uninitialised);
+//  - rays born on the device (camera) carry their stream word from birth: camera_stream_word(list index of the primary ray), and
+//    every later draw advances the word the ray carries.  A word of 0 means "no stream yet" and falls back to the first rule.
 __host__ __device__ inline uint32_t ray_stream_seed(uint32_t seed, uint64_t index) {
   uint32_t s = seed ^ (uint32_t)(index * 0x9E3779B9u) ^ (uint32_t)(index >> 32);
   s ^= s >> 16; s *= 0x85EBCA6Bu; s ^= s >> 13; s *= 0xC2B2AE35u; s ^= s >> 16;
   return s;
+}
+// ridx = pixel * samples^2 + sub-sample: the position of the ray in generateRays' own list (gvtCamera.cpp:262-305), whatever order
+// the rays are enumerated in here (tiles).  Never 0.
+__host__ __device__ inline uint32_t camera_stream_word(uint64_t ridx) {
+  const uint32_t s = ray_stream_seed(0x243F6A88u, ridx);
+  return s ? s : 0x9E3779B9u;
 }
 
 // wave64 helpers

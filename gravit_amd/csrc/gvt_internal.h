@@ -27,6 +27,7 @@ struct Knobs {
   int wide4 = 1;         // k_trace: traverse the compressed 4-wide collapse (64-B nodes, four 8-bit child boxes per fetch)
   int share = 1;         // k_trace drain-phase work sharing, bit 0: any-hit launches (0.66 vs 0.80 ms per 1 M shadow rays), bit 1: closest-hit
                          // launches (no gain: the pending subtrees of a closest-hit ray are mostly pruned by its eventual hit)
+  int share_min_rays = 131072; // ... only in launches of at least this many rays (15 K shadow rays: the hand-off costs more than the tail it trims)
   int sort_rays = 0;     // Morton-sort the rays of a list before traversal (pays on incoherent lists; camera rays arrive in 8x8 tiles and the shuffle keeps list order)
   int sort_gather = 0;   // after sorting, traverse a contiguous object-space copy (o,d) of the rays
   int sort_bits = 20;    // radix-sorted key width (8 bits per rocPRIM pass)
@@ -102,7 +103,7 @@ struct gvt_hip_mesh {
 };
 
 struct gvt_hip_queue {
-  float4 *d_planes = nullptr; // 4 planes of `cap`
+  float4 *d_planes = nullptr; // 4 float4 planes of `cap` + the uint32 stream-word plane (GVT_QUEUE_BYTES_PER_RAY * cap)
   size_t cap = 0;
   size_t size = 0;            // host mirror, always valid between API calls
   unsigned *d_count = nullptr;
@@ -147,6 +148,7 @@ struct TraceParams {
   int n_lights;
   TermSink sink;
   int update_in_place; // Adapter::trace updates rayList in place; device-queue callers clear the list afterwards and skip that write
+  int carried_rng;     // device-queue callers: a ray's RNG stream is the word it carries (gvt_device.h, plane 4)
 };
 
 // lbvh.hip

@@ -53,6 +53,7 @@ __device__ inline RayRec camera_ray(const CamArgs &A, unsigned long long ridx) {
   r.d = norm3(d); r.t_max = GVT_FLT_MAX;
   r.c = mk3(0.f, 0.f, 0.f); r.t = GVT_FLT_MAX;
   r.id = (int)pix; r.depth = A.depth; r.w = A.contri; r.type = 0;
+  r.rng = camera_stream_word((unsigned long long)pix * samples2 + sub);
   return r;
 }
 

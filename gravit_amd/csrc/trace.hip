@@ -208,6 +208,7 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
     for (int k = (int)lane_id(); k < n_pend; k += 64) {
       const unsigned src = pend[k];
       out.p0[base + k] = q.p0[src]; out.p1[base + k] = q.p1[src]; out.p2[base + k] = q.p2[src]; out.p3[base + k] = q.p3[src];
+      if (out.p4) out.p4[base + k] = 0u; // shadow rays never draw: their stream word is 0
     }
     return;
   }
@@ -235,7 +236,7 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
       unsigned base = 0;
       if (lane_id() == 0) base = atomicAdd(out_count, (unsigned)__popcll(m));
       base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-      if (go_on) { const unsigned slot = base + lanes_below(m); out.p0[slot] = a; out.p1[slot] = b; out.p2[slot] = c; out.p3[slot] = d; }
+      if (go_on) { const unsigned slot = base + lanes_below(m); out.p0[slot] = a; out.p1[slot] = b; out.p2[slot] = c; out.p3[slot] = d; if (out.p4) out.p4[slot] = 0u; }
     }
   }
 }
@@ -243,7 +244,7 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
 template <bool ANY, bool XFORM, int MODE, bool COOP, bool W4>
 __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, Trav T, float tnear,
                                                        gvt_hip_hit *__restrict__ hits, int *__restrict__ flags, RayPlanes out, unsigned *out_count,
-                                                       unsigned *counter, int *spill_base, int refill_min, int inner_min, const unsigned *__restrict__ n_dev, int share, TermSink sink, LongQ LQ) {
+                                                       unsigned *counter, int *spill_base, int refill_min, int inner_min, const unsigned *__restrict__ n_dev, int share, unsigned share_min, TermSink sink, LongQ LQ) {
   // Work distribution: wave w first takes the static range [w*chunk, (w+1)*chunk) -- no atomic, see the refill below -- and after that
   // dynamic ranges of `dyn` rays from the counter.  chunk is a fraction of a wave's fair share (3/8 for closest-hit launches, whose
   // per-ray cost varies most, 5/8 for any-hit; measured at 1 M rays: 96/128/160 rays -> 0.542/0.549/0.579 ms closest, 0.400/0.400/0.384
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
     //      its slowest ray (measured: up to 536 more inner steps at ~2.5 K cycles each while 63 lanes idle -- the fixed ~0.5 ms of
     //      every launch).  Now an idle lane takes the BOTTOM entry (the largest pending subtree) of a busy lane's stack together with a
     //      copy of its ray and best hit, and traverses that subtree as a helper; results are merged when lanes of a ray retire.
-    if ((ANY ? (share & 1) : (share & 2)) && exhausted && nidle > 0 && n >= 131072u) { // small launches: the hand-off costs more than the tail it trims (15 K shadow rays: 83 -> 66 us)
+    if ((ANY ? (share & 1) : (share & 2)) && exhausted && nidle > 0 && n >= share_min) { // small launches: the hand-off costs more than the tail it trims (15 K shadow rays: 83 -> 66 us)
       unsigned long long idle_m = idle;
       unsigned long long don_m = __ballot(active && cur != TRAV_DONE && (sp - sb) >= 2);
       const unsigned wave_tid0 = threadIdx.x & ~63u;
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
           bt = gbt; bu = gbu; bv = gbv; bden = gbden; bp = gbp; // the donor's best so far: a pruning bound, merged idempotently later
           sp = 0; sb = 0;
           donor_lane = d;
+          nsteps = 0; parked = false; // a fresh share of the ray: not the step count / parked state of the lane's previous ray
           active = true;
         }
         if ((int)lane_id() == d) sb++;
@@ -546,6 +548,8 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
           const int sidx = __ffsll((long long)src) - 1;
           const float st = __shfl(bt, sidx), su = __shfl(bu, sidx), sv = __shfl(bv, sidx), sd = __shfl(bden, sidx);
           const int spr = __shfl(bp, sidx);
+          const bool spk = __shfl((int)parked, sidx) != 0;
+          if (!ANY && (int)lane_id() == tgt && spk) parked = true; // a lane that gave up on its share: the whole ray goes to k_long_closest
           if (ANY) { if (spr >= 0) merged_occluded = true; }
           else if ((int)lane_id() == tgt && spr >= 0 && (bp < 0 || st < bt || (st == bt && spr < bp))) { bt = st; bp = spr; bu = su; bv = sv; bden = sd; }
           if ((int)lane_id() == sidx) active = false; // folded into tgt: retires without writing
@@ -764,7 +768,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_any(RayPlanes q, unsigned n, Mat
     }
     if (MODE == 1) {
       const unsigned slot = wave_alloc(out_count, survive);
-      if (survive) { out.p0[slot] = q.p0[j]; out.p1[slot] = q.p1[j]; out.p2[slot] = q.p2[j]; out.p3[slot] = q.p3[j]; }
+      if (survive) { out.p0[slot] = q.p0[j]; out.p1[slot] = q.p1[j]; out.p2[slot] = q.p2[j]; out.p3[slot] = q.p3[j]; if (out.p4) out.p4[slot] = 0u; }
     }
   }
 }
@@ -905,11 +909,12 @@ __device__ inline bool shade(const MatEval &m, const RayRec &ray, V3 N, const gv
 __device__ inline V3 cos_weighted_dir(V3 n, uint32_t &seed) {
   float Xi1 = gvt_fastrand01(seed);
   float Xi2 = gvt_fastrand01(seed);
-  float theta = (float)acos(sqrt(1.0 - (double)Xi1));
+  // acos / sinf / cosf: include/gvt_math.h, the definitions shared with the checker (no ocml call: bit-identical on both sides)
+  float theta = (float)gvt_acos(__builtin_sqrt(1.0 - (double)Xi1));
   float phi = (float)(2.0 * 3.1415926535897932384626433832795 * (double)Xi2);
-  float xs = sinf(theta) * cosf(phi);
-  float ys = cosf(theta);
-  float zs = sinf(theta) * sinf(phi);
+  float xs = gvt_sinf(theta) * gvt_cosf(phi);
+  float ys = gvt_cosf(theta);
+  float zs = gvt_sinf(theta) * gvt_sinf(phi);
   V3 y = n, h = y;
   if (fabsf(h.x) <= fabsf(h.y) && fabsf(h.x) <= fabsf(h.z)) h.x = 1.0f;
   else if (fabsf(h.y) <= fabsf(h.x) && fabsf(h.y) <= fabsf(h.z)) h.y = 1.0f;
@@ -937,8 +942,8 @@ struct ShadeArgs {
   unsigned n;
   unsigned long long index_base;
   const gvt_hip_hit *hits;
-  uint32_t *rng;           // per-ray stream state, indexed like `in`
   int first_pass;
+  int carried_rng;         // 1: a ray's stream is the word it carries (plane 4); 0: first pass keyed on (seed, index in rayList)
   RayPlanes out; unsigned *out_count;       // moved_rays
   RayPlanes shadow; unsigned *shadow_count; // shadowRays of this pass
   unsigned *next_idx; unsigned *next_count; // rays that bounce (valid[pi] stays set)
@@ -971,7 +976,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M) 
   if (in_range) {
     r = load_ray(A.in, i);
     h = A.hits[j];
-    g_seed = A.first_pass ? ray_stream_seed(A.seed, A.index_base + i) : A.rng[i];
+    g_seed = (A.first_pass && (!A.carried_rng || r.rng == 0u)) ? ray_stream_seed(A.seed, A.index_base + i) : r.rng;
     if (h.prim < 0) {
       miss = true; // :605-609
     } else if (r.type != 1) { // a SHADOW ray that hits is dropped :486-488
@@ -1042,6 +1047,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M) 
         s.t_max = 3.0f;   // dir.length() == glm component count (:347,355)
         s.c = c; s.t = r.t;
         s.id = r.id; s.depth = r.depth; s.w = r.w; s.type = 1;
+        s.rng = 0u;
       }
     }
     const unsigned slot = block_alloc(A.shadow_count, emit, &sh_alloc[2 * (2 + li)]);
@@ -1062,8 +1068,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M) 
       bounce = true;
     }
     if (bounce || A.update_in_place) { // rayList is updated in place; a list the caller discards anyway (device queues) only needs it for the next pass
+      r.rng = g_seed; // the stream goes on with the ray
       store_ray(A.in, i, r);
-      A.rng[i] = g_seed;
     }
   }
   {
@@ -1081,13 +1087,14 @@ __global__ __launch_bounds__(256) void k_aos_to_planes(const float4 *__restrict_
   if (i >= n) return;
   const float4 *s = src + (size_t)5 * i;
   dst.p0[off + i] = s[0]; dst.p1[off + i] = s[1]; dst.p2[off + i] = s[2]; dst.p3[off + i] = s[3];
+  if (dst.p4) dst.p4[off + i] = __float_as_uint(s[4].x); // bytes 64..67: the stream word
 }
 __global__ __launch_bounds__(256) void k_planes_to_aos(RayPlanes src, unsigned long long off, unsigned n, float4 *__restrict__ dst) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 *d = dst + (size_t)5 * i;
   d[0] = src.p0[off + i]; d[1] = src.p1[off + i]; d[2] = src.p2[off + i]; d[3] = src.p3[off + i];
-  d[4] = make_float4(0.f, 0.f, 0.f, 0.f);
+  d[4] = make_float4(__uint_as_float(src.p4 ? src.p4[off + i] : 0u), 0.f, 0.f, 0.f);
 }
 __global__ __launch_bounds__(256) void k_od_to_planes(const float *__restrict__ org, const float *__restrict__ dir, unsigned n, RayPlanes dst) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1132,6 +1139,13 @@ __global__ __launch_bounds__(256) void k_ray_keys(RayPlanes q, const unsigned *_
   const unsigned morton = (expand10(qx) << 2) | (expand10(qy) << 1) | expand10(qz);
   keys[j] = ((oct << 29) | (morton >> 1)) >> (32 - key_bits); // top key_bits bits: octant, then the coarsest Morton levels
   vals[j] = i;
+}
+
+__global__ __launch_bounds__(256) void k_math_probe(int kind, const float *__restrict__ in, unsigned n, float *__restrict__ out) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = in[i];
+  out[i] = kind == 0 ? gvt_sinf(x) : kind == 1 ? gvt_cosf(x) : (float)gvt_acos(__builtin_sqrt(1.0 - (double)x));
 }
 
 __global__ void k_set_u32(unsigned *p, unsigned v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
@@ -1251,8 +1265,8 @@ int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, 
     ProfScope ps(KC_CLOSEST);
     RayPlanes none{};
     if (C.trav_kernel == 1) {
-      if (xform) launch_trace<false, true, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{}, LQ);
-      else launch_trace<false, false, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{}, LQ);
+      if (xform) launch_trace<false, true, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
+      else launch_trace<false, false, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
     } else {
       if (xform) k_closest<true><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
       else k_closest<false><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
@@ -1299,8 +1313,8 @@ int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const M
   {
     ProfScope ps(KC_ANY);
     if (C.trav_kernel == 1) {
-      if (xform) launch_trace<true, true, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{}, LongQ{});
-      else launch_trace<true, false, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, TermSink{}, LongQ{});
+      if (xform) launch_trace<true, true, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LongQ{});
+      else launch_trace<true, false, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LongQ{});
     } else {
       if (xform) k_any<true, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
       else k_any<false, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
@@ -1323,13 +1337,12 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
   const int nL = P.n_lights;
   // scratch: hits, rng, shadow queue, two index lists, lights
   gvt_hip_hit *d_hits = (gvt_hip_hit *)scratch_get(0, sizeof(gvt_hip_hit) * n);
-  uint32_t *d_rng = (uint32_t *)scratch_get(1, sizeof(uint32_t) * n);
   const size_t shadow_cap = n * (size_t)(nL > 0 ? nL : 1);
   float4 *d_shadow = (float4 *)scratch_get(2, sizeof(float4) * 4 * shadow_cap);
   unsigned *d_idx_a = (unsigned *)scratch_get(3, sizeof(unsigned) * n);
   unsigned *d_idx_b = (unsigned *)scratch_get(4, sizeof(unsigned) * n);
   gvt_hip_light *d_lights = (gvt_hip_light *)scratch_get(5, sizeof(gvt_hip_light) * (nL > 0 ? nL : 1));
-  if (!d_hits || !d_rng || !d_shadow || !d_idx_a || !d_idx_b || !d_lights) return GVT_HIP_ERR_DEVICE;
+  if (!d_hits || !d_shadow || !d_idx_a || !d_idx_b || !d_lights) return GVT_HIP_ERR_DEVICE;
   { // the light list rarely changes between calls: upload only when it (or its scratch buffer) did
     static std::vector<unsigned char> cached;
     static const void *cached_dst = nullptr;
@@ -1342,6 +1355,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
     }
   }
   RayPlanes shadow = make_planes(d_shadow, shadow_cap);
+  shadow.p4 = nullptr; // shadow rays carry no stream
   RayPlanes outp = make_planes(out->d_planes, out->cap);
   unsigned *c_shadow = C.d_counters + 1, *c_next = C.d_counters + 2;
   k_trace_begin<<<1, 64, 0, st>>>(out->d_count, (unsigned)out->size, C.d_counters); // c_shadow, c_next, work counter
@@ -1380,15 +1394,15 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
         k_gather_od<<<blocks_for(n_active), 256, 0, st>>>(in, idx, (unsigned)n_active, P.minv, od, od + n);
       }
       HIPCHK(hipGetLastError());
-      RayPlanes sorted{ od, od + n, nullptr, nullptr };
+      RayPlanes sorted{ od, od + n, nullptr, nullptr, nullptr };
       rc = launch_closest(M, sorted, nullptr, n_active, false, P.minv, GVT_RAY_EPSILON, d_hits, pass == 0);
     } else
       rc = launch_closest(M, in, idx, n_active, true, P.minv, GVT_RAY_EPSILON, d_hits, pass == 0);
     if (rc) return rc;
     if (pass > 0) HIPCHK(hipMemsetAsync(c_shadow, 0, 2 * sizeof(unsigned), st)); // c_shadow, c_next adjacent (pass 0: k_trace_begin)
     ShadeArgs A;
-    A.in = in; A.idx = idx; A.n = (unsigned)n_active; A.index_base = index_base; A.hits = d_hits; A.rng = d_rng;
-    A.first_pass = (pass == 0); A.out = outp; A.out_count = out->d_count; A.shadow = shadow; A.shadow_count = c_shadow;
+    A.in = in; A.idx = idx; A.n = (unsigned)n_active; A.index_base = index_base; A.hits = d_hits;
+    A.first_pass = (pass == 0); A.carried_rng = P.carried_rng; A.out = outp; A.out_count = out->d_count; A.shadow = shadow; A.shadow_count = c_shadow;
     A.next_idx = next; A.next_count = c_next; A.lights = d_lights; A.normi = P.normi; A.normal_mode = P.normal_mode;
     A.n_lights = nL; A.seed = P.seed; A.zero_word = (C.trav_kernel == 1) ? C.d_counters + 0 : nullptr;
     A.sink = P.sink; A.update_in_place = P.update_in_place;
@@ -1410,7 +1424,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
         {
           ProfScope ps(KC_ANY);
           launch_trace<true, true, 1>(trav_grid2(shadow_ub), st, shadow, nullptr, 0u, P.minv, T, GVT_RAY_EPSILON, nullptr, nullptr, outp,
-                                                                               out->d_count, counter, C.d_spill, C.refill_min, C.inner_min, c_shadow, C.share, P.sink, LongQ{});
+                                                                               out->d_count, counter, C.d_spill, C.refill_min, C.inner_min, c_shadow, C.share, (unsigned)C.share_min_rays, P.sink, LongQ{});
         }
         HIPCHK(hipGetLastError());
         C.stats.launches_any++;
@@ -1450,6 +1464,21 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
   }
   C.stats.rays_forwarded += C.h_pinned[2] - out->size; // read back with the last pass
   out->size = C.h_pinned[2];
+  return 0;
+}
+
+extern "C" int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (kind < 0 || kind > 2 || (n && (!in || !out)) || n > 0xffffffffull) { set_error("math_probe: bad argument"); return GVT_HIP_ERR_INVALID; }
+  if (!n) return 0;
+  Ctx &C = gctx();
+  float *d = (float *)scratch_get(0, sizeof(float) * 2 * n);
+  if (!d) return GVT_HIP_ERR_DEVICE;
+  HIPCHK(hipMemcpyAsync(d, in, sizeof(float) * n, hipMemcpyHostToDevice, C.stream));
+  k_math_probe<<<blocks_for(n), 256, 0, C.stream>>>(kind, d, (unsigned)n, d + n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, d + n, sizeof(float) * n, hipMemcpyDeviceToHost, C.stream));
+  HIPCHK(hipStreamSynchronize(C.stream));
   return 0;
 }
 

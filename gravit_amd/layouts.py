@@ -17,9 +17,9 @@ FLT_MAX = np.float32(np.finfo(np.float32).max)
 
 RAY_DTYPE = np.dtype(
     {
-        "names": ["origin", "t_min", "direction", "t_max", "color", "t", "id", "depth", "w", "type"],
-        "formats": [("<f4", 3), "<f4", ("<f4", 3), "<f4", ("<f4", 3), "<f4", "<i4", "<i4", "<f4", "<i4"],
-        "offsets": [0, 12, 16, 28, 32, 44, 48, 52, 56, 60],
+        "names": ["origin", "t_min", "direction", "t_max", "color", "t", "id", "depth", "w", "type", "rng"],
+        "formats": [("<f4", 3), "<f4", ("<f4", 3), "<f4", ("<f4", 3), "<f4", "<i4", "<i4", "<f4", "<i4", "<u4"],
+        "offsets": [0, 12, 16, 28, 32, 44, 48, 52, 56, 60, 64],  # rng: the per-ray RNG stream word in Ray::data[64..67] (unused by the reference)
         "itemsize": 80,
     }
 )

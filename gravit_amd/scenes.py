@@ -250,9 +250,13 @@ def soup_scene(n_tris=10_000_000, width=1920, height=1080, seed=12345, half_exte
                      "soup-%d" % n_tris)
 
 
-def cathedral_scene(width=512, height=512, samples=2, depth=2, seed=7):
+def cathedral_scene(width=512, height=512, samples=2, depth=2, seed=7, eye=(0.0, 1.5, 9.0), light=(0.0, 2.5, 4.0)):
     """BASELINE config 5 stand-in (sibenik.obj is missing from the reference, .MISSING_LARGE_BLOBS):
-    a closed hall of long thin triangles (~80 K) -- deep BVH, AO-style secondary rays."""
+    a hall of long thin triangles (~80 K; floor, ceiling, side walls, back wall, two rows of columns; open at z = +10) --
+    deep BVH, AO-style secondary rays.  The default eye stands inside the hall (adapter-level tests: the schedulers never
+    assign a ray to an instance box it starts in, RayPacket.h:195-197); whole-frame tests look in from outside, e.g.
+    eye=(0, 1.5, 13), with the light in front of the opening, e.g. light=(0, 2.5, 12): a shadow ray is occluded by anything on the
+    whole half-line (tfar = FLT_MAX, EmbreeMeshAdapter.cpp:364-385), so a light inside the hall lights next to nothing."""
     rng = np.random.Generator(np.random.Philox(seed))
     vs, fs = [], []
 
@@ -286,8 +290,26 @@ def cathedral_scene(width=512, height=512, samples=2, depth=2, seed=7):
     v = np.array(vs, F)
     v += (rng.random(v.shape, dtype=F) - F(0.5)) * F(1e-3)
     mesh = MeshData(v, np.array(fs, np.int32), default_material(kd=(0.8, 0.8, 0.8)))
-    cam = Camera((0.0, 1.5, 9.0), (0.0, 1.4, 0.0), (0.0, 1.0, 0.0), float(F(60.0 * np.pi / 180.0)), width, height, samples, depth, 0.0)
-    return _assemble([mesh], [0], [mat_translate_scale((0, 0, 0), (1, 1, 1))], point_light((0.0, 2.5, 4.0)), cam, "cathedral")
+    cam = Camera(tuple(eye), (0.0, 1.4, 0.0), (0.0, 1.0, 0.0), float(F(60.0 * np.pi / 180.0)), width, height, samples, depth, 0.0)
+    return _assemble([mesh], [0], [mat_translate_scale((0, 0, 0), (1, 1, 1))], point_light(tuple(light)), cam, "cathedral")
+
+
+def split_into_domains(scene, n_domains, axis=2):
+    """A one-mesh scene cut into n_domains spatial domains along `axis` (triangles assigned by centroid slab, vertices
+    re-indexed per domain; one Mesh + the original instance matrix each) -- what a GraviT application does when it hands the
+    Domain scheduler one mesh per rank (DomainTracer.h:115-144)."""
+    assert len(scene.meshes) == 1 and scene.n_inst == 1
+    m = scene.meshes[0]
+    lo, hi = m.bbox()
+    c = m.verts[m.tris].mean(axis=1)[:, axis]
+    cell = np.clip(((c - lo[axis]) / max(float(hi[axis] - lo[axis]), 1e-30) * n_domains).astype(np.int64), 0, n_domains - 1)
+    meshes, mats = [], []
+    for d in range(n_domains):
+        sel = m.tris[cell == d]
+        used, inv = np.unique(sel.reshape(-1), return_inverse=True)
+        meshes.append(MeshData(np.ascontiguousarray(m.verts[used]), inv.astype(np.int32).reshape(-1, 3), m.material))
+        mats.append(scene.m[0].reshape(16))
+    return _assemble(meshes, list(range(n_domains)), mats, scene.lights, scene.camera, "%s-dom%d" % (scene.name, n_domains))
 
 
 # ------------------------------------------------------------------ domain decomposition of the soup

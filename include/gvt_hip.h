@@ -134,7 +134,7 @@ gvt_hip_queue *gvt_hip_queue_create(size_t capacity);
 void gvt_hip_queue_destroy(gvt_hip_queue *);
 int gvt_hip_queue_reserve(gvt_hip_queue *, size_t capacity); /* grows, keeps contents */
 int gvt_hip_queue_clear(gvt_hip_queue *);
-int gvt_hip_queue_size(gvt_hip_queue *, size_t *n);          /* synchronises */
+int gvt_hip_queue_size(gvt_hip_queue *, size_t *n);          /* host-side count, exact between API calls; no device access */
 /* append n 80-byte rays (host memory, or device memory when src_on_device) */
 int gvt_hip_queue_append(gvt_hip_queue *, const gvt_hip_ray *rays, size_t n, int src_on_device);
 /* copy the queue out as 80-byte rays (host or device destination) */
@@ -220,8 +220,12 @@ int gvt_hip_stats_reset(void);
 /* diagnostic, not on the hot path: per-ray visit counts of the closest-hit traversal over n object-space rays:
  * counts[3*j + 0..2] = inner-node visits / leaf visits / triangle tests of ray j. */
 int gvt_hip_visit_stats(gvt_hip_mesh *, const float *org, const float *dir, size_t n, float tnear, uint32_t *counts);
+/* diagnostic, not on the hot path: include/gvt_math.h evaluated on the device, element-wise over n floats -- kind 0 gvt_sinf(x),
+ * 1 gvt_cosf(x), 2 (float)gvt_acos(sqrt(1.0 - x)) -- so that a test can compare the device's bits with the host's for the
+ * functions the bounce path (EmbreeMeshAdapter.cpp:289-318) is built on. */
+int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
 /* adapter-internal tuning knobs (results never depend on them; gvt_internal.h `struct Knobs` lists them with their defaults):
- * "wide4", "blocks_per_cu", "refill_min", "inner_min", "share", "long_steps", "long_min_rays", "sort_rays", "sort_bits",
+ * "wide4", "blocks_per_cu", "refill_min", "inner_min", "share", "share_min_rays", "long_steps", "long_min_rays", "sort_rays", "sort_bits",
  * "top_ordered", "top_lds", "term_sink", "camera_tile", "trav_kernel", "coop_fetch"; ("defaults", 0) restores all of them. */
 int gvt_hip_set_option(const char *name, int value);
 

@@ -10,6 +10,7 @@
  */
 #define _GNU_SOURCE
 #include "gvt_oracle.h"
+#include "../include/gvt_math.h" /* acos / sinf / cosf of the bounce path: the definition shared with the device code */
 
 #include <float.h>
 #include <math.h>
@@ -84,13 +85,22 @@ float orc_fastrand_lcg(uint32_t *seedval, float mn, float mx) { /* :78-81 */
   return mn + (*seedval >> 16) * ff * (mx - mn);
 }
 /* per-ray stream seed: the reference seeds one engine per TBB chunk with the chunk's first ray index
- * (EmbreeMeshAdapter.cpp:446-447), which is schedule dependent; the restatement seeds one stream per
- * ray from (call seed, index of the ray in rayList) so that any execution order gives the same values. */
+ * (EmbreeMeshAdapter.cpp:446-447), which is schedule dependent; the restatement gives every ray its own stream so that any
+ * execution order, list order and rank count give the same values.  A stream starts either from (call seed, index of the ray in
+ * rayList) -- Adapter::trace on a host RayVector, orc_trace -- or from the word the ray carries in bytes 64..67 of its 80-byte
+ * image (inside Ray::data[68]: copied by every Ray copy / pack of the reference, never read by it, actor/Ray.h:95,128-151), set by
+ * the camera and advanced by every draw -- the schedulers, orc_render_image / orc_render_domain.  Word 0 = no stream yet. */
 static inline uint32_t ray_stream_seed(uint32_t seed, uint64_t index) {
   uint32_t s = seed ^ (uint32_t)(index * 0x9E3779B9u) ^ (uint32_t)(index >> 32);
   s ^= s >> 16; s *= 0x85EBCA6Bu; s ^= s >> 13; s *= 0xC2B2AE35u; s ^= s >> 16;
   return s;
 }
+static inline uint32_t camera_stream_word(uint64_t ridx) { /* ridx = position in generateRays' list (gvtCamera.cpp:262-305) */
+  const uint32_t s = ray_stream_seed(0x243F6A88u, ridx);
+  return s ? s : 0x9E3779B9u;
+}
+static inline uint32_t ray_word(const orc_ray *r) { uint32_t w; memcpy(&w, &r->pad[0], 4); return w; }
+static inline void set_ray_word(orc_ray *r, uint32_t w) { memcpy(&r->pad[0], &w, 4); }
 
 /* ------------------------------------------------------------------------- */
 /* Lights (data/scene/Light.cpp:58-133)                                       */
@@ -541,11 +551,12 @@ static void rv_append(rayvec *q, const orc_ray *r, size_t n) {
 static v3 cos_weighted_dir(v3 n, uint32_t *seed) {
   float Xi1 = fastrand01(seed);
   float Xi2 = fastrand01(seed);
-  float theta = (float)acos(sqrt(1.0 - Xi1));
-  float phi = (float)(2.0 * 3.1415926535897932384626433832795 * Xi2);
-  float xs = sinf(theta) * cosf(phi);
-  float ys = cosf(theta);
-  float zs = sinf(theta) * sinf(phi);
+  /* acos / sinf / cosf: the written-out definitions of include/gvt_math.h (libm's differ between machines in the last bit) */
+  float theta = (float)gvt_acos(__builtin_sqrt(1.0 - (double)Xi1));
+  float phi = (float)(2.0 * 3.1415926535897932384626433832795 * (double)Xi2);
+  float xs = gvt_sinf(theta) * gvt_cosf(phi);
+  float ys = gvt_cosf(theta);
+  float zs = gvt_sinf(theta) * gvt_sinf(phi);
   v3 y = n, h = y;
   if (fabsf(h.x) <= fabsf(h.y) && fabsf(h.x) <= fabsf(h.z)) h.x = 1.0f;
   else if (fabsf(h.y) <= fabsf(h.x) && fabsf(h.y) <= fabsf(h.z)) h.y = 1.0f;
@@ -554,6 +565,25 @@ static v3 cos_weighted_dir(v3 n, uint32_t *seed) {
   v3 z = cross3(x, y);
   v3 d = add3(add3(scl3(x, xs), scl3(y, ys)), scl3(z, zs));
   return norm3(d);
+}
+
+void orc_cos_weighted_dir(const float n[3], uint32_t *seed, float out[3]) {
+  v3 d = cos_weighted_dir(ld3(n), seed);
+  out[0] = d.x; out[1] = d.y; out[2] = d.z;
+}
+void orc_math_probe(int kind, const float *in, size_t n, float *out) {
+  for (size_t i = 0; i < n; i++) {
+    const float x = in[i];
+    switch (kind) {
+    case 0: out[i] = gvt_sinf(x); break;
+    case 1: out[i] = gvt_cosf(x); break;
+    case 2: out[i] = (float)gvt_acos(__builtin_sqrt(1.0 - (double)x)); break;
+    case 16: out[i] = sinf(x); break;
+    case 17: out[i] = cosf(x); break;
+    case 18: out[i] = (float)acos(sqrt(1.0 - (double)x)); break;
+    default: out[i] = 0.f;
+    }
+  }
 }
 
 typedef struct {
@@ -565,6 +595,7 @@ typedef struct {
   size_t nLights;
   int normal_mode;
   uint32_t seed;
+  int carried_rng; /* 1: a ray's stream is the word it carries; 0: keyed on (seed, index in rayList) */
   rayvec out;
   uint64_t n_closest, n_any;
 } trace_job;
@@ -574,7 +605,7 @@ static void trace_range(trace_job *J) {
   orc_ray shadow[64];
   for (size_t idx = J->begin; idx < J->end; idx++) {
     orc_ray *r = &J->rays[idx];
-    uint32_t g_seed = ray_stream_seed(J->seed, idx);
+    uint32_t g_seed = (J->carried_rng && ray_word(r) != 0u) ? ray_word(r) : ray_stream_seed(J->seed, idx);
     int alive = 1;
     while (alive) {
       /* prepGVT_EMBREE_PACKET_TYPE :255-287: tnear = RAY_EPSILON, tfar = FLT_MAX, ray t_min/t_max ignored.
@@ -664,6 +695,7 @@ static void trace_range(trace_job *J) {
       } else {
         alive = 0;
       }
+      set_ray_word(r, g_seed); /* the stream goes on with the ray (rayList is updated in place) */
       /* traceShadowRays :364-385: any-hit in (RAY_EPSILON, FLT_MAX) against the same instance */
       for (size_t s = 0; s < nShadow; s++) {
         v3 so = xfm_point(J->minv, ld3(shadow[s].origin));
@@ -699,7 +731,7 @@ void orc_trace_counts(uint64_t *c, uint64_t *a) { *c = g_last_closest; *a = g_la
 
 static void trace_to_vec(const orc_mesh *M, orc_ray *rays, size_t begin, size_t end, rayvec *out, const float *m,
                          const float *minv, const float *normi, const orc_light *lights, size_t nLights, int normal_mode,
-                         uint32_t seed, int nthreads) {
+                         uint32_t seed, int nthreads, int carried_rng) {
   if (end == 0 || end < begin) end = begin; /* caller resolves end==0 -> size */
   size_t n = end - begin;
   size_t chunk = 4096; /* work grain of EmbreeMeshAdapter.cpp:648 */
@@ -711,7 +743,7 @@ static void trace_to_vec(const orc_mesh *M, orc_ray *rays, size_t begin, size_t 
     J->M = M; J->rays = rays; J->begin = begin + j * chunk;
     J->end = (J->begin + chunk < end) ? J->begin + chunk : end;
     J->m = m; J->minv = minv; J->normi = normi; J->lights = lights; J->nLights = nLights;
-    J->normal_mode = normal_mode; J->seed = seed;
+    J->normal_mode = normal_mode; J->seed = seed; J->carried_rng = carried_rng;
   }
   trace_pool P = { jobs, nJobs, 0, PTHREAD_MUTEX_INITIALIZER };
   if (nthreads == 1 || nJobs <= 1) {
@@ -736,7 +768,7 @@ int orc_trace(const orc_mesh *M, orc_ray *rays, size_t begin, size_t end, orc_ra
               const float m[16], const float minv[16], const float normi[9], const orc_light *lights, size_t nLights,
               int normal_mode, uint32_t seed, int nthreads) {
   rayvec out = { 0 };
-  trace_to_vec(M, rays, begin, end, &out, m, minv, normi, lights, nLights, normal_mode, seed, nthreads);
+  trace_to_vec(M, rays, begin, end, &out, m, minv, normi, lights, nLights, normal_mode, seed, nthreads, 0);
   *n_out = out.n;
   int rc = 0;
   if (out.n > cap) rc = -1;
@@ -796,6 +828,7 @@ void orc_camera_generate(const float eye[3], const float focus[3], const float u
           r->w = contri;
           r->type = 0;
           r->depth = depth;
+          set_ray_word(r, camera_stream_word(ridx));
         }
       idx++;
     }
@@ -965,7 +998,7 @@ void orc_render_image(const orc_scene *S, orc_ray *cam, size_t nRays, int W, int
     if (target < 0) break;
     trace_to_vec(S->meshes[target], queues[target].v, 0, queues[target].n, &moved, S->m + 16 * target,
                  S->minv + 16 * target, S->normi + 9 * target, S->lights, S->nLights, S->normal_mode,
-                 (uint32_t)s.adapter_calls, S->nthreads);
+                 (uint32_t)s.adapter_calls, S->nthreads, 1);
     s.rays_closest += g_last_closest; s.rays_any += g_last_any; s.adapter_calls++;
     queues[target].n = 0;
     shuffle_rays(S, order, &moved, target, queues, fb);
@@ -1011,7 +1044,7 @@ void orc_render_domain(const orc_scene *S, const int32_t *owner, int P, const or
         if (target < 0) break;
         trace_to_vec(S->meshes[target], rq[p][target].v, 0, rq[p][target].n, &moved, S->m + 16 * target,
                      S->minv + 16 * target, S->normi + 9 * target, S->lights, S->nLights, S->normal_mode,
-                     (uint32_t)s.adapter_calls, S->nthreads);
+                     (uint32_t)s.adapter_calls, S->nthreads, 1);
         s.rays_closest += g_last_closest; s.rays_any += g_last_any; s.adapter_calls++;
         rq[p][target].n = 0;
         shuffle_rays(S, order, &moved, target, rq[p], rfb[p]);

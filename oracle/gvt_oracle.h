@@ -113,6 +113,11 @@ int orc_shade(const orc_material *mat, const orc_ray *ray, const float N[3], con
 void orc_light_contribution(const orc_light *, const float hit[3], const float samplePos[3], float out[3]);
 float orc_rng(uint32_t *seed);                                   /* RandEngine.h:43-56 */
 float orc_fastrand_lcg(uint32_t *seed, float mn, float mx);       /* RandEngine.h:78-81 */
+/* CosWeightedRandomHemisphereDirection2 (EmbreeMeshAdapter.cpp:289-318): advances *seed by two draws */
+void orc_cos_weighted_dir(const float n[3], uint32_t *seed, float out[3]);
+/* include/gvt_math.h evaluated on the host, element-wise: kind 0 gvt_sinf(x), 1 gvt_cosf(x), 2 (float)gvt_acos(sqrt(1.0 - x)),
+ * and the libm calls the reference makes in their place: 16 sinf, 17 cosf, 18 (float)acos(sqrt(1.0 - x)) */
+void orc_math_probe(int kind, const float *in, size_t n, float *out);
 
 /* ---- camera (gvtCamera.cpp:89-171, 233-312) ---- */
 void orc_camera_generate(const float eye[3], const float focus[3], const float up[3], float fov, int width,

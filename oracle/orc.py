@@ -15,9 +15,9 @@ REF_PATH = os.path.join(HERE, "_ref", "libgvtref.so")
 
 RAY_DTYPE = np.dtype(
     {
-        "names": ["origin", "t_min", "direction", "t_max", "color", "t", "id", "depth", "w", "type"],
-        "formats": [("<f4", 3), "<f4", ("<f4", 3), "<f4", ("<f4", 3), "<f4", "<i4", "<i4", "<f4", "<i4"],
-        "offsets": [0, 12, 16, 28, 32, 44, 48, 52, 56, 60],
+        "names": ["origin", "t_min", "direction", "t_max", "color", "t", "id", "depth", "w", "type", "rng"],
+        "formats": [("<f4", 3), "<f4", ("<f4", 3), "<f4", ("<f4", 3), "<f4", "<i4", "<i4", "<f4", "<i4", "<u4"],
+        "offsets": [0, 12, 16, 28, 32, 44, 48, 52, 56, 60, 64],  # rng: the per-ray RNG stream word in Ray::data[64..67] (unused by the reference)
         "itemsize": 80,
     }
 )
@@ -187,6 +187,21 @@ def fastrand_lcg(seed, mn=0.0, mx=1.0):
     s = C.c_uint32(seed)
     v = lib().orc_fastrand_lcg(C.byref(s), C.c_float(mn), C.c_float(mx))
     return v, s.value
+
+
+def cos_weighted_dir(n, seed):
+    s = C.c_uint32(seed)
+    out = np.zeros(3, np.float32)
+    lib().orc_cos_weighted_dir(_p(_f32(n, 3)), C.byref(s), _p(out))
+    return out, s.value
+
+
+def math_probe(kind, x):
+    """include/gvt_math.h on the host (kind 0 sinf, 1 cosf, 2 (float)acos(sqrt(1-x))); kind + 16: the libm calls of the reference."""
+    x = _f32(x, -1)
+    out = np.zeros_like(x)
+    lib().orc_math_probe(C.c_int(kind), _p(x), C.c_size_t(len(x)), _p(out))
+    return out
 
 
 def camera_rays(eye, focus, up, fov, width, height, samples=1, depth=1, jitter=0.0):

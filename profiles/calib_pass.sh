@@ -3,6 +3,8 @@
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/calib
 mkdir -p $OUT
+# the tool is built here from its source (no binaries in the tree)
+hipcc -O3 --offload-arch=gfx950 -o $REPO/tools/fetch_calib $REPO/tools/fetch_calib.hip || exit 1
 cd /tmp && export TMPDIR=/tmp
 timeout 120 $REPO/tools/fetch_calib 25 > $OUT/plain.log 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o pmc -- $REPO/tools/fetch_calib 25 > $OUT/fetch.log 2>&1

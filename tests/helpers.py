@@ -35,8 +35,8 @@ def oracle_render_domain(scene, owner, P, mode, nthreads=8):
 
 def sort_rays(r):
     """Canonical order of a ray list (the adapter's output order is unspecified)."""
-    raw = np.ascontiguousarray(r).view(np.uint8).reshape(len(r), 80)[:, :64]
-    keys = raw.view(np.uint32).reshape(len(r), 16)
+    raw = np.ascontiguousarray(r).view(np.uint8).reshape(len(r), 80)[:, :68]
+    keys = np.ascontiguousarray(raw).view(np.uint32).reshape(len(r), 17)
     idx = np.lexsort(keys.T[::-1])
     return r[idx]
 
@@ -44,8 +44,8 @@ def sort_rays(r):
 def rays_equal_bits(a, b):
     if len(a) != len(b):
         return False
-    ra = np.ascontiguousarray(a).view(np.uint8).reshape(len(a), 80)[:, :64]
-    rb = np.ascontiguousarray(b).view(np.uint8).reshape(len(b), 80)[:, :64]
+    ra = np.ascontiguousarray(a).view(np.uint8).reshape(len(a), 80)[:, :68]
+    rb = np.ascontiguousarray(b).view(np.uint8).reshape(len(b), 80)[:, :68]
     return bool((ra == rb).all())
 
 

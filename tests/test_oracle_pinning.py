@@ -228,3 +228,49 @@ def test_live_against_reference_build():
         assert int(ok) == ok_ref
         if ok:
             assert col.tobytes() == c.tobytes()
+
+
+def test_bounce_math_against_the_libm_the_reference_calls():
+    """include/gvt_math.h (the written-out acos / sinf / cosf shared by the oracle and the device code) against the host libm calls
+    CosWeightedRandomHemisphereDirection2 makes (EmbreeMeshAdapter.cpp:296-301), over every 16th value RandEngine::rng can return
+    (k / 2^24, RandEngine.h:55): theta identical in every case; sin / cos never more than 1 ulp from glibc's (which is not
+    correctly rounded: 0.56 ulp) and identical to the correctly rounded (float)sin((double)x)."""
+    xi = (np.arange(0, 1 << 24, 16, dtype=np.float64) / float(1 << 24)).astype(np.float32)
+    theta = orc.math_probe(2, xi)
+    assert (theta.view(np.uint32) == orc.math_probe(18, xi).view(np.uint32)).all()
+    phi = (2.0 * 3.1415926535897932384626433832795 * xi.astype(np.float64)).astype(np.float32)
+    for arg in (theta, phi):
+        for kind, f in ((0, np.sin), (1, np.cos)):
+            mine, libm = orc.math_probe(kind, arg), orc.math_probe(kind + 16, arg)
+            ulp = np.abs(mine.view(np.int32).astype(np.int64) - libm.view(np.int32).astype(np.int64))
+            assert ulp.max() <= 1 and (ulp == 0).mean() > 0.97
+            assert (mine.view(np.uint32) == f(arg.astype(np.float64)).astype(np.float32).view(np.uint32)).all()
+
+
+def test_bounce_direction_known_answers():
+    """cos_weighted_dir: unit length, in the hemisphere of n, two draws per call, and a fixed vector for seed 0 (regression pin)."""
+    n = np.array([0.0, 0.0, 1.0], np.float32)
+    d, s1 = orc.cos_weighted_dir(n, 0)
+    _, s_a = orc.rng(0)
+    _, s_b = orc.rng(s_a)
+    assert s1 == s_b and abs(float(np.linalg.norm(d)) - 1.0) < 1e-6 and d[2] > 0
+    acc = np.zeros(3)
+    s = 12345
+    for _ in range(4000):
+        d, s = orc.cos_weighted_dir(n, s)
+        assert d[2] >= 0
+        acc += d
+    assert abs(acc[2] / 4000 - 2.0 / 3.0) < 0.02 and abs(acc[0]) / 4000 < 0.03  # E[cos theta] of a cosine-weighted lobe = 2/3
+
+
+def test_depth2_frame_does_not_depend_on_rank_count():
+    """Carried RNG streams: a depth-2, 4-rays-per-pixel frame of the config-5 stand-in is the same image on 1, 2 and 4 ranks."""
+    one = scenes.cathedral_scene(96, 96, samples=2, depth=2, eye=(0.0, 1.5, 13.0), light=(0.0, 2.5, 12.0))
+    sc = scenes.split_into_domains(one, 4)
+    f1, s1 = oracle_render_domain(sc, [0] * 4, 1, 0)
+    f2, s2 = oracle_render_domain(sc, [0, 1, 0, 1], 2, 0)
+    f4, s4 = oracle_render_domain(sc, [0, 1, 2, 3], 4, 0)
+    assert (f1[..., :3].sum(axis=2) > 0).mean() > 0.2
+    assert np.abs(f1 - f2).max() < 1e-6 and np.abs(f1 - f4).max() < 1e-6
+    assert np.array_equal(f1[..., 3], f4[..., 3]) and s1.rays_closest == s4.rays_closest and s2.rays_any == s4.rays_any
+    assert s1.rays_sent == 0 and s4.rays_sent >= s2.rays_sent > 0
