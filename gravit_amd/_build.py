@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libgvt_hip.so")
-SOURCES = ["api.hip", "lbvh.hip", "trace.hip", "sched.hip"]
+SOURCES = ["api.hip", "lbvh.hip", "trace.hip", "sched.hip", "domain.hip"]
 HEADERS = ["gvt_device.h", "gvt_internal.h", os.path.join("..", "..", "include", "gvt_hip.h"),
            os.path.join("..", "..", "include", "gvt_math.h")]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-Wall",

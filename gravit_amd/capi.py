@@ -25,7 +25,10 @@ SYMBOLS = [
     "gvt_hip_fb_create", "gvt_hip_fb_destroy", "gvt_hip_fb_clear", "gvt_hip_fb_download", "gvt_hip_fb_device_ptr",
     "gvt_hip_fb_write_ppm_bytes",
     "gvt_hip_profile", "gvt_hip_stats_read", "gvt_hip_stats_reset", "gvt_hip_set_option", "gvt_hip_visit_stats", "gvt_hip_image_frame",
-    "gvt_hip_math_probe",
+    "gvt_hip_math_probe", "gvt_hip_ctx_create", "gvt_hip_ctx_make_current", "gvt_hip_ctx_destroy",
+    "gvt_hip_comm_unique_id", "gvt_hip_comm_create", "gvt_hip_hub_create", "gvt_hip_hub_abort", "gvt_hip_hub_destroy", "gvt_hip_comm_create_local",
+    "gvt_hip_comm_destroy", "gvt_hip_comm_rank", "gvt_hip_comm_world",
+    "gvt_hip_tracer_create", "gvt_hip_tracer_destroy", "gvt_hip_tracer_set_camera", "gvt_hip_tracer_set_domains", "gvt_hip_tracer_frame",
 ]
 
 
@@ -42,6 +45,17 @@ class MeshInfo(C.Structure):
 class CameraPod(C.Structure):
     _fields_ = [("eye", C.c_float * 3), ("focus", C.c_float * 3), ("up", C.c_float * 3), ("fov", C.c_float), ("width", C.c_int32),
                 ("height", C.c_int32), ("samples", C.c_int32), ("depth", C.c_int32), ("jitter_window_size", C.c_float)]
+
+
+class FrameStats(C.Structure):
+    _fields_ = [("rounds", C.c_uint64), ("chains", C.c_uint64), ("host_syncs", C.c_uint64), ("rays_sent", C.c_uint64),
+                ("rays_closest", C.c_uint64), ("rays_any", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+FRAME_BSP, FRAME_NO_COMPOSITE = 1, 2
 
 
 class Stats(C.Structure):
@@ -69,9 +83,11 @@ def load():
         for s in SYMBOLS:
             getattr(lib, s)  # AttributeError if the ABI is incomplete
         lib.gvt_hip_last_error.restype = C.c_char_p
-        for f in ("gvt_hip_mesh_create", "gvt_hip_queue_create", "gvt_hip_top_create", "gvt_hip_fb_create", "gvt_hip_fb_device_ptr"):
+        for f in ("gvt_hip_mesh_create", "gvt_hip_queue_create", "gvt_hip_top_create", "gvt_hip_fb_create", "gvt_hip_fb_device_ptr", "gvt_hip_ctx_create",
+                  "gvt_hip_comm_create", "gvt_hip_hub_create", "gvt_hip_comm_create_local", "gvt_hip_tracer_create"):
             getattr(lib, f).restype = C.c_void_p
-        for f in ("gvt_hip_mesh_destroy", "gvt_hip_queue_destroy", "gvt_hip_top_destroy", "gvt_hip_fb_destroy"):
+        for f in ("gvt_hip_mesh_destroy", "gvt_hip_queue_destroy", "gvt_hip_top_destroy", "gvt_hip_fb_destroy", "gvt_hip_ctx_destroy", "gvt_hip_hub_abort",
+                  "gvt_hip_hub_destroy", "gvt_hip_comm_destroy", "gvt_hip_tracer_destroy"):
             getattr(lib, f).restype = None
             getattr(lib, f).argtypes = [C.c_void_p]
         _lib = lib

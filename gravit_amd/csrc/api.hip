@@ -8,8 +8,10 @@ size_t trav_spill_ints_per_thread();
 int trav_block_threads();
 
 static thread_local std::string g_err;
-static Ctx g_ctx;
-Ctx &gctx() { return g_ctx; }
+static Ctx g_default_ctx;
+static thread_local Ctx *tl_ctx = nullptr;
+#define g_ctx (gctx())
+Ctx &gctx() { return tl_ctx ? *tl_ctx : g_default_ctx; }
 
 void set_error(const char *fmt, ...) {
   char buf[1024];
@@ -21,10 +23,7 @@ void set_error(const char *fmt, ...) {
 }
 extern "C" const char *gvt_hip_last_error(void) { return g_err.c_str(); }
 
-extern "C" int gvt_hip_init(int device) {
-  Ctx &C = g_ctx;
-  if (C.ready && C.device == device) return 0;
-  if (C.ready) { set_error("gvt_hip_init: already initialised on device %d", C.device); return GVT_HIP_ERR_INVALID; }
+static int ctx_setup(Ctx &C, int device) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { set_error("no HIP device visible"); return GVT_HIP_ERR_NODEVICE; }
   if (device < 0 || device >= count) { set_error("device %d out of range (%d visible)", device, count); return GVT_HIP_ERR_INVALID; }
@@ -46,12 +45,51 @@ extern "C" int gvt_hip_init(int device) {
   HIPCHK(hipMalloc((void **)&C.d_counters, 64 * sizeof(unsigned)));
   HIPCHK(hipMemset(C.d_counters, 0, 64 * sizeof(unsigned)));
   HIPCHK(hipHostMalloc((void **)&C.h_pinned, 64 * sizeof(unsigned), hipHostMallocDefault));
+  std::memset(C.h_pinned, 0, 64 * sizeof(unsigned));
   C.ready = true;
   return 0;
 }
 
+extern "C" int gvt_hip_init(int device) {
+  Ctx &C = g_default_ctx;
+  if (C.ready && C.device == device) { if (!tl_ctx) HIPCHK(hipSetDevice(device)); return 0; }
+  if (C.ready) { set_error("gvt_hip_init: already initialised on device %d", C.device); return GVT_HIP_ERR_INVALID; }
+  return ctx_setup(C, device);
+}
+
+// ---- additional contexts: one per thread that wants its own stream / scratch / statistics (e.g. several ranks of a scheduler in
+//      one process).  HIP's current device is per thread, so make_current also selects the context's device. ----
+extern "C" gvt_hip_ctx *gvt_hip_ctx_create(int device) {
+  Ctx *C = new Ctx();
+  if (ctx_setup(*C, device) != 0) { delete C; return nullptr; }
+  return (gvt_hip_ctx *)C;
+}
+extern "C" int gvt_hip_ctx_make_current(gvt_hip_ctx *c) {
+  tl_ctx = (Ctx *)c;
+  Ctx &C = gctx();
+  if (C.ready) HIPCHK(hipSetDevice(C.device));
+  return 0;
+}
+extern "C" void gvt_hip_ctx_destroy(gvt_hip_ctx *c) {
+  Ctx *C = (Ctx *)c;
+  if (!C) return;
+  if (tl_ctx == C) tl_ctx = nullptr;
+  if (C->ready) {
+    hipSetDevice(C->device);
+    hipStreamSynchronize(C->stream);
+    for (auto &p : C->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto e : C->event_pool) hipEventDestroy(e);
+    if (C->abi_qin) gvt_hip_queue_destroy(C->abi_qin);
+    if (C->abi_qout) gvt_hip_queue_destroy(C->abi_qout);
+    for (int k = 0; k < 24; k++) if (C->scratch[k]) hipFree(C->scratch[k]);
+    hipFree(C->d_spill); hipFree(C->d_counters); hipHostFree(C->h_pinned);
+    hipStreamDestroy(C->own_stream);
+  }
+  delete C;
+}
+
 int ensure_init() {
-  if (g_ctx.ready) return 0;
+  if (gctx().ready) return 0;
   return gvt_hip_init(0);
 }
 
@@ -402,8 +440,8 @@ extern "C" int gvt_hip_trace(gvt_hip_mesh *M, gvt_hip_ray *rays, size_t n_rays, 
   const size_t n = end - begin;
   *n_out = 0;
   if (!n) return 0;
-  static gvt_hip_queue *qin = nullptr, *qout = nullptr;
-  if (!qin) { qin = gvt_hip_queue_create(0); qout = gvt_hip_queue_create(0); }
+  if (!C.abi_qin) { C.abi_qin = gvt_hip_queue_create(0); C.abi_qout = gvt_hip_queue_create(0); }
+  gvt_hip_queue *qin = C.abi_qin, *qout = C.abi_qout;
   if (!qin || !qout) return GVT_HIP_ERR_DEVICE;
   if ((rc = gvt_hip_queue_clear(qin)) || (rc = gvt_hip_queue_clear(qout))) return rc;
   if ((rc = gvt_hip_queue_append(qin, rays + begin, n, 0))) return rc;
@@ -418,7 +456,6 @@ extern "C" int gvt_hip_trace(gvt_hip_mesh *M, gvt_hip_ray *rays, size_t n_rays, 
     if (!rays_out) { set_error("trace: null rays_out"); return GVT_HIP_ERR_INVALID; }
     if ((rc = gvt_hip_queue_export(qout, rays_out, cap, &got, 0))) return rc;
   }
-  (void)C;
   return 0;
 }
 

@@ -1,0 +1,728 @@
+// domain.hip -- the two live GraviT schedulers as native loops over device-resident queues:
+//
+//   Tracer<ImageScheduler>::operator()    src/gvt/render/algorithm/ImageTracer.h:127-269
+//   Tracer<DomainScheduler>::operator()   src/gvt/render/algorithm/DomainTracer.h:185-349, SendRays :370-496
+//   asynchronous Domain tracer            src/gvt/render/tracer/Domain/DomainTracer.cpp:109-192, vote: core/comm/vote/vote.cpp:47-152
+//
+// What the reference does one adapter call at a time (pick the fullest queue, trace it, shuffle the moved rays) runs here in ROUNDS:
+// all non-empty local queues of a rank go through ONE merged launch chain (closest hit -> shade -> any hit, trace.hip
+// wave_trace_chain) followed by ONE shuffle of all moved rays, with ray counts kept in device memory; the host reads the queue
+// sizes back ONCE per round.  A ray list's order carries no meaning in the reference and every ray owns its RNG stream, so the image
+// is the same (bit for bit where a pixel receives one deposit, within float-add reordering elsewhere).
+//
+// Under the Domain scheduler the ray exchange (MPI in the reference) is RCCL point-to-point on a dedicated communication stream:
+//   per round and peer  1. an "announce" of fixed size: {rays, bytes, this rank's total outgoing rays, its local pending rays,
+//                          rays per destination queue} -- SendRays' count exchange (:397-415) and the termination gather/scatter
+//                          (:337-349) in one message; built on the device, exchanged in one ncclGroup, read back with the queue sizes
+//                          in the round's single host synchronisation;
+//                       2. the payload in the reference's wire format, per queue [int32 queueId][int32 nRays][Ray x nRays] with the
+//                          80-byte Ray image (:441-455), sent while the next round's local chain runs; unpacked on the compute stream
+//                          behind an event.
+// Termination: every rank sees every rank's ballot (no local rays, nothing outgoing) in the same exchange and commits when all do --
+// the two-phase vote of the asynchronous tracer (propose / collect / commit) folded into the announce, with the guarantee the
+// reference's vote lacks: rays in flight are counted, because a round's announce is built after the previous payload was unpacked.
+// GVT_HIP_FRAME_BSP reproduces Tracer<DomainScheduler>: trace until the local queues are dry, then exchange.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+
+#include "gvt_internal.h"
+
+int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *from_arr, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
+                  gvt_hip_fb *fb, unsigned *d_overflow);
+
+// ------------------------------------------------------------------------------------------------
+// RCCL, resolved at first use (a single-GPU process never loads it)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+int rccl_load() {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (g_rccl.lib) return 0;
+  void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL); // the copy already in the process (e.g. PyTorch's) or the system one
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) { set_error("RCCL not found: %s", dlerror()); return GVT_HIP_ERR_DEVICE; }
+#define GVT_SYM(field, name)                                                                  \
+  *(void **)(&g_rccl.field) = dlsym(h, name);                                                 \
+  if (!g_rccl.field) { set_error("RCCL symbol %s missing", name); dlclose(h); return GVT_HIP_ERR_DEVICE; }
+  GVT_SYM(GetUniqueId, "ncclGetUniqueId") GVT_SYM(CommInitRank, "ncclCommInitRank") GVT_SYM(CommDestroy, "ncclCommDestroy")
+  GVT_SYM(GroupStart, "ncclGroupStart") GVT_SYM(GroupEnd, "ncclGroupEnd") GVT_SYM(Send, "ncclSend") GVT_SYM(Recv, "ncclRecv")
+  GVT_SYM(Reduce, "ncclReduce") GVT_SYM(GetErrorString, "ncclGetErrorString")
+#undef GVT_SYM
+  g_rccl.lib = h;
+  return 0;
+}
+#define NCCLCHK(expr)                                                                                      \
+  do {                                                                                                     \
+    ncclResult_t _r = (expr);                                                                              \
+    if (_r != ncclSuccess) {                                                                               \
+      set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, __LINE__);            \
+      return GVT_HIP_ERR_DEVICE;                                                                           \
+    }                                                                                                      \
+  } while (0)
+
+__global__ __launch_bounds__(256) void k_add_f32(float *__restrict__ dst, const float *__restrict__ src, unsigned long long n4) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = ((float4 *)dst)[i];
+  const float4 b = ((const float4 *)src)[i];
+  a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  ((float4 *)dst)[i] = a;
+}
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// In-process transport: the ranks are threads of one process (each with its own context) sharing one device.  Same call pattern as
+// the RCCL transport -- grouped point-to-point sends / receives ordered on the ranks' communication streams -- with the transfer done
+// by device-to-device copies.  Several ranks per node is how the reference is usually run (mpirun -np P); on a one-GPU box it is
+// also the only way to run the Domain scheduler's multi-rank control flow on the device.
+// ------------------------------------------------------------------------------------------------
+struct gvt_hip_hub {
+  int world = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  struct Slot {
+    const void *ptr = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ready = nullptr;  // recorded by the sender: the buffer is complete
+    hipEvent_t copied = nullptr; // recorded by the receiver: the buffer has been read
+    int state = 0;               // 0 empty, 1 posted, 2 consumed
+  };
+  std::vector<Slot> slots; // [dst * world + src]
+  bool aborted = false;
+};
+
+struct gvt_hip_comm {
+  int rank = 0, world = 1;
+  hipStream_t stream = nullptr; // communication stream
+  ncclComm_t nccl = nullptr;
+  gvt_hip_hub *hub = nullptr;
+  struct Op { int send; void *ptr; size_t bytes; int peer; int accumulate; };
+  std::vector<Op> ops; // the open group
+};
+
+extern "C" gvt_hip_hub *gvt_hip_hub_create(int world) {
+  if (world < 1) { set_error("hub_create: world < 1"); return nullptr; }
+  gvt_hip_hub *H = new gvt_hip_hub();
+  H->world = world;
+  H->slots.resize((size_t)world * world);
+  return H;
+}
+extern "C" void gvt_hip_hub_abort(gvt_hip_hub *H) { // wakes every rank blocked in an exchange (a rank failed)
+  if (!H) return;
+  { std::lock_guard<std::mutex> lk(H->mu); H->aborted = true; }
+  H->cv.notify_all();
+}
+extern "C" void gvt_hip_hub_destroy(gvt_hip_hub *H) {
+  if (!H) return;
+  for (auto &s : H->slots) { if (s.ready) hipEventDestroy(s.ready); if (s.copied) hipEventDestroy(s.copied); }
+  delete H;
+}
+
+extern "C" int gvt_hip_comm_unique_id(unsigned char id[128]) {
+  if (!id) { set_error("comm_unique_id: null"); return GVT_HIP_ERR_INVALID; }
+  int rc = rccl_load();
+  if (rc) return rc;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId u;
+  NCCLCHK(g_rccl.GetUniqueId(&u));
+  std::memcpy(id, &u, 128);
+  return 0;
+}
+
+static gvt_hip_comm *comm_new(int rank, int world) {
+  if (ensure_init()) return nullptr;
+  if (world < 1 || rank < 0 || rank >= world) { set_error("comm_create: bad rank %d of %d", rank, world); return nullptr; }
+  gvt_hip_comm *K = new gvt_hip_comm();
+  K->rank = rank; K->world = world;
+  if (hipStreamCreateWithFlags(&K->stream, hipStreamNonBlocking) != hipSuccess) { set_error("comm_create: stream"); delete K; return nullptr; }
+  return K;
+}
+extern "C" gvt_hip_comm *gvt_hip_comm_create(const unsigned char id[128], int rank, int world) {
+  if (!id) { set_error("comm_create: null id"); return nullptr; }
+  if (rccl_load()) return nullptr;
+  gvt_hip_comm *K = comm_new(rank, world);
+  if (!K) return nullptr;
+  ncclUniqueId u;
+  std::memcpy(&u, id, 128);
+  ncclResult_t r = g_rccl.CommInitRank(&K->nccl, world, u, rank);
+  if (r != ncclSuccess) { set_error("ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); hipStreamDestroy(K->stream); delete K; return nullptr; }
+  return K;
+}
+extern "C" gvt_hip_comm *gvt_hip_comm_create_local(gvt_hip_hub *hub, int rank) {
+  if (!hub) { set_error("comm_create_local: null hub"); return nullptr; }
+  gvt_hip_comm *K = comm_new(rank, hub->world);
+  if (K) K->hub = hub;
+  return K;
+}
+extern "C" void gvt_hip_comm_destroy(gvt_hip_comm *K) {
+  if (!K) return;
+  hipStreamSynchronize(K->stream);
+  if (K->nccl) g_rccl.CommDestroy(K->nccl);
+  hipStreamDestroy(K->stream);
+  delete K;
+}
+extern "C" int gvt_hip_comm_rank(const gvt_hip_comm *K) { return K ? K->rank : 0; }
+extern "C" int gvt_hip_comm_world(const gvt_hip_comm *K) { return K ? K->world : 1; }
+
+namespace {
+void comm_group_begin(gvt_hip_comm *K) { K->ops.clear(); }
+void comm_send(gvt_hip_comm *K, const void *p, size_t bytes, int peer) { K->ops.push_back({ 1, (void *)p, bytes, peer, 0 }); }
+void comm_recv(gvt_hip_comm *K, void *p, size_t bytes, int peer, int accumulate = 0) { K->ops.push_back({ 0, p, bytes, peer, accumulate }); }
+
+int hub_group_end(gvt_hip_comm *K) {
+  gvt_hip_hub *H = K->hub;
+  const int W = H->world, me = K->rank;
+  // 1. post every send (the slot is free: the previous group waited for its consumption)
+  for (auto &o : K->ops) {
+    if (!o.send) continue;
+    std::unique_lock<std::mutex> lk(H->mu);
+    gvt_hip_hub::Slot &s = H->slots[(size_t)o.peer * W + me];
+    H->cv.wait(lk, [&] { return s.state == 0 || H->aborted; });
+    if (H->aborted) { set_error("hub: aborted"); return GVT_HIP_ERR_DEVICE; }
+    if (!s.ready) { hipEventCreateWithFlags(&s.ready, hipEventDisableTiming); hipEventCreateWithFlags(&s.copied, hipEventDisableTiming); }
+    HIPCHK(hipEventRecord(s.ready, K->stream));
+    s.ptr = o.ptr; s.bytes = o.bytes; s.state = 1;
+    lk.unlock();
+    H->cv.notify_all();
+  }
+  // 2. every receive: wait for the matching send, copy behind its event
+  for (auto &o : K->ops) {
+    if (o.send) continue;
+    std::unique_lock<std::mutex> lk(H->mu);
+    gvt_hip_hub::Slot &s = H->slots[(size_t)me * W + o.peer];
+    H->cv.wait(lk, [&] { return s.state == 1 || H->aborted; });
+    if (H->aborted) { set_error("hub: aborted"); return GVT_HIP_ERR_DEVICE; }
+    if (s.bytes != o.bytes) { set_error("hub: rank %d expects %zu bytes from %d, which sends %zu", me, o.bytes, o.peer, s.bytes); H->aborted = true; H->cv.notify_all(); return GVT_HIP_ERR_INVALID; }
+    HIPCHK(hipStreamWaitEvent(K->stream, s.ready, 0));
+    if (o.bytes) {
+      if (o.accumulate) k_add_f32<<<(unsigned)((o.bytes / 16 + 255) / 256), 256, 0, K->stream>>>((float *)o.ptr, (const float *)s.ptr, o.bytes / 16);
+      else HIPCHK(hipMemcpyAsync(o.ptr, s.ptr, o.bytes, hipMemcpyDeviceToDevice, K->stream));
+    }
+    HIPCHK(hipEventRecord(s.copied, K->stream));
+    s.state = 2;
+    lk.unlock();
+    H->cv.notify_all();
+  }
+  // 3. own sends consumed: later work on this stream must not overwrite a buffer that is still being read
+  for (auto &o : K->ops) {
+    if (!o.send) continue;
+    std::unique_lock<std::mutex> lk(H->mu);
+    gvt_hip_hub::Slot &s = H->slots[(size_t)o.peer * W + me];
+    H->cv.wait(lk, [&] { return s.state == 2 || H->aborted; });
+    if (H->aborted) { set_error("hub: aborted"); return GVT_HIP_ERR_DEVICE; }
+    HIPCHK(hipStreamWaitEvent(K->stream, s.copied, 0));
+    s.state = 0;
+    lk.unlock();
+    H->cv.notify_all();
+  }
+  K->ops.clear();
+  return 0;
+}
+
+int comm_group_end(gvt_hip_comm *K) {
+  if (K->hub) return hub_group_end(K);
+  if (K->ops.empty()) return 0;
+  NCCLCHK(g_rccl.GroupStart());
+  for (auto &o : K->ops) {
+    if (!o.bytes) continue;
+    if (o.send) NCCLCHK(g_rccl.Send(o.ptr, o.bytes, ncclUint8, o.peer, K->nccl, K->stream));
+    else NCCLCHK(g_rccl.Recv(o.ptr, o.bytes, ncclUint8, o.peer, K->nccl, K->stream));
+  }
+  NCCLCHK(g_rccl.GroupEnd());
+  K->ops.clear();
+  return 0;
+}
+
+// sum of every rank's float buffer on `root`, in place (IceTComposite::composite, composite/IceTComposite.cpp:84-101)
+int comm_reduce_sum(gvt_hip_comm *K, float *buf, size_t n_floats, int root) {
+  if (K->world == 1) return 0;
+  if (!K->hub) {
+    NCCLCHK(g_rccl.Reduce(buf, buf, n_floats, ncclFloat, ncclSum, root, K->nccl, K->stream));
+    return 0;
+  }
+  comm_group_begin(K);
+  if (K->rank == root) { for (int p = 0; p < K->world; p++) if (p != root) comm_recv(K, buf, n_floats * 4, p, 1); }
+  else comm_send(K, buf, n_floats * 4, root);
+  return comm_group_end(K);
+}
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// device helpers of the scheduler loop
+// ------------------------------------------------------------------------------------------------
+namespace {
+#define ANN_HEAD 4 // announce row: {rays to you, bytes to you, my total outgoing rays, my local pending rays, rays per queue [n_inst]}
+
+// sizes[i] = *count_ptr[i]; the announce row for every peer; totals (2 x u64) and flags copied next to them so that ONE device-to-host
+// copy carries everything the host needs from a round
+__global__ void k_round_report(unsigned *const *__restrict__ count_ptr, const int *__restrict__ owner, int n_inst, int rank, int world,
+                               unsigned *__restrict__ sizes, int *__restrict__ ann /* [world][ANN_HEAD + n_inst] */, const unsigned *__restrict__ counters,
+                               const unsigned *__restrict__ overflow, unsigned *__restrict__ tail /* sizes + n_inst: tot[4], ovf trav, ovf queue */) {
+  __shared__ unsigned long long sh_out, sh_local;
+  if (threadIdx.x == 0) { sh_out = 0; sh_local = 0; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_inst; i += blockDim.x) {
+    const unsigned s = *count_ptr[i];
+    sizes[i] = s;
+    if (owner[i] == rank) atomicAdd(&sh_local, (unsigned long long)s); else atomicAdd(&sh_out, (unsigned long long)s);
+  }
+  __syncthreads();
+  const int row = ANN_HEAD + n_inst;
+  for (int p = threadIdx.x; p < world; p += blockDim.x) {
+    unsigned rays = 0, queues = 0;
+    for (int i = 0; i < n_inst; i++) {
+      const unsigned s = (owner[i] == p && p != rank) ? sizes[i] : 0u;
+      ann[p * row + ANN_HEAD + i] = (int)s;
+      rays += s; queues += s ? 1u : 0u;
+    }
+    ann[p * row + 0] = (int)rays;
+    ann[p * row + 1] = (int)(rays * 80u + queues * 8u); // SendRays: packed rays + {queue number, ray count} per queue (:397-407)
+    ann[p * row + 2] = (int)sh_out;
+    ann[p * row + 3] = (int)sh_local;
+  }
+  if (threadIdx.x == 0) {
+    tail[0] = counters[16]; tail[1] = counters[17]; tail[2] = counters[18]; tail[3] = counters[19];
+    tail[4] = counters[8]; tail[5] = *overflow;
+  }
+}
+
+__global__ void k_zero_counts(unsigned *const *__restrict__ count_ptr, const unsigned char *__restrict__ mask, int n_inst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_inst && mask[i]) *count_ptr[i] = 0u;
+}
+
+// wire image of one queue: [int32 queueId][int32 nRays][nRays x 80-byte Ray] (DomainTracer.h:441-455); one thread per dword
+__global__ __launch_bounds__(256) void k_pack_wire(RayPlanes q, unsigned n, int qid, unsigned *__restrict__ dst) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long total = 2ull + 20ull * n;
+  if (t >= total) return;
+  if (t < 2) { dst[t] = t == 0 ? (unsigned)qid : n; return; }
+  const unsigned long long d = t - 2;
+  const unsigned ray = (unsigned)(d / 20), w = (unsigned)(d % 20);
+  unsigned v = 0;
+  if (w < 16) { const float4 *pl = w < 4 ? q.p0 : w < 8 ? q.p1 : w < 12 ? q.p2 : q.p3; v = ((const unsigned *)(pl + ray))[w & 3]; }
+  else if (w == 16) v = q.p4[ray];
+  dst[t] = v;
+}
+// the reverse, appended behind the queue's current rays (its count word is advanced by k_add_count afterwards)
+__global__ __launch_bounds__(256) void k_unpack_wire(const unsigned *__restrict__ src, unsigned n, int qid, RayPlanes q, unsigned long long cap,
+                                                      const unsigned *__restrict__ count, unsigned *__restrict__ err) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0 && (src[0] != (unsigned)qid || src[1] != n)) atomicOr(err, 2u); // in-band header disagrees with the announce
+  if (t >= 20ull * n) return;
+  const unsigned ray = (unsigned)(t / 20), w = (unsigned)(t % 20);
+  const unsigned long long slot = (unsigned long long)*count + ray;
+  if (slot >= cap) { atomicOr(err, 1u); return; }
+  const unsigned v = src[2 + t];
+  if (w < 16) { float4 *pl = w < 4 ? q.p0 : w < 8 ? q.p1 : w < 12 ? q.p2 : q.p3; ((unsigned *)(pl + slot))[w & 3] = v; }
+  else if (w == 16) q.p4[slot] = v;
+}
+__global__ void k_add_count(unsigned *count, unsigned n) { if (!blockIdx.x && !threadIdx.x) *count += n; }
+__global__ void k_zero_totals(unsigned *c, unsigned *ovf) { if (!blockIdx.x && threadIdx.x < 4) c[16 + threadIdx.x] = 0u; if (!blockIdx.x && threadIdx.x == 4) *ovf = 0u; }
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// the tracer object: Tracer<ImageScheduler> / Tracer<DomainScheduler> for one rank
+// ------------------------------------------------------------------------------------------------
+struct gvt_hip_tracer {
+  gvt_hip_top *top = nullptr;
+  size_t n_inst = 0;
+  std::vector<gvt_hip_mesh *> meshes;
+  std::vector<float> m, minv, normi;
+  std::vector<gvt_hip_light> lights;
+  int normal_mode = 0;
+  gvt_hip_camera cam{};
+  gvt_hip_fb *fb = nullptr;
+  std::vector<gvt_hip_queue *> queues; // one per instance: local work (owned) or outgoing rays (not owned)
+  gvt_hip_queue *q_moved = nullptr;
+  std::vector<int> owner;
+  std::vector<uint8_t> owned;
+  gvt_hip_comm *comm = nullptr; // borrowed
+  int rank = 0, world = 1;
+  // device tables
+  WaveInst *d_insts = nullptr;
+  WaveSeg *d_segs = nullptr, *h_segs = nullptr;
+  unsigned **d_count_ptr = nullptr;
+  int *d_owner = nullptr;
+  unsigned char *d_mask = nullptr, *h_mask = nullptr;
+  unsigned *d_report = nullptr, *h_report = nullptr; // sizes[n_inst] + tail[8]
+  int *d_ann_out = nullptr, *d_ann_in = nullptr, *h_ann_in = nullptr; // [world][ANN_HEAD + n_inst]
+  unsigned *d_overflow = nullptr;
+  std::vector<void *> send_buf, recv_buf;
+  std::vector<size_t> send_cap, recv_cap;
+  hipEvent_t ev_compute = nullptr, ev_report = nullptr, ev_pack = nullptr, ev_recv = nullptr, ev_comm = nullptr;
+  std::vector<size_t> present; // host-known queue sizes as of the last report
+};
+
+extern "C" void gvt_hip_tracer_destroy(gvt_hip_tracer *R) {
+  if (!R) return;
+  if (gctx().ready) hipStreamSynchronize(gctx().stream);
+  if (R->comm) hipStreamSynchronize(R->comm->stream);
+  for (auto q : R->queues) gvt_hip_queue_destroy(q);
+  gvt_hip_queue_destroy(R->q_moved);
+  hipFree(R->d_insts); hipFree(R->d_segs); hipHostFree(R->h_segs); hipFree(R->d_count_ptr); hipFree(R->d_owner); hipFree(R->d_mask);
+  hipHostFree(R->h_mask); hipFree(R->d_report); hipHostFree(R->h_report); hipFree(R->d_ann_out); hipFree(R->d_ann_in); hipHostFree(R->h_ann_in);
+  hipFree(R->d_overflow);
+  for (void *p : R->send_buf) hipFree(p);
+  for (void *p : R->recv_buf) hipFree(p);
+  for (hipEvent_t e : { R->ev_compute, R->ev_report, R->ev_pack, R->ev_recv, R->ev_comm }) if (e) hipEventDestroy(e);
+  delete R;
+}
+
+static int tracer_alloc_tables(gvt_hip_tracer *R) {
+  const size_t n = R->n_inst ? R->n_inst : 1, W = (size_t)R->world;
+  const size_t row = ANN_HEAD + R->n_inst;
+  hipFree(R->d_ann_out); hipFree(R->d_ann_in); hipHostFree(R->h_ann_in);
+  R->d_ann_out = R->d_ann_in = R->h_ann_in = nullptr;
+  HIPCHK(hipMalloc((void **)&R->d_ann_out, sizeof(int) * W * row));
+  HIPCHK(hipMalloc((void **)&R->d_ann_in, sizeof(int) * W * row));
+  HIPCHK(hipHostMalloc((void **)&R->h_ann_in, sizeof(int) * W * row, hipHostMallocDefault));
+  HIPCHK(hipMemset(R->d_ann_in, 0, sizeof(int) * W * row));
+  std::memset(R->h_ann_in, 0, sizeof(int) * W * row);
+  for (void *p : R->send_buf) hipFree(p);
+  for (void *p : R->recv_buf) hipFree(p);
+  R->send_buf.assign(W, nullptr); R->recv_buf.assign(W, nullptr);
+  R->send_cap.assign(W, 0); R->recv_cap.assign(W, 0);
+  (void)n;
+  return 0;
+}
+
+extern "C" gvt_hip_tracer *gvt_hip_tracer_create(gvt_hip_top *T, gvt_hip_mesh *const *meshes, const float *m, const float *minv, const float *normi,
+                                                 size_t n_inst, const gvt_hip_light *lights, size_t n_lights, int normal_mode, const gvt_hip_camera *cam,
+                                                 gvt_hip_fb *fb) {
+  if (ensure_init()) return nullptr;
+  if (!T || !cam || !fb || (n_inst && (!meshes || !m || !minv || !normi)) || T->n != n_inst || (n_lights && !lights) || n_lights > 64) {
+    set_error("tracer_create: null or inconsistent argument");
+    return nullptr;
+  }
+  Ctx &C = gctx();
+  gvt_hip_tracer *R = new gvt_hip_tracer();
+  R->top = T; R->n_inst = n_inst; R->normal_mode = normal_mode; R->cam = *cam; R->fb = fb;
+  R->meshes.assign(meshes, meshes + n_inst);
+  R->m.assign(m, m + 16 * n_inst); R->minv.assign(minv, minv + 16 * n_inst); R->normi.assign(normi, normi + 9 * n_inst);
+  R->lights.assign(lights, lights + n_lights);
+  R->owner.assign(n_inst, 0); R->owned.assign(n_inst, 1); R->present.assign(n_inst, 0);
+  bool ok = true;
+  for (size_t i = 0; i < n_inst && ok; i++) { R->queues.push_back(gvt_hip_queue_create(0)); ok = R->queues.back() != nullptr; }
+  R->q_moved = gvt_hip_queue_create(0);
+  ok = ok && R->q_moved;
+  const size_t n1 = n_inst ? n_inst : 1;
+  std::vector<WaveInst> insts(n1);
+  std::vector<unsigned *> cptr(n1, nullptr);
+  for (size_t i = 0; i < n_inst && ok; i++) {
+    gvt_hip_mesh *M = meshes[i];
+    WaveInst &I = insts[i];
+    std::memset(&I, 0, sizeof I);
+    std::memcpy(I.minv.m, minv + 16 * i, 64);
+    std::memcpy(I.normi.n, normi + 9 * i, 36);
+    cptr[i] = R->queues[i]->d_count;
+    if (!M) continue; // an instance whose data lives on another rank (Domain scheduler): never traced here
+    if (!M->d_nodes4 && M->nNodes) ok = build_nodes4(M) == 0; // the merged kernels traverse the 4-wide layout
+    I.nodes4 = M->d_nodes4; I.tris = M->d_tri;
+    I.mv.verts = M->d_verts; I.mv.tris = M->d_tris; I.mv.normals = M->d_normals; I.mv.vcolors = M->d_vcolors;
+    I.mv.materials = M->d_materials; I.mv.n_mat = (unsigned)M->nMat; I.mv.face_mat = M->d_face_mat; I.mv.mat = M->mesh_mat;
+  }
+  ok = ok && hipMalloc((void **)&R->d_insts, sizeof(WaveInst) * n1) == hipSuccess && hipMalloc((void **)&R->d_segs, sizeof(WaveSeg) * n1) == hipSuccess &&
+       hipHostMalloc((void **)&R->h_segs, sizeof(WaveSeg) * n1, hipHostMallocDefault) == hipSuccess &&
+       hipMalloc((void **)&R->d_count_ptr, sizeof(unsigned *) * n1) == hipSuccess && hipMalloc((void **)&R->d_owner, sizeof(int) * n1) == hipSuccess &&
+       hipMalloc((void **)&R->d_mask, n1) == hipSuccess && hipHostMalloc((void **)&R->h_mask, n1, hipHostMallocDefault) == hipSuccess &&
+       hipMalloc((void **)&R->d_report, sizeof(unsigned) * (n1 + 8)) == hipSuccess &&
+       hipHostMalloc((void **)&R->h_report, sizeof(unsigned) * (n1 + 8), hipHostMallocDefault) == hipSuccess &&
+       hipMalloc((void **)&R->d_overflow, 64) == hipSuccess;
+  if (ok) {
+    ok = hipMemcpy(R->d_insts, insts.data(), sizeof(WaveInst) * n1, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(R->d_count_ptr, cptr.data(), sizeof(unsigned *) * n1, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemset(R->d_owner, 0, sizeof(int) * n1) == hipSuccess && hipMemset(R->d_overflow, 0, 64) == hipSuccess;
+  }
+  for (hipEvent_t *e : { &R->ev_compute, &R->ev_report, &R->ev_pack, &R->ev_recv, &R->ev_comm })
+    ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+  if (ok) ok = tracer_alloc_tables(R) == 0;
+  if (!ok) { if (!*gvt_hip_last_error()) set_error("tracer_create: device allocation failed"); gvt_hip_tracer_destroy(R); return nullptr; }
+  (void)C;
+  return R;
+}
+
+extern "C" int gvt_hip_tracer_set_camera(gvt_hip_tracer *R, const gvt_hip_camera *cam) {
+  if (!R || !cam) { set_error("tracer_set_camera: null"); return GVT_HIP_ERR_INVALID; }
+  R->cam = *cam;
+  return 0;
+}
+
+// mpiInstanceMap (DomainTracer.h:115-144): owner[i] = rank that holds instance i's data.  comm == NULL: one rank (Image scheduler).
+extern "C" int gvt_hip_tracer_set_domains(gvt_hip_tracer *R, const int32_t *owner, gvt_hip_comm *comm) {
+  if (!R) { set_error("tracer_set_domains: null"); return GVT_HIP_ERR_INVALID; }
+  R->comm = comm;
+  R->rank = comm ? comm->rank : 0;
+  R->world = comm ? comm->world : 1;
+  for (size_t i = 0; i < R->n_inst; i++) {
+    const int o = owner ? owner[i] : 0;
+    if (o < 0 || o >= R->world) { set_error("tracer_set_domains: owner[%zu] = %d of %d ranks", i, o, R->world); return GVT_HIP_ERR_INVALID; }
+    R->owner[i] = o;
+    R->owned[i] = o == R->rank ? 1 : 0;
+    if (R->owned[i] && !R->meshes[i]) { set_error("tracer_set_domains: instance %zu is owned by this rank but has no mesh", i); return GVT_HIP_ERR_INVALID; }
+  }
+  if (R->n_inst) HIPCHK(hipMemcpy(R->d_owner, R->owner.data(), sizeof(int) * R->n_inst, hipMemcpyHostToDevice));
+  return tracer_alloc_tables(R);
+}
+
+namespace {
+// the host's view after a round: queue sizes, frame totals, error flags
+struct Report {
+  uint64_t rays_closest, rays_any;
+};
+
+int grow(void **buf, size_t *cap, size_t bytes) {
+  if (bytes <= *cap) return 0;
+  if (*buf) HIPCHK(hipFree(*buf));
+  *buf = nullptr; *cap = 0;
+  const size_t want = bytes + bytes / 4 + 4096;
+  HIPCHK(hipMalloc(buf, want));
+  *cap = want;
+  return 0;
+}
+
+// (1) of a round: the merged launch chain over this rank's non-empty queues + the shuffle of everything that moved.  Host-known
+// sizes in R->present; on return they are stale until the next report.  extra_in[i]: rays about to be appended to queue i by a
+// pending unpack (room is reserved for them too).
+int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t *chains) {
+  Ctx &C = gctx();
+  const size_t nI = R->n_inst;
+  const int nL = (int)R->lights.size();
+  const int passes = R->cam.depth > 1 ? R->cam.depth : 1;
+  size_t N = 0;
+  int n_seg = 0;
+  for (size_t i = 0; i < nI; i++) {
+    R->h_mask[i] = 0;
+    if (!R->owned[i] || !R->present[i]) continue;
+    WaveSeg &sg = R->h_segs[n_seg++];
+    sg.planes = R->queues[i]->d_planes; sg.cap = R->queues[i]->cap; sg.begin = (unsigned)N; sg.n = (unsigned)R->present[i]; sg.inst = (int)i; sg.pad = 0;
+    R->h_mask[i] = 1;
+    N += R->present[i];
+  }
+  if (!N) return 0;
+  const size_t bound = N * (size_t)(1 + nL * passes); // rays one round can emit: a forward or nL shadow rays per pass and input ray
+  if (bound >= 0xffffffffull) { set_error("round: %zu rays exceed the 32-bit slot counters", bound); return GVT_HIP_ERR_INVALID; }
+  int rc = queue_reserve(R->q_moved, bound);
+  if (rc) return rc;
+  for (size_t i = 0; i < nI; i++) { // every destination has room for all of them (288 GB of HBM: worst-case room beats a read-back per shuffle)
+    const size_t stay = R->h_mask[i] ? 0 : R->present[i];
+    if ((rc = queue_reserve(R->queues[i], stay + bound + (extra_in ? (*extra_in)[i] : 0)))) return rc;
+  }
+  for (int k = 0; k < n_seg; k++) { // (a reserve above may have moved a traced queue)
+    gvt_hip_queue *q = R->queues[R->h_segs[k].inst];
+    R->h_segs[k].planes = q->d_planes; R->h_segs[k].cap = q->cap;
+  }
+  hipStream_t st = C.stream;
+  HIPCHK(hipMemcpyAsync(R->d_segs, R->h_segs, sizeof(WaveSeg) * n_seg, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(R->d_mask, R->h_mask, nI, hipMemcpyHostToDevice, st));
+  int *d_from = (int *)scratch_get(17, sizeof(int) * bound);
+  if (!d_from) return GVT_HIP_ERR_DEVICE;
+  TraceParams P{};
+  P.normal_mode = R->normal_mode; P.seed = 0; P.n_lights = nL; P.update_in_place = 0; P.carried_rng = 1;
+  P.sink = TermSink{};
+  if (C.term_sink) {
+    P.sink.blo = R->top->d_lo; P.sink.bhi = R->top->d_hi; P.sink.n_inst = (int)R->top->n; P.sink.from = -1;
+    P.sink.fb = R->fb->d_rgba; P.sink.n_pix = (unsigned)(R->fb->w * R->fb->h);
+  }
+  WaveSet W{ R->d_segs, R->d_insts, n_seg };
+  if ((rc = wave_trace_chain(W, N, passes, R->q_moved, d_from, P, R->lights.data()))) return rc;
+  k_zero_counts<<<(unsigned)((nI + 255) / 256), 256, 0, st>>>(R->d_count_ptr, R->d_mask, (int)nI); // queue[instTarget].clear()
+  HIPCHK(hipGetLastError());
+  if ((rc = shuffle_async(R->top, R->q_moved, bound, d_from, R->queues.data(), nullptr, R->fb, R->d_overflow))) return rc;
+  if (chains) (*chains)++;
+  return 0;
+}
+
+// (3)+(4)+(5): report kernel -> [announce exchange] -> ONE device-to-host copy -> ONE host synchronisation
+int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs) {
+  Ctx &C = gctx();
+  const size_t nI = R->n_inst, row = ANN_HEAD + nI;
+  hipStream_t st = C.stream;
+  k_round_report<<<1, 256, 0, st>>>(R->d_count_ptr, R->d_owner, (int)nI, R->rank, R->world, R->d_report, R->d_ann_out, C.d_counters, R->d_overflow,
+                                    R->d_report + nI);
+  HIPCHK(hipGetLastError());
+  if (exchange && R->world > 1) {
+    gvt_hip_comm *K = R->comm;
+    HIPCHK(hipEventRecord(R->ev_compute, st));
+    HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0));
+    comm_group_begin(K);
+    for (int p = 0; p < R->world; p++) {
+      if (p == R->rank) continue;
+      comm_send(K, R->d_ann_out + (size_t)p * row, sizeof(int) * row, p);
+      comm_recv(K, R->d_ann_in + (size_t)p * row, sizeof(int) * row, p);
+    }
+    int rc = comm_group_end(K);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(R->h_ann_in, R->d_ann_in, sizeof(int) * R->world * row, hipMemcpyDeviceToHost, K->stream));
+    HIPCHK(hipMemcpyAsync(R->h_report, R->d_report, sizeof(unsigned) * (nI + 8), hipMemcpyDeviceToHost, K->stream));
+    HIPCHK(hipEventRecord(R->ev_report, K->stream));
+    HIPCHK(hipEventSynchronize(R->ev_report));
+  } else {
+    HIPCHK(hipMemcpyAsync(R->h_report, R->d_report, sizeof(unsigned) * (nI + 8), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  if (syncs) (*syncs)++;
+  for (size_t i = 0; i < nI; i++) { R->present[i] = R->h_report[i]; R->queues[i]->size = R->h_report[i]; }
+  R->q_moved->size = 0;
+  const unsigned *tail = R->h_report + nI;
+  if (tail[4]) { set_error("BVH traversal stack overflow: results of this frame are incomplete"); return GVT_HIP_ERR_DEVICE; }
+  if (tail[5] & 1u) { set_error("a ray queue ran out of room inside a round (internal reservation error)"); return GVT_HIP_ERR_CAPACITY; }
+  if (tail[5] & 2u) { set_error("ray exchange: an in-band queue header disagrees with the announced counts"); return GVT_HIP_ERR_DEVICE; }
+  return 0;
+}
+} // namespace
+
+extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_stats *out) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!R) { set_error("tracer_frame: null"); return GVT_HIP_ERR_INVALID; }
+  Ctx &C = gctx();
+  hipStream_t st = C.stream;
+  const size_t nI = R->n_inst, row = ANN_HEAD + nI;
+  const bool bsp = (flags & GVT_HIP_FRAME_BSP) != 0;
+  gvt_hip_frame_stats S{};
+  int rc;
+  // clearBuffer + generateRays + FilterRaysLocally / shuffleDropRays (ImageTracer.h:137-146, DomainTracer.h:148-183, 204-211)
+  if ((rc = gvt_hip_fb_clear(R->fb))) return rc;
+  for (size_t i = 0; i < nI; i++) if ((rc = gvt_hip_queue_clear(R->queues[i]))) return rc;
+  if ((rc = gvt_hip_queue_clear(R->q_moved))) return rc;
+  k_zero_totals<<<1, 64, 0, st>>>(C.d_counters, R->d_overflow);
+  if ((rc = gvt_hip_camera_filter(R->top, &R->cam, C.camera_tile, R->queues.data(), R->world > 1 ? R->owned.data() : nullptr))) return rc;
+  S.host_syncs++;
+  for (size_t i = 0; i < nI; i++) R->present[i] = R->queues[i]->size;
+  std::vector<size_t> incoming(nI, 0);
+  bool payload_pending = false;
+  std::vector<int> pending_ann; // the announces the payload in flight was posted from
+
+  auto unpack_pending = [&]() -> int { // (2): append what the last exchange delivered, behind its event
+    if (!payload_pending) return 0;
+    HIPCHK(hipStreamWaitEvent(st, R->ev_recv, 0));
+    for (int p = 0; p < R->world; p++) {
+      if (p == R->rank) continue;
+      const int *a = pending_ann.data() + (size_t)p * row;
+      size_t off = 0;
+      for (size_t i = 0; i < nI; i++) {
+        const unsigned n = (unsigned)a[ANN_HEAD + i];
+        if (!n) continue;
+        gvt_hip_queue *q = R->queues[i];
+        const unsigned long long dwords = 20ull * n;
+        k_unpack_wire<<<(unsigned)((dwords + 255) / 256), 256, 0, st>>>((const unsigned *)((const char *)R->recv_buf[p] + off), n, (int)i,
+                                                                        make_planes(q->d_planes, q->cap), q->cap, q->d_count, R->d_overflow);
+        k_add_count<<<1, 64, 0, st>>>(q->d_count, n);
+        off += 8 + 80ull * n;
+      }
+    }
+    HIPCHK(hipGetLastError());
+    payload_pending = false;
+    for (size_t i = 0; i < nI; i++) { R->present[i] += incoming[i]; R->queues[i]->size = R->present[i]; incoming[i] = 0; } // exact: announced per queue
+    return 0;
+  };
+
+  for (;;) {
+    // (1) local work: one merged chain (asynchronous ticks), or chains until the local queues are dry (BSP rounds / one rank)
+    if (R->world == 1 || bsp) {
+      if ((rc = unpack_pending())) return rc;
+      for (;;) {
+        bool any = false;
+        for (size_t i = 0; i < nI; i++) any = any || (R->owned[i] && R->present[i]);
+        if (!any) break;
+        if ((rc = local_chain(R, nullptr, &S.chains))) return rc;
+        if ((rc = round_report(R, false, &S.host_syncs))) return rc;
+      }
+      if (R->world == 1) break;
+    } else {
+      if ((rc = local_chain(R, &incoming, &S.chains))) return rc;
+      if ((rc = unpack_pending())) return rc;
+    }
+    // (3)-(5) sizes + announce exchange, one synchronisation
+    if ((rc = round_report(R, true, &S.host_syncs))) return rc;
+    S.rounds++;
+    // (6) the vote: every rank reads the same ballots
+    uint64_t not_done = 0;
+    for (size_t i = 0; i < nI; i++) not_done += R->present[i];
+    for (int p = 0; p < R->world; p++)
+      if (p != R->rank) not_done += (uint64_t)(unsigned)R->h_ann_in[(size_t)p * row + 2] + (uint64_t)(unsigned)R->h_ann_in[(size_t)p * row + 3];
+    if (!not_done) break;
+    // (7) payload: pack what is outgoing, post sends / receives; it moves while the next local chain runs
+    gvt_hip_comm *K = R->comm;
+    bool any_traffic = false;
+    std::vector<size_t> bytes_out(R->world, 0), bytes_in(R->world, 0);
+    for (int p = 0; p < R->world; p++) {
+      if (p == R->rank) continue;
+      for (size_t i = 0; i < nI; i++) if (R->owner[i] == p && R->present[i]) bytes_out[p] += 8 + 80 * R->present[i];
+      bytes_in[p] = (size_t)(unsigned)R->h_ann_in[(size_t)p * row + 1];
+      if ((rc = grow(&R->send_buf[p], &R->send_cap[p], bytes_out[p]))) return rc;
+      if ((rc = grow(&R->recv_buf[p], &R->recv_cap[p], bytes_in[p]))) return rc;
+      size_t off = 0;
+      for (size_t i = 0; i < nI; i++) {
+        if (R->owner[i] != p || !R->present[i]) continue;
+        gvt_hip_queue *q = R->queues[i];
+        const unsigned n = (unsigned)R->present[i];
+        const unsigned long long dwords = 2ull + 20ull * n;
+        k_pack_wire<<<(unsigned)((dwords + 255) / 256), 256, 0, st>>>(make_planes(q->d_planes, q->cap), n, (int)i, (unsigned *)((char *)R->send_buf[p] + off));
+        off += 8 + 80ull * n;
+        S.rays_sent += n;
+        R->present[i] = 0; q->size = 0; // the sender's q.second.clear() (:455)
+        HIPCHK(hipMemsetAsync(q->d_count, 0, sizeof(unsigned), st));
+      }
+      any_traffic = any_traffic || bytes_out[p] || bytes_in[p];
+    }
+    HIPCHK(hipGetLastError());
+    pending_ann.assign(R->h_ann_in, R->h_ann_in + (size_t)R->world * row);
+    for (int p = 0; p < R->world; p++)
+      if (p != R->rank)
+        for (size_t i = 0; i < nI; i++) incoming[i] += (unsigned)pending_ann[(size_t)p * row + ANN_HEAD + i];
+    if (any_traffic) {
+      // room for what arrives, reserved now (the unpack kernels are launched later, behind the next local chain)
+      for (size_t i = 0; i < nI; i++)
+        if (incoming[i] && (rc = queue_reserve(R->queues[i], R->present[i] + incoming[i]))) return rc;
+      HIPCHK(hipEventRecord(R->ev_pack, st));
+      HIPCHK(hipStreamWaitEvent(K->stream, R->ev_pack, 0));
+      comm_group_begin(K); // sizes are known on both sides from the announces: no size handshake on the wire
+      for (int p = 0; p < R->world; p++) {
+        if (p == R->rank) continue;
+        if (bytes_out[p]) comm_send(K, R->send_buf[p], bytes_out[p], p);
+        if (bytes_in[p]) comm_recv(K, R->recv_buf[p], bytes_in[p], p);
+      }
+      if ((rc = comm_group_end(K))) return rc;
+      HIPCHK(hipEventRecord(R->ev_recv, K->stream));
+      payload_pending = true;
+    }
+  }
+  // IceTComposite::composite (composite/IceTComposite.cpp:84-101): the float framebuffers summed on rank 0
+  if (R->world > 1 && !(flags & GVT_HIP_FRAME_NO_COMPOSITE)) {
+    gvt_hip_comm *K = R->comm;
+    HIPCHK(hipEventRecord(R->ev_compute, st));
+    HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0));
+    if ((rc = comm_reduce_sum(K, R->fb->d_rgba, (size_t)R->fb->w * R->fb->h * 4, 0))) return rc;
+    HIPCHK(hipEventRecord(R->ev_comm, K->stream));
+    HIPCHK(hipStreamWaitEvent(st, R->ev_comm, 0));
+    HIPCHK(hipStreamSynchronize(K->stream));
+    S.host_syncs++;
+  }
+  const unsigned *tail = R->h_report + nI;
+  S.rays_closest = (uint64_t)tail[0] | ((uint64_t)tail[1] << 32);
+  S.rays_any = (uint64_t)tail[2] | ((uint64_t)tail[3] << 32);
+  C.stats.rays_closest += S.rays_closest;
+  C.stats.rays_any += S.rays_any;
+  if (out) *out = S;
+  return 0;
+}

@@ -56,9 +56,17 @@ struct Ctx : Knobs {
   // pinned host scratch for small read-backs
   unsigned *h_pinned = nullptr;
   // grow-only device scratch arenas (never freed inside hot calls)
-  void *scratch[16] = { nullptr };
-  size_t scratch_bytes[16] = { 0 };
+  void *scratch[24] = { nullptr };
+  size_t scratch_bytes[24] = { 0 };
+  // light list of the last trace call (uploaded only when it changes)
+  std::vector<unsigned char> lights_cached;
+  const void *lights_cached_dst = nullptr;
+  // staging queues of gvt_hip_trace (host RayVector in / out)
+  gvt_hip_queue *abi_qin = nullptr, *abi_qout = nullptr;
 };
+// The context API calls run on: the calling thread's current context (gvt_hip_ctx_make_current), else the process default one
+// (gvt_hip_init).  A context owns a stream, scratch arenas, counters, statistics and knobs; meshes / queues / framebuffers are plain
+// device objects usable from any context of their device, one at a time.
 Ctx &gctx();
 void set_error(const char *fmt, ...);
 int ensure_init();
@@ -151,6 +159,43 @@ struct TraceParams {
   int carried_rng;     // device-queue callers: a ray's RNG stream is the word it carries (gvt_device.h, plane 4)
 };
 
+// what k_shade needs of a mesh (shading attributes in their reference shapes)
+struct MeshView {
+  const float *verts;
+  const int *tris;
+  const float *normals;
+  const float *vcolors;
+  const gvt_hip_material *materials;
+  unsigned n_mat;
+  const int *face_mat;
+  gvt_hip_material mat; // Mesh::mat
+};
+
+// ---- merged ("wave") launches: the rays of ALL local instance queues of a scheduler round go through ONE closest-hit launch, one
+// shade launch and one any-hit launch.  A launch's ray index space [0, n_total) is the concatenation of the queues (segments); every
+// ray finds its segment (-> queue planes, instance) by a binary search over the segment starts, and its instance's transform,
+// acceleration structure and shading attributes in a per-instance table.  Replaces one adapter call per non-empty queue (each with
+// its own latency-bound traversal tail and read-backs) by one launch chain per round.
+struct WaveSeg { // one local queue: rays [begin, begin + n) of the launch
+  float4 *planes;
+  unsigned long long cap;
+  unsigned begin, n;
+  int inst, pad;
+};
+struct WaveInst { // per instance (Adapter::trace arguments m / minv / normi + the adapter's mesh)
+  Mat4 minv;
+  Mat3 normi;
+  int pad[3];
+  const uint4 *nodes4;
+  const float4 *tris;
+  MeshView mv;
+};
+struct WaveSet {
+  const WaveSeg *segs;
+  const WaveInst *insts;
+  int n_seg;
+};
+
 // lbvh.hip
 int build_lbvh(gvt_hip_mesh *M);
 int trav_overflow_fetch_async();
@@ -166,6 +211,10 @@ int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, 
 int launch_visit_stats(gvt_hip_mesh *M, RayPlanes q, size_t n, float tnear, unsigned *d_out);
 int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const Mat4 &minv, float tnear, int *d_flags);
 int set_device_u32(unsigned *p, unsigned v); // stream-ordered store of a host-known value
+// one round's merged launch chain (no host round trip inside); `out` must have room for n_total * (1 + n_lights * passes) rays and
+// is filled from slot 0 (its device count is reset); d_out_from receives the source instance of every ray appended
+int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
+                     const gvt_hip_light *lights_host);
 int convert_aos_to_planes(const gvt_hip_ray *d_src, size_t n, RayPlanes dst, size_t dst_off);
 int convert_planes_to_aos(RayPlanes src, size_t src_off, size_t n, gvt_hip_ray *d_dst);
 int convert_od_to_planes(const float *d_org, const float *d_dir, size_t n, RayPlanes dst);

@@ -76,10 +76,14 @@ struct RaySrc {
 // sustains only ~90 atomics/us chip-wide (2 M rays: 32 K wave-level atomics on one word cost ~0.35 ms).
 #define TOP_BLOCK 1024
 
+// n_dev (optional): the ray count in device memory (a list filled by the kernels just before, no host round trip; n is then only
+// the bound the grid was sized for).  from_arr (optional): the source instance per ray (lists that mix rays of several instances).
 __global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RaySrc S, unsigned n, const float4 *__restrict__ blo, const float4 *__restrict__ bhi,
                                                             int n_inst, int from, int *__restrict__ next_out, float *__restrict__ t_out,
-                                                            unsigned *__restrict__ hist, int use_lds, unsigned *__restrict__ blk_cnt) {
+                                                            unsigned *__restrict__ hist, int use_lds, unsigned *__restrict__ blk_cnt,
+                                                            const unsigned *__restrict__ n_dev = nullptr, const int *__restrict__ from_arr = nullptr) {
   extern __shared__ unsigned sh_cnt[];
+  if (n_dev) n = min(n, *n_dev);
   if (use_lds) {
     for (int d = threadIdx.x; d < n_inst; d += TOP_BLOCK) sh_cnt[d] = 0u;
     __syncthreads();
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RaySrc S, unsigned n
     float4 a, b;
     if (S.from_cam) { const RayRec r = camera_ray(S.cam, i); a = make_float4(r.o.x, r.o.y, r.o.z, r.t_min); b = make_float4(r.d.x, r.d.y, r.d.z, r.t_max); }
     else { a = S.q.p0[i]; b = S.q.p1[i]; }
-    next = top_nearest(a, b, blo, bhi, n_inst, from, ret_t);
+    next = top_nearest(a, b, blo, bhi, n_inst, from_arr ? from_arr[i] : from, ret_t);
     next_out[i] = next;
     t_out[i] = ret_t;
   }
@@ -150,8 +154,10 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_scan(unsigned *__restrict__ b
 
 __global__ __launch_bounds__(TOP_BLOCK) void k_top_scatter(RaySrc S, unsigned n, const int *__restrict__ next_in, const float *__restrict__ t_in,
                                                            const QueueDesc *__restrict__ queues, int n_inst, float *__restrict__ fb, unsigned n_pix,
-                                                           int use_lds, const unsigned *__restrict__ blk_base) {
+                                                           int use_lds, const unsigned *__restrict__ blk_base, const unsigned *__restrict__ n_dev = nullptr,
+                                                           unsigned *__restrict__ overflow = nullptr) {
   extern __shared__ unsigned sh[]; // [0,n_inst): rays of this block per destination, [n_inst,2n_inst): their base slot
+  if (n_dev) n = min(n, *n_dev);
   unsigned *sh_cnt = sh, *sh_base = sh + n_inst; // ordered mode: sh[w * n_inst + d] = rays of wave w for destination d
   if (blk_base) {
     for (int k = threadIdx.x; k < n_inst * (TOP_BLOCK / 64); k += TOP_BLOCK) sh[k] = 0u;
@@ -209,6 +215,7 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_scatter(RaySrc S, unsigned n,
   if (next >= 0) {
     const QueueDesc Q = queues[next];
     if (local < Q.cap) store_ray(make_planes(Q.planes, Q.cap), local, r);
+    else if (overflow) atomicOr(overflow, 1u); // a destination without room: reported by the caller, never silent
   }
 }
 
@@ -439,6 +446,49 @@ static int shuffle_impl(gvt_hip_top *T, const RaySrc &in, size_t n, int from, gv
   HIPCHK(hipStreamSynchronize(st)); // desc/hist are read by the copies above
   for (size_t i = 0; i < nI; i++)
     if (desc[i].keep) queues[i]->size += hist[i];
+  return 0;
+}
+
+// shuffleRays of a device-resident list whose length only the device knows (q_in's count word), launched without any host round
+// trip: every destination must already have room for its current rays + n_ub more.  Destination counts advance on the device only;
+// the caller learns them from its next read-back.  from_arr: source instance per ray (merged rounds).  Kernel order on the stream:
+// classify -> (scan) -> scatter -> q_in count := 0.
+int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *from_arr, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
+                  gvt_hip_fb *fb, unsigned *d_overflow) {
+  Ctx &C = gctx();
+  if (!n_ub) return 0;
+  hipStream_t st = C.stream;
+  int *d_next = (int *)scratch_get(6, sizeof(int) * n_ub);
+  float *d_t = (float *)scratch_get(7, sizeof(float) * n_ub);
+  if (!d_next || !d_t) return GVT_HIP_ERR_DEVICE;
+  const size_t nI = T->n;
+  const int use_lds = (C.top_lds && nI > 0 && nI <= 4096) ? 1 : 0;
+  const unsigned n_blk = blocks_for(n_ub, TOP_BLOCK);
+  unsigned *d_blk = nullptr;
+  if (C.top_ordered && use_lds && nI <= 64) {
+    d_blk = (unsigned *)scratch_get(14, sizeof(unsigned) * nI * n_blk);
+    if (!d_blk) return GVT_HIP_ERR_DEVICE;
+  }
+  QueueDesc *desc = (QueueDesc *)T->h_qdesc;
+  for (size_t i = 0; i < nI; i++) {
+    gvt_hip_queue *Q = queues[i];
+    desc[i].planes = Q->d_planes; desc[i].cap = Q->cap; desc[i].count = Q->d_count; desc[i].keep = (!keep_mask || keep_mask[i]) ? 1u : 0u;
+  }
+  if (nI) HIPCHK(hipMemcpyAsync(T->d_qdesc, desc, sizeof(QueueDesc) * nI, hipMemcpyHostToDevice, st));
+  RaySrc S{};
+  S.q = make_planes(q_in->d_planes, q_in->cap);
+  S.from_cam = 0;
+  {
+    ProfScope ps(KC_SHUFFLE);
+    k_top_classify<<<n_blk, TOP_BLOCK, use_lds ? sizeof(unsigned) * nI : 0, st>>>(S, (unsigned)n_ub, T->d_lo, T->d_hi, (int)nI, -1, d_next, d_t, nullptr, use_lds, d_blk,
+                                                                                q_in->d_count, from_arr);
+    if (d_blk) k_top_scan<<<(unsigned)nI, TOP_BLOCK, 0, st>>>(d_blk, n_blk, (const QueueDesc *)T->d_qdesc, nullptr);
+    const size_t lds = d_blk ? sizeof(unsigned) * nI * (TOP_BLOCK / 64) : (use_lds ? 2 * sizeof(unsigned) * nI : 0);
+    k_top_scatter<<<n_blk, TOP_BLOCK, lds, st>>>(S, (unsigned)n_ub, d_next, d_t, (const QueueDesc *)T->d_qdesc, (int)nI, fb ? fb->d_rgba : nullptr,
+                                               fb ? (unsigned)(fb->w * fb->h) : 0u, use_lds, d_blk, q_in->d_count, d_overflow);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemsetAsync(q_in->d_count, 0, sizeof(unsigned), st));
   return 0;
 }
 

@@ -147,7 +147,8 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_closest(RayPlanes q, const unsig
 #if GVT_STAMP
 __device__ unsigned long long g_stamp[16];
 #endif
-__device__ unsigned g_trav_overflow; // set by k_trace when a traversal stack would have exceeded LDS levels + spill entries
+#define TRAV_OVF_WORD 8 // d_counters[8] of the launching context: set by k_trace / k_long_closest when a traversal stack would have exceeded
+                        // LDS levels + spill entries (k_trace's `counter` is d_counters + 0, k_long_closest's d_counters + 4)
 #ifndef TRAV_CHUNK
 #define TRAV_CHUNK 256
 #endif
@@ -198,9 +199,21 @@ __device__ __forceinline__ void node4_test(const uint4 *__restrict__ nd, float i
 #undef GVT_SLAB4
 }
 
+// merged launches: segment of virtual ray index g (segments sorted by `begin`, n_seg small)
+__device__ inline int wave_find_seg(const WaveSet &W, unsigned g) {
+  int lo = 0, hi = W.n_seg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (W.segs[mid].begin <= g) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
 // copies the rays whose indices are parked in the wave's LDS list to consecutive slots of `out`; with a sink, rays that meet no
 // other instance end here (shuffleRays' terminal rule) and only the others are copied
-__device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const RayPlanes &q, const RayPlanes &out, unsigned *out_count, const TermSink &K) {
+// ray_inst / out_from (merged launches): instance a shadow ray was generated in, per ray of q / per ray of out (shuffleRays' `from`)
+__device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const RayPlanes &q, const RayPlanes &out, unsigned *out_count, const TermSink &K,
+                                     const int *__restrict__ ray_inst = nullptr, int *__restrict__ out_from = nullptr) {
   if (!K.fb) {
     unsigned base = 0;
     if (lane_id() == 0) base = atomicAdd(out_count, (unsigned)n_pend);
@@ -209,6 +222,7 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
       const unsigned src = pend[k];
       out.p0[base + k] = q.p0[src]; out.p1[base + k] = q.p1[src]; out.p2[base + k] = q.p2[src]; out.p3[base + k] = q.p3[src];
       if (out.p4) out.p4[base + k] = 0u; // shadow rays never draw: their stream word is 0
+      if (out_from) out_from[base + k] = ray_inst[src];
     }
     return;
   }
@@ -216,11 +230,13 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
     const int k = k0 + (int)lane_id();
     bool go_on = false;
     float4 a, b, c, d;
+    int from = K.from;
     if (k < n_pend) {
       const unsigned src = pend[k];
       a = q.p0[src]; b = q.p1[src]; c = q.p2[src]; d = q.p3[src];
+      if (ray_inst) from = ray_inst[src];
       float ret_t;
-      go_on = top_nearest(a, b, K.blo, K.bhi, K.n_inst, K.from, ret_t) >= 0;
+      go_on = top_nearest(a, b, K.blo, K.bhi, K.n_inst, from, ret_t) >= 0;
       if (!go_on) {
         const V3 col = mk3(c.x, c.y, c.z);
         const unsigned id = (unsigned)__float_as_int(d.x);
@@ -236,15 +252,24 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
       unsigned base = 0;
       if (lane_id() == 0) base = atomicAdd(out_count, (unsigned)__popcll(m));
       base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-      if (go_on) { const unsigned slot = base + lanes_below(m); out.p0[slot] = a; out.p1[slot] = b; out.p2[slot] = c; out.p3[slot] = d; if (out.p4) out.p4[slot] = 0u; }
+      if (go_on) { const unsigned slot = base + lanes_below(m); out.p0[slot] = a; out.p1[slot] = b; out.p2[slot] = c; out.p3[slot] = d; if (out.p4) out.p4[slot] = 0u; if (out_from) out_from[slot] = from; }
     }
   }
 }
 
-template <bool ANY, bool XFORM, int MODE, bool COOP, bool W4>
+// MULTI (merged launch, gvt_internal.h): closest hit -- ray j is virtual index (idx ? idx[j] : j) of the segment table MS.W; any hit --
+// ray j of q was generated in instance MS.ray_inst[j]; either way the lane takes transform and acceleration structure from
+// MS.W.insts[instance].  out_from receives the source instance of every survivor appended to `out`.
+struct MultiSrc {
+  WaveSet W;
+  const int *ray_inst;
+  int *out_from;
+};
+template <bool ANY, bool XFORM, int MODE, bool COOP, bool W4, bool MULTI = false>
 __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, Trav T, float tnear,
                                                        gvt_hip_hit *__restrict__ hits, int *__restrict__ flags, RayPlanes out, unsigned *out_count,
-                                                       unsigned *counter, int *spill_base, int refill_min, int inner_min, const unsigned *__restrict__ n_dev, int share, unsigned share_min, TermSink sink, LongQ LQ) {
+                                                       unsigned *counter, int *spill_base, int refill_min, int inner_min, const unsigned *__restrict__ n_dev, int share, unsigned share_min, TermSink sink, LongQ LQ,
+                                                       MultiSrc MS = MultiSrc{}) {
   // Work distribution: wave w first takes the static range [w*chunk, (w+1)*chunk) -- no atomic, see the refill below -- and after that
   // dynamic ranges of `dyn` rays from the counter.  chunk is a fraction of a wave's fair share (3/8 for closest-hit launches, whose
   // per-ray cost varies most, 5/8 for any-hit; measured at 1 M rays: 96/128/160 rays -> 0.542/0.549/0.579 ms closest, 0.400/0.400/0.384
@@ -286,6 +311,10 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
   int donor_lane = -1;  // helper: the lane it took its subtree from (to follow that lane's best hit)
   int nsteps = 0;       // closest hit: inner steps of this lane's ray; beyond LQ.steps the ray is parked for k_long_closest
   bool parked = false;
+  const uint4 *nodes4_l = T.nodes4; // MULTI: this lane's ray's instance
+  const float4 *tris_l = T.tris;
+  int inst_l = 0;
+  unsigned gidx = 0;                // MULTI closest: virtual index of the lane's ray
 #if GVT_STAMP
   unsigned long long st_refill = 0, st_inner = 0, st_leaf = 0, st_retire = 0, n_inner_it = 0, n_outer_it = 0, t_mark = 0, t_begin = __builtin_amdgcn_s_memtime();
   unsigned long long t_exh = 0, it_exh = 0, out_exh = 0, act_exh = 0;
@@ -327,9 +356,23 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
         if (!active && rank < take) {
           j = c_next + rank;
           const unsigned i = idx ? idx[j] : j;
-          const float4 a = q.p0[i], b = q.p1[i];
-          O = mk3(a.x, a.y, a.z); D = mk3(b.x, b.y, b.z);
-          if (XFORM) { O = xfm_point(minv, O); D = xfm_vector(minv, D); }
+          float4 a, b;
+          if (MULTI) {
+            if (ANY) { a = q.p0[i]; b = q.p1[i]; inst_l = MS.ray_inst[i]; }
+            else {
+              const WaveSeg sg = MS.W.segs[wave_find_seg(MS.W, i)];
+              const unsigned local = i - sg.begin;
+              a = sg.planes[local]; b = sg.planes[sg.cap + local];
+              inst_l = sg.inst; gidx = i;
+            }
+            const WaveInst *wi = MS.W.insts + inst_l;
+            nodes4_l = wi->nodes4; tris_l = wi->tris;
+            O = xfm_point(wi->minv, mk3(a.x, a.y, a.z)); D = xfm_vector(wi->minv, mk3(b.x, b.y, b.z));
+          } else {
+            a = q.p0[i]; b = q.p1[i];
+            O = mk3(a.x, a.y, a.z); D = mk3(b.x, b.y, b.z);
+            if (XFORM) { O = xfm_point(minv, O); D = xfm_vector(minv, D); }
+          }
           const float dx = fabsf(D.x) < 1e-30f ? copysignf(1e-30f, D.x) : D.x;
           const float dy = fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y;
           const float dz = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;
@@ -337,7 +380,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
           ox = O.x * ix; oy = O.y * iy; oz = O.z * iz;
           bt = GVT_FLT_MAX; bu = 0.f; bv = 0.f; bden = 1.f; bp = -1;
           sp = 0; sb = 0; donor_lane = -1; nsteps = 0; parked = false;
-          cur = T.nodes ? 0 : TRAV_DONE;
+          cur = (MULTI ? (nodes4_l != nullptr) : (T.nodes != nullptr)) ? 0 : TRAV_DONE;
           active = true;
         }
         c_next += take;
@@ -366,7 +409,10 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
         const float gox = __shfl(ox, d), goy = __shfl(oy, d), goz = __shfl(oz, d);
         const float gbt = __shfl(bt, d), gbu = __shfl(bu, d), gbv = __shfl(bv, d), gbden = __shfl(bden, d);
         const int gbp = __shfl(bp, d);
+        const int ginst = __shfl(inst_l, d);
+        const unsigned ggidx = (unsigned)__shfl((int)gidx, d);
         if ((int)lane_id() == h) {
+          if (MULTI) { inst_l = ginst; gidx = ggidx; nodes4_l = MS.W.insts[ginst].nodes4; tris_l = MS.W.insts[ginst].tris; }
           const unsigned tid_d = wave_tid0 + (unsigned)d;
           cur = (sbd < TRAV_STACK) ? stack[sbd * TRAV_BLOCK + tid_d]
                                    : spill_base[((size_t)blockIdx.x * TRAV_BLOCK + tid_d) * TRAV_SPILL + (sbd - TRAV_STACK)];
@@ -404,7 +450,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
         if (at_inner) { // one 64-byte fetch decides four children (8-bit boxes on the node's own grid)
           float tn[4];
           int rr[4];
-          node4_test(T.nodes4 + (size_t)GVT_NODE4_F4 * cur, ix, iy, iz, ox, oy, oz, ANY ? GVT_FLT_MAX : bt, tn, rr);
+          node4_test((MULTI ? nodes4_l : T.nodes4) + (size_t)GVT_NODE4_F4 * cur, ix, iy, iz, ox, oy, oz, ANY ? GVT_FLT_MAX : bt, tn, rr);
           if (!ANY) { // nearest first; for any-hit the order does not matter
 #define GVT_CE(A, B) { const bool sw_ = tn[B] < tn[A]; const float ta_ = sw_ ? tn[B] : tn[A], tb_ = sw_ ? tn[A] : tn[B]; \
                        const int ra_ = sw_ ? rr[B] : rr[A], rb_ = sw_ ? rr[A] : rr[B]; tn[A] = ta_; tn[B] = tb_; rr[A] = ra_; rr[B] = rb_; }
@@ -497,7 +543,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
       } else if (at_leaf) {
         const unsigned code = (unsigned)~cur;
         const unsigned first = code >> 3, ntri = code & 7u;
-        const float4 *ts = T.tris + 4 * (size_t)first;
+        const float4 *ts = (MULTI ? tris_l : T.tris) + 4 * (size_t)first;
         bool occluded = false;
         for (unsigned kb = 0; kb < ntri && !(ANY && occluded); kb += 2) { // two triangles per round trip
           float4 s0[2], s1[2], s2[2];
@@ -570,7 +616,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
         if (survive) pend[n_pend + lanes_below(sm)] = j;
         n_pend += __popcll(sm);
       }
-      if (n_pend >= 64) { flush_pending(pend, n_pend, q, out, out_count, sink); n_pend = 0; }
+      if (n_pend >= 64) { flush_pending(pend, n_pend, q, out, out_count, sink, MULTI ? MS.ray_inst : nullptr, MULTI ? MS.out_from : nullptr); n_pend = 0; }
     }
     if (!ANY && LQ.steps) {
       const unsigned long long pm = __ballot(fin && parked);
@@ -579,7 +625,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
         if ((int)lane_id() == __ffsll((long long)pm) - 1) base = atomicAdd(LQ.count, (unsigned)__popcll(pm));
         base = __shfl(base, __ffsll((long long)pm) - 1);
         if (fin && parked) {
-          LongRec R; R.j = j; R.i = idx ? idx[j] : j; R.bt = bt; R.bp = bp; R.bu = bu; R.bv = bv; R.bden = bden; R.pad = 0u;
+          LongRec R; R.j = j; R.i = MULTI ? gidx : (idx ? idx[j] : j); R.bt = bt; R.bp = bp; R.bu = bu; R.bv = bv; R.bden = bden; R.pad = 0u;
           LQ.recs[base + lanes_below(pm)] = R;
         }
       }
@@ -594,8 +640,8 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
   if (lane_id() == 0) { atomicAdd(&g_stamp[0], st_refill); atomicAdd(&g_stamp[1], st_inner); atomicAdd(&g_stamp[2], st_leaf); atomicAdd(&g_stamp[3], st_retire); atomicAdd(&g_stamp[4], n_inner_it); atomicAdd(&g_stamp[5], n_outer_it); atomicAdd(&g_stamp[6], 1ull); atomicAdd(&g_stamp[7], (unsigned long long)__builtin_amdgcn_s_memtime() - t_begin);
     if (t_exh) { atomicAdd(&g_stamp[8], (unsigned long long)__builtin_amdgcn_s_memtime() - t_exh); atomicAdd(&g_stamp[9], n_inner_it - it_exh); atomicAdd(&g_stamp[10], n_outer_it - out_exh); atomicAdd(&g_stamp[11], act_exh); atomicMax(&g_stamp[12], (unsigned long long)__builtin_amdgcn_s_memtime() - t_exh); atomicMax(&g_stamp[13], n_inner_it - it_exh); } }
 #endif
-  if (ANY && MODE == 1) { if (n_pend) flush_pending(pend, n_pend, q, out, out_count, sink); }
-  if (overflow) atomicOr(&g_trav_overflow, 1u);
+  if (ANY && MODE == 1) { if (n_pend) flush_pending(pend, n_pend, q, out, out_count, sink, MULTI ? MS.ray_inst : nullptr, MULTI ? MS.out_from : nullptr); }
+  if (overflow) atomicOr(counter + TRAV_OVF_WORD, 1u);
 #undef KT_PUSH
 #undef KT_POP
 }
@@ -606,9 +652,9 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
 // when they are taken.  LONG_CAP throttles the number of nodes opened per step so that the lists cannot outgrow LONG_PHYS.
 #define LONG_CAP 512
 #define LONG_PHYS (LONG_CAP + 256)
-template <bool XFORM>
+template <bool XFORM, bool MULTI = false>
 __global__ __launch_bounds__(256) void k_long_closest(RayPlanes q, const LongRec *__restrict__ recs, const unsigned *__restrict__ n_recs, Mat4 minv,
-                                                       Trav T, float tnear, gvt_hip_hit *__restrict__ hits, unsigned *counter) {
+                                                       Trav T, float tnear, gvt_hip_hit *__restrict__ hits, unsigned *counter, WaveSet W = WaveSet{}) {
   __shared__ int s_ref_all[4][LONG_PHYS];
   __shared__ float s_tn_all[4][LONG_PHYS];
   __shared__ int l_ref_all[4][LONG_PHYS];
@@ -632,9 +678,20 @@ __global__ __launch_bounds__(256) void k_long_closest(RayPlanes q, const LongRec
     }
     if (r >= n) break;
     const LongRec R = recs[r];
-    const float4 a = q.p0[R.i], b = q.p1[R.i];
-    V3 O = mk3(a.x, a.y, a.z), D = mk3(b.x, b.y, b.z);
-    if (XFORM) { O = xfm_point(minv, O); D = xfm_vector(minv, D); }
+    float4 a, b;
+    V3 O, D;
+    if (MULTI) {
+      const WaveSeg sg = W.segs[wave_find_seg(W, R.i)];
+      const unsigned local = R.i - sg.begin;
+      a = sg.planes[local]; b = sg.planes[sg.cap + local];
+      const WaveInst *wi = W.insts + sg.inst;
+      T.nodes4 = wi->nodes4; T.tris = wi->tris;
+      O = xfm_point(wi->minv, mk3(a.x, a.y, a.z)); D = xfm_vector(wi->minv, mk3(b.x, b.y, b.z));
+    } else {
+      a = q.p0[R.i]; b = q.p1[R.i];
+      O = mk3(a.x, a.y, a.z); D = mk3(b.x, b.y, b.z);
+      if (XFORM) { O = xfm_point(minv, O); D = xfm_vector(minv, D); }
+    }
     const float dx = fabsf(D.x) < 1e-30f ? copysignf(1e-30f, D.x) : D.x;
     const float dy = fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y;
     const float dz = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;
@@ -717,7 +774,7 @@ __global__ __launch_bounds__(256) void k_long_closest(RayPlanes q, const LongRec
     }
     if (lane == 0) { gvt_hip_hit h; h.t = bt; h.prim = bp; h.u = (bp >= 0) ? bu / bden : 0.f; h.v = (bp >= 0) ? bv / bden : 0.f; hits[R.j] = h; }
   }
-  if (overflow) atomicOr(&g_trav_overflow, 1u);
+  if (overflow) atomicOr(counter + (TRAV_OVF_WORD - 4), 1u);
 }
 
 // diagnostic (not on the hot path): per-ray visit counts of the closest-hit traversal.
@@ -925,17 +982,6 @@ __device__ inline V3 cos_weighted_dir(V3 n, uint32_t &seed) {
   return norm3(d);
 }
 
-struct MeshView {
-  const float *verts;
-  const int *tris;
-  const float *normals;
-  const float *vcolors;
-  const gvt_hip_material *materials;
-  unsigned n_mat;
-  const int *face_mat;
-  gvt_hip_material mat; // Mesh::mat
-};
-
 struct ShadeArgs {
   RayPlanes in;            // rayList (updated in place)
   const unsigned *idx;     // active list or null (identity)
@@ -954,54 +1000,74 @@ struct ShadeArgs {
   unsigned *zero_word;     // reset for the launch that follows (the any-hit kernel's work counter)
   TermSink sink;           // terminal rule of the shuffle for rays that leave this instance without a hit (fb == nullptr: off)
   int update_in_place;     // 1: every shaded ray is written back (gvt_hip_trace: the caller reads rayList); 0: only rays that bounce
+  const unsigned *n_dev;   // ray count of this pass in device memory (a pass launched without a host round trip); null: n
+  // merged launch (k_shade<true>): rays are virtual indices into W's segments; per-ray mesh / normi from W.insts
+  WaveSet W;
+  int *out_from;           // source instance of every ray appended to `out`
+  int *shadow_inst;        // instance of every ray appended to `shadow`
 };
 
 #define SHADE_BLOCK 512
-__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M) {
+template <bool MULTI>
+__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M1) {
   // one LDS (count, base) pair per output list use: moved_rays, next list, one per light
   __shared__ unsigned sh_alloc[2 * (2 + 64)];
   for (int k = threadIdx.x; k < 2 * (2 + 64); k += SHADE_BLOCK) sh_alloc[k] = 0u;
   __syncthreads();
   const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j == 0 && A.zero_word) *A.zero_word = 0u;
-  const bool in_range = j < A.n;
-  const unsigned i = in_range ? (A.idx ? A.idx[j] : j) : 0u;
+  const unsigned n = A.n_dev ? *A.n_dev : A.n;
+  const bool in_range = j < n;
+  unsigned i = in_range ? (A.idx ? A.idx[j] : j) : 0u; // index in rayList (MULTI: virtual index, then index in the ray's queue)
+  const unsigned gi = i;
+  RayPlanes in = A.in;
+  const MeshView *M = &M1;
+  Mat3 normi = A.normi;
+  int inst = A.sink.from;
+  if (MULTI && in_range) {
+    const WaveSeg sg = A.W.segs[wave_find_seg(A.W, i)];
+    in = make_planes(sg.planes, sg.cap);
+    i -= sg.begin;
+    inst = sg.inst;
+    M = &A.W.insts[inst].mv;
+    normi = A.W.insts[inst].normi;
+  }
   RayRec r;
   gvt_hip_hit h;
   h.prim = -1; h.t = 0.f; h.u = 0.f; h.v = 0.f;
   bool miss = false, shaded = false, bounce = false;
   uint32_t g_seed = 0;
   V3 N = mk3(0, 0, 0);
-  MatEval me = mat_eval(M.mat);
+  MatEval me = mat_eval(M->mat);
   if (in_range) {
-    r = load_ray(A.in, i);
+    r = load_ray(in, i);
     h = A.hits[j];
-    g_seed = (A.first_pass && (!A.carried_rng || r.rng == 0u)) ? ray_stream_seed(A.seed, A.index_base + i) : r.rng;
+    g_seed = (A.first_pass && (!A.carried_rng || r.rng == 0u)) ? ray_stream_seed(A.seed, A.index_base + gi) : r.rng;
     if (h.prim < 0) {
       miss = true; // :605-609
     } else if (r.type != 1) { // a SHADOW ray that hits is dropped :486-488
       shaded = true;
       float t = h.t;
       r.t = t; // :491
-      const int ia = M.tris[3 * h.prim], ib = M.tris[3 * h.prim + 1], ic = M.tris[3 * h.prim + 2];
-      const V3 v0 = ld3(M.verts + 3 * ia), v1 = ld3(M.verts + 3 * ib), v2 = ld3(M.verts + 3 * ic);
+      const int ia = M->tris[3 * h.prim], ib = M->tris[3 * h.prim + 1], ic = M->tris[3 * h.prim + 2];
+      const V3 v0 = ld3(M->verts + 3 * ia), v1 = ld3(M->verts + 3 * ib), v2 = ld3(M->verts + 3 * ic);
       const V3 negNg = cross3(sub3(v1, v0), sub3(v2, v0)); // -Ng of Embree (cf. OptixMeshAdapter.cu:280-287)
-      const V3 normalflat = norm3(mat3_mul(A.normi, negNg)); // :504
+      const V3 normalflat = norm3(mat3_mul(normi, negNg)); // :504
       if (A.normal_mode == GVT_HIP_NORMALS_SMOOTH) { // :505-518
-        const V3 a = ld3(M.normals + 3 * ib), b = ld3(M.normals + 3 * ic), c = ld3(M.normals + 3 * ia);
+        const V3 a = ld3(M->normals + 3 * ib), b = ld3(M->normals + 3 * ic), c = ld3(M->normals + 3 * ia);
         const V3 mn = add3(add3(scl3(a, h.u), scl3(b, h.v)), scl3(c, 1.0f - h.u - h.v));
-        N = norm3(mat3_mul(A.normi, mn));
+        N = norm3(mat3_mul(normi, mn));
       } else {
         N = normalflat; // :520-522
       }
       if (dot3(neg3(r.d), normalflat) <= 0.f) N = neg3(N); // :527-529
       // material pick :534-569
-      if (M.vcolors) {
-        const V3 c0 = ld3(M.vcolors + 3 * ia), c1 = ld3(M.vcolors + 3 * ib), c2 = ld3(M.vcolors + 3 * ic);
+      if (M->vcolors) {
+        const V3 c0 = ld3(M->vcolors + 3 * ia), c1 = ld3(M->vcolors + 3 * ib), c2 = ld3(M->vcolors + 3 * ic);
         me.kd = add3(add3(scl3(c0, 1.f - h.u - h.v), scl3(c1, h.u)), scl3(c2, h.v));
         me.type = 0; me.ks = mk3(.5f, .5f, .5f); me.alpha = 1.f;
-      } else if (M.face_mat && M.face_mat[h.prim] >= 0 && (unsigned)M.face_mat[h.prim] < M.n_mat) {
-        me = mat_eval(M.materials[M.face_mat[h.prim]]);
+      } else if (M->face_mat && M->face_mat[h.prim] >= 0 && (unsigned)M->face_mat[h.prim] < M->n_mat) {
+        me = mat_eval(M->materials[M->face_mat[h.prim]]);
       }
       if (r.type == 2) { // SECONDARY :572-575
         t = (t > 1) ? 1.f / t : t;
@@ -1016,7 +1082,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M) 
     if (miss && A.sink.fb) {
       float ret_t;
       const float4 a = make_float4(r.o.x, r.o.y, r.o.z, r.t_min), b = make_float4(r.d.x, r.d.y, r.d.z, r.t_max);
-      if (top_nearest(a, b, A.sink.blo, A.sink.bhi, A.sink.n_inst, A.sink.from, ret_t) < 0) {
+      if (top_nearest(a, b, A.sink.blo, A.sink.bhi, A.sink.n_inst, inst, ret_t) < 0) {
         forward = false;
         if (r.type == 1 && len3(r.c) > 0.f && (unsigned)r.id < A.sink.n_pix) {
           const V3 cw = scl3(r.c, r.w);
@@ -1026,7 +1092,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M) 
       }
     }
     const unsigned slot = block_alloc(A.out_count, forward, &sh_alloc[0]);
-    if (forward) store_ray(A.out, slot, r);
+    if (forward) { store_ray(A.out, slot, r); if (MULTI) A.out_from[slot] = inst; }
   }
   // generateShadowRays :320-358 -- one pass per light so that the wave allocates slots together
   for (int li = 0; li < A.n_lights; li++) {
@@ -1051,7 +1117,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M) 
       }
     }
     const unsigned slot = block_alloc(A.shadow_count, emit, &sh_alloc[2 * (2 + li)]);
-    if (emit) store_ray(A.shadow, slot, s);
+    if (emit) { store_ray(A.shadow, slot, s); if (MULTI) A.shadow_inst[slot] = inst; }
   }
   if (shaded) { // :584-602
     const int ndepth = r.depth - 1;
@@ -1069,12 +1135,12 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M) 
     }
     if (bounce || A.update_in_place) { // rayList is updated in place; a list the caller discards anyway (device queues) only needs it for the next pass
       r.rng = g_seed; // the stream goes on with the ray
-      store_ray(A.in, i, r);
+      store_ray(in, i, r);
     }
   }
   {
     const unsigned slot = block_alloc(A.next_count, bounce, &sh_alloc[2]);
-    if (bounce) A.next_idx[slot] = i;
+    if (bounce) A.next_idx[slot] = gi;
   }
 }
 
@@ -1176,9 +1242,8 @@ int trav_grid(size_t n) {
   return (int)(need < (size_t)C.trav_blocks ? (need ? need : 1) : (size_t)C.trav_blocks);
 }
 
-static bool g_have_nodes4 = false; // set by the launchers from the mesh being traced
-template <bool ANY, bool XFORM, int MODE, typename... Args> void launch_trace(int grid, hipStream_t st, Args... args) {
-  if (gctx().wide4 && g_have_nodes4) k_trace<ANY, XFORM, MODE, false, true><<<grid, TRAV_BLOCK, 0, st>>>(args...);
+template <bool ANY, bool XFORM, int MODE, typename... Args> void launch_trace(bool have_nodes4, int grid, hipStream_t st, Args... args) {
+  if (gctx().wide4 && have_nodes4) k_trace<ANY, XFORM, MODE, false, true><<<grid, TRAV_BLOCK, 0, st>>>(args...);
   else if (gctx().coop_fetch) k_trace<ANY, XFORM, MODE, true, false><<<grid, TRAV_BLOCK, 0, st>>>(args...);
   else k_trace<ANY, XFORM, MODE, false, false><<<grid, TRAV_BLOCK, 0, st>>>(args...);
 }
@@ -1208,15 +1273,14 @@ int debug_stamps(unsigned long long *out, int reset) {
 // queued behind the traversal launches on the stream; read after the caller's next synchronisation through trav_overflow_result()
 int trav_overflow_fetch_async() {
   Ctx &C = gctx();
-  HIPCHK(hipMemcpyFromSymbolAsync(C.h_pinned + 8, HIP_SYMBOL(g_trav_overflow), sizeof(unsigned), 0, hipMemcpyDeviceToHost, C.stream));
+  HIPCHK(hipMemcpyAsync(C.h_pinned + 8, C.d_counters + TRAV_OVF_WORD, sizeof(unsigned), hipMemcpyDeviceToHost, C.stream));
   return 0;
 }
 int trav_overflow_result() {
   Ctx &C = gctx();
   if (!C.h_pinned[8]) return 0;
   C.h_pinned[8] = 0;
-  const unsigned zero = 0;
-  hipMemcpyToSymbol(HIP_SYMBOL(g_trav_overflow), &zero, sizeof zero);
+  hipMemsetAsync(C.d_counters + TRAV_OVF_WORD, 0, sizeof(unsigned), C.stream);
   set_error("BVH traversal stack overflow (more than %d pending entries for one ray): results of this call are incomplete", TRAV_STACK + TRAV_SPILL);
   return GVT_HIP_ERR_DEVICE;
 }
@@ -1250,12 +1314,12 @@ int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, 
   if (!n) return 0;
   Ctx &C = gctx();
   if (gctx().wide4 && !M->d_nodes4) { int rc4 = build_nodes4(M); if (rc4) return rc4; }
-  g_have_nodes4 = M->d_nodes4 != nullptr;
+  const bool have_nodes4 = M->d_nodes4 != nullptr;
   Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
   unsigned *counter = C.d_counters + 0;
   if (!counter_is_zero) HIPCHK(hipMemsetAsync(C.d_counters, 0, 5 * sizeof(unsigned), C.stream));
   LongQ LQ{};
-  if (C.trav_kernel == 1 && C.wide4 && g_have_nodes4 && C.long_steps > 0 && n >= (size_t)C.long_min_rays) { // long rays are parked and traversed a wave per ray
+  if (C.trav_kernel == 1 && C.wide4 && have_nodes4 && C.long_steps > 0 && n >= (size_t)C.long_min_rays) { // long rays are parked and traversed a wave per ray
     LQ.recs = (LongRec *)scratch_get(15, sizeof(LongRec) * n);
     if (!LQ.recs) return GVT_HIP_ERR_DEVICE;
     LQ.count = C.d_counters + 3;
@@ -1265,8 +1329,8 @@ int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, 
     ProfScope ps(KC_CLOSEST);
     RayPlanes none{};
     if (C.trav_kernel == 1) {
-      if (xform) launch_trace<false, true, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
-      else launch_trace<false, false, 0>(trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
+      if (xform) launch_trace<false, true, 0>(have_nodes4, trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
+      else launch_trace<false, false, 0>(have_nodes4, trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
     } else {
       if (xform) k_closest<true><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
       else k_closest<false><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
@@ -1292,7 +1356,6 @@ int launch_visit_stats(gvt_hip_mesh *M, RayPlanes q, size_t n, float tnear, unsi
   if (!n) return 0;
   Ctx &C = gctx();
   if (gctx().wide4 && !M->d_nodes4) { int rc4 = build_nodes4(M); if (rc4) return rc4; }
-  g_have_nodes4 = M->d_nodes4 != nullptr;
   Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
   unsigned *counter = C.d_counters + 0;
   HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), C.stream));
@@ -1305,7 +1368,7 @@ int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const M
   if (!n) return 0;
   Ctx &C = gctx();
   if (gctx().wide4 && !M->d_nodes4) { int rc4 = build_nodes4(M); if (rc4) return rc4; }
-  g_have_nodes4 = M->d_nodes4 != nullptr;
+  const bool have_nodes4 = M->d_nodes4 != nullptr;
   Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
   unsigned *counter = C.d_counters + 0;
   HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), C.stream));
@@ -1313,8 +1376,8 @@ int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const M
   {
     ProfScope ps(KC_ANY);
     if (C.trav_kernel == 1) {
-      if (xform) launch_trace<true, true, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LongQ{});
-      else launch_trace<true, false, 0>(trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LongQ{});
+      if (xform) launch_trace<true, true, 0>(have_nodes4, trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LongQ{});
+      else launch_trace<true, false, 0>(have_nodes4, trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LongQ{});
     } else {
       if (xform) k_any<true, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
       else k_any<false, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
@@ -1344,8 +1407,8 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
   gvt_hip_light *d_lights = (gvt_hip_light *)scratch_get(5, sizeof(gvt_hip_light) * (nL > 0 ? nL : 1));
   if (!d_hits || !d_shadow || !d_idx_a || !d_idx_b || !d_lights) return GVT_HIP_ERR_DEVICE;
   { // the light list rarely changes between calls: upload only when it (or its scratch buffer) did
-    static std::vector<unsigned char> cached;
-    static const void *cached_dst = nullptr;
+    std::vector<unsigned char> &cached = C.lights_cached;
+    const void *&cached_dst = C.lights_cached_dst;
     const size_t bytes = sizeof(gvt_hip_light) * (size_t)nL;
     if (nL && (cached_dst != d_lights || cached.size() != bytes || std::memcmp(cached.data(), lights_host, bytes) != 0)) {
       cached.assign((const unsigned char *)lights_host, (const unsigned char *)lights_host + bytes);
@@ -1406,9 +1469,10 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
     A.next_idx = next; A.next_count = c_next; A.lights = d_lights; A.normi = P.normi; A.normal_mode = P.normal_mode;
     A.n_lights = nL; A.seed = P.seed; A.zero_word = (C.trav_kernel == 1) ? C.d_counters + 0 : nullptr;
     A.sink = P.sink; A.update_in_place = P.update_in_place;
+    A.n_dev = nullptr; A.W = WaveSet{}; A.out_from = nullptr; A.shadow_inst = nullptr;
     {
       ProfScope ps(KC_SHADE);
-      k_shade<<<blocks_for(n_active, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, mv);
+      k_shade<false><<<blocks_for(n_active, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, mv);
     }
     HIPCHK(hipGetLastError());
     C.stats.rays_shaded += n_active;
@@ -1418,12 +1482,11 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
     const size_t shadow_ub = n_active * (size_t)nL;
     if (C.trav_kernel == 1) {
       if (shadow_ub) {
-  g_have_nodes4 = M->d_nodes4 != nullptr;
-  Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
+        Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
         unsigned *counter = C.d_counters + 0; // zeroed by k_shade
         {
           ProfScope ps(KC_ANY);
-          launch_trace<true, true, 1>(trav_grid2(shadow_ub), st, shadow, nullptr, 0u, P.minv, T, GVT_RAY_EPSILON, nullptr, nullptr, outp,
+          launch_trace<true, true, 1>(M->d_nodes4 != nullptr, trav_grid2(shadow_ub), st, shadow, nullptr, 0u, P.minv, T, GVT_RAY_EPSILON, nullptr, nullptr, outp,
                                                                                out->d_count, counter, C.d_spill, C.refill_min, C.inner_min, c_shadow, C.share, (unsigned)C.share_min_rays, P.sink, LongQ{});
         }
         HIPCHK(hipGetLastError());
@@ -1441,8 +1504,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
       HIPCHK(hipStreamSynchronize(st));
       n_shadow = C.h_pinned[0]; n_next = C.h_pinned[1];
       if (n_shadow) {
-  g_have_nodes4 = M->d_nodes4 != nullptr;
-  Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
+        Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
         unsigned *counter = C.d_counters + 0;
         HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
         {
@@ -1479,6 +1541,111 @@ extern "C" int gvt_hip_math_probe(int kind, const float *in, size_t n, float *ou
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, d + n, sizeof(float) * n, hipMemcpyDeviceToHost, C.stream));
   HIPCHK(hipStreamSynchronize(C.stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Merged launch chain of one scheduler round (gvt_internal.h "wave"): closest hit -> shade -> any hit over the rays of all local
+// queues at once, `passes` times (bounces), WITHOUT any host round trip: later passes read their ray count from device memory.
+// Device counters of the context (d_counters): [0] work counter, [1] shadow rays of the pass, [2] / [5] bounce list counts
+// (alternating), [3] parked long rays, [4] their work counter, [8] stack overflow flag, [16..19] two 64-bit ray totals
+// (closest, any) accumulated over the frame and read back with the queue sizes.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void k_wave_pass_begin(unsigned *c, int pass, unsigned n_host, unsigned *out_count) {
+  if (blockIdx.x || threadIdx.x) return;
+  unsigned long long *tot = (unsigned long long *)(c + 16);
+  const int cur = (pass & 1) ? 5 : 2, prev = (pass & 1) ? 2 : 5;
+  if (pass == 0) { *out_count = 0u; c[2] = 0u; c[5] = 0u; tot[0] += n_host; }
+  else { tot[1] += c[1]; tot[0] += c[prev]; c[cur] = 0u; }
+  c[0] = 0u; c[1] = 0u; c[3] = 0u; c[4] = 0u;
+}
+__global__ void k_wave_end(unsigned *c) {
+  if (blockIdx.x || threadIdx.x) return;
+  unsigned long long *tot = (unsigned long long *)(c + 16);
+  tot[1] += c[1];
+}
+} // namespace
+
+int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
+                     const gvt_hip_light *lights_host) {
+  Ctx &C = gctx();
+  if (!n_total) return 0;
+  hipStream_t st = C.stream;
+  const int nL = P.n_lights;
+  const size_t n = n_total;
+  gvt_hip_hit *d_hits = (gvt_hip_hit *)scratch_get(0, sizeof(gvt_hip_hit) * n);
+  const size_t shadow_cap = n * (size_t)(nL > 0 ? nL : 1);
+  float4 *d_shadow = (float4 *)scratch_get(2, sizeof(float4) * 4 * shadow_cap);
+  unsigned *d_idx_a = (unsigned *)scratch_get(3, sizeof(unsigned) * n);
+  unsigned *d_idx_b = (unsigned *)scratch_get(4, sizeof(unsigned) * n);
+  gvt_hip_light *d_lights = (gvt_hip_light *)scratch_get(5, sizeof(gvt_hip_light) * (nL > 0 ? nL : 1));
+  int *d_shadow_inst = (int *)scratch_get(16, sizeof(int) * shadow_cap);
+  LongRec *d_long = (LongRec *)scratch_get(15, sizeof(LongRec) * n);
+  if (!d_hits || !d_shadow || !d_idx_a || !d_idx_b || !d_lights || !d_shadow_inst || !d_long) return GVT_HIP_ERR_DEVICE;
+  {
+    std::vector<unsigned char> &cached = C.lights_cached;
+    const void *&cached_dst = C.lights_cached_dst;
+    const size_t bytes = sizeof(gvt_hip_light) * (size_t)nL;
+    if (nL && (cached_dst != d_lights || cached.size() != bytes || std::memcmp(cached.data(), lights_host, bytes) != 0)) {
+      cached.assign((const unsigned char *)lights_host, (const unsigned char *)lights_host + bytes);
+      cached_dst = d_lights;
+      HIPCHK(hipMemcpyAsync(d_lights, cached.data(), bytes, hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st)); // pageable source: finish the copy before `cached` can change (first frame only)
+    }
+  }
+  RayPlanes shadow = make_planes(d_shadow, shadow_cap);
+  shadow.p4 = nullptr;
+  RayPlanes outp = make_planes(out->d_planes, out->cap);
+  RayPlanes none{};
+  unsigned *c = C.d_counters;
+  Trav T{};
+  Mat4 id{};
+  const bool use_long = C.long_steps > 0 && n >= (size_t)C.long_min_rays;
+  for (int pass = 0; pass < passes; pass++) {
+    const unsigned *n_dev = pass ? c + ((pass & 1) ? 2 : 5) : nullptr;          // count written by the previous pass's k_shade
+    const unsigned *idx = pass ? ((pass & 1) ? d_idx_a : d_idx_b) : nullptr;    // its bounce list
+    unsigned *next = (pass & 1) ? d_idx_b : d_idx_a;
+    unsigned *c_next = c + ((pass & 1) ? 5 : 2);
+    k_wave_pass_begin<<<1, 64, 0, st>>>(c, pass, (unsigned)n, out->d_count);
+    LongQ LQ{};
+    if (use_long) { LQ.recs = d_long; LQ.count = c + 3; LQ.steps = C.long_steps; }
+    MultiSrc MS{ W, nullptr, nullptr };
+    {
+      ProfScope ps(KC_CLOSEST);
+      k_trace<false, true, 0, false, true, true><<<trav_grid2(n), TRAV_BLOCK, 0, st>>>(none, idx, (unsigned)n, id, T, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
+                                                                                      c + 0, C.d_spill, C.refill_min, C.inner_min, n_dev, C.share, (unsigned)C.share_min_rays,
+                                                                                      TermSink{}, LQ, MS);
+    }
+    if (use_long) {
+      ProfScope ps(KC_LONG);
+      k_long_closest<true, true><<<C.n_cu * 3, 256, 0, st>>>(none, d_long, c + 3, id, T, GVT_RAY_EPSILON, d_hits, c + 4, W);
+    }
+    ShadeArgs A;
+    A.in = none; A.idx = idx; A.n = (unsigned)n; A.index_base = 0; A.hits = d_hits;
+    A.first_pass = (pass == 0); A.carried_rng = 1; A.out = outp; A.out_count = out->d_count; A.shadow = shadow; A.shadow_count = c + 1;
+    A.next_idx = next; A.next_count = c_next; A.lights = d_lights; A.normi = P.normi; A.normal_mode = P.normal_mode;
+    A.n_lights = nL; A.seed = P.seed; A.zero_word = c + 0;
+    A.sink = P.sink; A.update_in_place = 0;
+    A.n_dev = n_dev; A.W = W; A.out_from = d_out_from; A.shadow_inst = d_shadow_inst;
+    {
+      ProfScope ps(KC_SHADE);
+      k_shade<true><<<blocks_for(n, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, MeshView{});
+    }
+    if (nL) {
+      ProfScope ps(KC_ANY);
+      MultiSrc MA{ W, d_shadow_inst, d_out_from };
+      k_trace<true, true, 1, false, true, true><<<trav_grid2(shadow_cap), TRAV_BLOCK, 0, st>>>(shadow, nullptr, 0u, id, T, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
+                                                                                              c + 0, C.d_spill, C.refill_min, C.inner_min, c + 1, C.share, (unsigned)C.share_min_rays,
+                                                                                              P.sink, LongQ{}, MA);
+    }
+    HIPCHK(hipGetLastError());
+    C.stats.launches_closest++;
+    C.stats.launches_any++;
+  }
+  k_wave_end<<<1, 64, 0, st>>>(c);
+  HIPCHK(hipGetLastError());
+  C.stats.trace_calls++;
   return 0;
 }
 

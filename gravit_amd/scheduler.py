@@ -129,6 +129,117 @@ class HipBackend:
         capi.synchronize()
 
 
+class Context:
+    """gvt_hip_ctx: a stream + scratch + counters of its own, current for the calling thread (several ranks in one process)."""
+
+    def __init__(self, device=0):
+        import ctypes as C
+
+        self.lib = capi.load()
+        self.h = C.c_void_p(self.lib.gvt_hip_ctx_create(C.c_int(device)))
+        if not self.h:
+            raise capi.GvtHipError("gvt_hip_ctx_create: " + capi.last_error())
+        capi.check(self.lib.gvt_hip_ctx_make_current(self.h), "gvt_hip_ctx_make_current")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gvt_hip_ctx_make_current(None)
+            self.lib.gvt_hip_ctx_destroy(self.h)
+            self.h = None
+
+
+class Comm:
+    """gvt_hip_comm: one rank's endpoint of the ray exchange.  Comm.rccl(dist-like broadcast) for one process per GPU,
+    Comm.local(hub, rank) for in-process ranks."""
+
+    def __init__(self, h):
+        self.lib = capi.load()
+        self.h = h
+        self.rank = self.lib.gvt_hip_comm_rank(h)
+        self.world = self.lib.gvt_hip_comm_world(h)
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+
+        buf = (C.c_ubyte * 128)()
+        capi.check(capi.load().gvt_hip_comm_unique_id(buf), "gvt_hip_comm_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, uid, rank, world):
+        import ctypes as C
+
+        buf = (C.c_ubyte * 128).from_buffer_copy(uid)
+        h = C.c_void_p(capi.load().gvt_hip_comm_create(buf, C.c_int(rank), C.c_int(world)))
+        if not h:
+            raise capi.GvtHipError("gvt_hip_comm_create: " + capi.last_error())
+        return cls(h)
+
+    @classmethod
+    def local(cls, hub, rank):
+        import ctypes as C
+
+        h = C.c_void_p(capi.load().gvt_hip_comm_create_local(hub, C.c_int(rank)))
+        if not h:
+            raise capi.GvtHipError("gvt_hip_comm_create_local: " + capi.last_error())
+        return cls(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gvt_hip_comm_destroy(self.h)
+            self.h = None
+
+
+class NativeTracer:
+    """gvt_hip_tracer: Tracer<ImageScheduler> / Tracer<DomainScheduler> as a native loop inside libgvt_hip.so (csrc/domain.hip): rounds
+    of one merged launch chain over all local queues, one host synchronisation per round, ray exchange over RCCL (or the in-process
+    transport).  owner[i] = rank of instance i (mpiInstanceMap); comm=None: one rank."""
+
+    def __init__(self, scene, normal_mode=NORMALS_FLAT, owner=None, comm=None, backend=None):
+        import ctypes as C
+
+        self.lib = capi.load()
+        self.scene = scene
+        self.comm = comm
+        rank = comm.rank if comm is not None else 0
+        self.owner = [0] * scene.n_inst if owner is None else list(owner)
+        owned = [o == rank for o in self.owner]
+        self.backend = backend or HipBackend(scene, normal_mode, owned)
+        B = self.backend
+        cam = scene.camera
+        pod = capi.CameraPod((C.c_float * 3)(*cam.eye), (C.c_float * 3)(*cam.focus), (C.c_float * 3)(*cam.up), cam.fov, cam.width, cam.height,
+                             cam.samples, cam.depth, cam.jitter)
+        meshes = (C.c_void_p * max(1, scene.n_inst))(*[B.adapter(i).h if owned[i] else None for i in range(scene.n_inst)])
+        lights = np.ascontiguousarray(scene.lights)
+        self.h = C.c_void_p(self.lib.gvt_hip_tracer_create(
+            B.top.h, meshes, capi.ptr(capi.f32(scene.m)), capi.ptr(capi.f32(scene.minv)), capi.ptr(capi.f32(scene.normi)), C.c_size_t(scene.n_inst),
+            capi.ptr(lights), C.c_size_t(len(lights)), C.c_int(normal_mode), C.byref(pod), B.fb.h))
+        if not self.h:
+            raise capi.GvtHipError("gvt_hip_tracer_create: " + capi.last_error())
+        own = np.ascontiguousarray(self.owner, dtype=np.int32)
+        capi.check(self.lib.gvt_hip_tracer_set_domains(self.h, capi.ptr(own), comm.h if comm is not None else None), "gvt_hip_tracer_set_domains")
+        self.stats = {}
+
+    def __call__(self, bsp=False, composite=True):
+        import ctypes as C
+
+        st = capi.FrameStats()
+        flags = (capi.FRAME_BSP if bsp else 0) | (0 if composite else capi.FRAME_NO_COMPOSITE)
+        capi.check(self.lib.gvt_hip_tracer_frame(self.h, C.c_int(flags), C.byref(st)), "gvt_hip_tracer_frame")
+        self.stats = st.as_dict()
+        return self.backend
+
+    render = __call__
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gvt_hip_tracer_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
 def _pick_fullest(sizes, allowed=None):
     """ImageTracer.h:159-173 / DomainTracer.h:235-241: first queue with the strictly largest size."""
     target, cnt = -1, 0

@@ -17,9 +17,9 @@
  *   - Every function returning int returns 0 on success and a negative code on error; the
  *     message is available from gvt_hip_last_error().  Nothing calls exit() (the reference's
  *     Embree error handler does, EmbreeMeshAdapter.cpp:90-123).
- *   - All work is issued on one HIP stream per process (gvt_hip_set_stream); calls on one
- *     mesh/queue are serialised by the caller, as the reference's schedulers do
- *     (ImageTracer.h:241-248).
+ *   - All work of a context is issued on that context's HIP stream (gvt_hip_set_stream); a process has a default context and may
+ *     create more (gvt_hip_ctx_create), one per thread; calls on one mesh/queue are serialised by the caller, as the reference's
+ *     schedulers do (ImageTracer.h:241-248).
  */
 #ifndef GVT_HIP_H
 #define GVT_HIP_H
@@ -88,7 +88,14 @@ typedef struct gvt_hip_top gvt_hip_top;     /* top-level instance set (accel/BVH
 typedef struct gvt_hip_fb gvt_hip_fb;       /* float RGBA framebuffer (IceTComposite) */
 
 /* ---- process / device ---- */
-int gvt_hip_init(int device);                 /* select device, create stream + workspace */
+typedef struct gvt_hip_ctx gvt_hip_ctx;       /* a stream + scratch arenas + counters + statistics + knobs */
+int gvt_hip_init(int device);                 /* select device, create the process's default context */
+/* Additional contexts, e.g. one per rank when several ranks of a scheduler share a process (the reference runs several MPI ranks per
+ * node): every API call runs on the calling thread's current context (NULL = the default one).  Device objects (meshes, queues,
+ * framebuffers, top-level sets) may be used from any context of their device, by one context at a time. */
+gvt_hip_ctx *gvt_hip_ctx_create(int device);
+int gvt_hip_ctx_make_current(gvt_hip_ctx *);  /* for the calling thread; also selects the context's device (hipSetDevice) */
+void gvt_hip_ctx_destroy(gvt_hip_ctx *);
 int gvt_hip_set_stream(void *hip_stream);     /* issue all later work on this hipStream_t (NULL = own stream) */
 int gvt_hip_synchronize(void);
 const char *gvt_hip_last_error(void);
@@ -194,6 +201,53 @@ int gvt_hip_camera_filter(gvt_hip_top *, const gvt_hip_camera *cam, int tile, gv
 int gvt_hip_image_frame(gvt_hip_top *, gvt_hip_mesh *const *meshes, const float *m /* n_inst*16 */, const float *minv, const float *normi /* n_inst*9 */,
                         size_t n_inst, const gvt_hip_light *lights, size_t n_lights, int normal_mode, const gvt_hip_camera *cam,
                         gvt_hip_queue *const *queues, gvt_hip_queue *q_cam, gvt_hip_queue *q_moved, gvt_hip_fb *fb, uint64_t *adapter_calls);
+
+/* ---- the schedulers as native loops (csrc/domain.hip): Tracer<ImageScheduler>::operator() (ImageTracer.h:127-269) and
+ *      Tracer<DomainScheduler>::operator() with SendRays (DomainTracer.h:185-496); asynchronous variant tracer/Domain/DomainTracer.cpp:109-192.
+ *      Every round, all non-empty local queues go through ONE merged launch chain (closest hit, shade, any hit) and one shuffle, with
+ *      one host synchronisation per round; the Domain scheduler's ray exchange is RCCL point-to-point on its own stream (announce =
+ *      SendRays' count exchange + the termination vote, then the payload in the reference's wire format
+ *      [int32 queueId][int32 nRays][80-byte Ray x nRays], :441-455). ---- */
+typedef struct gvt_hip_comm gvt_hip_comm;     /* one rank's endpoint of the ray exchange */
+typedef struct gvt_hip_hub gvt_hip_hub;       /* rendezvous of in-process ranks */
+typedef struct gvt_hip_tracer gvt_hip_tracer; /* a Tracer<...> object for one rank */
+/* RCCL transport: rank 0 calls gvt_hip_comm_unique_id, the 128 bytes reach the other ranks out of band (e.g. a torch.distributed or
+ * MPI broadcast), every rank calls gvt_hip_comm_create on its own device.  Collective. */
+int gvt_hip_comm_unique_id(unsigned char id[128]);
+gvt_hip_comm *gvt_hip_comm_create(const unsigned char id[128], int rank, int world);
+/* In-process transport: the ranks are threads of one process (one context each, gvt_hip_ctx_create) sharing a device; transfers are
+ * device-to-device copies ordered by events.  Same protocol, no RCCL: several ranks per node on one GPU, and the way the Domain
+ * scheduler's multi-rank control flow is exercised on a one-GPU machine. */
+gvt_hip_hub *gvt_hip_hub_create(int world);
+void gvt_hip_hub_abort(gvt_hip_hub *);        /* a rank failed: wake the ranks blocked in an exchange (they return an error) */
+void gvt_hip_hub_destroy(gvt_hip_hub *);
+gvt_hip_comm *gvt_hip_comm_create_local(gvt_hip_hub *, int rank);
+void gvt_hip_comm_destroy(gvt_hip_comm *);
+int gvt_hip_comm_rank(const gvt_hip_comm *);
+int gvt_hip_comm_world(const gvt_hip_comm *);
+
+/* The tracer copies matrices, lights and camera, creates its own per-instance queues, and borrows top, meshes and fb. */
+gvt_hip_tracer *gvt_hip_tracer_create(gvt_hip_top *, gvt_hip_mesh *const *meshes, const float *m /* n_inst*16 */, const float *minv,
+                                      const float *normi /* n_inst*9 */, size_t n_inst, const gvt_hip_light *lights, size_t n_lights,
+                                      int normal_mode, const gvt_hip_camera *cam, gvt_hip_fb *fb);
+void gvt_hip_tracer_destroy(gvt_hip_tracer *);
+int gvt_hip_tracer_set_camera(gvt_hip_tracer *, const gvt_hip_camera *cam);
+/* mpiInstanceMap (DomainTracer.h:115-144): owner[i] = rank holding instance i.  comm == NULL (or never called): one rank, Image scheduler. */
+int gvt_hip_tracer_set_domains(gvt_hip_tracer *, const int32_t *owner /* n_inst */, gvt_hip_comm *comm);
+#define GVT_HIP_FRAME_BSP 1          /* Domain: trace until the local queues are dry, then exchange (Tracer<DomainScheduler>); default:
+                                        one local chain per exchange, the payload moving while the next chain runs (asynchronous tracer) */
+#define GVT_HIP_FRAME_NO_COMPOSITE 2 /* leave the per-rank framebuffers un-reduced */
+typedef struct gvt_hip_frame_stats {
+  uint64_t rounds;       /* exchanges (Domain) */
+  uint64_t chains;       /* merged launch chains on this rank */
+  uint64_t host_syncs;   /* host synchronisations of the frame */
+  uint64_t rays_sent;    /* rays this rank sent to other ranks */
+  uint64_t rays_closest; /* rays this rank pushed through the closest-hit kernel */
+  uint64_t rays_any;     /* ... through the any-hit kernel */
+} gvt_hip_frame_stats;
+/* One frame: clearBuffer, generateRays + FilterRaysLocally / shuffleDropRays, rounds until every queue of every rank is empty, then
+ * (Domain) the composite: the sum of the ranks' float framebuffers on rank 0 (IceTComposite.cpp:84-101).  Collective under a comm. */
+int gvt_hip_tracer_frame(gvt_hip_tracer *, int flags, gvt_hip_frame_stats *stats);
 
 /* ---- framebuffer: IceTComposite (composite/IceTComposite.cpp:79-157) ---- */
 gvt_hip_fb *gvt_hip_fb_create(int width, int height);

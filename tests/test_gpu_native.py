@@ -1,0 +1,172 @@
+"""The schedulers as native loops (gvt_hip_tracer, csrc/domain.hip): rounds of ONE merged launch chain over all local queues, the
+Domain scheduler's ray exchange through the library's own transport.  On the one-GPU box the ranks of Tracer<DomainScheduler> are
+threads of one process, each with its own context (stream, scratch, counters), joined by the in-process transport -- the same
+protocol (announce + payload in the reference's wire format, termination from the announces) that runs over RCCL on 8 GPUs; RCCL
+itself is exercised as far as one GPU allows (communicator of one rank)."""
+import threading
+
+import numpy as np
+import pytest
+
+from gravit_amd import capi, scenes
+from gravit_amd.layouts import NORMALS_FLAT, NORMALS_SMOOTH
+from gravit_amd.scheduler import Comm, Context, HipBackend, ImageTracer, NativeTracer
+from tests.helpers import oracle_render, oracle_render_domain
+
+pytestmark = pytest.mark.gpu
+
+
+def config5(size, n_dom):
+    one = scenes.cathedral_scene(size, size, samples=2, depth=2, eye=(0.0, 1.5, 13.0), light=(0.0, 2.5, 12.0))
+    return one if n_dom <= 1 else scenes.split_into_domains(one, n_dom)
+
+
+@pytest.mark.parametrize("name,mode,exact", [("simple", NORMALS_SMOOTH, True), ("bunny_grid", NORMALS_SMOOTH, True), ("bunny_conf", NORMALS_SMOOTH, True),
+                                             ("soup", NORMALS_FLAT, True), ("soup4", NORMALS_FLAT, True), ("config5", NORMALS_FLAT, False),
+                                             ("config5x4", NORMALS_FLAT, False), ("grid96", NORMALS_SMOOTH, True)])
+def test_rounds_equal_the_reference_order_loop(hip, name, mode, exact):
+    """Image scheduler, one rank: the round loop (all non-empty queues per launch chain) gives the image of the reference's
+    fullest-queue-first loop as restated by the oracle -- bit for bit where a pixel receives one deposit, 1e-5 where several meet."""
+    import os
+
+    from tests.conftest import GOLDEN
+    sc = {"simple": lambda: scenes.simple_scene(256, 256), "bunny_grid": lambda: scenes.bunny_grid_scene(width=475, height=270),
+          "bunny_conf": lambda: scenes.load_conf(os.path.join(GOLDEN, "bunny.conf"), width=475, height=270),
+          "soup": lambda: scenes.soup_scene(200_000, 320, 180), "soup4": lambda: scenes.soup_domains_scene(200_000, 4, 320, 180),
+          "config5": lambda: config5(512, 1), "config5x4": lambda: config5(384, 4),
+          "grid96": lambda: scenes.bunny_grid_scene(nx=12, ny=8, pitch=0.22, width=240, height=160)}[name]()
+    tr = NativeTracer(sc, mode)
+    B = tr()
+    fb = B.framebuffer(True)
+    ref, st = oracle_render(sc, mode, nthreads=8)
+    assert (ref[..., :3].sum(axis=2) > 0).sum() > 500
+    if exact:
+        assert np.array_equal(fb[..., :3], ref[..., :3])
+    else:
+        assert np.abs(fb[..., :3] - ref[..., :3]).max() <= 1e-5
+    assert np.array_equal(fb[..., 3], ref[..., 3])
+    assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any
+    assert tr.stats["host_syncs"] == tr.stats["chains"] + 1  # one per round + the camera filter
+    # a second frame of the same tracer: same image (queues, scratch and counters are reused)
+    fb2 = tr().framebuffer(True)
+    assert np.abs(fb2 - fb).max() <= (0.0 if exact else 1e-5)
+    tr.close()
+
+
+def run_native_ranks(scene, owner, world, mode, bsp):
+    hub = capi.load().gvt_hip_hub_create(world)
+    out, errs = {}, []
+
+    def rank_main(rank):
+        ctx = None
+        try:
+            ctx = Context(0)
+            comm = Comm.local(hub, rank)
+            tr = NativeTracer(scene, mode, owner, comm)
+            B = tr(bsp=bsp)
+            out[rank] = (B.framebuffer(True) if rank == 0 else None, dict(tr.stats))
+            tr.close()
+            comm.close()
+            B = None
+        except Exception:  # noqa: BLE001
+            import traceback
+            errs.append(traceback.format_exc())
+            capi.load().gvt_hip_hub_abort(hub)
+        finally:
+            import gc
+            gc.collect()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=600) for t in th]
+    capi.load().gvt_hip_hub_destroy(hub)
+    assert not errs, errs[0]
+    return out
+
+
+@pytest.mark.parametrize("world,bsp", [(2, True), (4, True), (8, True), (2, False), (4, False), (8, False), (3, False)])
+def test_native_domain_scheduler_config4(hip, world, bsp):
+    """BASELINE config 4 (reduced film): 8 bunny instances, one domain per rank round-robin, BSP rounds (Tracer<DomainScheduler>) and
+    asynchronous ticks: the composited image equals the oracle's restated DomainTracer and the 1-rank image; rays sent agree."""
+    sc = scenes.bunny_grid_scene(width=380, height=216)
+    owner = [i % world for i in range(sc.n_inst)]
+    res = run_native_ranks(sc, owner, world, NORMALS_SMOOTH, bsp)
+    fb = res[0][0]
+    ref, st = oracle_render_domain(sc, owner, world, 1)
+    assert np.array_equal(fb[..., :3], ref[..., :3])
+    one, _ = oracle_render(sc, 1)
+    assert np.array_equal(fb[..., :3], one[..., :3])
+    assert sum(r[1]["rays_sent"] for r in res.values()) == st.rays_sent and st.rays_sent > 0
+    assert sum(r[1]["rays_closest"] for r in res.values()) == st.rays_closest
+    for r in res.values():  # ONE host synchronisation per local chain / exchange round (+ camera filter + composite)
+        assert r[1]["host_syncs"] <= r[1]["rounds"] + r[1]["chains"] + 2
+    if bsp:
+        assert all(r[1]["rounds"] == st.rounds for r in res.values())
+
+
+@pytest.mark.parametrize("size,n_dom,world,bsp", [(768, 4, 4, True), (384, 8, 8, False), (384, 4, 2, False), (256, 8, 3, True)])
+def test_native_domain_scheduler_config5(hip, size, n_dom, world, bsp):
+    """BASELINE config 5 stand-in (4 rays per pixel, depth 2) under the native Domain scheduler: bounce and shadow rays cross slabs
+    and ranks in the reference's wire format with their RNG stream word."""
+    sc = config5(size, n_dom)
+    owner = [i % world for i in range(sc.n_inst)]
+    res = run_native_ranks(sc, owner, world, NORMALS_FLAT, bsp)
+    fb = res[0][0]
+    ref, st = oracle_render_domain(sc, owner, world, 0)
+    assert (ref[..., :3].sum(axis=2) > 0).mean() > 0.2
+    assert np.abs(fb[..., :3] - ref[..., :3]).max() <= 1e-5
+    assert np.array_equal(fb[..., 3], ref[..., 3])
+    assert sum(r[1]["rays_sent"] for r in res.values()) == st.rays_sent and st.rays_sent > 10_000
+    assert sum(r[1]["rays_closest"] for r in res.values()) == st.rays_closest
+    assert sum(r[1]["rays_any"] for r in res.values()) == st.rays_any
+
+
+def test_soup_domains_with_cross_traffic_native(hip):
+    sc = scenes.soup_domains_scene(200_000, 4, 320, 180)
+    sc.camera.eye, sc.camera.focus = (3.0, 0.6, 0.4), (0.5, 0.5, 0.5)  # along -x: rays cross the x-tiled domains
+    sc.lights["position"] = (2.0, 2.5, 1.5)
+    owner = [i % 2 for i in range(sc.n_inst)]
+    for bsp in (True, False):
+        res = run_native_ranks(sc, owner, 2, NORMALS_FLAT, bsp)
+        ref, st = oracle_render_domain(sc, owner, 2, 0)
+        assert np.array_equal(res[0][0][..., :3], ref[..., :3])
+        assert sum(r[1]["rays_sent"] for r in res.values()) == st.rays_sent and st.rays_sent > 1000
+
+
+def test_rccl_communicator_of_one_rank(hip):
+    """RCCL itself, as far as one GPU allows: the library resolves librccl, creates a communicator from a unique id and runs a
+    Domain frame on it (no peers: no sends; the composite reduce is skipped for one rank)."""
+    uid = Comm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = Comm.rccl(uid, 0, 1)
+    assert comm.rank == 0 and comm.world == 1
+    sc = scenes.bunny_grid_scene(width=190, height=108)
+    tr = NativeTracer(sc, NORMALS_SMOOTH, [0] * sc.n_inst, comm)
+    fb = tr(bsp=True).framebuffer(True)
+    ref, _ = oracle_render(sc, 1)
+    assert np.array_equal(fb[..., :3], ref[..., :3])
+    tr.close()
+    comm.close()
+
+
+def test_two_contexts_trace_concurrently(hip):
+    """Per-context state: two threads, each with its own context, render different scenes at the same time; both equal the oracle."""
+    scs = [scenes.bunny_grid_scene(width=240, height=136), scenes.simple_scene(192, 192)]
+    refs = [oracle_render(s, 1)[0] for s in scs]
+    out, errs = {}, []
+
+    def work(k):
+        try:
+            Context(0)
+            for _ in range(3):
+                out[k] = ImageTracer(scs[k], NORMALS_SMOOTH)().framebuffer(True)
+        except Exception:  # noqa: BLE001
+            import traceback
+            errs.append(traceback.format_exc())
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not errs, errs[0]
+    for k in range(2):
+        assert np.array_equal(out[k][..., :3], refs[k][..., :3])
