@@ -180,7 +180,7 @@ class Comm:
     def local(cls, hub, rank):
         import ctypes as C
 
-        h = C.c_void_p(capi.load().gvt_hip_comm_create_local(hub, C.c_int(rank)))
+        h = C.c_void_p(capi.load().gvt_hip_comm_create_local(C.c_void_p(hub), C.c_int(rank)))
         if not h:
             raise capi.GvtHipError("gvt_hip_comm_create_local: " + capi.last_error())
         return cls(h)
