@@ -4,10 +4,12 @@
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 10,000,000 random triangles,
 1920x1080, one point light at the eye, depth 1 (primary + 1 shadow ray), AO off.  A step = one frame:
 camera rays -> top-level test -> Adapter::trace (closest hit, shade, shadow rays, any hit) -> shuffle ->
-framebuffer, all resident in HBM.  N = 1: Image scheduler, one domain.  N > 1: the same soup cut into N
-spatial domains, one per GPU, Domain scheduler with the ray exchange over RCCL (strong scaling: the frame
-is fixed).  value = (rays through the closest-hit kernel + rays through the any-hit kernel, all ranks) /
-wall time of the timed steps.
+framebuffer, all resident in HBM, driven by the native scheduler loop (gvt_hip_tracer_frame).  N = 1: Image
+scheduler, one domain.  N > 1: the same soup cut into N spatial domains, one per GPU, Domain scheduler with the
+ray exchange as RCCL point-to-point issued by the library itself (strong scaling: the frame is fixed);
+torch.distributed (gloo) only carries the rendezvous: the RCCL unique id, barriers, the sums of the report.
+value = (rays through the closest-hit kernel + rays through the any-hit kernel, all ranks) / wall time of the
+timed steps.
 
   python bench.py --gpus 1 --steps 10 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -16,13 +18,14 @@ import argparse
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
 def algorithmic_bytes_per_ray(n_tris):
@@ -31,10 +34,39 @@ def algorithmic_bytes_per_ray(n_tris):
     return 32 + 16 + 32 * levels + 4 * 48
 
 
+def host_cores():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands a 1-GPU job a share)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(math.ceil(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
+    except Exception:
+        return None
+
+
 def cpu_baseline(scene, row_stride, nthreads, repeats=3, gpu_fb=None, parity_out=None):
     """The CPU oracle (a port of the reference's Embree adapter path; Embree 2.x itself is not in the tree) timed on a
-    bounded sample of the same frame: every row_stride-th scanline of the 1080p camera (default: the whole frame), on the
-    host cores, best of `repeats` passes."""
+    bounded sample of the same frame: every row_stride-th scanline of the 1080p camera (default: the whole frame) on all
+    host cores, best of `repeats` passes; and every 16*row_stride-th scanline on ONE thread."""
     import numpy as np
 
     from oracle import orc
@@ -43,17 +75,21 @@ def cpu_baseline(scene, row_stride, nthreads, repeats=3, gpu_fb=None, parity_out
     m = scene.meshes[0]
     om = orc.Mesh(m.verts, m.tris, mesh_mat=m.material)  # BVH build excluded, like on the GPU side
     rays = orc.camera_rays(cam.eye, cam.focus, cam.up, cam.fov, cam.width, cam.height)
-    rows = np.arange(0, cam.height, row_stride)
-    sel = (rows[:, None] * cam.width + np.arange(cam.width)[None, :]).reshape(-1)
-    sample = rays[sel].copy()
-    nxt, tt = orc.toplevel_intersect(scene.inst_lo, scene.inst_hi, [0], sample)
-    hit = nxt >= 0
-    s2 = sample[hit].copy()
-    s2["origin"] += s2["direction"] * (tt[hit] * np.float32(0.95))[:, None]
-    dt = None
-    moved = None
+
+    def sample(stride):
+        rows = np.arange(0, cam.height, stride)
+        sel = (rows[:, None] * cam.width + np.arange(cam.width)[None, :]).reshape(-1)
+        s = rays[sel].copy()
+        nxt, tt = orc.toplevel_intersect(scene.inst_lo, scene.inst_hi, [0], s)
+        hit = nxt >= 0
+        s2 = s[hit].copy()
+        s2["origin"] += s2["direction"] * (tt[hit] * np.float32(0.95))[:, None]
+        return s2
+
+    s_all = sample(row_stride)
+    dt, moved = None, None
     for _ in range(repeats):
-        rays_in = s2.copy()
+        rays_in = s_all.copy()
         t0 = time.perf_counter()
         moved = om.trace(rays_in, scene.m[0], scene.minv[0], scene.normi[0], scene.lights, 0, 0, nthreads)
         d = time.perf_counter() - t0
@@ -70,25 +106,78 @@ def cpu_baseline(scene, row_stride, nthreads, repeats=3, gpu_fb=None, parity_out
         parity_out["parity"] = {"checked": "whole %dx%d frame of the timed loop vs the CPU oracle" % (cam.width, cam.height),
                                 "lit_pixels": int((ref[:, 3] > 0).sum()), "max_abs_diff": float(np.abs(got - ref).max()),
                                 "bit_exact": bool(np.array_equal(got, ref))}
+    s_one = sample(16 * row_stride)
+    t0 = time.perf_counter()
+    om.trace(s_one.copy(), scene.m[0], scene.minv[0], scene.normi[0], scene.lights, 0, 0, 1)
+    dt1 = time.perf_counter() - t0
+    c1, a1 = orc.trace_counts()
     return {"value": (c + a) / dt / 1e6, "unit": "Mrays/s", "cores": nthreads, "kind": "port",
-            "sample": "scanlines 0,%d,.. of the %dx%d frame: %d primary + %d shadow rays in %.3f s wall on %d threads (best of %d; "
-                      "%.0f core-seconds per pass), BVH build excluded; CPU oracle = port of the Embree adapter path (Embree 2.x not in the tree)"
-                      % (row_stride, cam.width, cam.height, c, a, dt, nthreads, repeats, dt * nthreads)}
+            "value_1_thread": (c1 + a1) / dt1 / 1e6, "cpu_model": cpu_model(),
+            "sample": "scanlines 0,%d,.. of the %dx%d frame: %d primary + %d shadow rays in %.3f s wall on %d pinned threads (best of %d); "
+                      "1 thread: scanlines 0,%d,..: %d rays in %.3f s; BVH build excluded; CPU oracle = port of the Embree adapter path "
+                      "(Embree 2.x not in the tree)" % (row_stride, cam.width, cam.height, c, a, dt, nthreads, repeats, 16 * row_stride, c1 + a1, dt1)}
+
+
+def measured_stream_peak(torch, dev):
+    """HBM rate of a plain device-to-device copy of 1 GiB (read + write), best of 5: the achievable peak beside the 8 TB/s spec."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 2.0 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return best
+
+
+def abi_path(scene, tracer, capi, np):
+    """The literal drop-in path: Adapter::trace on a HOST RayVector (gvt_hip_trace: 80-byte rays in over PCIe, moved rays + the
+    updated rayList back), timed on the frame's primary rays."""
+    B = tracer.backend
+    B.begin_frame()
+    B.generate_and_filter(None)  # the frame's primary rays as the scheduler hands them to the adapter (device camera + FilterRaysLocally)
+    s2 = B.queues[0].to_numpy()
+    B.begin_frame()
+    ad = B.adapter(0)
+    best, n_out = None, 0
+    for _ in range(4):
+        r = s2.copy()
+        t0 = time.perf_counter()
+        out = ad.trace(r, scene.m[0], scene.minv[0], scene.normi[0], scene.lights)
+        d = time.perf_counter() - t0
+        best = d if best is None else min(best, d)
+        n_out = len(out)
+    n_traced = len(s2) + n_out  # depth 1, light at the eye: every shadow ray survives (31 of 1 M are occluded)
+    bytes_pcie = 80 * (2 * len(s2) + n_out)
+    return {"Mrays/s": n_traced / best / 1e6, "ms": best * 1e3, "rays_in": int(len(s2)), "rays_out": int(n_out),
+            "pcie_GB/s": bytes_pcie / best / 1e9,
+            "note": "gvt_hip_trace on host rays (pageable numpy buffers), best of 4: H2D of the 80-byte rays, trace, D2H of the updated "
+                    "rayList and of moved_rays; never `value`"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--tris", type=int, default=10_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--domains", type=int, default=0, help="N=1 only: cut the soup into this many domains and use the Domain scheduler")
-    ap.add_argument("--full-reduce", action="store_true", help="N>1: composite by a sum-reduce of whole frames instead of each rank's written rectangle")
-    ap.add_argument("--bsp", action="store_true", help="N>1: bulk-synchronous exchange rounds instead of the overlapped exchange")
+    ap.add_argument("--domains", type=int, default=0, help="N=1 only: cut the soup into this many domains (one rank owns them all)")
+    ap.add_argument("--bsp", action="store_true", help="N>1: trace until dry before every exchange (Tracer<DomainScheduler>) instead of asynchronous ticks")
+    ap.add_argument("--harness", choices=["native", "python", "checker"], default="native",
+                    help="native: gvt_hip_tracer (the product path).  python: the Python scheduler loops over the same C ABI (test harness).  "
+                         "checker: the Python loops over the CPU checker backend -- no GPU, rehearses this script's N>1 plumbing under gloo")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (gvt_hip_set_option), for experiments")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-abi-path", action="store_true")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
     args = ap.parse_args()
 
@@ -104,90 +193,115 @@ def main():
         sys.exit(2)
     import torch.distributed as dist
 
-    if not torch.cuda.is_available():
+    on_gpu = args.harness != "checker"
+    if on_gpu and not torch.cuda.is_available():
         print("bench.py: no GPU visible; the adapter has no CPU path", file=sys.stderr)
         sys.exit(3)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # rendezvous only (unique id, barriers, the report's sums): the ray exchange is the library's own RCCL communicator.
+        # The python harness moves rays through torch.distributed instead: nccl (= RCCL) on GPUs, gloo on the CPU rehearsal.
+        dist.init_process_group("nccl" if args.harness == "python" else "gloo", rank=rank, world_size=world,
+                                **({"device_id": dev} if args.harness == "python" else {}))
 
-    from gravit_amd import capi, scenes
+    from gravit_amd import scenes
     from gravit_amd.layouts import NORMALS_FLAT
-    from gravit_amd.scheduler import DomainTracer, ImageTracer
 
-    capi.init(local_rank)
-    for o in args.opt:
-        k, v = o.split("=")
-        capi.set_option(k, int(v))
-    if world == 1:
-        capi.set_stream(torch.cuda.current_stream().cuda_stream)
-    # world > 1: the adapter keeps its own non-blocking stream, so that RCCL transfers posted on torch's side really run beside the
-    # traversal kernels; the scheduler synchronises explicitly where the two meet (DomainTracer._post_exchange / _complete_exchange)
+    capi = None
+    if on_gpu:
+        from gravit_amd import capi
+        from gravit_amd.scheduler import Comm, DomainTracer, ImageTracer, NativeTracer
 
-    if world == 1 and args.domains > 1:
-        scene = scenes.soup_domains_scene(args.tris, args.domains, args.width, args.height)
-        tracer = DomainTracer(scene, [0] * scene.n_inst, dist, torch, dev, NORMALS_FLAT)
-    elif world == 1:
-        scene = scenes.soup_scene(args.tris, args.width, args.height)
-        tracer = ImageTracer(scene, NORMALS_FLAT)
+        capi.init(local_rank)
+        for o in args.opt:
+            k, v = o.split("=")
+            capi.set_option(k, int(v))
     else:
-        scene = scenes.soup_domains_scene(args.tris, world, args.width, args.height)
-        owner = [i % world for i in range(scene.n_inst)]
-        tracer = DomainTracer(scene, owner, dist, torch, dev, NORMALS_FLAT, overlap=not args.bsp)
-    build_ms = sum(a.info()["build_ms"] for a in tracer.backend.adapter_cache.values())
+        from gravit_amd.scheduler import DomainTracer, ImageTracer
+        from tests.oracle_backend import OracleBackend
+
+    n_dom = world if world > 1 else max(1, args.domains)
+    scene = scenes.soup_scene(args.tris, args.width, args.height) if n_dom == 1 else scenes.soup_domains_scene(args.tris, n_dom, args.width, args.height)
+    owner = [i % world for i in range(scene.n_inst)]
+    comm = None
+    if args.harness == "native":
+        if world > 1:
+            uid = [Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = Comm.rccl(uid[0], rank, world)
+        tracer = NativeTracer(scene, NORMALS_FLAT, owner, comm)
+        frame_stats = lambda: tracer.stats  # noqa: E731
+    else:
+        backend = None if on_gpu else OracleBackend(scene, NORMALS_FLAT, [o == rank for o in owner])
+        if world == 1 and n_dom == 1:
+            tracer = ImageTracer(scene, NORMALS_FLAT, backend=backend)
+        else:
+            tracer = DomainTracer(scene, owner, dist, torch, dev, NORMALS_FLAT, backend=backend, overlap=not args.bsp)
+        frame_stats = lambda: {}  # noqa: E731
+    build_ms = sum(a.info()["build_ms"] for a in tracer.backend.adapter_cache.values()) if on_gpu else 0.0
+
+    def device_sync():
+        if on_gpu:
+            capi.synchronize()
+            torch.cuda.synchronize()
 
     def barrier():
-        torch.cuda.synchronize()
+        device_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     def frame():
-        tracer()
-        if world > 1:
-            tracer.composite(download=False, rows_only=not args.full_reduce)  # IceTComposite::composite is part of the frame, the PPM download is not
+        if args.harness == "native":
+            tracer(bsp=args.bsp)  # includes IceTComposite::composite (the reduce to rank 0); the PPM download is not part of the frame
+        else:
+            tracer()
+            if world > 1:
+                tracer.composite(download=False)
 
     for _ in range(args.warmup):
         frame()
     barrier()
-    capi.stats_reset()
-    capi.profile(True)  # HIP events around every kernel, on the launch stream
+    if on_gpu:
+        capi.stats_reset()
+        capi.profile(True)  # HIP events around every kernel, on the launch stream
+    else:
+        tracer.backend.rays_closest = tracer.backend.rays_any = 0
+    per_frame, sums = [], {"rays_closest": 0, "rays_any": 0, "rays_sent": 0, "rounds": 0, "chains": 0, "host_syncs": 0}
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        f0 = time.perf_counter()
         frame()
-    capi.synchronize()
+        per_frame.append(time.perf_counter() - f0)  # a frame ends with a host synchronisation (the last round's report / the composite)
+        for k, v in frame_stats().items():
+            sums[k] += v
     barrier()
     t1 = time.perf_counter()
-    st = capi.stats()
-    capi.profile(False)
+    st = capi.stats() if on_gpu else {}
+    if on_gpu:
+        capi.profile(False)
+    if args.harness != "native":  # the harness counts through the library's own counters (or the checker's)
+        sums["rays_closest"] = st.get("rays_closest", getattr(tracer.backend, "rays_closest", 0))
+        sums["rays_any"] = st.get("rays_any", getattr(tracer.backend, "rays_any", 0))
+        sums["rays_sent"] = getattr(tracer, "rays_sent", 0) * args.steps
 
     elapsed = t1 - t0
-    tot = torch.tensor([float(st["rays_closest"]), float(st["rays_any"]), elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(sums["rays_closest"]), float(sums["rays_any"]), float(sums["rays_sent"]), elapsed], dtype=torch.float64)
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        elapsed = float(mx[2].item())
-    rays_closest, rays_any = float(tot[0].item()), float(tot[1].item())
+        elapsed = float(mx[3].item())
+    rays_closest, rays_any, rays_sent = float(tot[0].item()), float(tot[1].item()), float(tot[2].item())
     rays_total = rays_closest + rays_any
 
     if rank == 0:
+        gpu_fb = tracer.backend.framebuffer(False) if (on_gpu and world == 1 and n_dom == 1) else None  # before the extra legs reuse the backend
         n_tris_local = max(m.tris.shape[0] for m in scene.meshes)
         b_ray = algorithmic_bytes_per_ray(n_tris_local)
-        dom = "closest" if st["ms_closest"] >= st["ms_any"] else "any"
-        ms_dom = st["ms_%s" % dom]
-        n_launch = max(1, st["launches_%s" % dom])
-        rays_dom = st["rays_%s" % dom]
-        achieved = (rays_dom * b_ray / n_launch) / (ms_dom / n_launch / 1e3) / 1e9 if ms_dom > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch, committed with its provenance
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get("k_%s_bytes_per_launch" % dom)
-            except Exception:
-                traffic = None
         out = {
             "metric": "Mrays/s (primary+shadow) at 1080p, 10M-tri scene",
             "value": rays_total / elapsed / 1e6,
@@ -196,6 +310,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_median": float(np.median(per_frame)) * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -205,23 +320,66 @@ def main():
                 "workload": "soup-%d: %d random triangles (Philox seed 12345, half-extent 0.005), %dx%d, eye (.5,.5,3)->(.5,.5,.5), "
                             "fov 30deg, 1 point light at the eye, depth 1 (primary + 1 shadow ray), AO off"
                             % (args.tris, args.tris, args.width, args.height),
-                "scheduler": ("image (1 domain)" if args.domains <= 1 else "domain (%d spatial domains on 1 GPU)" % args.domains) if world == 1 else "domain (%d spatial domains, 1 per GPU, RCCL p2p ray exchange)" % world,
+                "scheduler": ("image, 1 domain" if n_dom == 1 else "domain, %d spatial domains on 1 GPU" % n_dom) if world == 1
+                             else "domain, %d spatial domains, 1 per GPU, %s, ray exchange = RCCL p2p issued by libgvt_hip.so"
+                                  % (world, "BSP rounds" if args.bsp else "asynchronous ticks"),
+                "harness": args.harness,
                 "rays_per_step": rays_total / args.steps,
                 "primary_traced_per_step": rays_closest / args.steps,
                 "shadow_traced_per_step": rays_any / args.steps,
-                "bvh_build_ms": build_ms,
+                "rays_sent_per_step": rays_sent / args.steps,
+                "rounds_per_step": sums["rounds"] / args.steps, "launch_chains_per_step": sums["chains"] / args.steps,
+                "host_syncs_per_step": sums["host_syncs"] / args.steps,
+                "bvh_build_ms": build_ms, "bvh_build_Mtris_per_s": (sum(m.tris.shape[0] for m in scene.meshes) / world / (build_ms * 1e-3) / 1e6) if build_ms else None,
                 "normal_mode": "flat",
             },
-            "roofline": {
-                "bound": "hbm", "kernel": "k_%s" % dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        }
+        if on_gpu:
+            dom = "closest" if st["ms_closest"] >= st["ms_any"] else "any"
+            ms_dom = st["ms_%s" % dom]
+            n_launch = max(1, st["launches_%s" % dom])
+            rays_dom = {"closest": sums["rays_closest"], "any": sums["rays_any"]}[dom]  # this rank's
+            achieved = (rays_dom * b_ray / n_launch) / (ms_dom / n_launch / 1e3) / 1e9 if ms_dom > 0 else 0.0
+            merged = args.harness == "native"
+            symbol = ("k_trace<%s, true, %d, false, true, %s>" % ("false" if dom == "closest" else "true", 0 if dom == "closest" else 1, "true" if merged else "false"))
+            traffic, traffic_src = None, None
+            tf = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch, committed with its provenance
+            if os.path.exists(tf):
+                try:
+                    tj = json.load(open(tf))
+                    traffic = tj.get("k_%s_bytes_per_launch" % dom)
+                    traffic_src = {"file": "profiles/traffic.json", "tag": tj.get("tag"), "profiled_commit": tj.get("commit"), "kernel": tj.get("k_%s_kernel" % dom)}
+                except Exception:
+                    traffic = None
+            peak_meas = measured_stream_peak(torch, dev)
+            out["roofline"] = {
+                "bound": "hbm", "kernel": symbol, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "peak_measured_copy": peak_meas, "frac_of_measured_copy": achieved / peak_meas if peak_meas else None,
                 "algorithmic_bytes_per_ray": b_ray, "rays_per_launch": rays_dom / n_launch, "avg_launch_ms": ms_dom / n_launch,
                 "kernel_ms": {k: st[k] for k in ("ms_closest", "ms_any", "ms_shade", "ms_shuffle", "ms_camera", "ms_convert", "ms_sort", "ms_long")},
-            },
-        }
-        if world == 1 and args.domains <= 1 and not args.no_cpu_baseline:
+                "commit": git_head(),
+            }
+            if world == 1 and n_dom == 1:
+                try:  # mean visits per primary ray (diagnostic kernel over the binary LBVH; the traversal itself walks its 4-wide collapse)
+                    B = tracer.backend
+                    B.begin_frame()
+                    B.generate_and_filter(None)
+                    rr = B.queues[0].to_numpy()[::17]
+                    B.begin_frame()
+                    vs = B.adapter(0).visit_stats(rr["origin"], rr["direction"])
+                    out["roofline"]["visits_per_primary_ray"] = {"inner_nodes_binary": vs["inner_per_ray"], "leaves": vs["leaf_per_ray"],
+                                                                  "triangle_tests": vs["tri_tests_per_ray"], "sample_rays": int(len(rr))}
+                except Exception as e:
+                    out["roofline"]["visits_per_primary_ray"] = "failed: %r" % (e,)
+        if on_gpu and world == 1 and n_dom == 1 and not args.no_abi_path:
             try:
-                out["cpu_baseline"] = cpu_baseline(scene, args.cpu_row_stride, os.cpu_count() or 1, gpu_fb=tracer.backend.framebuffer(False), parity_out=out)
+                out["abi_path"] = abi_path(scene, tracer, capi, np)
+            except Exception as e:
+                out["abi_path"] = {"failed": repr(e)}
+        if on_gpu and world == 1 and n_dom == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(scene, args.cpu_row_stride, host_cores(), gpu_fb=gpu_fb, parity_out=out)
             except Exception as e:  # the checker is optional for the measurement itself
                 out["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))

@@ -292,6 +292,7 @@ class DomainTracer:
         self.scene = scene
         self.owner = list(owner)
         self.dist, self.torch, self.dev = dist, torch, comm_device
+        self.on_cuda = torch.device(comm_device).type == "cuda"
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.owned = [o == self.rank for o in self.owner]
@@ -327,7 +328,7 @@ class DomainTracer:
         n_inst = len(self.owner)
         for req in reqs:
             req.wait()
-        if self.dev != "cpu":
+        if self.on_cuda:
             self.torch.cuda.current_stream().synchronize()
         for p, buf in recv_bufs.items():  # unpack into queue[q] (:466-481)
             off = 0
@@ -417,7 +418,7 @@ class DomainTracer:
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
-            if self.dev != "cpu":
+            if self.on_cuda:
                 torch.cuda.current_stream().synchronize()
             for p, buf in recv_bufs.items():  # unpack into queue[q] (:466-481)
                 off = 0
@@ -472,7 +473,7 @@ class DomainTracer:
                 for p, buf in bufs.items():
                     y0, y1, x0, x1 = (int(v) for v in boxes[p])
                     img[y0:y1, x0:x1] += buf
-        if self.dev != "cpu":
+        if self.on_cuda:
             torch.cuda.current_stream().synchronize()
         if self.rank != 0 or not download:
             return None

@@ -9,12 +9,14 @@
  * Citations are relative to /root/reference/.
  */
 #define _GNU_SOURCE
+#define _GNU_SOURCE /* sched_getaffinity, pthread_setaffinity_np: the worker pool pins its threads */
 #include "gvt_oracle.h"
 #include "../include/gvt_math.h" /* acos / sinf / cosf of the bounce path: the definition shared with the device code */
 
 #include <float.h>
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -707,23 +709,61 @@ static void trace_range(trace_job *J) {
   }
 }
 
+/* Persistent worker pool.  Threads are created once and each is pinned to one CPU of the process's affinity mask: threads created
+ * per call were observed to share ONE core for the first ~second on this class of machine (the kernel's load balancer had not
+ * spread them yet), which made a first multi-threaded call run at single-thread speed. */
 typedef struct {
   trace_job *jobs;
   size_t nJobs;
-  size_t next;
+  size_t next;     /* next job to hand out */
+  size_t done;     /* jobs finished */
+  int limit;       /* workers allowed to take part in the current batch */
+  uint64_t batch;  /* generation counter */
+} trace_batch;
+static struct {
   pthread_mutex_t mu;
-} trace_pool;
+  pthread_cond_t work, idle;
+  pthread_t th[1024];
+  int n;
+  trace_batch b;
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, { 0 }, 0, { 0 } };
 
-static void *trace_worker(void *arg) {
-  trace_pool *P = arg;
+static void *pool_worker(void *arg) {
+  const int me = (int)(intptr_t)arg;
+  pthread_mutex_lock(&g_pool.mu);
   for (;;) {
-    pthread_mutex_lock(&P->mu);
-    size_t j = P->next++;
-    pthread_mutex_unlock(&P->mu);
-    if (j >= P->nJobs) break;
-    trace_range(&P->jobs[j]);
+    while (!(me < g_pool.b.limit && g_pool.b.next < g_pool.b.nJobs)) pthread_cond_wait(&g_pool.work, &g_pool.mu);
+    const size_t j = g_pool.b.next++;
+    trace_job *J = &g_pool.b.jobs[j];
+    pthread_mutex_unlock(&g_pool.mu);
+    trace_range(J);
+    pthread_mutex_lock(&g_pool.mu);
+    if (++g_pool.b.done == g_pool.b.nJobs) pthread_cond_signal(&g_pool.idle);
   }
   return NULL;
+}
+static void pool_run(trace_job *jobs, size_t nJobs, int nthreads) {
+  if (nthreads > 1024) nthreads = 1024;
+  pthread_mutex_lock(&g_pool.mu);
+  if (g_pool.n < nthreads) {
+    cpu_set_t allowed;
+    int ncpu = 0, cpus[1024];
+    if (sched_getaffinity(0, sizeof allowed, &allowed) == 0)
+      for (int c = 0; c < CPU_SETSIZE && ncpu < 1024; c++) if (CPU_ISSET(c, &allowed)) cpus[ncpu++] = c;
+    while (g_pool.n < nthreads) {
+      const int k = g_pool.n;
+      if (pthread_create(&g_pool.th[k], NULL, pool_worker, (void *)(intptr_t)k) != 0) break;
+      if (ncpu > 0) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpus[k % ncpu], &one); pthread_setaffinity_np(g_pool.th[k], sizeof one, &one); }
+      pthread_detach(g_pool.th[k]);
+      g_pool.n++;
+    }
+  }
+  g_pool.b.jobs = jobs; g_pool.b.nJobs = nJobs; g_pool.b.next = 0; g_pool.b.done = 0; g_pool.b.limit = nthreads < g_pool.n ? nthreads : g_pool.n;
+  g_pool.b.batch++;
+  pthread_cond_broadcast(&g_pool.work);
+  while (g_pool.b.done < nJobs) pthread_cond_wait(&g_pool.idle, &g_pool.mu);
+  g_pool.b.nJobs = 0; g_pool.b.limit = 0;
+  pthread_mutex_unlock(&g_pool.mu);
 }
 
 static uint64_t g_last_closest, g_last_any;
@@ -745,14 +785,10 @@ static void trace_to_vec(const orc_mesh *M, orc_ray *rays, size_t begin, size_t 
     J->m = m; J->minv = minv; J->normi = normi; J->lights = lights; J->nLights = nLights;
     J->normal_mode = normal_mode; J->seed = seed; J->carried_rng = carried_rng;
   }
-  trace_pool P = { jobs, nJobs, 0, PTHREAD_MUTEX_INITIALIZER };
   if (nthreads == 1 || nJobs <= 1) {
-    trace_worker(&P);
+    for (size_t j = 0; j < nJobs; j++) trace_range(&jobs[j]);
   } else {
-    pthread_t *th = malloc(sizeof(pthread_t) * (size_t)nthreads);
-    for (int i = 0; i < nthreads; i++) pthread_create(&th[i], NULL, trace_worker, &P);
-    for (int i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
-    free(th);
+    pool_run(jobs, nJobs, nthreads);
   }
   g_last_closest = g_last_any = 0;
   for (size_t j = 0; j < nJobs; j++) { /* chunk order: deterministic output order */

@@ -34,6 +34,7 @@ class OracleBackend:
         cam = scene.camera
         self.fb = np.zeros((cam.height * cam.width, 4), np.float32)
         self.calls = 0
+        self.rays_closest = self.rays_any = 0
         self._fbt = None
 
     def begin_frame(self):
@@ -69,6 +70,9 @@ class OracleBackend:
         s = self.scene
         rays = np.ascontiguousarray(self.queues[inst])
         moved = self.meshes[s.inst_mesh[inst]].trace(rays, s.m[inst], s.minv[inst], s.normi[inst], s.lights, self.normal_mode, self.calls, 2)
+        c, a = orc.trace_counts()
+        self.rays_closest += c
+        self.rays_any += a
         self.calls += 1
         self.queues[inst] = np.zeros(0, orc.RAY_DTYPE)
         self._shuffle(moved, inst, None)

@@ -12,6 +12,7 @@ import torch.multiprocessing as mp
 
 from gravit_amd import scenes
 from gravit_amd.scheduler import DomainTracer, ImageTracer
+from tests.conftest import ROOT
 from tests.helpers import oracle_render, oracle_render_domain
 from tests.oracle_backend import OracleBackend
 
@@ -101,3 +102,28 @@ def test_single_rank_domain_tracer_needs_no_process_group():
     tr()
     ref_fb, _ = oracle_render(sc, 1)
     assert np.array_equal(tr.composite()[..., :3], ref_fb[..., :3])
+
+
+def test_bench_script_multi_rank_branch_under_gloo(tmp_path):
+    """bench.py's N > 1 branch end to end (rendezvous, scene cut into one domain per rank, owner map, the timed loop, the reductions of
+    the report, the JSON line) with --harness checker: world 2 over gloo on CPU, toy size.  A Python-level bug in that plumbing must not
+    be what the first multi-GPU run finds; the native loop itself is covered on the device (tests/test_gpu_native.py)."""
+    import json
+    import subprocess
+    import sys
+
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", OMP_NUM_THREADS="1")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--harness", "checker", "--tris", "20000",
+                                       "--width", "96", "--height", "54", "--steps", "2", "--warmup", "1"],
+                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][1][-2000:] + outs[1][1][-2000:]
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "strong" and j["value"] > 0
+    assert j["config"]["primary_traced_per_step"] > 1000 and j["config"]["shadow_traced_per_step"] > 100
+    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")], "only rank 0 prints the line"
