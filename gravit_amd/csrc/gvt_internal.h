@@ -33,6 +33,9 @@ struct Knobs {
   int sort_bits = 20;    // radix-sorted key width (8 bits per rocPRIM pass)
   int long_steps = 96;   // closest hit: a ray that exceeds this many 4-wide node steps is parked and finished by a whole wave (0: off)
   int long_min_rays = 65536; // ... only in launches of at least this many rays (small launches have no tail to speak of)
+  int fused = 0;         // scheduler rounds: closest hit + shade + first-light shadow rays in one kernel (k_fused) instead of three launches.
+                         // Measured 2.4x SLOWER than the three launches: shading inside the persistent kernel is latency-exposed
+  int shadow_direct = 1; // scheduler rounds: shadow rays in direct-mapped slots (the order of the traced list) instead of block-arrival order
   int term_sink = 1;     // gvt_hip_trace_queue_sink: deposit terminal shadow rays from the any-hit kernel (0: always through moved_rays)
   int camera_tile = 8;   // gvt_hip_image_frame: camera rays listed in 8x8-pixel tiles (0: pixel-major like generateRays)
   int top_ordered = 1;   // shuffle: order-preserving, deterministic slots (<= 64 destinations) instead of arrival-order atomics

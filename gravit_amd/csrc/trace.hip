@@ -262,8 +262,9 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
 // MS.W.insts[instance].  out_from receives the source instance of every survivor appended to `out`.
 struct MultiSrc {
   WaveSet W;
-  const int *ray_inst;
+  const int *ray_inst;          // any hit: instance per ray of q; < 0 = an empty slot of a direct-mapped shadow list (skipped)
   int *out_from;
+  unsigned long long *tot_any;  // any hit over a direct-mapped list: the rays actually traced are added here (one atomic per wave)
 };
 template <bool ANY, bool XFORM, int MODE, bool COOP, bool W4, bool MULTI = false>
 __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, Trav T, float tnear,
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
   const float4 *tris_l = T.tris;
   int inst_l = 0;
   unsigned gidx = 0;                // MULTI closest: virtual index of the lane's ray
+  unsigned n_started = 0;           // MULTI any hit: rays this wave really traced (wave-uniform)
 #if GVT_STAMP
   unsigned long long st_refill = 0, st_inner = 0, st_leaf = 0, st_retire = 0, n_inner_it = 0, n_outer_it = 0, t_mark = 0, t_begin = __builtin_amdgcn_s_memtime();
   unsigned long long t_exh = 0, it_exh = 0, out_exh = 0, act_exh = 0;
@@ -353,36 +355,46 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
         }
         const unsigned take = min(c_end - c_next, (unsigned)nidle);
         const unsigned rank = lanes_below(idle);
+        bool start = false;
         if (!active && rank < take) {
           j = c_next + rank;
           const unsigned i = idx ? idx[j] : j;
           float4 a, b;
+          start = true;
           if (MULTI) {
-            if (ANY) { a = q.p0[i]; b = q.p1[i]; inst_l = MS.ray_inst[i]; }
-            else {
+            if (ANY) {
+              inst_l = MS.ray_inst[i];
+              start = inst_l >= 0; // direct-mapped shadow list: a slot whose primary emitted nothing
+              if (start) { a = q.p0[i]; b = q.p1[i]; }
+            } else {
               const WaveSeg sg = MS.W.segs[wave_find_seg(MS.W, i)];
               const unsigned local = i - sg.begin;
               a = sg.planes[local]; b = sg.planes[sg.cap + local];
               inst_l = sg.inst; gidx = i;
             }
-            const WaveInst *wi = MS.W.insts + inst_l;
-            nodes4_l = wi->nodes4; tris_l = wi->tris;
-            O = xfm_point(wi->minv, mk3(a.x, a.y, a.z)); D = xfm_vector(wi->minv, mk3(b.x, b.y, b.z));
+            if (start) {
+              const WaveInst *wi = MS.W.insts + inst_l;
+              nodes4_l = wi->nodes4; tris_l = wi->tris;
+              O = xfm_point(wi->minv, mk3(a.x, a.y, a.z)); D = xfm_vector(wi->minv, mk3(b.x, b.y, b.z));
+            }
           } else {
             a = q.p0[i]; b = q.p1[i];
             O = mk3(a.x, a.y, a.z); D = mk3(b.x, b.y, b.z);
             if (XFORM) { O = xfm_point(minv, O); D = xfm_vector(minv, D); }
           }
-          const float dx = fabsf(D.x) < 1e-30f ? copysignf(1e-30f, D.x) : D.x;
-          const float dy = fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y;
-          const float dz = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;
-          ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
-          ox = O.x * ix; oy = O.y * iy; oz = O.z * iz;
-          bt = GVT_FLT_MAX; bu = 0.f; bv = 0.f; bden = 1.f; bp = -1;
-          sp = 0; sb = 0; donor_lane = -1; nsteps = 0; parked = false;
-          cur = (MULTI ? (nodes4_l != nullptr) : (T.nodes != nullptr)) ? 0 : TRAV_DONE;
-          active = true;
+          if (start) {
+            const float dx = fabsf(D.x) < 1e-30f ? copysignf(1e-30f, D.x) : D.x;
+            const float dy = fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y;
+            const float dz = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;
+            ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
+            ox = O.x * ix; oy = O.y * iy; oz = O.z * iz;
+            bt = GVT_FLT_MAX; bu = 0.f; bv = 0.f; bden = 1.f; bp = -1;
+            sp = 0; sb = 0; donor_lane = -1; nsteps = 0; parked = false;
+            cur = (MULTI ? (nodes4_l != nullptr) : (T.nodes != nullptr)) ? 0 : TRAV_DONE;
+            active = true;
+          }
         }
+        if (MULTI && ANY) n_started += (unsigned)__popcll(__ballot(start));
         c_next += take;
         idle = __ballot(!active);
         nidle = __popcll(idle);
@@ -641,6 +653,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
     if (t_exh) { atomicAdd(&g_stamp[8], (unsigned long long)__builtin_amdgcn_s_memtime() - t_exh); atomicAdd(&g_stamp[9], n_inner_it - it_exh); atomicAdd(&g_stamp[10], n_outer_it - out_exh); atomicAdd(&g_stamp[11], act_exh); atomicMax(&g_stamp[12], (unsigned long long)__builtin_amdgcn_s_memtime() - t_exh); atomicMax(&g_stamp[13], n_inner_it - it_exh); } }
 #endif
   if (ANY && MODE == 1) { if (n_pend) flush_pending(pend, n_pend, q, out, out_count, sink, MULTI ? MS.ray_inst : nullptr, MULTI ? MS.out_from : nullptr); }
+  if (MULTI && ANY && MS.tot_any && n_started && lane_id() == 0) atomicAdd(MS.tot_any, (unsigned long long)n_started);
   if (overflow) atomicOr(counter + TRAV_OVF_WORD, 1u);
 #undef KT_PUSH
 #undef KT_POP
@@ -962,6 +975,12 @@ __device__ inline bool shade(const MatEval &m, const RayRec &ray, V3 N, const gv
   return true;
 }
 
+// out-of-line copies for k_fused: the shading code runs once per ray, the traversal loop thousands of times -- keeping it a call
+// keeps its registers out of the loop's allocation
+__device__ __attribute__((noinline)) bool shade_call(const MatEval &m, const RayRec &ray, V3 N, const gvt_hip_light &L, V3 lightPos, V3 &out) {
+  return shade(m, ray, N, L, lightPos, out);
+}
+
 // CosWeightedRandomHemisphereDirection2 (EmbreeMeshAdapter.cpp:289-318)
 __device__ inline V3 cos_weighted_dir(V3 n, uint32_t &seed) {
   float Xi1 = gvt_fastrand01(seed);
@@ -1005,6 +1024,8 @@ struct ShadeArgs {
   WaveSet W;
   int *out_from;           // source instance of every ray appended to `out`
   int *shadow_inst;        // instance of every ray appended to `shadow`
+  unsigned shadow_stride;  // != 0: the shadow list is direct-mapped -- light li's ray of thread j at slot li * stride + j, in the order of the
+                           // traced list (its tile coherence kept for the any-hit launch, no slot atomics); shadow_inst < 0 marks empty slots
 };
 
 #define SHADE_BLOCK 512
@@ -1116,8 +1137,16 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M1)
         s.rng = 0u;
       }
     }
-    const unsigned slot = block_alloc(A.shadow_count, emit, &sh_alloc[2 * (2 + li)]);
-    if (emit) { store_ray(A.shadow, slot, s); if (MULTI) A.shadow_inst[slot] = inst; }
+    if (MULTI && A.shadow_stride) {
+      if (j < A.shadow_stride) {
+        const unsigned slot = (unsigned)li * A.shadow_stride + j;
+        A.shadow_inst[slot] = emit ? inst : -1;
+        if (emit) store_ray(A.shadow, slot, s);
+      }
+    } else {
+      const unsigned slot = block_alloc(A.shadow_count, emit, &sh_alloc[2 * (2 + li)]);
+      if (emit) { store_ray(A.shadow, slot, s); if (MULTI) A.shadow_inst[slot] = inst; }
+    }
   }
   if (shaded) { // :584-602
     const int ndepth = r.depth - 1;
@@ -1142,6 +1171,386 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M1)
     const unsigned slot = block_alloc(A.next_count, bounce, &sh_alloc[2]);
     if (bounce) A.next_idx[slot] = gi;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_fused: closest hit -> shade -> shadow ray (any hit) of the first light -> terminal rule, in ONE persistent-wave kernel.
+//
+// k_trace / k_shade / k_trace<ANY> as three launches pay two drains (a launch of 1 M rays is only ~16 K wave-loads of work for
+// 4,096 resident waves: ~45 % of each traversal launch is its tail) plus a round trip of hit records and shadow rays through HBM.
+// Here a lane that finishes a closest-hit ray keeps the hit in registers; at the next refill point the lanes holding a hit are
+// shaded together (same code as k_shade: normal, material, Shade per light, shadow-ray generation, bounce) and each CONTINUES
+// with the shadow ray it just generated -- which starts where the primary ended, i.e. in nodes and triangles that are still in
+// L1 / L2 -- while lanes without one take the next ray of the list.  One tail instead of two; shadow work fills the primary drain.
+//   ray kinds per lane: 0 closest hit (PRIMARY / SECONDARY of the list), 1 shadow ray generated here (payload in registers),
+//                       2 SHADOW ray of the list (EmbreeMeshAdapter.cpp:486-488: dropped if it hits anything, else forwarded)
+//   outputs: `out` (+ out_from) moved rays that have another instance ahead (shuffleRays' terminal rule applied here: deposits go
+//            straight to the framebuffer); shadow rays of lights 1.. -> `shadow` list for a follow-up any-hit launch; bounced rays
+//            -> written back in place + `next` list for the next pass.
+// Rays to append are staged per wave in LDS and flushed 32+ at a time (one atomic on the queue counter per flush).
+// ------------------------------------------------------------------------------------------------
+#define FUSED_PEND 64 // rays staged per wave in LDS; flushed when a retirement would not fit and whenever 32 or more are staged
+#ifndef FUSED_STACK
+#define FUSED_STACK 20 // LDS stack levels per lane (deeper: per-thread global spill): 20 KiB + 18 KiB of staging per block -> 4 blocks per CU
+#endif
+__device__ inline void fused_flush(volatile unsigned *pend, int n_pend, const RayPlanes &out, unsigned *out_count, int *__restrict__ out_from) {
+  unsigned base = 0;
+  if (lane_id() == 0) base = atomicAdd(out_count, (unsigned)n_pend);
+  base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+  for (int k = (int)lane_id(); k < n_pend; k += 64) {
+    const unsigned s = base + (unsigned)k;
+    out.p0[s] = make_float4(__uint_as_float(pend[0 * FUSED_PEND + k]), __uint_as_float(pend[1 * FUSED_PEND + k]), __uint_as_float(pend[2 * FUSED_PEND + k]), __uint_as_float(pend[3 * FUSED_PEND + k]));
+    out.p1[s] = make_float4(__uint_as_float(pend[4 * FUSED_PEND + k]), __uint_as_float(pend[5 * FUSED_PEND + k]), __uint_as_float(pend[6 * FUSED_PEND + k]), __uint_as_float(pend[7 * FUSED_PEND + k]));
+    out.p2[s] = make_float4(__uint_as_float(pend[8 * FUSED_PEND + k]), __uint_as_float(pend[9 * FUSED_PEND + k]), __uint_as_float(pend[10 * FUSED_PEND + k]), __uint_as_float(pend[11 * FUSED_PEND + k]));
+    out.p3[s] = make_float4(__uint_as_float(pend[12 * FUSED_PEND + k]), __uint_as_float(pend[13 * FUSED_PEND + k]), __uint_as_float(pend[14 * FUSED_PEND + k]), __uint_as_float(pend[15 * FUSED_PEND + k]));
+    if (out.p4) out.p4[s] = pend[16 * FUSED_PEND + k];
+    if (out_from) out_from[s] = (int)pend[17 * FUSED_PEND + k];
+  }
+}
+struct FusedArgs {
+  WaveSet W;
+  const unsigned *idx;       // bounce list of the previous pass or null
+  unsigned n;
+  const unsigned *n_dev;
+  const gvt_hip_light *lights;
+  int n_lights, normal_mode, first_pass;
+  uint32_t seed;
+  RayPlanes out; unsigned *out_count; int *out_from;
+  RayPlanes shadow; unsigned *shadow_count; int *shadow_inst;
+  unsigned *next_idx; unsigned *next_count;
+  TermSink sink;             // required: blo/bhi/n_inst/fb
+  unsigned *counter;         // d_counters + 0
+  int *spill_base;
+  int refill_min, inner_min;
+  unsigned long long *tot;   // [0] closest, [1] any: this kernel adds the shadow rays it traces inline to tot[1]
+  float tnear;
+};
+#define FUSED_PEND_FIELDS 18
+
+__global__ __launch_bounds__(TRAV_BLOCK, 4) void k_fused(FusedArgs A) {
+  const unsigned n_waves_total = gridDim.x * (unsigned)(TRAV_BLOCK / 64);
+  const unsigned n = A.n_dev ? *A.n_dev : A.n;
+  const unsigned share_w = n / n_waves_total;
+  const unsigned chunk = max(64u, ((share_w * 3u / 8u) + 16u) & ~31u);
+  const unsigned dyn = max(64u, (share_w / 16u) & ~63u);
+  __shared__ int stack[FUSED_STACK * TRAV_BLOCK];
+  __shared__ unsigned pend_all[(TRAV_BLOCK / 64) * FUSED_PEND_FIELDS * FUSED_PEND];
+  int *lds = &stack[threadIdx.x];
+  int *spill = A.spill_base + (size_t)(blockIdx.x * TRAV_BLOCK + threadIdx.x) * TRAV_SPILL;
+  volatile unsigned *pend = &pend_all[(threadIdx.x >> 6) * FUSED_PEND_FIELDS * FUSED_PEND]; // pend[field * FUSED_PEND + slot]
+  bool overflow = false;
+#define KF_PUSH(REF)                                                                  \
+  {                                                                                   \
+    if (sp < FUSED_STACK) { lds[sp * TRAV_BLOCK] = (REF); sp++; }                     \
+    else if (sp - FUSED_STACK < TRAV_SPILL) { spill[sp - FUSED_STACK] = (REF); sp++; } \
+    else overflow = true;                                                             \
+  }
+#define KF_POP()                                                                      \
+  {                                                                                   \
+    if (sp == 0) cur = TRAV_DONE;                                                     \
+    else { sp--; if (sp < FUSED_STACK) cur = lds[sp * TRAV_BLOCK]; else cur = spill[sp - FUSED_STACK]; } \
+  }
+  int n_pend = 0;
+  unsigned c_next = 0, c_end = 0;
+  bool exhausted = false, first_chunk = true;
+  unsigned n_inline_shadow = 0; // wave-uniform
+  // lane state
+  bool active = false, pending = false;
+  int kind = 0;
+  unsigned gidx = 0;
+  V3 O = mk3(0, 0, 0), D = mk3(0, 0, 1);
+  float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0;
+  float bt = GVT_FLT_MAX, bu = 0.f, bv = 0.f, bden = 1.f;
+  int bp = -1, sp = 0, cur = TRAV_DONE;
+  const uint4 *nodes4_l = nullptr;
+  const float4 *tris_l = nullptr;
+  int inst_l = 0;
+  RayRec sr; // kind 1: the shadow ray this lane is tracing (world space)
+  sr.o = sr.d = sr.c = mk3(0, 0, 0); sr.t_min = sr.t_max = sr.t = sr.w = 0.f; sr.id = sr.depth = sr.type = 0; sr.rng = 0u;
+
+  // object-space ray -> traversal registers
+#define KF_START(OW, DW)                                                                                   \
+  {                                                                                                        \
+    const WaveInst *wi_ = A.W.insts + inst_l;                                                              \
+    nodes4_l = wi_->nodes4; tris_l = wi_->tris;                                                            \
+    O = xfm_point(wi_->minv, (OW)); D = xfm_vector(wi_->minv, (DW));                                        \
+    const float dx_ = fabsf(D.x) < 1e-30f ? copysignf(1e-30f, D.x) : D.x;                                  \
+    const float dy_ = fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y;                                  \
+    const float dz_ = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;                                  \
+    ix = 1.0f / dx_; iy = 1.0f / dy_; iz = 1.0f / dz_;                                                     \
+    ox = O.x * ix; oy = O.y * iy; oz = O.z * iz;                                                           \
+    bt = GVT_FLT_MAX; bu = 0.f; bv = 0.f; bden = 1.f; bp = -1; sp = 0;                                     \
+    cur = nodes4_l ? 0 : TRAV_DONE;                                                                        \
+    active = true;                                                                                         \
+  }
+  // stage one ray per lane with `want` for appending to `out`; flush when 32 or more are staged
+#define KF_STAGE(want, R, FROM)                                                                            \
+  {                                                                                                        \
+    const unsigned long long m_ = __ballot(want);                                                          \
+    if (m_) {                                                                                              \
+      if (n_pend + __popcll(m_) > FUSED_PEND) { fused_flush(pend, n_pend, A.out, A.out_count, A.out_from); n_pend = 0; } \
+      if (want) {                                                                                          \
+        const int s_ = n_pend + (int)lanes_below(m_);                                                      \
+        pend[0 * FUSED_PEND + s_] = __float_as_uint((R).o.x); pend[1 * FUSED_PEND + s_] = __float_as_uint((R).o.y);   \
+        pend[2 * FUSED_PEND + s_] = __float_as_uint((R).o.z); pend[3 * FUSED_PEND + s_] = __float_as_uint((R).t_min); \
+        pend[4 * FUSED_PEND + s_] = __float_as_uint((R).d.x); pend[5 * FUSED_PEND + s_] = __float_as_uint((R).d.y);   \
+        pend[6 * FUSED_PEND + s_] = __float_as_uint((R).d.z); pend[7 * FUSED_PEND + s_] = __float_as_uint((R).t_max); \
+        pend[8 * FUSED_PEND + s_] = __float_as_uint((R).c.x); pend[9 * FUSED_PEND + s_] = __float_as_uint((R).c.y);   \
+        pend[10 * FUSED_PEND + s_] = __float_as_uint((R).c.z); pend[11 * FUSED_PEND + s_] = __float_as_uint((R).t);   \
+        pend[12 * FUSED_PEND + s_] = (unsigned)(R).id; pend[13 * FUSED_PEND + s_] = (unsigned)(R).depth;              \
+        pend[14 * FUSED_PEND + s_] = __float_as_uint((R).w); pend[15 * FUSED_PEND + s_] = (unsigned)(R).type;          \
+        pend[16 * FUSED_PEND + s_] = (R).rng; pend[17 * FUSED_PEND + s_] = (unsigned)(FROM);                           \
+      }                                                                                                    \
+      n_pend += __popcll(m_);                                                                              \
+      if (n_pend >= 32) { fused_flush(pend, n_pend, A.out, A.out_count, A.out_from); n_pend = 0; }         \
+    }                                                                                                      \
+  }
+
+  for (;;) {
+    unsigned long long idle = __ballot(!active);
+    int nidle = __popcll(idle);
+    const unsigned long long pendm = __ballot(!active && pending);
+    if ((nidle >= A.refill_min || nidle == 64 || (exhausted && pendm)) && (!exhausted || pendm)) {
+      // ---- 1. lanes holding a closest hit: shade, emit, continue with the first light's shadow ray
+      if (pendm) {
+        RayRec fwd_dummy; (void)fwd_dummy;
+        bool emit0 = false, bounce = false;
+        RayRec r, s0;
+        RayPlanes in{};
+        unsigned local = 0;
+        V3 N = mk3(0, 0, 0);
+        uint32_t g_seed = 0;
+        const bool sh = !active && pending;
+        MatEval me;
+        if (sh) {
+          const WaveSeg sg = A.W.segs[wave_find_seg(A.W, gidx)];
+          in = make_planes(sg.planes, sg.cap);
+          local = gidx - sg.begin;
+          const WaveInst *wi = A.W.insts + inst_l;
+          const MeshView *M = &wi->mv;
+          me = mat_eval(M->mat);
+          r = load_ray(in, local);
+          g_seed = (A.first_pass && r.rng == 0u) ? ray_stream_seed(A.seed, gidx) : r.rng;
+          const float hu = bu / bden, hv = bv / bden;
+          float t = bt;
+          r.t = t;
+          const int ia = M->tris[3 * bp], ib = M->tris[3 * bp + 1], ic = M->tris[3 * bp + 2];
+          const V3 v0 = ld3(M->verts + 3 * ia), v1 = ld3(M->verts + 3 * ib), v2 = ld3(M->verts + 3 * ic);
+          const V3 negNg = cross3(sub3(v1, v0), sub3(v2, v0));
+          const V3 normalflat = norm3(mat3_mul(wi->normi, negNg));
+          if (A.normal_mode == GVT_HIP_NORMALS_SMOOTH) {
+            const V3 a = ld3(M->normals + 3 * ib), b = ld3(M->normals + 3 * ic), c = ld3(M->normals + 3 * ia);
+            const V3 mn = add3(add3(scl3(a, hu), scl3(b, hv)), scl3(c, 1.0f - hu - hv));
+            N = norm3(mat3_mul(wi->normi, mn));
+          } else {
+            N = normalflat;
+          }
+          if (dot3(neg3(r.d), normalflat) <= 0.f) N = neg3(N);
+          if (M->vcolors) {
+            const V3 c0 = ld3(M->vcolors + 3 * ia), c1 = ld3(M->vcolors + 3 * ib), c2 = ld3(M->vcolors + 3 * ic);
+            me.kd = add3(add3(scl3(c0, 1.f - hu - hv), scl3(c1, hu)), scl3(c2, hv));
+            me.type = 0; me.ks = mk3(.5f, .5f, .5f); me.alpha = 1.f;
+          } else if (M->face_mat && M->face_mat[bp] >= 0 && (unsigned)M->face_mat[bp] < M->n_mat) {
+            me = mat_eval(M->materials[M->face_mat[bp]]);
+          }
+          if (r.type == 2) { t = (t > 1) ? 1.f / t : t; r.w = r.w * t; }
+        }
+        for (int li = 0; li < A.n_lights; li++) { // generateShadowRays :320-358
+          bool emit = false;
+          RayRec s;
+          if (sh) {
+            const gvt_hip_light L = A.lights[li];
+            const V3 lightPos = (L.type == GVT_HIP_LIGHT_AREA) ? area_light_position(L, g_seed) : ld3(L.position);
+            V3 c;
+            if (shade_call(me, r, N, L, lightPos, c)) {
+              emit = true;
+              const float multiplier = 1.0f - GVT_RAY_EPSILON * 16;
+              const float t_shadow = multiplier * r.t;
+              const V3 origin = add3(r.o, scl3(r.d, t_shadow));
+              const V3 dir = sub3(lightPos, origin);
+              s.o = origin; s.t_min = GVT_RAY_EPSILON;
+              s.d = norm3(dir);
+              s.t_max = 3.0f;
+              s.c = c; s.t = r.t;
+              s.id = r.id; s.depth = r.depth; s.w = r.w; s.type = 1;
+              s.rng = 0u;
+            }
+          }
+          if (li == 0) { emit0 = emit; if (emit) s0 = s; }
+          else {
+            const unsigned slot = wave_alloc(A.shadow_count, emit);
+            if (emit) { store_ray(A.shadow, slot, s); A.shadow_inst[slot] = inst_l; }
+          }
+        }
+        if (sh) { // bounce :584-602
+          const int ndepth = r.depth - 1;
+          const float p = 1.f - gvt_fastrand01(g_seed);
+          if (ndepth > 0 && r.w > p) {
+            r.type = 2;
+            const float multiplier = 1.0f - 16.0f * GVT_FLT_EPSILON;
+            const float t_secondary = multiplier * r.t;
+            r.o = add3(r.o, scl3(r.d, t_secondary));
+            const V3 nd = cos_weighted_dir(N, g_seed);
+            r.d = nd;
+            r.w = r.w * dot3(nd, N);
+            r.depth = ndepth;
+            r.rng = g_seed;
+            store_ray(in, local, r);
+            bounce = true;
+          }
+        }
+        {
+          const unsigned slot = wave_alloc(A.next_count, bounce);
+          if (bounce) A.next_idx[slot] = gidx;
+        }
+        if (sh) {
+          pending = false;
+          if (emit0) { sr = s0; kind = 1; KF_START(sr.o, sr.d) }
+        }
+        n_inline_shadow += (unsigned)__popcll(__ballot(sh && emit0));
+        idle = __ballot(!active);
+        nidle = __popcll(idle);
+      }
+      // ---- 2. empty lanes take the next rays of the list
+      while (!exhausted && nidle > 0) {
+        if (c_next == c_end) {
+          unsigned base = 0, this_chunk = chunk;
+          if (first_chunk) {
+            first_chunk = false;
+            base = (blockIdx.x * (unsigned)(TRAV_BLOCK / 64) + (threadIdx.x >> 6)) * chunk;
+          } else {
+            if (lane_id() == 0) base = atomicAdd(A.counter, dyn);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + n_waves_total * chunk;
+            this_chunk = dyn;
+          }
+          if (base >= n) { exhausted = true; break; }
+          c_next = base;
+          c_end = min(base + this_chunk, n);
+        }
+        const unsigned take = min(c_end - c_next, (unsigned)nidle);
+        const unsigned rank = lanes_below(idle);
+        if (!active && rank < take) {
+          const unsigned j = c_next + rank;
+          gidx = A.idx ? A.idx[j] : j;
+          const WaveSeg sg = A.W.segs[wave_find_seg(A.W, gidx)];
+          const unsigned local = gidx - sg.begin;
+          const float4 a = sg.planes[local], b = sg.planes[sg.cap + local];
+          const int type = __float_as_int(sg.planes[3 * sg.cap + local].w);
+          inst_l = sg.inst;
+          kind = type == 1 ? 2 : 0;
+          KF_START(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z))
+        }
+        c_next += take;
+        idle = __ballot(!active);
+        nidle = __popcll(idle);
+      }
+    }
+    if (nidle == 64) {
+      if (exhausted && !__ballot(pending)) break;
+      if (!exhausted) continue; // (cannot happen: the refill above ran)
+    }
+    // ---- inner nodes
+    unsigned long long im = __ballot(active && cur >= 0);
+    while (im) {
+      if (active && cur >= 0) {
+        float tn[4];
+        int rr[4];
+        node4_test(nodes4_l + (size_t)GVT_NODE4_F4 * cur, ix, iy, iz, ox, oy, oz, kind ? GVT_FLT_MAX : bt, tn, rr);
+#define GVT_CE(A_, B_) { const bool sw_ = tn[B_] < tn[A_]; const float ta_ = sw_ ? tn[B_] : tn[A_], tb_ = sw_ ? tn[A_] : tn[B_]; \
+                         const int ra_ = sw_ ? rr[B_] : rr[A_], rb_ = sw_ ? rr[A_] : rr[B_]; tn[A_] = ta_; tn[B_] = tb_; rr[A_] = ra_; rr[B_] = rb_; }
+        GVT_CE(0, 1) GVT_CE(2, 3) GVT_CE(0, 2) GVT_CE(1, 3) GVT_CE(1, 2)
+#undef GVT_CE
+        int nxt = TRAV_DONE;
+        bool have = false;
+#pragma unroll
+        for (int c4 = 3; c4 >= 0; c4--) {
+          if (tn[c4] < GVT_FLT_MAX) {
+            if (have) KF_PUSH(nxt)
+            nxt = rr[c4]; have = true;
+          }
+        }
+        if (have) cur = nxt;
+        else KF_POP()
+      }
+      im = __ballot(active && cur >= 0);
+      if (__popcll(im) < A.inner_min) break;
+    }
+    // ---- leaves
+    {
+      const bool at_leaf = active && cur < 0 && cur != TRAV_DONE;
+      if (at_leaf) {
+        const unsigned code = (unsigned)~cur;
+        const unsigned first = code >> 3, ntri = code & 7u;
+        const float4 *ts = tris_l + 4 * (size_t)first;
+        bool occluded = false;
+        for (unsigned kb = 0; kb < ntri && !(kind && occluded); kb += 2) {
+          float4 s0[2], s1[2], s2[2];
+#pragma unroll
+          for (unsigned k = 0; k < 2; k++)
+            if (kb + k < ntri) { s0[k] = ts[4 * (kb + k)]; s1[k] = ts[4 * (kb + k) + 1]; s2[k] = ts[4 * (kb + k) + 2]; }
+#pragma unroll
+          for (unsigned k = 0; k < 2; k++) {
+            if (kb + k < ntri && !(kind && occluded)) {
+              const V3 e1 = mk3(s1[k].x, s1[k].y, s1[k].z), e2 = mk3(s2[k].x, s2[k].y, s2[k].z);
+              float TT, U, V, aden;
+              if (tri_test_raw(O, D, mk3(s0[k].x, s0[k].y, s0[k].z), e1, e2, cross3(e1, e2), A.tnear, TT, U, V, aden)) {
+                const float t = TT / aden;
+                if (t <= GVT_FLT_MAX) {
+                  if (kind) occluded = true;
+                  else {
+                    const int prim = __float_as_int(s0[k].w);
+                    if (bp < 0 || t < bt || (t == bt && prim < bp)) { bt = t; bp = prim; bu = U; bv = V; bden = aden; }
+                  }
+                }
+              }
+            }
+          }
+        }
+        if (kind && occluded) { bp = 0; cur = TRAV_DONE; }
+        else KF_POP()
+      }
+    }
+    // ---- retire
+    {
+      const bool fin = active && cur == TRAV_DONE;
+      if (__ballot(fin)) {
+        bool consider = false; // a ray that leaves this instance: miss of the list (kinds 0, 2) or un-occluded shadow ray (kind 1)
+        RayRec R = sr;
+        if (fin) {
+          if (kind == 0 && bp >= 0) pending = true; // shaded at the next refill point
+          else if (bp < 0) {
+            consider = true;
+            if (kind != 1) {
+              const WaveSeg sg = A.W.segs[wave_find_seg(A.W, gidx)];
+              R = load_ray(make_planes(sg.planes, sg.cap), gidx - sg.begin);
+            }
+          }
+          active = false;
+        }
+        // shuffleRays' terminal rule (TracerBase.h:396-400): no other instance ahead -> a SHADOW ray that carries colour deposits, any
+        // other ray is dropped; otherwise it is moved on
+        bool go_on = false;
+        if (consider) {
+          float ret_t;
+          const float4 a4 = make_float4(R.o.x, R.o.y, R.o.z, R.t_min), b4 = make_float4(R.d.x, R.d.y, R.d.z, R.t_max);
+          go_on = top_nearest(a4, b4, A.sink.blo, A.sink.bhi, A.sink.n_inst, inst_l, ret_t) >= 0;
+          if (!go_on && R.type == 1 && len3(R.c) > 0.f && (unsigned)R.id < A.sink.n_pix) {
+            const V3 cw = scl3(R.c, R.w);
+            float *px = A.sink.fb + (size_t)4 * (unsigned)R.id;
+            atomicAdd(px + 0, cw.x); atomicAdd(px + 1, cw.y); atomicAdd(px + 2, cw.z); atomicAdd(px + 3, 1.f);
+          }
+        }
+        KF_STAGE(go_on, R, inst_l)
+      }
+    }
+  }
+  if (n_pend) fused_flush(pend, n_pend, A.out, A.out_count, A.out_from);
+  if (lane_id() == 0 && n_inline_shadow) atomicAdd(A.tot + 1, (unsigned long long)n_inline_shadow);
+  if (overflow) atomicOr(A.counter + TRAV_OVF_WORD, 1u);
+#undef KF_PUSH
+#undef KF_POP
+#undef KF_START
+#undef KF_STAGE
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1469,7 +1878,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
     A.next_idx = next; A.next_count = c_next; A.lights = d_lights; A.normi = P.normi; A.normal_mode = P.normal_mode;
     A.n_lights = nL; A.seed = P.seed; A.zero_word = (C.trav_kernel == 1) ? C.d_counters + 0 : nullptr;
     A.sink = P.sink; A.update_in_place = P.update_in_place;
-    A.n_dev = nullptr; A.W = WaveSet{}; A.out_from = nullptr; A.shadow_inst = nullptr;
+    A.n_dev = nullptr; A.W = WaveSet{}; A.out_from = nullptr; A.shadow_inst = nullptr; A.shadow_stride = 0;
     {
       ProfScope ps(KC_SHADE);
       k_shade<false><<<blocks_for(n_active, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, mv);
@@ -1608,9 +2017,34 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     unsigned *next = (pass & 1) ? d_idx_b : d_idx_a;
     unsigned *c_next = c + ((pass & 1) ? 5 : 2);
     k_wave_pass_begin<<<1, 64, 0, st>>>(c, pass, (unsigned)n, out->d_count);
+    if (C.fused && P.sink.fb) {
+      // one launch: closest hit, shade, the first light's shadow rays, terminal rule (k_fused); lights 1.. through the list
+      FusedArgs F;
+      F.W = W; F.idx = idx; F.n = (unsigned)n; F.n_dev = n_dev; F.lights = d_lights; F.n_lights = nL; F.normal_mode = P.normal_mode;
+      F.first_pass = (pass == 0); F.seed = P.seed; F.out = outp; F.out_count = out->d_count; F.out_from = d_out_from;
+      F.shadow = shadow; F.shadow_count = c + 1; F.shadow_inst = d_shadow_inst; F.next_idx = next; F.next_count = c_next; F.sink = P.sink;
+      F.counter = c + 0; F.spill_base = C.d_spill; F.refill_min = C.refill_min; F.inner_min = C.inner_min;
+      F.tot = (unsigned long long *)(c + 16); F.tnear = GVT_RAY_EPSILON;
+      {
+        ProfScope ps(KC_CLOSEST);
+        k_fused<<<trav_grid2(n), TRAV_BLOCK, 0, st>>>(F);
+      }
+      if (nL > 1) {
+        k_set_u32<<<1, 64, 0, st>>>(c + 0, 0u); // the work counter of the launch that follows
+        ProfScope ps(KC_ANY);
+        MultiSrc MA{ W, d_shadow_inst, d_out_from, nullptr };
+        k_trace<true, true, 1, false, true, true><<<trav_grid2(n * (size_t)(nL - 1)), TRAV_BLOCK, 0, st>>>(shadow, nullptr, 0u, id, T, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
+                                                                                                       c + 0, C.d_spill, C.refill_min, C.inner_min, c + 1, C.share, (unsigned)C.share_min_rays,
+                                                                                                       P.sink, LongQ{}, MA);
+        C.stats.launches_any++;
+      }
+      HIPCHK(hipGetLastError());
+      C.stats.launches_closest++;
+      continue;
+    }
     LongQ LQ{};
     if (use_long) { LQ.recs = d_long; LQ.count = c + 3; LQ.steps = C.long_steps; }
-    MultiSrc MS{ W, nullptr, nullptr };
+    MultiSrc MS{ W, nullptr, nullptr, nullptr };
     {
       ProfScope ps(KC_CLOSEST);
       k_trace<false, true, 0, false, true, true><<<trav_grid2(n), TRAV_BLOCK, 0, st>>>(none, idx, (unsigned)n, id, T, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
@@ -1628,15 +2062,16 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     A.n_lights = nL; A.seed = P.seed; A.zero_word = c + 0;
     A.sink = P.sink; A.update_in_place = 0;
     A.n_dev = n_dev; A.W = W; A.out_from = d_out_from; A.shadow_inst = d_shadow_inst;
+    A.shadow_stride = C.shadow_direct ? (unsigned)n : 0u;
     {
       ProfScope ps(KC_SHADE);
       k_shade<true><<<blocks_for(n, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, MeshView{});
     }
     if (nL) {
       ProfScope ps(KC_ANY);
-      MultiSrc MA{ W, d_shadow_inst, d_out_from };
-      k_trace<true, true, 1, false, true, true><<<trav_grid2(shadow_cap), TRAV_BLOCK, 0, st>>>(shadow, nullptr, 0u, id, T, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
-                                                                                              c + 0, C.d_spill, C.refill_min, C.inner_min, c + 1, C.share, (unsigned)C.share_min_rays,
+      MultiSrc MA{ W, d_shadow_inst, d_out_from, C.shadow_direct ? (unsigned long long *)(c + 18) : nullptr };
+      k_trace<true, true, 1, false, true, true><<<trav_grid2(shadow_cap), TRAV_BLOCK, 0, st>>>(shadow, nullptr, C.shadow_direct ? (unsigned)shadow_cap : 0u, id, T, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
+                                                                                              c + 0, C.d_spill, C.refill_min, C.inner_min, C.shadow_direct ? nullptr : c + 1, C.share, (unsigned)C.share_min_rays,
                                                                                               P.sink, LongQ{}, MA);
     }
     HIPCHK(hipGetLastError());
