@@ -415,7 +415,7 @@ extern "C" int gvt_hip_trace_queue_sink(gvt_hip_mesh *M, gvt_hip_queue *q_in, gv
   int rc = fill_params(P, m, minv, normi, n_lights, normal_mode, seed, lights);
   if (rc) return rc;
   if (top && fb && g_ctx.term_sink) {
-    P.sink.blo = top->d_lo; P.sink.bhi = top->d_hi; P.sink.n_inst = (int)top->n; P.sink.from = from_inst;
+    P.sink.top = top->dev(); P.sink.from = from_inst;
     P.sink.fb = fb->d_rgba; P.sink.n_pix = (unsigned)(fb->w * fb->h);
   }
   const size_t n = q_in->size;

@@ -540,7 +540,7 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
   P.normal_mode = R->normal_mode; P.seed = 0; P.n_lights = nL; P.update_in_place = 0; P.carried_rng = 1;
   P.sink = TermSink{};
   if (C.term_sink) {
-    P.sink.blo = R->top->d_lo; P.sink.bhi = R->top->d_hi; P.sink.n_inst = (int)R->top->n; P.sink.from = -1;
+    P.sink.top = R->top->dev(); P.sink.from = -1;
     P.sink.fb = R->fb->d_rgba; P.sink.n_pix = (unsigned)(R->fb->w * R->fb->h);
   }
   WaveSet W{ R->d_segs, R->d_insts, n_seg };

@@ -288,31 +288,81 @@ __device__ inline void quad_fetch64(const float4 *__restrict__ base, unsigned re
 __device__ inline float fmin_ref(float a, float b) { return (a < b) ? a : b; }
 __device__ inline float fmax_ref(float a, float b) { return (a > b) ? a : b; }
 
-// per ray: nearest other instance box with tfar>tnear && tnear>eps && t>tnear; instances visited in the
-// reference BVH's leaf order so that equal entry distances resolve identically.
-__device__ inline int top_nearest(const float4 a, const float4 b, const float4 *__restrict__ blo, const float4 *__restrict__ bhi, int n_inst,
-                                  int from, float &ret_t) {
+// The top-level instance set on the device: instance boxes in the leaf order of the reference's BVH (blo.w = instance id) and,
+// for larger sets, the BVH's own nodes (accel/BVH.cpp:77-171 restated on the host, sched.hip): node k covers the leaves
+// [first, first + count) of that order; nlo[k].w = left child (inner node) or ~first (leaf), nhi[k].w = right child or count.
+struct TopDev {
+  const float4 *blo, *bhi;
+  int n_inst;
+  const float4 *nlo, *nhi; // null / n_nodes == 0: no tree (linear scan in leaf order)
+  int n_nodes;
+};
+#define GVT_TOP_BVH_MIN 48 // instance sets smaller than this are scanned linearly (no stack, no dependent node fetches)
+
+// RayPacketIntersection::intersect for one ray and one box (RayPacket.h:111-193): entry / exit distances in the reference's order
+__device__ inline void top_slab(const float4 lo, const float4 hi, float ox, float oy, float oz, float dx, float dy, float dz, float &tnear, float &tfar) {
+  const float lx = (lo.x - ox) * dx, ly = (lo.y - oy) * dy, lz = (lo.z - oz) * dz;
+  const float ux = (hi.x - ox) * dx, uy = (hi.y - oy) * dy, uz = (hi.z - oz) * dz;
+  const float minx = fmin_ref(lx, ux), maxx = fmax_ref(lx, ux);
+  const float miny = fmin_ref(ly, uy), maxy = fmax_ref(ly, uy);
+  const float minz = fmin_ref(lz, uz), maxz = fmax_ref(lz, uz);
+  tnear = fmax_ref(fmax_ref(minx, miny), minz);
+  tfar = fmin_ref(fmin_ref(maxx, maxy), maxz);
+}
+
+// per ray: nearest other instance box with tfar>tnear && tnear>eps && t>tnear (BVH::intersect, accel/BVH.h:61-135); instances are
+// visited in the reference BVH's leaf order so that equal entry distances resolve identically.  With nodes: the reference's own
+// traversal -- left child first, a node is entered when tfar > tnear && t > tnear with the ray's current t (RayPacket.h:190, update
+// = false) -- which visits the same leaves in the same order minus those a node test prunes (they could not have passed).
+__device__ inline int top_nearest(const float4 a, const float4 b, const TopDev &T, int from, float &ret_t) {
   const float ox = a.x, oy = a.y, oz = a.z;
   const float dx = 1.f / b.x, dy = 1.f / b.y, dz = 1.f / b.z;
   float t = b.w; // ray t_max
   int next = -1;
   ret_t = GVT_FLT_MAX;
-  for (int k = 0; k < n_inst; k++) {
-    const float4 lo = blo[k], hi = bhi[k];
-    const int inst = __float_as_int(lo.w);
-    if (from == inst) continue;
-    const float lx = (lo.x - ox) * dx, ly = (lo.y - oy) * dy, lz = (lo.z - oz) * dz;
-    const float ux = (hi.x - ox) * dx, uy = (hi.y - oy) * dy, uz = (hi.z - oz) * dz;
-    const float minx = fmin_ref(lx, ux), maxx = fmax_ref(lx, ux);
-    const float miny = fmin_ref(ly, uy), maxy = fmax_ref(ly, uy);
-    const float minz = fmin_ref(lz, uz), maxz = fmax_ref(lz, uz);
-    const float tnear = fmax_ref(fmax_ref(minx, miny), minz);
-    const float tfar = fmin_ref(fmin_ref(maxx, maxy), maxz);
-    if (tfar > tnear && tnear > GVT_RAY_EPSILON && t > tnear) {
-      t = tnear;
-      if (ret_t > t) { next = inst; ret_t = t; }
-    }
+#define GVT_TOP_LEAF(K)                                                                  \
+  {                                                                                      \
+    const float4 lo_ = T.blo[K], hi_ = T.bhi[K];                                          \
+    const int inst_ = __float_as_int(lo_.w);                                             \
+    if (from != inst_) {                                                                 \
+      float tn_, tf_;                                                                    \
+      top_slab(lo_, hi_, ox, oy, oz, dx, dy, dz, tn_, tf_);                               \
+      if (tf_ > tn_ && tn_ > GVT_RAY_EPSILON && t > tn_) {                                \
+        t = tn_;                                                                         \
+        if (ret_t > t) { next = inst_; ret_t = t; }                                      \
+      }                                                                                  \
+    }                                                                                    \
   }
+  if (T.n_nodes > 0 && T.n_inst >= GVT_TOP_BVH_MIN) {
+    int stack[48];
+    int sp = 0, cur = 0;
+    bool fallback = false;
+    for (;;) {
+      const float4 nl = T.nlo[cur], nh = T.nhi[cur];
+      float tn, tf;
+      top_slab(nl, nh, ox, oy, oz, dx, dy, dz, tn, tf);
+      bool pop = true;
+      if (tf > tn && t > tn) {
+        const int l = __float_as_int(nl.w);
+        if (l < 0) { // leaf: its instances in order
+          const int first = ~l, count = __float_as_int(nh.w);
+          for (int k = first; k < first + count; k++) GVT_TOP_LEAF(k)
+        } else {
+          if (sp == 48) { fallback = true; break; }
+          stack[sp++] = __float_as_int(nh.w); // right child later
+          cur = l;
+          pop = false;
+        }
+      }
+      if (pop) {
+        if (sp == 0) break;
+        cur = stack[--sp];
+      }
+    }
+    if (!fallback) return next;
+    t = b.w; next = -1; ret_t = GVT_FLT_MAX; // a tree deeper than the stack: scan (same result)
+  }
+  for (int k = 0; k < T.n_inst; k++) GVT_TOP_LEAF(k)
+#undef GVT_TOP_LEAF
   return next;
 }
-

@@ -125,6 +125,9 @@ struct gvt_hip_top {
   std::vector<int> order;   // DFS leaf order of the reference's top-level BVH
   float4 *d_lo = nullptr;   // in `order` order: (lo.xyz, inst id)
   float4 *d_hi = nullptr;
+  float4 *d_nlo = nullptr, *d_nhi = nullptr; // the BVH's nodes (gvt_device.h TopDev), root = 0
+  size_t n_nodes = 0;
+  TopDev dev() const { return TopDev{ d_lo, d_hi, (int)n, d_nlo, d_nhi, (int)n_nodes }; }
   unsigned *d_hist = nullptr; // n counters
   void **d_qdesc = nullptr;   // device array of queue descriptors
   unsigned *h_hist = nullptr; // pinned staging for the two (asynchronous copies, no pageable bounce)
@@ -146,8 +149,8 @@ struct QueueDesc { // device-visible view of one destination queue
 // Terminal rule of shuffleRays (TracerBase.h:396-400) applied where the any-hit kernel retires an un-occluded shadow ray: a ray that
 // meets no other instance is not appended to moved_rays but deposits color*w in the framebuffer at once (fb == nullptr: disabled).
 struct TermSink {
-  const float4 *blo, *bhi; // instance boxes in the reference BVH's leaf order (gvt_hip_top)
-  int n_inst, from;
+  TopDev top; // the instance set (gvt_hip_top)
+  int from;
   float *fb;
   unsigned n_pix;
 };

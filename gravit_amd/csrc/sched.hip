@@ -75,10 +75,14 @@ struct RaySrc {
 // (__ballot over equal destinations) and per 1024-thread block (LDS counters), because one global counter word
 // sustains only ~90 atomics/us chip-wide (2 M rays: 32 K wave-level atomics on one word cost ~0.35 ms).
 #define TOP_BLOCK 1024
+// Scan-ordered (deterministic, order-preserving) slots up to this many destinations: one scan block per destination and
+// n_dest x 16 LDS words per scatter block.  Beyond it: LDS-aggregated atomics (arrival order) -- since every ray carries its RNG
+// stream, queue order no longer influences any result, only the coherence of the next traversal launch.
+#define GVT_TOP_ORDERED_MAX 256
 
 // n_dev (optional): the ray count in device memory (a list filled by the kernels just before, no host round trip; n is then only
 // the bound the grid was sized for).  from_arr (optional): the source instance per ray (lists that mix rays of several instances).
-__global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RaySrc S, unsigned n, const float4 *__restrict__ blo, const float4 *__restrict__ bhi,
+__global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RaySrc S, unsigned n, TopDev top,
                                                             int n_inst, int from, int *__restrict__ next_out, float *__restrict__ t_out,
                                                             unsigned *__restrict__ hist, int use_lds, unsigned *__restrict__ blk_cnt,
                                                             const unsigned *__restrict__ n_dev = nullptr, const int *__restrict__ from_arr = nullptr) {
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RaySrc S, unsigned n
     float4 a, b;
     if (S.from_cam) { const RayRec r = camera_ray(S.cam, i); a = make_float4(r.o.x, r.o.y, r.o.z, r.t_min); b = make_float4(r.d.x, r.d.y, r.d.z, r.t_max); }
     else { a = S.q.p0[i]; b = S.q.p1[i]; }
-    next = top_nearest(a, b, blo, bhi, n_inst, from_arr ? from_arr[i] : from, ret_t);
+    next = top_nearest(a, b, top, from_arr ? from_arr[i] : from, ret_t);
     next_out[i] = next;
     t_out[i] = ret_t;
   }
@@ -286,9 +290,11 @@ extern "C" int gvt_hip_camera_generate_tiled(gvt_hip_queue *q, const float eye[3
 
 // ---- top-level BVH order: accel/BVH.cpp:77-216 restated on the host (tiny: <= #domains) ----
 namespace {
+struct TopNode { float lo[3], hi[3]; int left, right; }; // left >= 0: inner (children); left < 0: leaf of `right` instances from ~left
 struct TopBuild {
   const float *lo, *hi;
   std::vector<int> set, sorted;
+  std::vector<TopNode> nodes;
   float centroid(int inst, int ax) const { return 0.5f * lo[3 * inst + ax] + 0.5f * hi[3 * inst + ax]; } // BBox.cpp:128
   static float fmn(float a, float b) { return (a < b) ? a : b; }
   static float fmx(float a, float b) { return (a > b) ? a : b; }
@@ -316,10 +322,17 @@ struct TopBuild {
       }
     return splitPoint;
   }
-  void build(int start, int end) { // BVH.cpp:77-171 (LEAF_SIZE 1)
+  int leaf(int me, int start, int end) {
+    nodes[me].left = ~(int)sorted.size(); nodes[me].right = end - start;
+    for (int i = start; i < end; ++i) sorted.push_back(set[i]);
+    return me;
+  }
+  int build(int start, int end) { // BVH.cpp:77-171 (LEAF_SIZE 1); returns the node's index
     float l[3] = { GVT_FLT_MAX, GVT_FLT_MAX, GVT_FLT_MAX }, h[3] = { -GVT_FLT_MAX, -GVT_FLT_MAX, -GVT_FLT_MAX };
     for (int i = start; i < end; ++i) merge(l, h, set[i]);
-    if (end - start <= 1) { for (int i = start; i < end; ++i) sorted.push_back(set[i]); return; }
+    const int me = (int)nodes.size();
+    nodes.push_back(TopNode{ { l[0], l[1], l[2] }, { h[0], h[1], h[2] }, 0, 0 });
+    if (end - start <= 1) return leaf(me, start, end);
     float dx = h[0] - l[0], dy = h[1] - l[1], dz = h[2] - l[2];
     int ax = (dx > dy && dx > dz) ? 0 : (dy > dz) ? 1 : 2; // BBox.cpp:117-126
     float sp = split_point(ax, start, end);
@@ -335,9 +348,11 @@ struct TopBuild {
       ++first;
     }
     int splitIdx = first;
-    if (splitIdx == start || splitIdx == end) { for (int i = start; i < end; ++i) sorted.push_back(set[i]); return; }
-    build(start, splitIdx);
-    build(splitIdx, end);
+    if (splitIdx == start || splitIdx == end) return leaf(me, start, end);
+    const int a = build(start, splitIdx);
+    const int b = build(splitIdx, end);
+    nodes[me].left = a; nodes[me].right = b;
+    return me;
   }
 };
 } // namespace
@@ -347,7 +362,7 @@ extern "C" gvt_hip_top *gvt_hip_top_create(const float *inst_lo, const float *in
   if (!inst_lo || !inst_hi) { set_error("top_create: null boxes"); return nullptr; }
   gvt_hip_top *T = new gvt_hip_top();
   T->n = n;
-  TopBuild B{ inst_lo, inst_hi, {}, {} };
+  TopBuild B{ inst_lo, inst_hi, {}, {}, {} };
   B.set.resize(n);
   for (size_t i = 0; i < n; i++) B.set[i] = (int)i;
   if (n) B.build(0, (int)n);
@@ -368,12 +383,25 @@ extern "C" gvt_hip_top *gvt_hip_top_create(const float *inst_lo, const float *in
     ok = hipMemcpy(T->d_lo, lo.data(), sizeof(float4) * n, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(T->d_hi, hi.data(), sizeof(float4) * n, hipMemcpyHostToDevice) == hipSuccess;
   }
+  if (ok && !B.nodes.empty()) { // the tree itself, for larger sets (gvt_device.h top_nearest)
+    const size_t nn = B.nodes.size();
+    std::vector<float4> nlo(nn), nhi(nn);
+    for (size_t k = 0; k < nn; k++) {
+      const TopNode &N = B.nodes[k];
+      nlo[k] = make_float4(N.lo[0], N.lo[1], N.lo[2], __builtin_bit_cast(float, N.left));
+      nhi[k] = make_float4(N.hi[0], N.hi[1], N.hi[2], __builtin_bit_cast(float, N.right));
+    }
+    ok = hipMalloc((void **)&T->d_nlo, sizeof(float4) * nn) == hipSuccess && hipMalloc((void **)&T->d_nhi, sizeof(float4) * nn) == hipSuccess &&
+         hipMemcpy(T->d_nlo, nlo.data(), sizeof(float4) * nn, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(T->d_nhi, nhi.data(), sizeof(float4) * nn, hipMemcpyHostToDevice) == hipSuccess;
+    T->n_nodes = nn;
+  }
   if (!ok) { set_error("top_create: device allocation failed"); gvt_hip_top_destroy(T); return nullptr; }
   return T;
 }
 extern "C" void gvt_hip_top_destroy(gvt_hip_top *T) {
   if (!T) return;
-  hipFree(T->d_lo); hipFree(T->d_hi); hipFree(T->d_hist); hipFree(T->d_qdesc); hipHostFree(T->h_hist); hipHostFree(T->h_qdesc);
+  hipFree(T->d_lo); hipFree(T->d_hi); hipFree(T->d_nlo); hipFree(T->d_nhi); hipFree(T->d_hist); hipFree(T->d_qdesc); hipHostFree(T->h_hist); hipHostFree(T->h_qdesc);
   delete T;
 }
 extern "C" int gvt_hip_top_order(const gvt_hip_top *T, int32_t *out) {
@@ -394,7 +422,7 @@ static int shuffle_impl(gvt_hip_top *T, const RaySrc &in, size_t n, int from, gv
   const int use_lds = (C.top_lds && nI > 0 && nI <= 4096) ? 1 : 0; // LDS counters per destination; beyond that straight to the global ones
   const unsigned n_blk = blocks_for(n, TOP_BLOCK);
   unsigned *d_blk = nullptr; // ordered mode: [destination][block] counts, then base slots
-  if (C.top_ordered && use_lds && nI <= 64) {
+  if (C.top_ordered && use_lds && nI <= GVT_TOP_ORDERED_MAX) {
     d_blk = (unsigned *)scratch_get(14, sizeof(unsigned) * nI * n_blk);
     if (!d_blk) return GVT_HIP_ERR_DEVICE;
   }
@@ -416,7 +444,7 @@ static int shuffle_impl(gvt_hip_top *T, const RaySrc &in, size_t n, int from, gv
   if (nI && !scan_totals) HIPCHK(hipMemsetAsync(T->d_hist, 0, sizeof(unsigned) * nI, st));
   {
     ProfScope ps(KC_SHUFFLE);
-    k_top_classify<<<n_blk, TOP_BLOCK, use_lds ? sizeof(unsigned) * nI : 0, st>>>(in, (unsigned)n, T->d_lo, T->d_hi, (int)nI, from, d_next, d_t,
+    k_top_classify<<<n_blk, TOP_BLOCK, use_lds ? sizeof(unsigned) * nI : 0, st>>>(in, (unsigned)n, T->dev(), (int)nI, from, d_next, d_t,
                                                                                 scan_totals ? nullptr : T->d_hist, use_lds, d_blk);
   }
   HIPCHK(hipGetLastError());
@@ -465,7 +493,7 @@ int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *f
   const int use_lds = (C.top_lds && nI > 0 && nI <= 4096) ? 1 : 0;
   const unsigned n_blk = blocks_for(n_ub, TOP_BLOCK);
   unsigned *d_blk = nullptr;
-  if (C.top_ordered && use_lds && nI <= 64) {
+  if (C.top_ordered && use_lds && nI <= GVT_TOP_ORDERED_MAX) {
     d_blk = (unsigned *)scratch_get(14, sizeof(unsigned) * nI * n_blk);
     if (!d_blk) return GVT_HIP_ERR_DEVICE;
   }
@@ -480,7 +508,7 @@ int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *f
   S.from_cam = 0;
   {
     ProfScope ps(KC_SHUFFLE);
-    k_top_classify<<<n_blk, TOP_BLOCK, use_lds ? sizeof(unsigned) * nI : 0, st>>>(S, (unsigned)n_ub, T->d_lo, T->d_hi, (int)nI, -1, d_next, d_t, nullptr, use_lds, d_blk,
+    k_top_classify<<<n_blk, TOP_BLOCK, use_lds ? sizeof(unsigned) * nI : 0, st>>>(S, (unsigned)n_ub, T->dev(), (int)nI, -1, d_next, d_t, nullptr, use_lds, d_blk,
                                                                                 q_in->d_count, from_arr);
     if (d_blk) k_top_scan<<<(unsigned)nI, TOP_BLOCK, 0, st>>>(d_blk, n_blk, (const QueueDesc *)T->d_qdesc, nullptr);
     const size_t lds = d_blk ? sizeof(unsigned) * nI * (TOP_BLOCK / 64) : (use_lds ? 2 * sizeof(unsigned) * nI : 0);

@@ -236,7 +236,7 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
       a = q.p0[src]; b = q.p1[src]; c = q.p2[src]; d = q.p3[src];
       if (ray_inst) from = ray_inst[src];
       float ret_t;
-      go_on = top_nearest(a, b, K.blo, K.bhi, K.n_inst, from, ret_t) >= 0;
+      go_on = top_nearest(a, b, K.top, from, ret_t) >= 0;
       if (!go_on) {
         const V3 col = mk3(c.x, c.y, c.z);
         const unsigned id = (unsigned)__float_as_int(d.x);
@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M1)
     if (miss && A.sink.fb) {
       float ret_t;
       const float4 a = make_float4(r.o.x, r.o.y, r.o.z, r.t_min), b = make_float4(r.d.x, r.d.y, r.d.z, r.t_max);
-      if (top_nearest(a, b, A.sink.blo, A.sink.bhi, A.sink.n_inst, inst, ret_t) < 0) {
+      if (top_nearest(a, b, A.sink.top, inst, ret_t) < 0) {
         forward = false;
         if (r.type == 1 && len3(r.c) > 0.f && (unsigned)r.id < A.sink.n_pix) {
           const V3 cw = scl3(r.c, r.w);
@@ -1533,7 +1533,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 4) void k_fused(FusedArgs A) {
         if (consider) {
           float ret_t;
           const float4 a4 = make_float4(R.o.x, R.o.y, R.o.z, R.t_min), b4 = make_float4(R.d.x, R.d.y, R.d.z, R.t_max);
-          go_on = top_nearest(a4, b4, A.sink.blo, A.sink.bhi, A.sink.n_inst, inst_l, ret_t) >= 0;
+          go_on = top_nearest(a4, b4, A.sink.top, inst_l, ret_t) >= 0;
           if (!go_on && R.type == 1 && len3(R.c) > 0.f && (unsigned)R.id < A.sink.n_pix) {
             const V3 cw = scl3(R.c, R.w);
             float *px = A.sink.fb + (size_t)4 * (unsigned)R.id;

@@ -170,3 +170,57 @@ def test_two_contexts_trace_concurrently(hip):
     assert not errs, errs[0]
     for k in range(2):
         assert np.array_equal(out[k][..., :3], refs[k][..., :3])
+
+
+def many_instances_scene(nx, ny, width, height):
+    """nx * ny instances of two small meshes (cube / cone like gvtSimple) on a jittered grid with overlapping boxes."""
+    base = scenes.simple_scene(width, height)
+    rng = np.random.Generator(np.random.Philox(5))
+    mats, inst_mesh = [], []
+    for j in range(ny):
+        for i in range(nx):
+            s = 0.35 + 0.3 * rng.random()
+            t = ((i - nx / 2) * 0.9 + 0.3 * rng.random(), (j - ny / 2) * 0.9 + 0.3 * rng.random(), 2.0 * rng.random())
+            mats.append(scenes.mat_translate_scale(t, (s, s, s)))
+            inst_mesh.append((i + j) % len(base.meshes))
+    cam = scenes.Camera((0.0, 0.0, 40.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.9, width, height, 1, 1, 0.0)
+    from gravit_amd.layouts import point_light
+    return scenes._assemble(base.meshes, inst_mesh, mats, point_light((5.0, 8.0, 30.0)), cam, "grid-%dx%d" % (nx, ny))
+
+
+def test_top_level_bvh_with_1056_instances(hip):
+    """A top-level set far beyond the linear-scan and scan-ordered-shuffle sizes (1,056 instances): the device walks the
+    reference BVH's own nodes (left child first, RayPacket's node test) and must pick the instance the oracle's leaf-order scan
+    picks, for camera rays and for every moved ray of the frame -- image, ray counts and adapter-call count equal the oracle."""
+    from gravit_amd.adapter import RayQueue, TopLevel, camera_generate
+    from oracle import orc
+    from tests.helpers import bits, oracle_camera_rays
+
+    sc = many_instances_scene(33, 32, 384, 384)
+    assert sc.n_inst == 1056
+    top = TopLevel(sc.inst_lo, sc.inst_hi)
+    assert (top.order() == orc.toplevel_order(sc.inst_lo, sc.inst_hi)).all()
+    # per-ray decisions of FilterRaysLocally against the oracle's scan
+    rays = oracle_camera_rays(sc)
+    q = RayQueue()
+    camera_generate(q, sc.camera, 0)
+    queues = [RayQueue() for _ in range(sc.n_inst)]
+    top.shuffle(q, -1, queues, None)
+    nxt, t = orc.toplevel_intersect(sc.inst_lo, sc.inst_hi, top.order(), rays, -1)
+    sizes = np.array([len(x) for x in queues])
+    assert (sizes == np.bincount(nxt[nxt >= 0], minlength=sc.n_inst)).all() and (sizes > 0).sum() > 500
+    for i in np.nonzero(sizes)[0][:40]:
+        got = queues[i].to_numpy()
+        exp = rays[nxt == i].copy()
+        exp["origin"] = exp["origin"] + exp["direction"] * (t[nxt == i] * np.float32(0.95))[:, None]
+        assert (np.sort(got["id"]) == np.sort(exp["id"])).all()
+        o = np.argsort(got["id"]); e = np.argsort(exp["id"])
+        assert (bits(got["origin"][o]) == bits(exp["origin"][e])).all()
+    # whole frames: rounds and the reference-order loop
+    ref, st = oracle_render(sc, NORMALS_SMOOTH, nthreads=8)
+    assert (ref[..., :3].sum(axis=2) > 0).mean() > 0.1 and st.adapter_calls > 1000
+    tr = NativeTracer(sc, NORMALS_SMOOTH)
+    fb = tr().framebuffer(True)
+    assert np.array_equal(fb[..., :3], ref[..., :3]) and tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any
+    it = ImageTracer(sc, NORMALS_SMOOTH)
+    assert np.array_equal(it().framebuffer(True)[..., :3], ref[..., :3]) and it.adapter_calls == st.adapter_calls
