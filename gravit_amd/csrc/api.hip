@@ -191,6 +191,7 @@ extern "C" int gvt_hip_set_option(const char *name, int value) {
   if (!std::strcmp(name, "coop_fetch")) { g_ctx.coop_fetch = value; return 0; }
   if (!std::strcmp(name, "top_lds")) { g_ctx.top_lds = value; return 0; }
   if (!std::strcmp(name, "trav_kernel")) { g_ctx.trav_kernel = value; return 0; }
+  if (!std::strcmp(name, "blocks_per_cu_closest")) { if (value < 0 || value > 6) { set_error("blocks_per_cu_closest must be 0..6"); return GVT_HIP_ERR_INVALID; } g_ctx.blocks_per_cu_closest = value; return 0; }
   if (!std::strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 6) { set_error("blocks_per_cu must be 1..6"); return GVT_HIP_ERR_INVALID; } g_ctx.blocks_per_cu = value; return 0; }
   if (!std::strcmp(name, "inner_min")) { if (value < 1 || value > 64) { set_error("inner_min must be 1..64"); return GVT_HIP_ERR_INVALID; } g_ctx.inner_min = value; return 0; }
   if (!std::strcmp(name, "refill_min")) { if (value < 1 || value > 64) { set_error("refill_min must be 1..64"); return GVT_HIP_ERR_INVALID; } g_ctx.refill_min = value; return 0; }

@@ -21,6 +21,7 @@ struct PendingEvent {
 struct Knobs {
   int trav_kernel = 1;   // 1 = persistent waves with lane refill (k_trace), 0 = one 64-ray batch at a time (k_closest/k_any)
   int blocks_per_cu = 4; // k_trace grid: resident 256-thread blocks per CU
+  int blocks_per_cu_closest = 5; // ... for closest-hit launches (0: blocks_per_cu); 5: 0.528 vs 0.554 ms per 1 M rays (4) and 0.552 (6); any-hit: 4 is best (5: 0.50 vs 0.40)
   int refill_min = 16;   // k_trace: idle lanes needed before a refill
   int inner_min = 32;    // k_trace: the inner-node loop is left once fewer lanes than this still descend
   int coop_fetch = 0;    // k_trace: quad-cooperative 64-byte fetches (DPP transpose) instead of 4 loads per lane

@@ -1658,9 +1658,9 @@ template <bool ANY, bool XFORM, int MODE, typename... Args> void launch_trace(bo
 }
 
 // persistent-wave kernel: fewer, longer-lived waves so that every lane is refilled several times
-int trav_grid2(size_t n) {
+int trav_grid2(size_t n, bool closest = false) {
   Ctx &C = gctx();
-  size_t want = (size_t)C.n_cu * (size_t)C.blocks_per_cu;
+  size_t want = (size_t)C.n_cu * (size_t)((closest && C.blocks_per_cu_closest) ? C.blocks_per_cu_closest : C.blocks_per_cu);
   size_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
   if (want > (size_t)C.trav_blocks) want = (size_t)C.trav_blocks;
   return (int)(need < want ? (need ? need : 1) : want);
@@ -1738,8 +1738,8 @@ int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, 
     ProfScope ps(KC_CLOSEST);
     RayPlanes none{};
     if (C.trav_kernel == 1) {
-      if (xform) launch_trace<false, true, 0>(have_nodes4, trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
-      else launch_trace<false, false, 0>(have_nodes4, trav_grid2(n), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
+      if (xform) launch_trace<false, true, 0>(have_nodes4, trav_grid2(n, true), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
+      else launch_trace<false, false, 0>(have_nodes4, trav_grid2(n, true), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
     } else {
       if (xform) k_closest<true><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
       else k_closest<false><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
@@ -2047,7 +2047,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     MultiSrc MS{ W, nullptr, nullptr, nullptr };
     {
       ProfScope ps(KC_CLOSEST);
-      k_trace<false, true, 0, false, true, true><<<trav_grid2(n), TRAV_BLOCK, 0, st>>>(none, idx, (unsigned)n, id, T, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
+      k_trace<false, true, 0, false, true, true><<<trav_grid2(n, true), TRAV_BLOCK, 0, st>>>(none, idx, (unsigned)n, id, T, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
                                                                                       c + 0, C.d_spill, C.refill_min, C.inner_min, n_dev, C.share, (unsigned)C.share_min_rays,
                                                                                       TermSink{}, LQ, MS);
     }

@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 200 rocprofv3 --pmc $CNT --output-format csv -d $OUT -o pmc -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench.log 2>&1
+timeout 200 rocprofv3 --pmc $CNT --output-format csv -d $OUT -o pmc -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-abi-path "$@" > $OUT/bench.log 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, re, sys, collections
 out = sys.argv[1]

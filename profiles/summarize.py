@@ -26,7 +26,7 @@ def find(pattern):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     base = os.path.join(ROOT, "gpurun_out", "prof_%s" % tag)
     out_stats = os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag)
     stats = find(os.path.join(base, "trace", "**", "*kernel_stats.csv"))
@@ -62,7 +62,7 @@ def main():
                 e[1] += 1
     summary = {}
     for k, cs in pmc.items():
-        if not any(s in k for s in ("k_trace", "k_closest", "k_any", "k_shade", "k_top", "k_camera", "k_planes", "k_aos", "k_ray_keys")):
+        if not any(s in k for s in ("k_trace", "k_closest", "k_any", "k_shade", "k_top", "k_camera", "k_planes", "k_aos", "k_ray_keys", "k_long", "k_fused", "k_round", "k_wave", "k_pack", "k_unpack")):
             continue
         e = {c: {"sum": v[0], "launches": v[1], "per_launch": v[0] / max(1, v[1])} for c, v in cs.items()}
         e["resources"] = regs.get(k, {})
@@ -86,7 +86,12 @@ def main():
     # global_load_dwordx4 per lane -- 1.035 requests per node, no 32-byte requests, FETCH_SIZE = 1.035 x the useful bytes, and the
     # pass takes 2.2x the streaming read of the same table (6.0 TB/s if each request moves a 128-byte line, 3.0 TB/s otherwise,
     # against 6.5 TB/s streamed): a node miss moves a whole 128-byte line, so the same x2 applies (profiles/r01_fetch_calibration.txt).
-    traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE over `bench.py --steps 5 --warmup 2`, tag %s" % tag,
+    commit = None
+    cf = os.path.join(ROOT, "profiles", ".profiled_commit")  # written by the caller before the tree travels to the GPU box (no .git there)
+    if os.path.exists(cf):
+        commit = open(cf).read().strip() or None
+    traffic = {"tag": tag, "commit": commit,
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE over `bench.py --steps 5 --warmup 2`, tag %s" % tag,
                "note": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch; x2 on reads: gfx950 tallies 128-byte fabric requests "
                        "as 64 bytes (MI355X guide), confirmed for this kernel's 64-byte gathers by profiles/r01_fetch_calibration.txt"}
     for k, e in summary.items():
