@@ -31,7 +31,7 @@
 
 #include "gvt_internal.h"
 
-int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *from_arr, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
+int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *from_arr, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
                   gvt_hip_fb *fb, unsigned *d_overflow);
 
 // ------------------------------------------------------------------------------------------------
@@ -544,10 +544,21 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
     P.sink.fb = R->fb->d_rgba; P.sink.n_pix = (unsigned)(R->fb->w * R->fb->h);
   }
   WaveSet W{ R->d_segs, R->d_insts, n_seg };
-  if ((rc = wave_trace_chain(W, N, passes, R->q_moved, d_from, P, R->lights.data()))) return rc;
+  WaveSingle one{};
+  if (n_seg == 1 && R->meshes[R->h_segs[0].inst] && C.wave_single) {
+    const int i0 = R->h_segs[0].inst;
+    one.planes = make_planes(R->h_segs[0].planes, R->h_segs[0].cap);
+    one.mesh = R->meshes[i0]; one.inst = i0;
+    std::memcpy(one.minv.m, R->minv.data() + 16 * (size_t)i0, 64);
+    std::memcpy(one.normi.n, R->normi.data() + 9 * (size_t)i0, 36);
+  }
+  const bool single = one.mesh != nullptr;
+  if ((rc = wave_trace_chain(W, N, passes, R->q_moved, d_from, P, R->lights.data(), single ? &one : nullptr))) return rc;
   k_zero_counts<<<(unsigned)((nI + 255) / 256), 256, 0, st>>>(R->d_count_ptr, R->d_mask, (int)nI); // queue[instTarget].clear()
   HIPCHK(hipGetLastError());
-  if ((rc = shuffle_async(R->top, R->q_moved, bound, d_from, R->queues.data(), nullptr, R->fb, R->d_overflow))) return rc;
+  // one instance in the whole scene and the terminal rule applied inside the kernels: nothing can have moved
+  if (!(nI == 1 && P.sink.fb) &&
+      (rc = shuffle_async(R->top, R->q_moved, bound, single ? nullptr : d_from, single ? one.inst : -1, R->queues.data(), nullptr, R->fb, R->d_overflow))) return rc;
   if (chains) (*chains)++;
   return 0;
 }

@@ -36,6 +36,7 @@ struct Knobs {
   int long_min_rays = 65536; // ... only in launches of at least this many rays (small launches have no tail to speak of)
   int fused = 0;         // scheduler rounds: closest hit + shade + first-light shadow rays in one kernel (k_fused) instead of three launches.
                          // Measured 2.4x SLOWER than the three launches: shading inside the persistent kernel is latency-exposed
+  int wave_single = 1;   // scheduler rounds: a round with ONE non-empty local queue uses the single-mesh kernels (no per-ray segment / instance lookups)
   int shadow_direct = 1; // scheduler rounds: shadow rays in direct-mapped slots (the order of the traced list) instead of block-arrival order
   int term_sink = 1;     // gvt_hip_trace_queue_sink: deposit terminal shadow rays from the any-hit kernel (0: always through moved_rays)
   int camera_tile = 8;   // gvt_hip_image_frame: camera rays listed in 8x8-pixel tiles (0: pixel-major like generateRays)
@@ -220,8 +221,15 @@ int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const M
 int set_device_u32(unsigned *p, unsigned v); // stream-ordered store of a host-known value
 // one round's merged launch chain (no host round trip inside); `out` must have room for n_total * (1 + n_lights * passes) rays and
 // is filled from slot 0 (its device count is reset); d_out_from receives the source instance of every ray appended
+struct WaveSingle { // the launch has ONE segment: its queue planes and instance, for the single-mesh kernels
+  RayPlanes planes;
+  gvt_hip_mesh *mesh;
+  Mat4 minv;
+  Mat3 normi;
+  int inst;
+};
 int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
-                     const gvt_hip_light *lights_host);
+                     const gvt_hip_light *lights_host, const WaveSingle *single);
 int convert_aos_to_planes(const gvt_hip_ray *d_src, size_t n, RayPlanes dst, size_t dst_off);
 int convert_planes_to_aos(RayPlanes src, size_t src_off, size_t n, gvt_hip_ray *d_dst);
 int convert_od_to_planes(const float *d_org, const float *d_dir, size_t n, RayPlanes dst);

@@ -479,9 +479,9 @@ static int shuffle_impl(gvt_hip_top *T, const RaySrc &in, size_t n, int from, gv
 
 // shuffleRays of a device-resident list whose length only the device knows (q_in's count word), launched without any host round
 // trip: every destination must already have room for its current rays + n_ub more.  Destination counts advance on the device only;
-// the caller learns them from its next read-back.  from_arr: source instance per ray (merged rounds).  Kernel order on the stream:
+// the caller learns them from its next read-back.  from_arr: source instance per ray (merged rounds), else `from` for all.  Kernel order on the stream:
 // classify -> (scan) -> scatter -> q_in count := 0.
-int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *from_arr, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
+int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *from_arr, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
                   gvt_hip_fb *fb, unsigned *d_overflow) {
   Ctx &C = gctx();
   if (!n_ub) return 0;
@@ -508,7 +508,7 @@ int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *f
   S.from_cam = 0;
   {
     ProfScope ps(KC_SHUFFLE);
-    k_top_classify<<<n_blk, TOP_BLOCK, use_lds ? sizeof(unsigned) * nI : 0, st>>>(S, (unsigned)n_ub, T->dev(), (int)nI, -1, d_next, d_t, nullptr, use_lds, d_blk,
+    k_top_classify<<<n_blk, TOP_BLOCK, use_lds ? sizeof(unsigned) * nI : 0, st>>>(S, (unsigned)n_ub, T->dev(), (int)nI, from, d_next, d_t, nullptr, use_lds, d_blk,
                                                                                 q_in->d_count, from_arr);
     if (d_blk) k_top_scan<<<(unsigned)nI, TOP_BLOCK, 0, st>>>(d_blk, n_blk, (const QueueDesc *)T->d_qdesc, nullptr);
     const size_t lds = d_blk ? sizeof(unsigned) * nI * (TOP_BLOCK / 64) : (use_lds ? 2 * sizeof(unsigned) * nI : 0);

@@ -1977,7 +1977,7 @@ __global__ void k_wave_end(unsigned *c) {
 } // namespace
 
 int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
-                     const gvt_hip_light *lights_host) {
+                     const gvt_hip_light *lights_host, const WaveSingle *single) {
   Ctx &C = gctx();
   if (!n_total) return 0;
   hipStream_t st = C.stream;
@@ -2017,6 +2017,49 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     unsigned *next = (pass & 1) ? d_idx_b : d_idx_a;
     unsigned *c_next = c + ((pass & 1) ? 5 : 2);
     k_wave_pass_begin<<<1, 64, 0, st>>>(c, pass, (unsigned)n, out->d_count);
+    if (single) {
+      // one segment (a single non-empty local queue, e.g. the one-domain benchmark): the single-mesh kernels -- no segment lookup and
+      // no per-ray table loads at a refill -- with the same device-side counts
+      gvt_hip_mesh *M = single->mesh;
+      const bool have4 = M->d_nodes4 != nullptr;
+      Trav TS{ M->d_nodes, M->d_tri, M->d_nodes4 };
+      LongQ LQ{};
+      if (use_long && have4) { LQ.recs = d_long; LQ.count = c + 3; LQ.steps = C.long_steps; }
+      {
+        ProfScope ps(KC_CLOSEST);
+        launch_trace<false, true, 0>(have4, trav_grid2(n, true), st, single->planes, idx, (unsigned)n, single->minv, TS, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
+                                     c + 0, C.d_spill, C.refill_min, C.inner_min, n_dev, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
+      }
+      if (LQ.steps) {
+        ProfScope ps(KC_LONG);
+        k_long_closest<true><<<C.n_cu * 3, 256, 0, st>>>(single->planes, d_long, c + 3, single->minv, TS, GVT_RAY_EPSILON, d_hits, c + 4);
+      }
+      ShadeArgs A;
+      A.in = single->planes; A.idx = idx; A.n = (unsigned)n; A.index_base = 0; A.hits = d_hits;
+      A.first_pass = (pass == 0); A.carried_rng = 1; A.out = outp; A.out_count = out->d_count; A.shadow = shadow; A.shadow_count = c + 1;
+      A.next_idx = next; A.next_count = c_next; A.lights = d_lights; A.normi = single->normi; A.normal_mode = P.normal_mode;
+      A.n_lights = nL; A.seed = P.seed; A.zero_word = c + 0;
+      A.sink = P.sink; A.sink.from = single->inst; A.update_in_place = 0;
+      A.n_dev = n_dev; A.W = WaveSet{}; A.out_from = nullptr; A.shadow_inst = nullptr; A.shadow_stride = 0;
+      MeshView mv;
+      mv.verts = M->d_verts; mv.tris = M->d_tris; mv.normals = M->d_normals; mv.vcolors = M->d_vcolors;
+      mv.materials = M->d_materials; mv.n_mat = (unsigned)M->nMat; mv.face_mat = M->d_face_mat; mv.mat = M->mesh_mat;
+      {
+        ProfScope ps(KC_SHADE);
+        k_shade<false><<<blocks_for(n, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, mv);
+      }
+      if (nL) {
+        ProfScope ps(KC_ANY);
+        TermSink sk = P.sink;
+        sk.from = single->inst;
+        launch_trace<true, true, 1>(have4, trav_grid2(shadow_cap), st, shadow, nullptr, 0u, single->minv, TS, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
+                                    c + 0, C.d_spill, C.refill_min, C.inner_min, c + 1, C.share, (unsigned)C.share_min_rays, sk, LongQ{});
+      }
+      HIPCHK(hipGetLastError());
+      C.stats.launches_closest++;
+      C.stats.launches_any++;
+      continue;
+    }
     if (C.fused && P.sink.fb) {
       // one launch: closest hit, shade, the first light's shadow rays, terminal rule (k_fused); lights 1.. through the list
       FusedArgs F;
@@ -2062,16 +2105,17 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     A.n_lights = nL; A.seed = P.seed; A.zero_word = c + 0;
     A.sink = P.sink; A.update_in_place = 0;
     A.n_dev = n_dev; A.W = W; A.out_from = d_out_from; A.shadow_inst = d_shadow_inst;
-    A.shadow_stride = C.shadow_direct ? (unsigned)n : 0u;
+    const bool direct = C.shadow_direct && pass == 0; // later passes hold few rays: compacted slots
+    A.shadow_stride = direct ? (unsigned)n : 0u;
     {
       ProfScope ps(KC_SHADE);
       k_shade<true><<<blocks_for(n, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, MeshView{});
     }
     if (nL) {
       ProfScope ps(KC_ANY);
-      MultiSrc MA{ W, d_shadow_inst, d_out_from, C.shadow_direct ? (unsigned long long *)(c + 18) : nullptr };
-      k_trace<true, true, 1, false, true, true><<<trav_grid2(shadow_cap), TRAV_BLOCK, 0, st>>>(shadow, nullptr, C.shadow_direct ? (unsigned)shadow_cap : 0u, id, T, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
-                                                                                              c + 0, C.d_spill, C.refill_min, C.inner_min, C.shadow_direct ? nullptr : c + 1, C.share, (unsigned)C.share_min_rays,
+      MultiSrc MA{ W, d_shadow_inst, d_out_from, direct ? (unsigned long long *)(c + 18) : nullptr };
+      k_trace<true, true, 1, false, true, true><<<trav_grid2(shadow_cap), TRAV_BLOCK, 0, st>>>(shadow, nullptr, direct ? (unsigned)shadow_cap : 0u, id, T, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
+                                                                                              c + 0, C.d_spill, C.refill_min, C.inner_min, direct ? nullptr : c + 1, C.share, (unsigned)C.share_min_rays,
                                                                                               P.sink, LongQ{}, MA);
     }
     HIPCHK(hipGetLastError());

@@ -1,52 +1,45 @@
-"""Frame time and ray rate of the BASELINE.json parity configurations (1, 2, 4, 5) through the Image scheduler on one GPU.
+"""Frame time and ray rate of the BASELINE.json configurations on ONE GPU through the native tracer (rounds; gvt_hip_tracer) and, for
+comparison, through the reference-order loop (one adapter call at a time, gvt_hip_image_frame).
    usage (GPU box): python tools/bench_configs.py"""
-import sys, time, json
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gravit_amd import capi, scenes
 from gravit_amd.layouts import NORMALS_SMOOTH, NORMALS_FLAT
-from gravit_amd.scheduler import ImageTracer
+from gravit_amd.scheduler import ImageTracer, NativeTracer
+
 capi.init(0)
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def config5(size, n_dom):
+    one = scenes.cathedral_scene(size, size, samples=2, depth=2, eye=(0.0, 1.5, 13.0), light=(0.0, 2.5, 12.0))
+    return one if n_dom <= 1 else scenes.split_into_domains(one, n_dom)
+
+
 cfgs = [
     ("config 1: data/bunny.conf, 3 bunny instances, 1900x1080", lambda: scenes.load_conf(os.path.join(GOLDEN, "bunny.conf")), NORMALS_SMOOTH),
     ("config 2: bun_zipper (69 K tris), 1920x1080", lambda: scenes.bunny70k_scene(), NORMALS_SMOOTH),
-    ("config 4: 8-instance bunny grid, 1900x1080", lambda: scenes.bunny_grid_scene(), NORMALS_SMOOTH),
     ("config 3: 10 M-triangle soup, 1920x1080", lambda: scenes.soup_scene(10_000_000), NORMALS_FLAT),
+    ("config 4: 8-instance bunny grid, 1900x1080", lambda: scenes.bunny_grid_scene(), NORMALS_SMOOTH),
+    ("config 5 stand-in: hall 80 K tris, 1024x1024, 2x2 samples, depth 2", lambda: config5(1024, 1), NORMALS_FLAT),
+    ("config 5 stand-in cut into 8 domains (one rank)", lambda: config5(1024, 8), NORMALS_FLAT),
 ]
 for name, mk, mode in cfgs:
     sc = mk()
-    tr = ImageTracer(sc, mode)
-    for _ in range(3): tr()
-    capi.synchronize(); capi.stats_reset()
-    n = 10
-    t = time.perf_counter()
-    for _ in range(n): tr()
-    capi.synchronize(); dt = (time.perf_counter() - t) / n
-    st = capi.stats()
-    rays = (st["rays_closest"] + st["rays_any"]) / n
     tris = sum(len(m.tris) for m in sc.meshes)
-    print("%-62s %8.3f ms/frame  %8.1f Mrays/s  (%d rays/frame, %d adapter calls, %d tris, %d instances)" % (
-        name, dt * 1e3, rays / dt / 1e6, rays, tr.adapter_calls, tris, sc.n_inst), flush=True)
-
-# config 5 stand-in (sibenik.obj is missing from the reference tree): camera inside the hall.  The reference's top-level test never
-# assigns a ray to an instance box it starts in (RayPacket.h:195-197, tnear > epsilon), so this one is driven at the adapter:
-# generateRays -> Adapter::trace on device queues (2x2 samples, depth 3: shadow rays + cosine-weighted bounces).
-from gravit_amd.adapter import HipMeshAdapter, RayQueue, camera_generate
-sc = scenes.cathedral_scene(1024, 1024, samples=2, depth=3)
-ad = HipMeshAdapter(sc.meshes[0], NORMALS_FLAT)
-q, moved = RayQueue(), RayQueue()
-def frame(seed):
-    camera_generate(q, sc.camera, tile=8)
-    moved.clear()
-    ad.trace_queue(q, moved, sc.m[0], sc.minv[0], sc.normi[0], sc.lights, seed=seed)
-for k in range(3): frame(k)
-capi.synchronize(); capi.stats_reset()
-n = 10
-t = time.perf_counter()
-for k in range(n): frame(k)
-capi.synchronize(); dt = (time.perf_counter() - t) / n
-st = capi.stats()
-rays = (st["rays_closest"] + st["rays_any"]) / n
-print("%-62s %8.3f ms/frame  %8.1f Mrays/s  (%d rays/frame incl. bounces, %d tris)" % (
-    "config 5 stand-in: cathedral 1024x1024, 2x2 samples, depth 3", dt * 1e3, rays / dt / 1e6, rays, len(sc.meshes[0].tris)), flush=True)
+    for label, tr in (("rounds", NativeTracer(sc, mode)), ("reference order", ImageTracer(sc, mode))):
+        for _ in range(3):
+            tr()
+        capi.synchronize(); capi.stats_reset()
+        n = 10
+        t = time.perf_counter()
+        for _ in range(n):
+            tr()
+        capi.synchronize(); dt = (time.perf_counter() - t) / n
+        st = capi.stats()
+        rays = (st["rays_closest"] + st["rays_any"]) / n
+        extra = ("%d launch chains, %d host syncs" % (tr.stats["chains"], tr.stats["host_syncs"])) if label == "rounds" else ("%d adapter calls" % tr.adapter_calls)
+        print("%-70s %-16s %8.3f ms/frame %8.1f Mrays/s  (%d rays/frame, %s, %d tris, %d instances)" % (
+            name, label, dt * 1e3, rays / dt / 1e6, rays, extra, tris, sc.n_inst), flush=True)
+        if hasattr(tr, "close"):
+            tr.close()
