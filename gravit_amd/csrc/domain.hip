@@ -270,13 +270,16 @@ int comm_reduce_sum(gvt_hip_comm *K, float *buf, size_t n_floats, int root) {
 // device helpers of the scheduler loop
 // ------------------------------------------------------------------------------------------------
 namespace {
-#define ANN_HEAD 4 // announce row: {rays to you, bytes to you, my total outgoing rays, my local pending rays, rays per queue [n_inst]}
+#define ANN_HEAD 8 // announce row: {rays to you, bytes to you, my total outgoing rays, my local pending rays, the bounding rectangle of the
+                   // pixels my framebuffer holds deposits in (x0, y0, x1, y1; for the composite), rays per queue [n_inst]}
+#define REPORT_TAIL 12 // words behind the queue sizes in the round's report
 
 // sizes[i] = *count_ptr[i]; the announce row for every peer; totals (2 x u64) and flags copied next to them so that ONE device-to-host
 // copy carries everything the host needs from a round
 __global__ void k_round_report(unsigned *const *__restrict__ count_ptr, const int *__restrict__ owner, int n_inst, int rank, int world,
                                unsigned *__restrict__ sizes, int *__restrict__ ann /* [world][ANN_HEAD + n_inst] */, const unsigned *__restrict__ counters,
-                               const unsigned *__restrict__ overflow, unsigned *__restrict__ tail /* sizes + n_inst: tot[4], ovf trav, ovf queue */) {
+                               const unsigned *__restrict__ overflow, unsigned *__restrict__ tail /* sizes + n_inst: tot[4], ovf trav, ovf queue, bbox[4] */,
+                               const int *__restrict__ bbox) {
   __shared__ unsigned long long sh_out, sh_local;
   if (threadIdx.x == 0) { sh_out = 0; sh_local = 0; }
   __syncthreads();
@@ -298,10 +301,12 @@ __global__ void k_round_report(unsigned *const *__restrict__ count_ptr, const in
     ann[p * row + 1] = (int)(rays * 80u + queues * 8u); // SendRays: packed rays + {queue number, ray count} per queue (:397-407)
     ann[p * row + 2] = (int)sh_out;
     ann[p * row + 3] = (int)sh_local;
+    for (int k = 0; k < 4; k++) ann[p * row + 4 + k] = bbox[k];
   }
   if (threadIdx.x == 0) {
     tail[0] = counters[16]; tail[1] = counters[17]; tail[2] = counters[18]; tail[3] = counters[19];
     tail[4] = counters[8]; tail[5] = *overflow;
+    for (int k = 0; k < 4; k++) tail[6 + k] = (unsigned)bbox[k];
   }
 }
 
@@ -335,6 +340,28 @@ __global__ __launch_bounds__(256) void k_unpack_wire(const unsigned *__restrict_
   const unsigned v = src[2 + t];
   if (w < 16) { float4 *pl = w < 4 ? q.p0 : w < 8 ? q.p1 : w < 12 ? q.p2 : q.p3; ((unsigned *)(pl + slot))[w & 3] = v; }
   else if (w == 16) q.p4[slot] = v;
+}
+// bounding rectangle (x0, y0, x1, y1 exclusive) of the pixels that hold a deposit (every deposit adds 1.0 to alpha, IceTComposite::localAdd)
+__global__ void k_bbox_init(int *bbox, int W, int H) { if (!blockIdx.x && !threadIdx.x) { bbox[0] = W; bbox[1] = H; bbox[2] = 0; bbox[3] = 0; } }
+__global__ __launch_bounds__(256) void k_fb_bbox(const float4 *__restrict__ fb, int W, int H, int *__restrict__ bbox) {
+  __shared__ int sh[4];
+  if (threadIdx.x == 0) { sh[0] = W; sh[1] = H; sh[2] = 0; sh[3] = 0; }
+  __syncthreads();
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (unsigned)(W * H) && fb[i].w > 0.f) {
+    const int x = (int)(i % (unsigned)W), y = (int)(i / (unsigned)W);
+    atomicMin(&sh[0], x); atomicMin(&sh[1], y); atomicMax(&sh[2], x + 1); atomicMax(&sh[3], y + 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && sh[2] > sh[0]) { atomicMin(&bbox[0], sh[0]); atomicMin(&bbox[1], sh[1]); atomicMax(&bbox[2], sh[2]); atomicMax(&bbox[3], sh[3]); }
+}
+// rectangle of the framebuffer <-> contiguous buffer (float4 pixels); ADD: buffer added into the framebuffer
+template <bool ADD> __global__ __launch_bounds__(256) void k_rect(float4 *__restrict__ fb, int W, int x0, int y0, int w, int h, float4 *__restrict__ buf) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (unsigned)(w * h)) return;
+  const size_t px = (size_t)(y0 + (int)(i / (unsigned)w)) * W + x0 + (int)(i % (unsigned)w);
+  if (ADD) { float4 a = fb[px]; const float4 b = buf[i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; fb[px] = a; }
+  else buf[i] = fb[px];
 }
 __global__ void k_add_count(unsigned *count, unsigned n) { if (!blockIdx.x && !threadIdx.x) *count += n; }
 __global__ void k_zero_totals(unsigned *c, unsigned *ovf) { if (!blockIdx.x && threadIdx.x < 4) c[16 + threadIdx.x] = 0u; if (!blockIdx.x && threadIdx.x == 4) *ovf = 0u; }
@@ -445,8 +472,8 @@ extern "C" gvt_hip_tracer *gvt_hip_tracer_create(gvt_hip_top *T, gvt_hip_mesh *c
        hipHostMalloc((void **)&R->h_segs, sizeof(WaveSeg) * n1, hipHostMallocDefault) == hipSuccess &&
        hipMalloc((void **)&R->d_count_ptr, sizeof(unsigned *) * n1) == hipSuccess && hipMalloc((void **)&R->d_owner, sizeof(int) * n1) == hipSuccess &&
        hipMalloc((void **)&R->d_mask, n1) == hipSuccess && hipHostMalloc((void **)&R->h_mask, n1, hipHostMallocDefault) == hipSuccess &&
-       hipMalloc((void **)&R->d_report, sizeof(unsigned) * (n1 + 8)) == hipSuccess &&
-       hipHostMalloc((void **)&R->h_report, sizeof(unsigned) * (n1 + 8), hipHostMallocDefault) == hipSuccess &&
+       hipMalloc((void **)&R->d_report, sizeof(unsigned) * (n1 + REPORT_TAIL)) == hipSuccess &&
+       hipHostMalloc((void **)&R->h_report, sizeof(unsigned) * (n1 + REPORT_TAIL), hipHostMallocDefault) == hipSuccess &&
        hipMalloc((void **)&R->d_overflow, 64) == hipSuccess;
   if (ok) {
     ok = hipMemcpy(R->d_insts, insts.data(), sizeof(WaveInst) * n1, hipMemcpyHostToDevice) == hipSuccess &&
@@ -568,8 +595,12 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs) {
   Ctx &C = gctx();
   const size_t nI = R->n_inst, row = ANN_HEAD + nI;
   hipStream_t st = C.stream;
+  int *d_bbox = (int *)(R->d_overflow + 4);
+  k_bbox_init<<<1, 64, 0, st>>>(d_bbox, R->fb->w, R->fb->h);
+  if (exchange && R->world > 1) // the rectangle this rank's deposits lie in, for the composite: carried by the announce
+    k_fb_bbox<<<(unsigned)(((size_t)R->fb->w * R->fb->h + 255) / 256), 256, 0, st>>>((const float4 *)R->fb->d_rgba, R->fb->w, R->fb->h, d_bbox);
   k_round_report<<<1, 256, 0, st>>>(R->d_count_ptr, R->d_owner, (int)nI, R->rank, R->world, R->d_report, R->d_ann_out, C.d_counters, R->d_overflow,
-                                    R->d_report + nI);
+                                    R->d_report + nI, d_bbox);
   HIPCHK(hipGetLastError());
   if (exchange && R->world > 1) {
     gvt_hip_comm *K = R->comm;
@@ -584,11 +615,11 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs) {
     int rc = comm_group_end(K);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(R->h_ann_in, R->d_ann_in, sizeof(int) * R->world * row, hipMemcpyDeviceToHost, K->stream));
-    HIPCHK(hipMemcpyAsync(R->h_report, R->d_report, sizeof(unsigned) * (nI + 8), hipMemcpyDeviceToHost, K->stream));
+    HIPCHK(hipMemcpyAsync(R->h_report, R->d_report, sizeof(unsigned) * (nI + REPORT_TAIL), hipMemcpyDeviceToHost, K->stream));
     HIPCHK(hipEventRecord(R->ev_report, K->stream));
     HIPCHK(hipEventSynchronize(R->ev_report));
   } else {
-    HIPCHK(hipMemcpyAsync(R->h_report, R->d_report, sizeof(unsigned) * (nI + 8), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(R->h_report, R->d_report, sizeof(unsigned) * (nI + REPORT_TAIL), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
   }
   if (syncs) (*syncs)++;
@@ -718,12 +749,53 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
       payload_pending = true;
     }
   }
-  // IceTComposite::composite (composite/IceTComposite.cpp:84-101): the float framebuffers summed on rank 0
+  // IceTComposite::composite (composite/IceTComposite.cpp:84-101): the float framebuffers summed on rank 0.  A rank's deposits lie
+  // where its domains project, so every rank sends rank 0 only the bounding rectangle of the pixels it wrote to -- known to both
+  // sides from the last round's announce, no extra handshake -- and rank 0 adds the rectangles: about one frame of traffic in
+  // total, spread over the links of all peers, instead of a reduce of whole W x H x 16-byte frames.  (GVT_HIP_FRAME_FULL_REDUCE:
+  // ncclReduce of the whole frame.)  Same sums in rank order; exact wherever one rank writes a pixel.
   if (R->world > 1 && !(flags & GVT_HIP_FRAME_NO_COMPOSITE)) {
     gvt_hip_comm *K = R->comm;
-    HIPCHK(hipEventRecord(R->ev_compute, st));
-    HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0));
-    if ((rc = comm_reduce_sum(K, R->fb->d_rgba, (size_t)R->fb->w * R->fb->h * 4, 0))) return rc;
+    const int W = R->fb->w;
+    if (flags & GVT_HIP_FRAME_FULL_REDUCE) {
+      HIPCHK(hipEventRecord(R->ev_compute, st));
+      HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0));
+      if ((rc = comm_reduce_sum(K, R->fb->d_rgba, (size_t)R->fb->w * R->fb->h * 4, 0))) return rc;
+    } else if (R->rank != 0) {
+      const int *bb = (const int *)(R->h_report + nI + 6);
+      const int w = bb[2] - bb[0], h = bb[3] - bb[1];
+      if (w > 0 && h > 0) {
+        const size_t bytes = (size_t)w * h * 16;
+        if ((rc = grow(&R->send_buf[0], &R->send_cap[0], bytes))) return rc;
+        k_rect<false><<<(unsigned)(((size_t)w * h + 255) / 256), 256, 0, st>>>((float4 *)R->fb->d_rgba, W, bb[0], bb[1], w, h, (float4 *)R->send_buf[0]);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(R->ev_compute, st));
+        HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0));
+        comm_group_begin(K);
+        comm_send(K, R->send_buf[0], bytes, 0);
+        if ((rc = comm_group_end(K))) return rc;
+      }
+    } else {
+      HIPCHK(hipEventRecord(R->ev_compute, st));
+      HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0));
+      comm_group_begin(K);
+      for (int p = 1; p < R->world; p++) {
+        const int *bb = R->h_ann_in + (size_t)p * row + 4;
+        const int w = bb[2] - bb[0], h = bb[3] - bb[1];
+        if (w <= 0 || h <= 0) continue;
+        const size_t bytes = (size_t)w * h * 16;
+        if ((rc = grow(&R->recv_buf[p], &R->recv_cap[p], bytes))) return rc;
+        comm_recv(K, R->recv_buf[p], bytes, p);
+      }
+      if ((rc = comm_group_end(K))) return rc;
+      for (int p = 1; p < R->world; p++) {
+        const int *bb = R->h_ann_in + (size_t)p * row + 4;
+        const int w = bb[2] - bb[0], h = bb[3] - bb[1];
+        if (w <= 0 || h <= 0) continue;
+        k_rect<true><<<(unsigned)(((size_t)w * h + 255) / 256), 256, 0, K->stream>>>((float4 *)R->fb->d_rgba, W, bb[0], bb[1], w, h, (float4 *)R->recv_buf[p]);
+      }
+      HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(R->ev_comm, K->stream));
     HIPCHK(hipStreamWaitEvent(st, R->ev_comm, 0));
     HIPCHK(hipStreamSynchronize(K->stream));

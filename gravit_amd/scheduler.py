@@ -221,11 +221,11 @@ class NativeTracer:
         capi.check(self.lib.gvt_hip_tracer_set_domains(self.h, capi.ptr(own), comm.h if comm is not None else None), "gvt_hip_tracer_set_domains")
         self.stats = {}
 
-    def __call__(self, bsp=False, composite=True):
+    def __call__(self, bsp=False, composite=True, full_reduce=False):
         import ctypes as C
 
         st = capi.FrameStats()
-        flags = (capi.FRAME_BSP if bsp else 0) | (0 if composite else capi.FRAME_NO_COMPOSITE)
+        flags = (capi.FRAME_BSP if bsp else 0) | (0 if composite else capi.FRAME_NO_COMPOSITE) | (capi.FRAME_FULL_REDUCE if full_reduce else 0)
         capi.check(self.lib.gvt_hip_tracer_frame(self.h, C.c_int(flags), C.byref(st)), "gvt_hip_tracer_frame")
         self.stats = st.as_dict()
         return self.backend

@@ -237,6 +237,7 @@ int gvt_hip_tracer_set_domains(gvt_hip_tracer *, const int32_t *owner /* n_inst 
 #define GVT_HIP_FRAME_BSP 1          /* Domain: trace until the local queues are dry, then exchange (Tracer<DomainScheduler>); default:
                                         one local chain per exchange, the payload moving while the next chain runs (asynchronous tracer) */
 #define GVT_HIP_FRAME_NO_COMPOSITE 2 /* leave the per-rank framebuffers un-reduced */
+#define GVT_HIP_FRAME_FULL_REDUCE 4  /* composite by a sum-reduce of whole frames (ncclReduce) instead of each rank's written rectangle */
 typedef struct gvt_hip_frame_stats {
   uint64_t rounds;       /* exchanges (Domain) */
   uint64_t chains;       /* merged launch chains on this rank */

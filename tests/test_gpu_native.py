@@ -53,7 +53,7 @@ def test_rounds_equal_the_reference_order_loop(hip, name, mode, exact):
     tr.close()
 
 
-def run_native_ranks(scene, owner, world, mode, bsp):
+def run_native_ranks(scene, owner, world, mode, bsp, full_reduce=False):
     hub = capi.load().gvt_hip_hub_create(world)
     out, errs = {}, []
 
@@ -63,7 +63,7 @@ def run_native_ranks(scene, owner, world, mode, bsp):
             ctx = Context(0)
             comm = Comm.local(hub, rank)
             tr = NativeTracer(scene, mode, owner, comm)
-            B = tr(bsp=bsp)
+            B = tr(bsp=bsp, full_reduce=full_reduce)
             out[rank] = (B.framebuffer(True) if rank == 0 else None, dict(tr.stats))
             tr.close()
             comm.close()
@@ -131,6 +131,16 @@ def test_soup_domains_with_cross_traffic_native(hip):
         ref, st = oracle_render_domain(sc, owner, 2, 0)
         assert np.array_equal(res[0][0][..., :3], ref[..., :3])
         assert sum(r[1]["rays_sent"] for r in res.values()) == st.rays_sent and st.rays_sent > 1000
+
+
+def test_composite_rectangles_equal_the_full_reduce(hip):
+    """The composite sends rank 0 each rank's written rectangle (known from the last announce); the result equals the sum-reduce of
+    whole frames, on a scene where ranks write overlapping pixel sets (bounce rays deposit anywhere)."""
+    sc = config5(256, 4)
+    owner = [0, 1, 2, 1]
+    a = run_native_ranks(sc, owner, 3, NORMALS_FLAT, False)[0][0]
+    b = run_native_ranks(sc, owner, 3, NORMALS_FLAT, False, full_reduce=True)[0][0]
+    assert np.abs(a - b).max() <= 1e-5 and np.array_equal(a[..., 3], b[..., 3]) and (a[..., 3] > 0).mean() > 0.2
 
 
 def test_rccl_communicator_of_one_rank(hip):
