@@ -691,6 +691,9 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
       }
       if (R->world == 1) break;
     } else {
+      bool have_local = false;
+      for (size_t i = 0; i < nI; i++) have_local = have_local || (R->owned[i] && R->present[i]);
+      if (!have_local && (rc = unpack_pending())) return rc; // nothing to overlap the transfer with: take what arrived first
       if ((rc = local_chain(R, &incoming, &S.chains))) return rc;
       if ((rc = unpack_pending())) return rc;
     }

@@ -36,6 +36,8 @@ struct Knobs {
   int long_min_rays = 65536; // ... only in launches of at least this many rays (small launches have no tail to speak of)
   int fused = 0;         // scheduler rounds: closest hit + shade + first-light shadow rays in one kernel (k_fused) instead of three launches.
                          // Measured 2.4x SLOWER than the three launches: shading inside the persistent kernel is latency-exposed
+  int small_rays = 4096; // scheduler rounds holding at most this many rays give every ray a whole wave (k_long_closest / k_wave_any): ~40 us
+                         // per traversal launch instead of the ~150 us latency floor of a one-lane-per-ray launch
   int wave_single = 1;   // scheduler rounds: a round with ONE non-empty local queue uses the single-mesh kernels (no per-ray segment / instance lookups)
   int shadow_direct = 1; // scheduler rounds: shadow rays in direct-mapped slots (the order of the traced list) instead of block-arrival order
   int term_sink = 1;     // gvt_hip_trace_queue_sink: deposit terminal shadow rays from the any-hit kernel (0: always through moved_rays)

@@ -790,6 +790,135 @@ __global__ __launch_bounds__(256) void k_long_closest(RayPlanes q, const LongRec
   if (overflow) atomicOr(counter + (TRAV_OVF_WORD - 4), 1u);
 }
 
+// Small launches.  A persistent one-lane-per-ray launch cannot be faster than its slowest ray's chain of dependent fetches
+// (100-350 steps of ~1 us): a round that holds a few hundred rays -- every later round of a multi-domain frame -- cost ~150 us
+// per traversal launch whatever its size.  Below `small_rays` the rounds therefore give EVERY ray a whole wave (the k_long_closest
+// scheme: 64 pending nodes opened per step, ~15-25 steps per ray): k_long_seed turns the ray list into LongRecs, k_long_closest
+// finds the closest hits, k_wave_any below is the same traversal for shadow rays (stops at the first occluder).
+__global__ __launch_bounds__(256) void k_long_seed(LongRec *__restrict__ recs, unsigned *__restrict__ count, const unsigned *__restrict__ idx, unsigned n,
+                                                    const unsigned *__restrict__ n_dev) {
+  if (n_dev) n = *n_dev;
+  const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) *count = n;
+  if (j >= n) return;
+  LongRec R; R.j = j; R.i = idx ? idx[j] : j; R.bt = GVT_FLT_MAX; R.bp = -1; R.bu = 0.f; R.bv = 0.f; R.bden = 1.f; R.pad = 0u;
+  recs[j] = R;
+}
+
+template <bool MULTI>
+__global__ __launch_bounds__(256) void k_wave_any(RayPlanes q, const unsigned *__restrict__ n_dev, Mat4 minv, Trav T, float tnear, RayPlanes out,
+                                                   unsigned *out_count, unsigned *counter, TermSink sink, MultiSrc MS) {
+  __shared__ int s_ref_all[4][LONG_PHYS];
+  __shared__ int l_ref_all[4][LONG_PHYS];
+  const int wv = threadIdx.x >> 6;
+  const int lane = (int)lane_id();
+  volatile int *s_ref = s_ref_all[wv];
+  volatile int *l_ref = l_ref_all[wv];
+  const unsigned n = *n_dev;
+  bool overflow = false, first = true;
+  for (;;) {
+    unsigned r = 0;
+    if (first) { first = false; r = blockIdx.x * 4u + (unsigned)wv; }
+    else {
+      if (lane == 0) r = atomicAdd(counter, 1u);
+      r = (unsigned)__builtin_amdgcn_readfirstlane((int)r) + gridDim.x * 4u;
+    }
+    if (r >= n) break;
+    const float4 a = q.p0[r], b = q.p1[r];
+    int inst = sink.from;
+    V3 O, D;
+    if (MULTI) {
+      inst = MS.ray_inst[r];
+      const WaveInst *wi = MS.W.insts + inst;
+      T.nodes4 = wi->nodes4; T.tris = wi->tris;
+      O = xfm_point(wi->minv, mk3(a.x, a.y, a.z)); D = xfm_vector(wi->minv, mk3(b.x, b.y, b.z));
+    } else {
+      O = xfm_point(minv, mk3(a.x, a.y, a.z)); D = xfm_vector(minv, mk3(b.x, b.y, b.z));
+    }
+    const float dx = fabsf(D.x) < 1e-30f ? copysignf(1e-30f, D.x) : D.x;
+    const float dy = fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y;
+    const float dz = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    const float ox = O.x * ix, oy = O.y * iy, oz = O.z * iz;
+    int ns = T.nodes4 ? 1 : 0, nl = 0; // wave-uniform
+    bool occluded = false;             // wave-uniform
+    if (lane == 0) s_ref[0] = 0;
+    __builtin_amdgcn_wave_barrier();
+    while (!occluded && (ns > 0 || nl > 0)) {
+      const bool do_leaf = nl > 0 && (ns == 0 || nl >= 64 || nl > LONG_CAP - 256);
+      if (!do_leaf) {
+        int take = min(min(ns, 64), min((LONG_CAP - ns) / 3, (LONG_CAP - nl) / 4));
+        take = max(take, 1);
+        const bool mine = lane < take;
+        int ref = 0;
+        if (mine) ref = s_ref[ns - 1 - lane];
+        __builtin_amdgcn_wave_barrier();
+        ns -= take;
+        float tn[4];
+        int rr[4];
+        if (mine) node4_test(T.nodes4 + (size_t)GVT_NODE4_F4 * ref, ix, iy, iz, ox, oy, oz, GVT_FLT_MAX, tn, rr);
+#pragma unroll
+        for (int c = 3; c >= 0; c--) {
+          const bool hit = mine && tn[c] < GVT_FLT_MAX;
+          const unsigned long long mi = __ballot(hit && rr[c] >= 0), ml = __ballot(hit && rr[c] < 0);
+          if (hit && rr[c] >= 0) { const int pos = ns + (int)lanes_below(mi); if (pos < LONG_PHYS) s_ref[pos] = rr[c]; else overflow = true; }
+          if (hit && rr[c] < 0) { const int pos = nl + (int)lanes_below(ml); if (pos < LONG_PHYS) l_ref[pos] = rr[c]; else overflow = true; }
+          ns = min(ns + __popcll(mi), LONG_PHYS);
+          nl = min(nl + __popcll(ml), LONG_PHYS);
+        }
+        __builtin_amdgcn_wave_barrier();
+      } else {
+        const int take = min(nl, 64);
+        const bool mine = lane < take;
+        int ref = -1;
+        if (mine) ref = l_ref[nl - 1 - lane];
+        __builtin_amdgcn_wave_barrier();
+        nl -= take;
+        bool hit_any = false;
+        if (mine) {
+          const unsigned code = (unsigned)~ref;
+          const unsigned first_slot = code >> 3, ntri = code & 7u;
+          const float4 *ts = T.tris + 4 * (size_t)first_slot;
+          for (unsigned k = 0; k < ntri && !hit_any; k++) {
+            const float4 s0 = ts[4 * k], s1 = ts[4 * k + 1], s2 = ts[4 * k + 2];
+            const V3 e1 = mk3(s1.x, s1.y, s1.z), e2 = mk3(s2.x, s2.y, s2.z);
+            float TT, U, V, aden;
+            if (tri_test_raw(O, D, mk3(s0.x, s0.y, s0.z), e1, e2, cross3(e1, e2), tnear, TT, U, V, aden)) {
+              const float t = TT / aden;
+              if (t <= GVT_FLT_MAX) hit_any = true;
+            }
+          }
+        }
+        occluded = __ballot(hit_any) != 0ull;
+      }
+    }
+    if (!occluded && lane == 0) { // un-occluded: moved on, or ended here by shuffleRays' terminal rule (TracerBase.h:396-400)
+      const float4 c = q.p2[r], d = q.p3[r];
+      bool go_on = true;
+      if (sink.fb) {
+        float ret_t;
+        go_on = top_nearest(a, b, sink.top, inst, ret_t) >= 0;
+        if (!go_on) {
+          const V3 col = mk3(c.x, c.y, c.z);
+          const unsigned id = (unsigned)__float_as_int(d.x);
+          if (__float_as_int(d.w) == 1 && len3(col) > 0.f && id < sink.n_pix) {
+            const V3 cw = scl3(col, d.z);
+            float *px = sink.fb + (size_t)4 * id;
+            atomicAdd(px + 0, cw.x); atomicAdd(px + 1, cw.y); atomicAdd(px + 2, cw.z); atomicAdd(px + 3, 1.f);
+          }
+        }
+      }
+      if (go_on) {
+        const unsigned slot = atomicAdd(out_count, 1u);
+        out.p0[slot] = a; out.p1[slot] = b; out.p2[slot] = c; out.p3[slot] = d;
+        if (out.p4) out.p4[slot] = 0u;
+        if (MULTI && MS.out_from) MS.out_from[slot] = inst;
+      }
+    }
+  }
+  if (overflow) atomicOr(counter + TRAV_OVF_WORD, 1u);
+}
+
 // diagnostic (not on the hot path): per-ray visit counts of the closest-hit traversal.
 // out[3*j + 0..2] = inner-node visits / leaf visits / triangle tests of ray j (reduced on the host).
 __global__ __launch_bounds__(TRAV_BLOCK) void k_visit_stats(RayPlanes q, unsigned n, Trav T, float tnear, unsigned *__restrict__ out,
@@ -2011,6 +2140,8 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
   Trav T{};
   Mat4 id{};
   const bool use_long = C.long_steps > 0 && n >= (size_t)C.long_min_rays;
+  const bool small = n <= (size_t)C.small_rays; // a wave per ray (see k_long_seed)
+  const int small_grid = (int)std::min<size_t>((n + 3) / 4, (size_t)C.n_cu * 3);
   for (int pass = 0; pass < passes; pass++) {
     const unsigned *n_dev = pass ? c + ((pass & 1) ? 2 : 5) : nullptr;          // count written by the previous pass's k_shade
     const unsigned *idx = pass ? ((pass & 1) ? d_idx_a : d_idx_b) : nullptr;    // its bounce list
@@ -2025,12 +2156,17 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       Trav TS{ M->d_nodes, M->d_tri, M->d_nodes4 };
       LongQ LQ{};
       if (use_long && have4) { LQ.recs = d_long; LQ.count = c + 3; LQ.steps = C.long_steps; }
-      {
+      const bool small1 = small && have4;
+      if (small1) {
+        ProfScope ps(KC_CLOSEST);
+        k_long_seed<<<blocks_for(n), 256, 0, st>>>(d_long, c + 3, idx, (unsigned)n, n_dev);
+        k_long_closest<true><<<small_grid, 256, 0, st>>>(single->planes, d_long, c + 3, single->minv, TS, GVT_RAY_EPSILON, d_hits, c + 4);
+      } else {
         ProfScope ps(KC_CLOSEST);
         launch_trace<false, true, 0>(have4, trav_grid2(n, true), st, single->planes, idx, (unsigned)n, single->minv, TS, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
                                      c + 0, C.d_spill, C.refill_min, C.inner_min, n_dev, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
       }
-      if (LQ.steps) {
+      if (LQ.steps && !small1) {
         ProfScope ps(KC_LONG);
         k_long_closest<true><<<C.n_cu * 3, 256, 0, st>>>(single->planes, d_long, c + 3, single->minv, TS, GVT_RAY_EPSILON, d_hits, c + 4);
       }
@@ -2052,8 +2188,9 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
         ProfScope ps(KC_ANY);
         TermSink sk = P.sink;
         sk.from = single->inst;
-        launch_trace<true, true, 1>(have4, trav_grid2(shadow_cap), st, shadow, nullptr, 0u, single->minv, TS, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
-                                    c + 0, C.d_spill, C.refill_min, C.inner_min, c + 1, C.share, (unsigned)C.share_min_rays, sk, LongQ{});
+        if (small1) k_wave_any<false><<<(int)std::min<size_t>((shadow_cap + 3) / 4, (size_t)C.n_cu * 3), 256, 0, st>>>(shadow, c + 1, single->minv, TS, GVT_RAY_EPSILON, outp, out->d_count, c + 0, sk, MultiSrc{});
+        else launch_trace<true, true, 1>(have4, trav_grid2(shadow_cap), st, shadow, nullptr, 0u, single->minv, TS, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
+                                         c + 0, C.d_spill, C.refill_min, C.inner_min, c + 1, C.share, (unsigned)C.share_min_rays, sk, LongQ{});
       }
       HIPCHK(hipGetLastError());
       C.stats.launches_closest++;
@@ -2088,13 +2225,17 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     LongQ LQ{};
     if (use_long) { LQ.recs = d_long; LQ.count = c + 3; LQ.steps = C.long_steps; }
     MultiSrc MS{ W, nullptr, nullptr, nullptr };
-    {
+    if (small) {
+      ProfScope ps(KC_CLOSEST);
+      k_long_seed<<<blocks_for(n), 256, 0, st>>>(d_long, c + 3, idx, (unsigned)n, n_dev);
+      k_long_closest<true, true><<<small_grid, 256, 0, st>>>(none, d_long, c + 3, id, T, GVT_RAY_EPSILON, d_hits, c + 4, W);
+    } else {
       ProfScope ps(KC_CLOSEST);
       k_trace<false, true, 0, false, true, true><<<trav_grid2(n, true), TRAV_BLOCK, 0, st>>>(none, idx, (unsigned)n, id, T, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
                                                                                       c + 0, C.d_spill, C.refill_min, C.inner_min, n_dev, C.share, (unsigned)C.share_min_rays,
                                                                                       TermSink{}, LQ, MS);
     }
-    if (use_long) {
+    if (use_long && !small) {
       ProfScope ps(KC_LONG);
       k_long_closest<true, true><<<C.n_cu * 3, 256, 0, st>>>(none, d_long, c + 3, id, T, GVT_RAY_EPSILON, d_hits, c + 4, W);
     }
@@ -2105,7 +2246,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     A.n_lights = nL; A.seed = P.seed; A.zero_word = c + 0;
     A.sink = P.sink; A.update_in_place = 0;
     A.n_dev = n_dev; A.W = W; A.out_from = d_out_from; A.shadow_inst = d_shadow_inst;
-    const bool direct = C.shadow_direct && pass == 0; // later passes hold few rays: compacted slots
+    const bool direct = C.shadow_direct && pass == 0 && !small; // later passes and small rounds hold few rays: compacted slots
     A.shadow_stride = direct ? (unsigned)n : 0u;
     {
       ProfScope ps(KC_SHADE);
@@ -2114,6 +2255,8 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     if (nL) {
       ProfScope ps(KC_ANY);
       MultiSrc MA{ W, d_shadow_inst, d_out_from, direct ? (unsigned long long *)(c + 18) : nullptr };
+      if (small) k_wave_any<true><<<(int)std::min<size_t>((shadow_cap + 3) / 4, (size_t)C.n_cu * 3), 256, 0, st>>>(shadow, c + 1, id, T, GVT_RAY_EPSILON, outp, out->d_count, c + 0, P.sink, MA);
+      else
       k_trace<true, true, 1, false, true, true><<<trav_grid2(shadow_cap), TRAV_BLOCK, 0, st>>>(shadow, nullptr, direct ? (unsigned)shadow_cap : 0u, id, T, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
                                                                                               c + 0, C.d_spill, C.refill_min, C.inner_min, direct ? nullptr : c + 1, C.share, (unsigned)C.share_min_rays,
                                                                                               P.sink, LongQ{}, MA);
