@@ -32,7 +32,7 @@
 #include "gvt_internal.h"
 
 int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *from_arr, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
-                  gvt_hip_fb *fb, unsigned *d_overflow);
+                  gvt_hip_fb *fb, unsigned *d_overflow, const void *d_qdesc);
 
 // ------------------------------------------------------------------------------------------------
 // RCCL, resolved at first use (a single-GPU process never loads it)
@@ -310,9 +310,9 @@ __global__ void k_round_report(unsigned *const *__restrict__ count_ptr, const in
   }
 }
 
-__global__ void k_zero_counts(unsigned *const *__restrict__ count_ptr, const unsigned char *__restrict__ mask, int n_inst) {
+__global__ void k_zero_counts(unsigned *const *__restrict__ count_ptr, const unsigned char *__restrict__ mask /* null: all */, int n_inst) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_inst && mask[i]) *count_ptr[i] = 0u;
+  if (i < n_inst && (!mask || mask[i])) *count_ptr[i] = 0u;
 }
 
 // wire image of one queue: [int32 queueId][int32 nRays][nRays x 80-byte Ray] (DomainTracer.h:441-455); one thread per dword
@@ -387,7 +387,11 @@ struct gvt_hip_tracer {
   int rank = 0, world = 1;
   // device tables
   WaveInst *d_insts = nullptr;
+  // per-round tables in ONE pinned block / ONE device block (a single host-to-device copy per round): segments, queue descriptors, mask
+  void *d_round = nullptr, *h_round = nullptr;
+  size_t round_bytes = 0;
   WaveSeg *d_segs = nullptr, *h_segs = nullptr;
+  QueueDesc *d_qdesc = nullptr, *h_qdesc = nullptr;
   unsigned **d_count_ptr = nullptr;
   int *d_owner = nullptr;
   unsigned char *d_mask = nullptr, *h_mask = nullptr;
@@ -406,8 +410,8 @@ extern "C" void gvt_hip_tracer_destroy(gvt_hip_tracer *R) {
   if (R->comm) hipStreamSynchronize(R->comm->stream);
   for (auto q : R->queues) gvt_hip_queue_destroy(q);
   gvt_hip_queue_destroy(R->q_moved);
-  hipFree(R->d_insts); hipFree(R->d_segs); hipHostFree(R->h_segs); hipFree(R->d_count_ptr); hipFree(R->d_owner); hipFree(R->d_mask);
-  hipHostFree(R->h_mask); hipFree(R->d_report); hipHostFree(R->h_report); hipFree(R->d_ann_out); hipFree(R->d_ann_in); hipHostFree(R->h_ann_in);
+  hipFree(R->d_insts); hipFree(R->d_round); hipHostFree(R->h_round); hipFree(R->d_count_ptr); hipFree(R->d_owner);
+  hipFree(R->d_report); hipHostFree(R->h_report); hipFree(R->d_ann_out); hipFree(R->d_ann_in); hipHostFree(R->h_ann_in);
   hipFree(R->d_overflow);
   for (void *p : R->send_buf) hipFree(p);
   for (void *p : R->recv_buf) hipFree(p);
@@ -468,14 +472,17 @@ extern "C" gvt_hip_tracer *gvt_hip_tracer_create(gvt_hip_top *T, gvt_hip_mesh *c
     I.mv.verts = M->d_verts; I.mv.tris = M->d_tris; I.mv.normals = M->d_normals; I.mv.vcolors = M->d_vcolors;
     I.mv.materials = M->d_materials; I.mv.n_mat = (unsigned)M->nMat; I.mv.face_mat = M->d_face_mat; I.mv.mat = M->mesh_mat;
   }
-  ok = ok && hipMalloc((void **)&R->d_insts, sizeof(WaveInst) * n1) == hipSuccess && hipMalloc((void **)&R->d_segs, sizeof(WaveSeg) * n1) == hipSuccess &&
-       hipHostMalloc((void **)&R->h_segs, sizeof(WaveSeg) * n1, hipHostMallocDefault) == hipSuccess &&
+  R->round_bytes = (sizeof(WaveSeg) + sizeof(QueueDesc)) * n1 + ((n1 + 15) & ~(size_t)15);
+  ok = ok && hipMalloc((void **)&R->d_insts, sizeof(WaveInst) * n1) == hipSuccess && hipMalloc(&R->d_round, R->round_bytes) == hipSuccess &&
+       hipHostMalloc(&R->h_round, R->round_bytes, hipHostMallocDefault) == hipSuccess &&
        hipMalloc((void **)&R->d_count_ptr, sizeof(unsigned *) * n1) == hipSuccess && hipMalloc((void **)&R->d_owner, sizeof(int) * n1) == hipSuccess &&
-       hipMalloc((void **)&R->d_mask, n1) == hipSuccess && hipHostMalloc((void **)&R->h_mask, n1, hipHostMallocDefault) == hipSuccess &&
        hipMalloc((void **)&R->d_report, sizeof(unsigned) * (n1 + REPORT_TAIL)) == hipSuccess &&
        hipHostMalloc((void **)&R->h_report, sizeof(unsigned) * (n1 + REPORT_TAIL), hipHostMallocDefault) == hipSuccess &&
        hipMalloc((void **)&R->d_overflow, 64) == hipSuccess;
   if (ok) {
+    R->h_segs = (WaveSeg *)R->h_round; R->d_segs = (WaveSeg *)R->d_round;
+    R->h_qdesc = (QueueDesc *)(R->h_segs + n1); R->d_qdesc = (QueueDesc *)(R->d_segs + n1);
+    R->h_mask = (unsigned char *)(R->h_qdesc + n1); R->d_mask = (unsigned char *)(R->d_qdesc + n1);
     ok = hipMemcpy(R->d_insts, insts.data(), sizeof(WaveInst) * n1, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(R->d_count_ptr, cptr.data(), sizeof(unsigned *) * n1, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemset(R->d_owner, 0, sizeof(int) * n1) == hipSuccess && hipMemset(R->d_overflow, 0, 64) == hipSuccess;
@@ -559,8 +566,11 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
     R->h_segs[k].planes = q->d_planes; R->h_segs[k].cap = q->cap;
   }
   hipStream_t st = C.stream;
-  HIPCHK(hipMemcpyAsync(R->d_segs, R->h_segs, sizeof(WaveSeg) * n_seg, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(R->d_mask, R->h_mask, nI, hipMemcpyHostToDevice, st));
+  for (size_t i = 0; i < nI; i++) { // the shuffle's destinations
+    gvt_hip_queue *Q = R->queues[i];
+    R->h_qdesc[i].planes = Q->d_planes; R->h_qdesc[i].cap = Q->cap; R->h_qdesc[i].count = Q->d_count; R->h_qdesc[i].keep = 1u;
+  }
+  HIPCHK(hipMemcpyAsync(R->d_round, R->h_round, R->round_bytes, hipMemcpyHostToDevice, st)); // segments + descriptors + mask in one copy
   int *d_from = (int *)scratch_get(17, sizeof(int) * bound);
   if (!d_from) return GVT_HIP_ERR_DEVICE;
   TraceParams P{};
@@ -585,7 +595,7 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
   HIPCHK(hipGetLastError());
   // one instance in the whole scene and the terminal rule applied inside the kernels: nothing can have moved
   if (!(nI == 1 && P.sink.fb) &&
-      (rc = shuffle_async(R->top, R->q_moved, bound, single ? nullptr : d_from, single ? one.inst : -1, R->queues.data(), nullptr, R->fb, R->d_overflow))) return rc;
+      (rc = shuffle_async(R->top, R->q_moved, bound, single ? nullptr : d_from, single ? one.inst : -1, R->queues.data(), nullptr, R->fb, R->d_overflow, R->d_qdesc))) return rc;
   if (chains) (*chains)++;
   return 0;
 }
@@ -644,8 +654,9 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   int rc;
   // clearBuffer + generateRays + FilterRaysLocally / shuffleDropRays (ImageTracer.h:137-146, DomainTracer.h:148-183, 204-211)
   if ((rc = gvt_hip_fb_clear(R->fb))) return rc;
-  for (size_t i = 0; i < nI; i++) if ((rc = gvt_hip_queue_clear(R->queues[i]))) return rc;
-  if ((rc = gvt_hip_queue_clear(R->q_moved))) return rc;
+  for (size_t i = 0; i < nI; i++) R->queues[i]->size = 0;
+  R->q_moved->size = 0;
+  if (nI) k_zero_counts<<<(unsigned)((nI + 255) / 256), 256, 0, st>>>(R->d_count_ptr, nullptr, (int)nI); // every queue.clear() in one launch
   k_zero_totals<<<1, 64, 0, st>>>(C.d_counters, R->d_overflow);
   if ((rc = gvt_hip_camera_filter(R->top, &R->cam, C.camera_tile, R->queues.data(), R->world > 1 ? R->owned.data() : nullptr))) return rc;
   S.host_syncs++;

@@ -480,9 +480,10 @@ static int shuffle_impl(gvt_hip_top *T, const RaySrc &in, size_t n, int from, gv
 // shuffleRays of a device-resident list whose length only the device knows (q_in's count word), launched without any host round
 // trip: every destination must already have room for its current rays + n_ub more.  Destination counts advance on the device only;
 // the caller learns them from its next read-back.  from_arr: source instance per ray (merged rounds), else `from` for all.  Kernel order on the stream:
-// classify -> (scan) -> scatter -> q_in count := 0.
+// classify -> (scan) -> scatter.
+// d_qdesc: the queue descriptors already on the device (uploaded by the caller with its other per-round tables), or null.
 int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *from_arr, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
-                  gvt_hip_fb *fb, unsigned *d_overflow) {
+                  gvt_hip_fb *fb, unsigned *d_overflow, const void *d_qdesc) {
   Ctx &C = gctx();
   if (!n_ub) return 0;
   hipStream_t st = C.stream;
@@ -497,12 +498,16 @@ int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *f
     d_blk = (unsigned *)scratch_get(14, sizeof(unsigned) * nI * n_blk);
     if (!d_blk) return GVT_HIP_ERR_DEVICE;
   }
-  QueueDesc *desc = (QueueDesc *)T->h_qdesc;
-  for (size_t i = 0; i < nI; i++) {
-    gvt_hip_queue *Q = queues[i];
-    desc[i].planes = Q->d_planes; desc[i].cap = Q->cap; desc[i].count = Q->d_count; desc[i].keep = (!keep_mask || keep_mask[i]) ? 1u : 0u;
+  const QueueDesc *qd = (const QueueDesc *)d_qdesc;
+  if (!qd) {
+    QueueDesc *desc = (QueueDesc *)T->h_qdesc;
+    for (size_t i = 0; i < nI; i++) {
+      gvt_hip_queue *Q = queues[i];
+      desc[i].planes = Q->d_planes; desc[i].cap = Q->cap; desc[i].count = Q->d_count; desc[i].keep = (!keep_mask || keep_mask[i]) ? 1u : 0u;
+    }
+    if (nI) HIPCHK(hipMemcpyAsync(T->d_qdesc, desc, sizeof(QueueDesc) * nI, hipMemcpyHostToDevice, st));
+    qd = (const QueueDesc *)T->d_qdesc;
   }
-  if (nI) HIPCHK(hipMemcpyAsync(T->d_qdesc, desc, sizeof(QueueDesc) * nI, hipMemcpyHostToDevice, st));
   RaySrc S{};
   S.q = make_planes(q_in->d_planes, q_in->cap);
   S.from_cam = 0;
@@ -510,14 +515,13 @@ int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *f
     ProfScope ps(KC_SHUFFLE);
     k_top_classify<<<n_blk, TOP_BLOCK, use_lds ? sizeof(unsigned) * nI : 0, st>>>(S, (unsigned)n_ub, T->dev(), (int)nI, from, d_next, d_t, nullptr, use_lds, d_blk,
                                                                                 q_in->d_count, from_arr);
-    if (d_blk) k_top_scan<<<(unsigned)nI, TOP_BLOCK, 0, st>>>(d_blk, n_blk, (const QueueDesc *)T->d_qdesc, nullptr);
+    if (d_blk) k_top_scan<<<(unsigned)nI, TOP_BLOCK, 0, st>>>(d_blk, n_blk, qd, nullptr);
     const size_t lds = d_blk ? sizeof(unsigned) * nI * (TOP_BLOCK / 64) : (use_lds ? 2 * sizeof(unsigned) * nI : 0);
-    k_top_scatter<<<n_blk, TOP_BLOCK, lds, st>>>(S, (unsigned)n_ub, d_next, d_t, (const QueueDesc *)T->d_qdesc, (int)nI, fb ? fb->d_rgba : nullptr,
+    k_top_scatter<<<n_blk, TOP_BLOCK, lds, st>>>(S, (unsigned)n_ub, d_next, d_t, qd, (int)nI, fb ? fb->d_rgba : nullptr,
                                                fb ? (unsigned)(fb->w * fb->h) : 0u, use_lds, d_blk, q_in->d_count, d_overflow);
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemsetAsync(q_in->d_count, 0, sizeof(unsigned), st));
-  return 0;
+  return 0; // q_in's count word is left as it is: the caller's next launch chain resets it (k_wave_pass_begin)
 }
 
 extern "C" int gvt_hip_shuffle(gvt_hip_top *T, gvt_hip_queue *q_in, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
