@@ -8,13 +8,15 @@
 //   k_trace<true,..>   rtcOccluded  (:364-385): un-occluded shadow rays are appended to moved_rays -- or, with a sink, end
 //                      right there by the terminal rule of the shuffleRays that would follow (TracerBase.h:396-400)
 //   trace_core         the host side of one Adapter::trace call: closest -> shade -> any, one read-back per pass
+//   wave_trace_chain   the same chain for a whole scheduler ROUND (all non-empty local queues at once, MULTI kernel variants),
+//                      ray counts in device memory, no host round trip; k_long_seed / k_wave_any: a wave per ray for small rounds
 //
 // One lane per ray.  k_trace runs persistent waves: a wave pulls index ranges from a device counter (an exit every wave
 // reaches), refills lanes whose ray has finished while the others go on, alternates a tight loop over the compressed 4-wide
 // nodes with a leaf phase, keeps its traversal stacks in LDS (stack[level][lane]: lane-contiguous, bank conflict free) and
-// compacts survivors per wave (__ballot + mbcnt, one atomic per >= 64 rays).  k_closest / k_any / traverse() further down are
-// the first version (one 64-ray batch per wave over the binary tree), kept as the trav_kernel=0 baseline and for the
-// visit-count diagnostic; DESIGN.md 4.1 lists what was measured on the way.
+// compacts survivors per wave (__ballot + mbcnt, one atomic per >= 64 rays).  Not in this file: diag_kernels.inc (the first
+// version -- one 64-ray batch per wave over the binary tree -- kept as the trav_kernel=0 baseline and for the visit-count
+// diagnostic) and fused_kernel.inc (k_fused, measured slower); DESIGN.md 4.1 lists what was measured on the way.
 #include "gvt_internal.h"
 
 #define TRAV_BLOCK 256
@@ -30,102 +32,7 @@ struct Trav {
   const uint4 *__restrict__ nodes4;  // compressed 4-wide collapse (64 B per node) or null
 };
 
-template <bool ANY, bool COUNT = false>
-__device__ inline bool traverse(const Trav &T, V3 O, V3 D, float tnear, int *__restrict__ lds /* &stack[0][tid] */, int *__restrict__ spill,
-                                float &best_t, int &best_prim, float &best_u, float &best_v, unsigned *cnt = nullptr) {
-  // reciprocal direction for the slab test only (never feeds a result)
-  float dx = fabsf(D.x) < 1e-30f ? copysignf(1e-30f, D.x) : D.x;
-  float dy = fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y;
-  float dz = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;
-  const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-  const float ox = O.x * ix, oy = O.y * iy, oz = O.z * iz;
-  int sp = 0;
-  int cur = 0;
-  for (;;) {
-    if (cur >= 0) {
-      if (COUNT) cnt[0]++;
-      const BvhNode *nd = T.nodes + cur;
-      const float4 n0 = nd->n0, n1 = nd->n1, n2 = nd->n2, n3 = nd->n3;
-      float a0 = __builtin_fmaf(n0.x, ix, -ox), a1 = __builtin_fmaf(n0.y, ix, -ox);
-      float b0 = __builtin_fmaf(n0.z, iy, -oy), b1 = __builtin_fmaf(n0.w, iy, -oy);
-      float c0 = __builtin_fmaf(n2.x, iz, -oz), c1 = __builtin_fmaf(n2.y, iz, -oz);
-      float tn0 = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.f));
-      float tf0 = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1)) * 1.0000004f;
-      a0 = __builtin_fmaf(n1.x, ix, -ox); a1 = __builtin_fmaf(n1.y, ix, -ox);
-      b0 = __builtin_fmaf(n1.z, iy, -oy); b1 = __builtin_fmaf(n1.w, iy, -oy);
-      c0 = __builtin_fmaf(n2.z, iz, -oz); c1 = __builtin_fmaf(n2.w, iz, -oz);
-      float tn1 = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.f));
-      float tf1 = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1)) * 1.0000004f;
-      const float lim = ANY ? GVT_FLT_MAX : best_t;
-      const bool h0 = (tn0 <= tf0) && (tn0 <= lim);
-      const bool h1 = (tn1 <= tf1) && (tn1 <= lim);
-      const int r0 = __float_as_int(n3.x), r1 = __float_as_int(n3.y);
-      if (h0 && h1) {
-        const bool swap = tn1 < tn0;
-        const int nearc = swap ? r1 : r0, farc = swap ? r0 : r1;
-        if (sp < TRAV_STACK) lds[sp * TRAV_BLOCK] = farc; else spill[sp - TRAV_STACK] = farc;
-        sp++;
-        cur = nearc;
-      } else if (h0) {
-        cur = r0;
-      } else if (h1) {
-        cur = r1;
-      } else {
-        if (sp == 0) break;
-        sp--;
-        cur = (sp < TRAV_STACK) ? lds[sp * TRAV_BLOCK] : spill[sp - TRAV_STACK];
-      }
-    } else {
-      const unsigned code = (unsigned)~cur;
-      const unsigned first = code >> 3, ntri = code & 7u;
-      if (COUNT) { cnt[1]++; cnt[2] += ntri; }
-      for (unsigned k = 0; k < ntri; k++) {
-        const float4 t0 = T.tris[4 * (first + k)], t1 = T.tris[4 * (first + k) + 1], t2 = T.tris[4 * (first + k) + 2];
-        float t, u, v;
-        if (tri_test(O, D, mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), tnear, t, u, v)) {
-          if (ANY) return true;
-          const int prim = __float_as_int(t0.w);
-          if (best_prim < 0 || t < best_t || (t == best_t && prim < best_prim)) { best_t = t; best_prim = prim; best_u = u; best_v = v; }
-        }
-      }
-      if (sp == 0) break;
-      sp--;
-      cur = (sp < TRAV_STACK) ? lds[sp * TRAV_BLOCK] : spill[sp - TRAV_STACK];
-    }
-  }
-  return false;
-}
-
-// wave-level work fetch: 64 rays per grab; every wave leaves as soon as the counter passes n
-__device__ inline unsigned fetch_batch(unsigned *counter) {
-  unsigned base = 0;
-  if (lane_id() == 0) base = atomicAdd(counter, 64u);
-  return (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-}
-
-template <bool XFORM>
-__global__ __launch_bounds__(TRAV_BLOCK) void k_closest(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, Trav T,
-                                                         float tnear, gvt_hip_hit *__restrict__ hits, unsigned *counter, int *spill_base) {
-  __shared__ int stack[TRAV_STACK * TRAV_BLOCK];
-  int *lds = &stack[threadIdx.x];
-  int *spill = spill_base + (size_t)(blockIdx.x * TRAV_BLOCK + threadIdx.x) * TRAV_SPILL;
-  for (;;) {
-    const unsigned base = fetch_batch(counter);
-    if (base >= n) break;
-    const unsigned j = base + lane_id();
-    if (j < n) {
-      const unsigned i = idx ? idx[j] : j;
-      const float4 a = q.p0[i], b = q.p1[i];
-      V3 O = mk3(a.x, a.y, a.z), D = mk3(b.x, b.y, b.z);
-      if (XFORM) { O = xfm_point(minv, O); D = xfm_vector(minv, D); }
-      float bt = GVT_FLT_MAX, bu = 0.f, bv = 0.f;
-      int bp = -1;
-      if (T.nodes) traverse<false>(T, O, D, tnear, lds, spill, bt, bp, bu, bv);
-      gvt_hip_hit h; h.t = bt; h.prim = bp; h.u = bu; h.v = bv;
-      hits[j] = h;
-    }
-  }
-}
+#include "diag_kernels.inc" // the first-version kernels (one 64-ray batch per wave over the binary tree): trav_kernel=0 baseline + visit counts
 
 // ------------------------------------------------------------------------------------------------
 // Persistent-wave traversal with lane refill ("wavefront compaction of active rays").
@@ -919,59 +826,6 @@ __global__ __launch_bounds__(256) void k_wave_any(RayPlanes q, const unsigned *_
   if (overflow) atomicOr(counter + TRAV_OVF_WORD, 1u);
 }
 
-// diagnostic (not on the hot path): per-ray visit counts of the closest-hit traversal.
-// out[3*j + 0..2] = inner-node visits / leaf visits / triangle tests of ray j (reduced on the host).
-__global__ __launch_bounds__(TRAV_BLOCK) void k_visit_stats(RayPlanes q, unsigned n, Trav T, float tnear, unsigned *__restrict__ out,
-                                                             unsigned *counter, int *spill_base) {
-  __shared__ int stack[TRAV_STACK * TRAV_BLOCK];
-  int *lds = &stack[threadIdx.x];
-  int *spill = spill_base + (size_t)(blockIdx.x * TRAV_BLOCK + threadIdx.x) * TRAV_SPILL;
-  for (;;) {
-    const unsigned base = fetch_batch(counter);
-    if (base >= n) break;
-    const unsigned j = base + lane_id();
-    if (j < n) {
-      unsigned c[3] = { 0, 0, 0 };
-      if (T.nodes) {
-        const float4 a = q.p0[j], b = q.p1[j];
-        float bt = GVT_FLT_MAX, bu, bv;
-        int bp = -1;
-        traverse<false, true>(T, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), tnear, lds, spill, bt, bp, bu, bv, c);
-      }
-      out[3 * j] = c[0]; out[3 * j + 1] = c[1]; out[3 * j + 2] = c[2];
-    }
-  }
-}
-
-// MODE 0: flags[j] = occluded.  MODE 1: un-occluded rays of q are appended to `out` (moved_rays).
-template <bool XFORM, int MODE>
-__global__ __launch_bounds__(TRAV_BLOCK) void k_any(RayPlanes q, unsigned n, Mat4 minv, Trav T, float tnear, int *__restrict__ flags,
-                                                     RayPlanes out, unsigned *out_count, unsigned *counter, int *spill_base) {
-  __shared__ int stack[TRAV_STACK * TRAV_BLOCK];
-  int *lds = &stack[threadIdx.x];
-  int *spill = spill_base + (size_t)(blockIdx.x * TRAV_BLOCK + threadIdx.x) * TRAV_SPILL;
-  for (;;) {
-    const unsigned base = fetch_batch(counter);
-    if (base >= n) break;
-    const unsigned j = base + lane_id();
-    bool survive = false;
-    if (j < n) {
-      const float4 a = q.p0[j], b = q.p1[j];
-      V3 O = mk3(a.x, a.y, a.z), D = mk3(b.x, b.y, b.z);
-      if (XFORM) { O = xfm_point(minv, O); D = xfm_vector(minv, D); }
-      float bt = GVT_FLT_MAX, bu, bv;
-      int bp = -1;
-      const bool occ = T.nodes ? traverse<true>(T, O, D, tnear, lds, spill, bt, bp, bu, bv) : false;
-      if (MODE == 0) flags[j] = occ ? 1 : 0;
-      survive = !occ;
-    }
-    if (MODE == 1) {
-      const unsigned slot = wave_alloc(out_count, survive);
-      if (survive) { out.p0[slot] = q.p0[j]; out.p1[slot] = q.p1[j]; out.p2[slot] = q.p2[j]; out.p3[slot] = q.p3[j]; if (out.p4) out.p4[slot] = 0u; }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Shading (Material.cpp:50-139, Light.cpp:58-133), in the oracle's evaluation order
 // ------------------------------------------------------------------------------------------------
@@ -1302,385 +1156,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M1)
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_fused: closest hit -> shade -> shadow ray (any hit) of the first light -> terminal rule, in ONE persistent-wave kernel.
-//
-// k_trace / k_shade / k_trace<ANY> as three launches pay two drains (a launch of 1 M rays is only ~16 K wave-loads of work for
-// 4,096 resident waves: ~45 % of each traversal launch is its tail) plus a round trip of hit records and shadow rays through HBM.
-// Here a lane that finishes a closest-hit ray keeps the hit in registers; at the next refill point the lanes holding a hit are
-// shaded together (same code as k_shade: normal, material, Shade per light, shadow-ray generation, bounce) and each CONTINUES
-// with the shadow ray it just generated -- which starts where the primary ended, i.e. in nodes and triangles that are still in
-// L1 / L2 -- while lanes without one take the next ray of the list.  One tail instead of two; shadow work fills the primary drain.
-//   ray kinds per lane: 0 closest hit (PRIMARY / SECONDARY of the list), 1 shadow ray generated here (payload in registers),
-//                       2 SHADOW ray of the list (EmbreeMeshAdapter.cpp:486-488: dropped if it hits anything, else forwarded)
-//   outputs: `out` (+ out_from) moved rays that have another instance ahead (shuffleRays' terminal rule applied here: deposits go
-//            straight to the framebuffer); shadow rays of lights 1.. -> `shadow` list for a follow-up any-hit launch; bounced rays
-//            -> written back in place + `next` list for the next pass.
-// Rays to append are staged per wave in LDS and flushed 32+ at a time (one atomic on the queue counter per flush).
-// ------------------------------------------------------------------------------------------------
-#define FUSED_PEND 64 // rays staged per wave in LDS; flushed when a retirement would not fit and whenever 32 or more are staged
-#ifndef FUSED_STACK
-#define FUSED_STACK 20 // LDS stack levels per lane (deeper: per-thread global spill): 20 KiB + 18 KiB of staging per block -> 4 blocks per CU
-#endif
-__device__ inline void fused_flush(volatile unsigned *pend, int n_pend, const RayPlanes &out, unsigned *out_count, int *__restrict__ out_from) {
-  unsigned base = 0;
-  if (lane_id() == 0) base = atomicAdd(out_count, (unsigned)n_pend);
-  base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-  for (int k = (int)lane_id(); k < n_pend; k += 64) {
-    const unsigned s = base + (unsigned)k;
-    out.p0[s] = make_float4(__uint_as_float(pend[0 * FUSED_PEND + k]), __uint_as_float(pend[1 * FUSED_PEND + k]), __uint_as_float(pend[2 * FUSED_PEND + k]), __uint_as_float(pend[3 * FUSED_PEND + k]));
-    out.p1[s] = make_float4(__uint_as_float(pend[4 * FUSED_PEND + k]), __uint_as_float(pend[5 * FUSED_PEND + k]), __uint_as_float(pend[6 * FUSED_PEND + k]), __uint_as_float(pend[7 * FUSED_PEND + k]));
-    out.p2[s] = make_float4(__uint_as_float(pend[8 * FUSED_PEND + k]), __uint_as_float(pend[9 * FUSED_PEND + k]), __uint_as_float(pend[10 * FUSED_PEND + k]), __uint_as_float(pend[11 * FUSED_PEND + k]));
-    out.p3[s] = make_float4(__uint_as_float(pend[12 * FUSED_PEND + k]), __uint_as_float(pend[13 * FUSED_PEND + k]), __uint_as_float(pend[14 * FUSED_PEND + k]), __uint_as_float(pend[15 * FUSED_PEND + k]));
-    if (out.p4) out.p4[s] = pend[16 * FUSED_PEND + k];
-    if (out_from) out_from[s] = (int)pend[17 * FUSED_PEND + k];
-  }
-}
-struct FusedArgs {
-  WaveSet W;
-  const unsigned *idx;       // bounce list of the previous pass or null
-  unsigned n;
-  const unsigned *n_dev;
-  const gvt_hip_light *lights;
-  int n_lights, normal_mode, first_pass;
-  uint32_t seed;
-  RayPlanes out; unsigned *out_count; int *out_from;
-  RayPlanes shadow; unsigned *shadow_count; int *shadow_inst;
-  unsigned *next_idx; unsigned *next_count;
-  TermSink sink;             // required: blo/bhi/n_inst/fb
-  unsigned *counter;         // d_counters + 0
-  int *spill_base;
-  int refill_min, inner_min;
-  unsigned long long *tot;   // [0] closest, [1] any: this kernel adds the shadow rays it traces inline to tot[1]
-  float tnear;
-};
-#define FUSED_PEND_FIELDS 18
-
-__global__ __launch_bounds__(TRAV_BLOCK, 4) void k_fused(FusedArgs A) {
-  const unsigned n_waves_total = gridDim.x * (unsigned)(TRAV_BLOCK / 64);
-  const unsigned n = A.n_dev ? *A.n_dev : A.n;
-  const unsigned share_w = n / n_waves_total;
-  const unsigned chunk = max(64u, ((share_w * 3u / 8u) + 16u) & ~31u);
-  const unsigned dyn = max(64u, (share_w / 16u) & ~63u);
-  __shared__ int stack[FUSED_STACK * TRAV_BLOCK];
-  __shared__ unsigned pend_all[(TRAV_BLOCK / 64) * FUSED_PEND_FIELDS * FUSED_PEND];
-  int *lds = &stack[threadIdx.x];
-  int *spill = A.spill_base + (size_t)(blockIdx.x * TRAV_BLOCK + threadIdx.x) * TRAV_SPILL;
-  volatile unsigned *pend = &pend_all[(threadIdx.x >> 6) * FUSED_PEND_FIELDS * FUSED_PEND]; // pend[field * FUSED_PEND + slot]
-  bool overflow = false;
-#define KF_PUSH(REF)                                                                  \
-  {                                                                                   \
-    if (sp < FUSED_STACK) { lds[sp * TRAV_BLOCK] = (REF); sp++; }                     \
-    else if (sp - FUSED_STACK < TRAV_SPILL) { spill[sp - FUSED_STACK] = (REF); sp++; } \
-    else overflow = true;                                                             \
-  }
-#define KF_POP()                                                                      \
-  {                                                                                   \
-    if (sp == 0) cur = TRAV_DONE;                                                     \
-    else { sp--; if (sp < FUSED_STACK) cur = lds[sp * TRAV_BLOCK]; else cur = spill[sp - FUSED_STACK]; } \
-  }
-  int n_pend = 0;
-  unsigned c_next = 0, c_end = 0;
-  bool exhausted = false, first_chunk = true;
-  unsigned n_inline_shadow = 0; // wave-uniform
-  // lane state
-  bool active = false, pending = false;
-  int kind = 0;
-  unsigned gidx = 0;
-  V3 O = mk3(0, 0, 0), D = mk3(0, 0, 1);
-  float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0;
-  float bt = GVT_FLT_MAX, bu = 0.f, bv = 0.f, bden = 1.f;
-  int bp = -1, sp = 0, cur = TRAV_DONE;
-  const uint4 *nodes4_l = nullptr;
-  const float4 *tris_l = nullptr;
-  int inst_l = 0;
-  RayRec sr; // kind 1: the shadow ray this lane is tracing (world space)
-  sr.o = sr.d = sr.c = mk3(0, 0, 0); sr.t_min = sr.t_max = sr.t = sr.w = 0.f; sr.id = sr.depth = sr.type = 0; sr.rng = 0u;
-
-  // object-space ray -> traversal registers
-#define KF_START(OW, DW)                                                                                   \
-  {                                                                                                        \
-    const WaveInst *wi_ = A.W.insts + inst_l;                                                              \
-    nodes4_l = wi_->nodes4; tris_l = wi_->tris;                                                            \
-    O = xfm_point(wi_->minv, (OW)); D = xfm_vector(wi_->minv, (DW));                                        \
-    const float dx_ = fabsf(D.x) < 1e-30f ? copysignf(1e-30f, D.x) : D.x;                                  \
-    const float dy_ = fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y;                                  \
-    const float dz_ = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;                                  \
-    ix = 1.0f / dx_; iy = 1.0f / dy_; iz = 1.0f / dz_;                                                     \
-    ox = O.x * ix; oy = O.y * iy; oz = O.z * iz;                                                           \
-    bt = GVT_FLT_MAX; bu = 0.f; bv = 0.f; bden = 1.f; bp = -1; sp = 0;                                     \
-    cur = nodes4_l ? 0 : TRAV_DONE;                                                                        \
-    active = true;                                                                                         \
-  }
-  // stage one ray per lane with `want` for appending to `out`; flush when 32 or more are staged
-#define KF_STAGE(want, R, FROM)                                                                            \
-  {                                                                                                        \
-    const unsigned long long m_ = __ballot(want);                                                          \
-    if (m_) {                                                                                              \
-      if (n_pend + __popcll(m_) > FUSED_PEND) { fused_flush(pend, n_pend, A.out, A.out_count, A.out_from); n_pend = 0; } \
-      if (want) {                                                                                          \
-        const int s_ = n_pend + (int)lanes_below(m_);                                                      \
-        pend[0 * FUSED_PEND + s_] = __float_as_uint((R).o.x); pend[1 * FUSED_PEND + s_] = __float_as_uint((R).o.y);   \
-        pend[2 * FUSED_PEND + s_] = __float_as_uint((R).o.z); pend[3 * FUSED_PEND + s_] = __float_as_uint((R).t_min); \
-        pend[4 * FUSED_PEND + s_] = __float_as_uint((R).d.x); pend[5 * FUSED_PEND + s_] = __float_as_uint((R).d.y);   \
-        pend[6 * FUSED_PEND + s_] = __float_as_uint((R).d.z); pend[7 * FUSED_PEND + s_] = __float_as_uint((R).t_max); \
-        pend[8 * FUSED_PEND + s_] = __float_as_uint((R).c.x); pend[9 * FUSED_PEND + s_] = __float_as_uint((R).c.y);   \
-        pend[10 * FUSED_PEND + s_] = __float_as_uint((R).c.z); pend[11 * FUSED_PEND + s_] = __float_as_uint((R).t);   \
-        pend[12 * FUSED_PEND + s_] = (unsigned)(R).id; pend[13 * FUSED_PEND + s_] = (unsigned)(R).depth;              \
-        pend[14 * FUSED_PEND + s_] = __float_as_uint((R).w); pend[15 * FUSED_PEND + s_] = (unsigned)(R).type;          \
-        pend[16 * FUSED_PEND + s_] = (R).rng; pend[17 * FUSED_PEND + s_] = (unsigned)(FROM);                           \
-      }                                                                                                    \
-      n_pend += __popcll(m_);                                                                              \
-      if (n_pend >= 32) { fused_flush(pend, n_pend, A.out, A.out_count, A.out_from); n_pend = 0; }         \
-    }                                                                                                      \
-  }
-
-  for (;;) {
-    unsigned long long idle = __ballot(!active);
-    int nidle = __popcll(idle);
-    const unsigned long long pendm = __ballot(!active && pending);
-    if ((nidle >= A.refill_min || nidle == 64 || (exhausted && pendm)) && (!exhausted || pendm)) {
-      // ---- 1. lanes holding a closest hit: shade, emit, continue with the first light's shadow ray
-      if (pendm) {
-        RayRec fwd_dummy; (void)fwd_dummy;
-        bool emit0 = false, bounce = false;
-        RayRec r, s0;
-        RayPlanes in{};
-        unsigned local = 0;
-        V3 N = mk3(0, 0, 0);
-        uint32_t g_seed = 0;
-        const bool sh = !active && pending;
-        MatEval me;
-        if (sh) {
-          const WaveSeg sg = A.W.segs[wave_find_seg(A.W, gidx)];
-          in = make_planes(sg.planes, sg.cap);
-          local = gidx - sg.begin;
-          const WaveInst *wi = A.W.insts + inst_l;
-          const MeshView *M = &wi->mv;
-          me = mat_eval(M->mat);
-          r = load_ray(in, local);
-          g_seed = (A.first_pass && r.rng == 0u) ? ray_stream_seed(A.seed, gidx) : r.rng;
-          const float hu = bu / bden, hv = bv / bden;
-          float t = bt;
-          r.t = t;
-          const int ia = M->tris[3 * bp], ib = M->tris[3 * bp + 1], ic = M->tris[3 * bp + 2];
-          const V3 v0 = ld3(M->verts + 3 * ia), v1 = ld3(M->verts + 3 * ib), v2 = ld3(M->verts + 3 * ic);
-          const V3 negNg = cross3(sub3(v1, v0), sub3(v2, v0));
-          const V3 normalflat = norm3(mat3_mul(wi->normi, negNg));
-          if (A.normal_mode == GVT_HIP_NORMALS_SMOOTH) {
-            const V3 a = ld3(M->normals + 3 * ib), b = ld3(M->normals + 3 * ic), c = ld3(M->normals + 3 * ia);
-            const V3 mn = add3(add3(scl3(a, hu), scl3(b, hv)), scl3(c, 1.0f - hu - hv));
-            N = norm3(mat3_mul(wi->normi, mn));
-          } else {
-            N = normalflat;
-          }
-          if (dot3(neg3(r.d), normalflat) <= 0.f) N = neg3(N);
-          if (M->vcolors) {
-            const V3 c0 = ld3(M->vcolors + 3 * ia), c1 = ld3(M->vcolors + 3 * ib), c2 = ld3(M->vcolors + 3 * ic);
-            me.kd = add3(add3(scl3(c0, 1.f - hu - hv), scl3(c1, hu)), scl3(c2, hv));
-            me.type = 0; me.ks = mk3(.5f, .5f, .5f); me.alpha = 1.f;
-          } else if (M->face_mat && M->face_mat[bp] >= 0 && (unsigned)M->face_mat[bp] < M->n_mat) {
-            me = mat_eval(M->materials[M->face_mat[bp]]);
-          }
-          if (r.type == 2) { t = (t > 1) ? 1.f / t : t; r.w = r.w * t; }
-        }
-        for (int li = 0; li < A.n_lights; li++) { // generateShadowRays :320-358
-          bool emit = false;
-          RayRec s;
-          if (sh) {
-            const gvt_hip_light L = A.lights[li];
-            const V3 lightPos = (L.type == GVT_HIP_LIGHT_AREA) ? area_light_position(L, g_seed) : ld3(L.position);
-            V3 c;
-            if (shade_call(me, r, N, L, lightPos, c)) {
-              emit = true;
-              const float multiplier = 1.0f - GVT_RAY_EPSILON * 16;
-              const float t_shadow = multiplier * r.t;
-              const V3 origin = add3(r.o, scl3(r.d, t_shadow));
-              const V3 dir = sub3(lightPos, origin);
-              s.o = origin; s.t_min = GVT_RAY_EPSILON;
-              s.d = norm3(dir);
-              s.t_max = 3.0f;
-              s.c = c; s.t = r.t;
-              s.id = r.id; s.depth = r.depth; s.w = r.w; s.type = 1;
-              s.rng = 0u;
-            }
-          }
-          if (li == 0) { emit0 = emit; if (emit) s0 = s; }
-          else {
-            const unsigned slot = wave_alloc(A.shadow_count, emit);
-            if (emit) { store_ray(A.shadow, slot, s); A.shadow_inst[slot] = inst_l; }
-          }
-        }
-        if (sh) { // bounce :584-602
-          const int ndepth = r.depth - 1;
-          const float p = 1.f - gvt_fastrand01(g_seed);
-          if (ndepth > 0 && r.w > p) {
-            r.type = 2;
-            const float multiplier = 1.0f - 16.0f * GVT_FLT_EPSILON;
-            const float t_secondary = multiplier * r.t;
-            r.o = add3(r.o, scl3(r.d, t_secondary));
-            const V3 nd = cos_weighted_dir(N, g_seed);
-            r.d = nd;
-            r.w = r.w * dot3(nd, N);
-            r.depth = ndepth;
-            r.rng = g_seed;
-            store_ray(in, local, r);
-            bounce = true;
-          }
-        }
-        {
-          const unsigned slot = wave_alloc(A.next_count, bounce);
-          if (bounce) A.next_idx[slot] = gidx;
-        }
-        if (sh) {
-          pending = false;
-          if (emit0) { sr = s0; kind = 1; KF_START(sr.o, sr.d) }
-        }
-        n_inline_shadow += (unsigned)__popcll(__ballot(sh && emit0));
-        idle = __ballot(!active);
-        nidle = __popcll(idle);
-      }
-      // ---- 2. empty lanes take the next rays of the list
-      while (!exhausted && nidle > 0) {
-        if (c_next == c_end) {
-          unsigned base = 0, this_chunk = chunk;
-          if (first_chunk) {
-            first_chunk = false;
-            base = (blockIdx.x * (unsigned)(TRAV_BLOCK / 64) + (threadIdx.x >> 6)) * chunk;
-          } else {
-            if (lane_id() == 0) base = atomicAdd(A.counter, dyn);
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + n_waves_total * chunk;
-            this_chunk = dyn;
-          }
-          if (base >= n) { exhausted = true; break; }
-          c_next = base;
-          c_end = min(base + this_chunk, n);
-        }
-        const unsigned take = min(c_end - c_next, (unsigned)nidle);
-        const unsigned rank = lanes_below(idle);
-        if (!active && rank < take) {
-          const unsigned j = c_next + rank;
-          gidx = A.idx ? A.idx[j] : j;
-          const WaveSeg sg = A.W.segs[wave_find_seg(A.W, gidx)];
-          const unsigned local = gidx - sg.begin;
-          const float4 a = sg.planes[local], b = sg.planes[sg.cap + local];
-          const int type = __float_as_int(sg.planes[3 * sg.cap + local].w);
-          inst_l = sg.inst;
-          kind = type == 1 ? 2 : 0;
-          KF_START(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z))
-        }
-        c_next += take;
-        idle = __ballot(!active);
-        nidle = __popcll(idle);
-      }
-    }
-    if (nidle == 64) {
-      if (exhausted && !__ballot(pending)) break;
-      if (!exhausted) continue; // (cannot happen: the refill above ran)
-    }
-    // ---- inner nodes
-    unsigned long long im = __ballot(active && cur >= 0);
-    while (im) {
-      if (active && cur >= 0) {
-        float tn[4];
-        int rr[4];
-        node4_test(nodes4_l + (size_t)GVT_NODE4_F4 * cur, ix, iy, iz, ox, oy, oz, kind ? GVT_FLT_MAX : bt, tn, rr);
-#define GVT_CE(A_, B_) { const bool sw_ = tn[B_] < tn[A_]; const float ta_ = sw_ ? tn[B_] : tn[A_], tb_ = sw_ ? tn[A_] : tn[B_]; \
-                         const int ra_ = sw_ ? rr[B_] : rr[A_], rb_ = sw_ ? rr[A_] : rr[B_]; tn[A_] = ta_; tn[B_] = tb_; rr[A_] = ra_; rr[B_] = rb_; }
-        GVT_CE(0, 1) GVT_CE(2, 3) GVT_CE(0, 2) GVT_CE(1, 3) GVT_CE(1, 2)
-#undef GVT_CE
-        int nxt = TRAV_DONE;
-        bool have = false;
-#pragma unroll
-        for (int c4 = 3; c4 >= 0; c4--) {
-          if (tn[c4] < GVT_FLT_MAX) {
-            if (have) KF_PUSH(nxt)
-            nxt = rr[c4]; have = true;
-          }
-        }
-        if (have) cur = nxt;
-        else KF_POP()
-      }
-      im = __ballot(active && cur >= 0);
-      if (__popcll(im) < A.inner_min) break;
-    }
-    // ---- leaves
-    {
-      const bool at_leaf = active && cur < 0 && cur != TRAV_DONE;
-      if (at_leaf) {
-        const unsigned code = (unsigned)~cur;
-        const unsigned first = code >> 3, ntri = code & 7u;
-        const float4 *ts = tris_l + 4 * (size_t)first;
-        bool occluded = false;
-        for (unsigned kb = 0; kb < ntri && !(kind && occluded); kb += 2) {
-          float4 s0[2], s1[2], s2[2];
-#pragma unroll
-          for (unsigned k = 0; k < 2; k++)
-            if (kb + k < ntri) { s0[k] = ts[4 * (kb + k)]; s1[k] = ts[4 * (kb + k) + 1]; s2[k] = ts[4 * (kb + k) + 2]; }
-#pragma unroll
-          for (unsigned k = 0; k < 2; k++) {
-            if (kb + k < ntri && !(kind && occluded)) {
-              const V3 e1 = mk3(s1[k].x, s1[k].y, s1[k].z), e2 = mk3(s2[k].x, s2[k].y, s2[k].z);
-              float TT, U, V, aden;
-              if (tri_test_raw(O, D, mk3(s0[k].x, s0[k].y, s0[k].z), e1, e2, cross3(e1, e2), A.tnear, TT, U, V, aden)) {
-                const float t = TT / aden;
-                if (t <= GVT_FLT_MAX) {
-                  if (kind) occluded = true;
-                  else {
-                    const int prim = __float_as_int(s0[k].w);
-                    if (bp < 0 || t < bt || (t == bt && prim < bp)) { bt = t; bp = prim; bu = U; bv = V; bden = aden; }
-                  }
-                }
-              }
-            }
-          }
-        }
-        if (kind && occluded) { bp = 0; cur = TRAV_DONE; }
-        else KF_POP()
-      }
-    }
-    // ---- retire
-    {
-      const bool fin = active && cur == TRAV_DONE;
-      if (__ballot(fin)) {
-        bool consider = false; // a ray that leaves this instance: miss of the list (kinds 0, 2) or un-occluded shadow ray (kind 1)
-        RayRec R = sr;
-        if (fin) {
-          if (kind == 0 && bp >= 0) pending = true; // shaded at the next refill point
-          else if (bp < 0) {
-            consider = true;
-            if (kind != 1) {
-              const WaveSeg sg = A.W.segs[wave_find_seg(A.W, gidx)];
-              R = load_ray(make_planes(sg.planes, sg.cap), gidx - sg.begin);
-            }
-          }
-          active = false;
-        }
-        // shuffleRays' terminal rule (TracerBase.h:396-400): no other instance ahead -> a SHADOW ray that carries colour deposits, any
-        // other ray is dropped; otherwise it is moved on
-        bool go_on = false;
-        if (consider) {
-          float ret_t;
-          const float4 a4 = make_float4(R.o.x, R.o.y, R.o.z, R.t_min), b4 = make_float4(R.d.x, R.d.y, R.d.z, R.t_max);
-          go_on = top_nearest(a4, b4, A.sink.top, inst_l, ret_t) >= 0;
-          if (!go_on && R.type == 1 && len3(R.c) > 0.f && (unsigned)R.id < A.sink.n_pix) {
-            const V3 cw = scl3(R.c, R.w);
-            float *px = A.sink.fb + (size_t)4 * (unsigned)R.id;
-            atomicAdd(px + 0, cw.x); atomicAdd(px + 1, cw.y); atomicAdd(px + 2, cw.z); atomicAdd(px + 3, 1.f);
-          }
-        }
-        KF_STAGE(go_on, R, inst_l)
-      }
-    }
-  }
-  if (n_pend) fused_flush(pend, n_pend, A.out, A.out_count, A.out_from);
-  if (lane_id() == 0 && n_inline_shadow) atomicAdd(A.tot + 1, (unsigned long long)n_inline_shadow);
-  if (overflow) atomicOr(A.counter + TRAV_OVF_WORD, 1u);
-#undef KF_PUSH
-#undef KF_POP
-#undef KF_START
-#undef KF_STAGE
-}
+#include "fused_kernel.inc" // k_fused: the one-kernel closest + shade + shadow variant (measured slower; knob `fused`)
 
 // ------------------------------------------------------------------------------------------------
 // layout conversions at the ABI boundary: 80-byte Ray AoS <-> planes
