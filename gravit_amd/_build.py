@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libgvt_hip.so")
 SOURCES = ["api.hip", "lbvh.hip", "trace.hip", "sched.hip", "domain.hip"]
-HEADERS = ["gvt_device.h", "gvt_internal.h", "diag_kernels.inc", "fused_kernel.inc", os.path.join("..", "..", "include", "gvt_hip.h"),
+HEADERS = ["gvt_device.h", "gvt_internal.h", "diag_kernels.inc", "fused_kernel.inc", "packet_kernel.inc", os.path.join("..", "..", "include", "gvt_hip.h"),
            os.path.join("..", "..", "include", "gvt_math.h")]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]

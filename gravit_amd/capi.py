@@ -49,7 +49,7 @@ class CameraPod(C.Structure):
 
 class FrameStats(C.Structure):
     _fields_ = [("rounds", C.c_uint64), ("chains", C.c_uint64), ("host_syncs", C.c_uint64), ("rays_sent", C.c_uint64),
-                ("rays_closest", C.c_uint64), ("rays_any", C.c_uint64)]
+                ("rays_closest", C.c_uint64), ("rays_any", C.c_uint64), ("packets_bailed", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

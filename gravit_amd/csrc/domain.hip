@@ -307,6 +307,7 @@ __global__ void k_round_report(unsigned *const *__restrict__ count_ptr, const in
     tail[0] = counters[16]; tail[1] = counters[17]; tail[2] = counters[18]; tail[3] = counters[19];
     tail[4] = counters[8]; tail[5] = *overflow;
     for (int k = 0; k < 4; k++) tail[6 + k] = (unsigned)bbox[k];
+    tail[10] = counters[9]; // packets handed over by k_packet
   }
 }
 
@@ -364,7 +365,7 @@ template <bool ADD> __global__ __launch_bounds__(256) void k_rect(float4 *__rest
   else buf[i] = fb[px];
 }
 __global__ void k_add_count(unsigned *count, unsigned n) { if (!blockIdx.x && !threadIdx.x) *count += n; }
-__global__ void k_zero_totals(unsigned *c, unsigned *ovf) { if (!blockIdx.x && threadIdx.x < 4) c[16 + threadIdx.x] = 0u; if (!blockIdx.x && threadIdx.x == 4) *ovf = 0u; }
+__global__ void k_zero_totals(unsigned *c, unsigned *ovf) { if (!blockIdx.x && threadIdx.x < 4) c[16 + threadIdx.x] = 0u; if (!blockIdx.x && threadIdx.x == 4) { *ovf = 0u; c[9] = 0u; } }
 } // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -537,7 +538,7 @@ int grow(void **buf, size_t *cap, size_t bytes) {
 // (1) of a round: the merged launch chain over this rank's non-empty queues + the shuffle of everything that moved.  Host-known
 // sizes in R->present; on return they are stale until the next report.  extra_in[i]: rays about to be appended to queue i by a
 // pending unpack (room is reserved for them too).
-int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t *chains) {
+int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t *chains, bool fresh_from_camera) {
   Ctx &C = gctx();
   const size_t nI = R->n_inst;
   const int nL = (int)R->lights.size();
@@ -586,6 +587,7 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
     const int i0 = R->h_segs[0].inst;
     one.planes = make_planes(R->h_segs[0].planes, R->h_segs[0].cap);
     one.mesh = R->meshes[i0]; one.inst = i0;
+    one.coherent = (fresh_from_camera && C.camera_tile == 8) ? 1 : 0;
     std::memcpy(one.minv.m, R->minv.data() + 16 * (size_t)i0, 64);
     std::memcpy(one.normi.n, R->normi.data() + 9 * (size_t)i0, 36);
   }
@@ -697,7 +699,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
         bool any = false;
         for (size_t i = 0; i < nI; i++) any = any || (R->owned[i] && R->present[i]);
         if (!any) break;
-        if ((rc = local_chain(R, nullptr, &S.chains))) return rc;
+        if ((rc = local_chain(R, nullptr, &S.chains, S.chains == 0))) return rc;
         if ((rc = round_report(R, false, &S.host_syncs))) return rc;
       }
       if (R->world == 1) break;
@@ -705,7 +707,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
       bool have_local = false;
       for (size_t i = 0; i < nI; i++) have_local = have_local || (R->owned[i] && R->present[i]);
       if (!have_local && (rc = unpack_pending())) return rc; // nothing to overlap the transfer with: take what arrived first
-      if ((rc = local_chain(R, &incoming, &S.chains))) return rc;
+      if ((rc = local_chain(R, &incoming, &S.chains, S.chains == 0))) return rc;
       if ((rc = unpack_pending())) return rc;
     }
     // (3)-(5) sizes + announce exchange, one synchronisation
@@ -818,6 +820,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   const unsigned *tail = R->h_report + nI;
   S.rays_closest = (uint64_t)tail[0] | ((uint64_t)tail[1] << 32);
   S.rays_any = (uint64_t)tail[2] | ((uint64_t)tail[3] << 32);
+  S.packets_bailed = tail[10];
   C.stats.rays_closest += S.rays_closest;
   C.stats.rays_any += S.rays_any;
   if (out) *out = S;

@@ -36,6 +36,8 @@ struct Knobs {
   int long_min_rays = 65536; // ... only in launches of at least this many rays (small launches have no tail to speak of)
   int fused = 0;         // scheduler rounds: closest hit + shade + first-light shadow rays in one kernel (k_fused) instead of three launches.
                          // Measured 2.4x SLOWER than the three launches: shading inside the persistent kernel is latency-exposed
+  int packet = 0;        // scheduler rounds: camera rays in tile order (and their direct-mapped shadow rays) traversed a packet of 64 per wave (k_packet).
+                         // Off: 8 % faster on a surface mesh (bun_zipper), 2.5x-20x SLOWER on the random soups
   int small_rays = 4096; // scheduler rounds holding at most this many rays give every ray a whole wave (k_long_closest / k_wave_any): ~40 us
                          // per traversal launch instead of the ~150 us latency floor of a one-lane-per-ray launch
   int wave_single = 1;   // scheduler rounds: a round with ONE non-empty local queue uses the single-mesh kernels (no per-ray segment / instance lookups)
@@ -229,6 +231,7 @@ struct WaveSingle { // the launch has ONE segment: its queue planes and instance
   Mat4 minv;
   Mat3 normi;
   int inst;
+  int coherent; // the queue holds camera rays in tile order, straight from the filter: packet traversal (k_packet)
 };
 int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
                      const gvt_hip_light *lights_host, const WaveSingle *single);

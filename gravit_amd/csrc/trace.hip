@@ -826,6 +826,8 @@ __global__ __launch_bounds__(256) void k_wave_any(RayPlanes q, const unsigned *_
   if (overflow) atomicOr(counter + TRAV_OVF_WORD, 1u);
 }
 
+#include "packet_kernel.inc" // k_packet: a wave walks the BVH for a packet of 64 coherent rays
+
 // ------------------------------------------------------------------------------------------------
 // Shading (Material.cpp:50-139, Light.cpp:58-133), in the oracle's evaluation order
 // ------------------------------------------------------------------------------------------------
@@ -1120,10 +1122,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M1)
         s.rng = 0u;
       }
     }
-    if (MULTI && A.shadow_stride) {
+    if (A.shadow_stride) {
       if (j < A.shadow_stride) {
         const unsigned slot = (unsigned)li * A.shadow_stride + j;
-        A.shadow_inst[slot] = emit ? inst : -1;
+        A.shadow_inst[slot] = emit ? (MULTI ? inst : 0) : -1;
         if (emit) store_ray(A.shadow, slot, s);
       }
     } else {
@@ -1572,7 +1574,7 @@ __global__ void k_wave_pass_begin(unsigned *c, int pass, unsigned n_host, unsign
   const int cur = (pass & 1) ? 5 : 2, prev = (pass & 1) ? 2 : 5;
   if (pass == 0) { *out_count = 0u; c[2] = 0u; c[5] = 0u; tot[0] += n_host; }
   else { tot[1] += c[1]; tot[0] += c[prev]; c[cur] = 0u; }
-  c[0] = 0u; c[1] = 0u; c[3] = 0u; c[4] = 0u;
+  c[0] = 0u; c[1] = 0u; c[3] = 0u; c[4] = 0u; c[6] = 0u;
 }
 __global__ void k_wave_end(unsigned *c) {
   if (blockIdx.x || threadIdx.x) return;
@@ -1633,7 +1635,15 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       LongQ LQ{};
       if (use_long && have4) { LQ.recs = d_long; LQ.count = c + 3; LQ.steps = C.long_steps; }
       const bool small1 = small && have4;
-      if (small1) {
+      // a coherent list (camera rays in 8x8 tiles, straight from the filter): a wave walks the tree for 64 rays at once (k_packet)
+      const bool pkt = C.packet && single->coherent && pass == 0 && have4 && !small1;
+      if (pkt) {
+        ProfScope ps(KC_CLOSEST);
+        LongQ LP{ d_long, c + 3, 0 };
+        k_packet<false><<<blocks_for(n), 256, 0, st>>>(single->planes, (unsigned)n, nullptr, single->minv, TS, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
+                                                     TermSink{}, LP, nullptr, nullptr, nullptr, c + 9);
+        k_long_closest<true><<<C.n_cu * 3, 256, 0, st>>>(single->planes, d_long, c + 3, single->minv, TS, GVT_RAY_EPSILON, d_hits, c + 4); // packets that bailed out
+      } else if (small1) {
         ProfScope ps(KC_CLOSEST);
         k_long_seed<<<blocks_for(n), 256, 0, st>>>(d_long, c + 3, idx, (unsigned)n, n_dev);
         k_long_closest<true><<<small_grid, 256, 0, st>>>(single->planes, d_long, c + 3, single->minv, TS, GVT_RAY_EPSILON, d_hits, c + 4);
@@ -1642,7 +1652,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
         launch_trace<false, true, 0>(have4, trav_grid2(n, true), st, single->planes, idx, (unsigned)n, single->minv, TS, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
                                      c + 0, C.d_spill, C.refill_min, C.inner_min, n_dev, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
       }
-      if (LQ.steps && !small1) {
+      if (LQ.steps && !small1 && !pkt) {
         ProfScope ps(KC_LONG);
         k_long_closest<true><<<C.n_cu * 3, 256, 0, st>>>(single->planes, d_long, c + 3, single->minv, TS, GVT_RAY_EPSILON, d_hits, c + 4);
       }
@@ -1653,6 +1663,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       A.n_lights = nL; A.seed = P.seed; A.zero_word = c + 0;
       A.sink = P.sink; A.sink.from = single->inst; A.update_in_place = 0;
       A.n_dev = n_dev; A.W = WaveSet{}; A.out_from = nullptr; A.shadow_inst = nullptr; A.shadow_stride = 0;
+      if (pkt) { A.shadow_inst = d_shadow_inst; A.shadow_stride = (unsigned)n; } // shadow rays in the primaries' order: packets again
       MeshView mv;
       mv.verts = M->d_verts; mv.tris = M->d_tris; mv.normals = M->d_normals; mv.vcolors = M->d_vcolors;
       mv.materials = M->d_materials; mv.n_mat = (unsigned)M->nMat; mv.face_mat = M->d_face_mat; mv.mat = M->mesh_mat;
@@ -1664,7 +1675,15 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
         ProfScope ps(KC_ANY);
         TermSink sk = P.sink;
         sk.from = single->inst;
-        if (small1) k_wave_any<false><<<(int)std::min<size_t>((shadow_cap + 3) / 4, (size_t)C.n_cu * 3), 256, 0, st>>>(shadow, c + 1, single->minv, TS, GVT_RAY_EPSILON, outp, out->d_count, c + 0, sk, MultiSrc{});
+        if (pkt) {
+          unsigned *d_retry = (unsigned *)scratch_get(18, sizeof(unsigned) * shadow_cap);
+          if (!d_retry) return GVT_HIP_ERR_DEVICE;
+          k_packet<true><<<blocks_for(shadow_cap), 256, 0, st>>>(shadow, (unsigned)shadow_cap, nullptr, single->minv, TS, GVT_RAY_EPSILON, nullptr, d_shadow_inst, outp, out->d_count,
+                                                               sk, LongQ{}, d_retry, c + 6, (unsigned long long *)(c + 18), c + 9);
+          // rays of packets that bailed out: one lane per ray (an empty list costs a few microseconds)
+          launch_trace<true, true, 1>(have4, trav_grid2(4096), st, shadow, d_retry, 0u, single->minv, TS, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
+                                      c + 0, C.d_spill, C.refill_min, C.inner_min, c + 6, C.share, (unsigned)C.share_min_rays, sk, LongQ{});
+        } else if (small1) k_wave_any<false><<<(int)std::min<size_t>((shadow_cap + 3) / 4, (size_t)C.n_cu * 3), 256, 0, st>>>(shadow, c + 1, single->minv, TS, GVT_RAY_EPSILON, outp, out->d_count, c + 0, sk, MultiSrc{});
         else launch_trace<true, true, 1>(have4, trav_grid2(shadow_cap), st, shadow, nullptr, 0u, single->minv, TS, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
                                          c + 0, C.d_spill, C.refill_min, C.inner_min, c + 1, C.share, (unsigned)C.share_min_rays, sk, LongQ{});
       }

@@ -236,7 +236,7 @@ def test_top_level_bvh_with_1056_instances(hip):
     assert np.array_equal(it().framebuffer(True)[..., :3], ref[..., :3]) and it.adapter_calls == st.adapter_calls
 
 
-@pytest.mark.parametrize("opts", [dict(small_rays=0), dict(small_rays=1 << 30), dict(wave_single=0), dict(shadow_direct=0), dict(fused=1),
+@pytest.mark.parametrize("opts", [dict(packet=0), dict(packet=1, camera_tile=0), dict(small_rays=0), dict(small_rays=1 << 30), dict(wave_single=0), dict(shadow_direct=0), dict(fused=1),
                                   dict(small_rays=1 << 30, wave_single=0), dict(blocks_per_cu_closest=0, term_sink=0)])
 def test_round_results_do_not_depend_on_knobs(hip, opts):
     """The round chain's variants -- a wave per ray for small rounds, single-mesh kernels for one-queue rounds, direct-mapped shadow

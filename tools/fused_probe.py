@@ -26,16 +26,6 @@ def run(tag, opts, tracer=tr, steps=10):
     st = capi.stats(); capi.profile(False)
     print("%-40s frame %.3f ms  closest %.3f any %.3f shade %.3f shuffle %.3f long %.3f" % (
         tag, dt, st["ms_closest"] / steps, st["ms_any"] / steps, st["ms_shade"] / steps, st["ms_shuffle"] / steps, st["ms_long"] / steps), flush=True)
-run("default", dict())
-for bc in (5, 6):
-    run("blocks_per_cu_closest=%d" % bc, dict(blocks_per_cu_closest=bc))
-run("bpc_closest=5 long_steps=0", dict(blocks_per_cu_closest=5, long_steps=0))
-run("bpc_closest=5 long_steps=64", dict(blocks_per_cu_closest=5, long_steps=64))
-run("bpc_closest=5 long_steps=128", dict(blocks_per_cu_closest=5, long_steps=128))
-run("bpc_closest=5 refill_min=8", dict(blocks_per_cu_closest=5, refill_min=8))
-run("bpc_closest=5 refill_min=24", dict(blocks_per_cu_closest=5, refill_min=24))
-run("bpc_closest=5 inner_min=24", dict(blocks_per_cu_closest=5, inner_min=24))
-run("bpc_closest=5 inner_min=40", dict(blocks_per_cu_closest=5, inner_min=40))
-run("shadow_direct=0", dict(shadow_direct=0))
-if "--fused" in sys.argv:
-    run("fused (k_fused)", dict(fused=1))
+run("default (packets)", dict())
+run("packet=0", dict(packet=0))
+run("packet=1 blocks irrelevant, camera_tile=0", dict(camera_tile=0))
