@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-abi-path", action="store_true")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
+    ap.add_argument("--same-gpu", action="store_true", help="rehearsal only: every rank uses device 0 (needs an RCCL that tolerates it)")
     args = ap.parse_args()
 
     import numpy as np
@@ -186,7 +187,7 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.same_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
@@ -277,7 +278,7 @@ def main():
         frame()
         per_frame.append(time.perf_counter() - f0)  # a frame ends with a host synchronisation (the last round's report / the composite)
         for k, v in frame_stats().items():
-            sums[k] += v
+            sums[k] = sums.get(k, 0) + v
     barrier()
     t1 = time.perf_counter()
     st = capi.stats() if on_gpu else {}

@@ -33,6 +33,7 @@
 
 int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *from_arr, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
                   gvt_hip_fb *fb, unsigned *d_overflow, const void *d_qdesc);
+int camera_filter_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *const *queues, const uint8_t *keep_mask, unsigned *d_overflow);
 
 // ------------------------------------------------------------------------------------------------
 // RCCL, resolved at first use (a single-GPU process never loads it)
@@ -538,7 +539,7 @@ int grow(void **buf, size_t *cap, size_t bytes) {
 // (1) of a round: the merged launch chain over this rank's non-empty queues + the shuffle of everything that moved.  Host-known
 // sizes in R->present; on return they are stale until the next report.  extra_in[i]: rays about to be appended to queue i by a
 // pending unpack (room is reserved for them too).
-int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t *chains, bool fresh_from_camera) {
+int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t *chains, bool fresh_from_camera, bool count_on_device = false) {
   Ctx &C = gctx();
   const size_t nI = R->n_inst;
   const int nL = (int)R->lights.size();
@@ -588,6 +589,7 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
     one.planes = make_planes(R->h_segs[0].planes, R->h_segs[0].cap);
     one.mesh = R->meshes[i0]; one.inst = i0;
     one.coherent = (fresh_from_camera && C.camera_tile == 8) ? 1 : 0;
+    one.n_dev = count_on_device ? R->queues[i0]->d_count : nullptr; // present[i0] is then only the bound (the whole camera list)
     std::memcpy(one.minv.m, R->minv.data() + 16 * (size_t)i0, 64);
     std::memcpy(one.normi.n, R->normi.data() + 9 * (size_t)i0, 36);
   }
@@ -660,9 +662,23 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   R->q_moved->size = 0;
   if (nI) k_zero_counts<<<(unsigned)((nI + 255) / 256), 256, 0, st>>>(R->d_count_ptr, nullptr, (int)nI); // every queue.clear() in one launch
   k_zero_totals<<<1, 64, 0, st>>>(C.d_counters, R->d_overflow);
-  if ((rc = gvt_hip_camera_filter(R->top, &R->cam, C.camera_tile, R->queues.data(), R->world > 1 ? R->owned.data() : nullptr))) return rc;
-  S.host_syncs++;
-  for (size_t i = 0; i < nI; i++) R->present[i] = R->queues[i]->size;
+  // One instance, one rank, terminal rule inside the kernels: the first (and only) launch chain takes its ray count from the queue's
+  // count word on the device -- the camera filter needs no read-back and the frame has ONE host synchronisation.
+  const bool one_shot = nI == 1 && R->world == 1 && C.term_sink && C.wave_single && R->meshes[0] && C.first_round_async;
+  if (one_shot) {
+    const size_t n_cam = (size_t)R->cam.width * R->cam.height * R->cam.samples * R->cam.samples;
+    const int passes0 = R->cam.depth > 1 ? R->cam.depth : 1;
+    if ((rc = queue_reserve(R->queues[0], n_cam * (size_t)(1 + (int)R->lights.size() * passes0)))) return rc; // what local_chain will ask for: no move later
+    if ((rc = camera_filter_async(R->top, &R->cam, C.camera_tile, R->queues.data(), nullptr, R->d_overflow))) return rc;
+    R->present[0] = n_cam;
+    R->queues[0]->size = n_cam; // bound of what the device holds (a reallocation would copy at least that)
+    if ((rc = local_chain(R, nullptr, &S.chains, true, true))) return rc;
+    if ((rc = round_report(R, false, &S.host_syncs))) return rc;
+  } else {
+    if ((rc = gvt_hip_camera_filter(R->top, &R->cam, C.camera_tile, R->queues.data(), R->world > 1 ? R->owned.data() : nullptr))) return rc;
+    S.host_syncs++;
+    for (size_t i = 0; i < nI; i++) R->present[i] = R->queues[i]->size;
+  }
   std::vector<size_t> incoming(nI, 0);
   bool payload_pending = false;
   std::vector<int> pending_ann; // the announces the payload in flight was posted from

@@ -40,6 +40,7 @@ struct Knobs {
                          // Off: 8 % faster on a surface mesh (bun_zipper), 2.5x-20x SLOWER on the random soups
   int small_rays = 4096; // scheduler rounds holding at most this many rays give every ray a whole wave (k_long_closest / k_wave_any): ~40 us
                          // per traversal launch instead of the ~150 us latency floor of a one-lane-per-ray launch
+  int first_round_async = 1; // one-instance scenes on one rank: no read-back after the camera filter (the chain reads its ray count on the device)
   int wave_single = 1;   // scheduler rounds: a round with ONE non-empty local queue uses the single-mesh kernels (no per-ray segment / instance lookups)
   int shadow_direct = 1; // scheduler rounds: shadow rays in direct-mapped slots (the order of the traced list) instead of block-arrival order
   int term_sink = 1;     // gvt_hip_trace_queue_sink: deposit terminal shadow rays from the any-hit kernel (0: always through moved_rays)
@@ -232,6 +233,7 @@ struct WaveSingle { // the launch has ONE segment: its queue planes and instance
   Mat3 normi;
   int inst;
   int coherent; // the queue holds camera rays in tile order, straight from the filter: packet traversal (k_packet)
+  const unsigned *n_dev; // the first pass's ray count lives in device memory (the queue's count word; n_total is only its bound)
 };
 int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
                      const gvt_hip_light *lights_host, const WaveSingle *single);

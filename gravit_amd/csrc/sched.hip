@@ -482,8 +482,27 @@ static int shuffle_impl(gvt_hip_top *T, const RaySrc &in, size_t n, int from, gv
 // the caller learns them from its next read-back.  from_arr: source instance per ray (merged rounds), else `from` for all.  Kernel order on the stream:
 // classify -> (scan) -> scatter.
 // d_qdesc: the queue descriptors already on the device (uploaded by the caller with its other per-round tables), or null.
+static int shuffle_async_src(gvt_hip_top *T, const RaySrc &S, size_t n_ub, const unsigned *n_dev, const int *from_arr, int from, gvt_hip_queue *const *queues,
+                             const uint8_t *keep_mask, gvt_hip_fb *fb, unsigned *d_overflow, const void *d_qdesc);
 int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *from_arr, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
                   gvt_hip_fb *fb, unsigned *d_overflow, const void *d_qdesc) {
+  RaySrc S{};
+  S.q = make_planes(q_in->d_planes, q_in->cap);
+  S.from_cam = 0;
+  return shuffle_async_src(T, S, n_ub, q_in->d_count, from_arr, from, queues, keep_mask, fb, d_overflow, d_qdesc);
+}
+// generateRays + FilterRaysLocally without a read-back: every kept queue must have room for all W*H*samples^2 rays; the queue counts
+// advance on the device only (the caller's first launch chain reads its ray count from there)
+int camera_filter_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *const *queues, const uint8_t *keep_mask, unsigned *d_overflow) {
+  const size_t n = (size_t)cam->width * cam->height * cam->samples * cam->samples;
+  if (n > 0xffffffffull) { set_error("camera_filter: more than 2^32 rays"); return GVT_HIP_ERR_INVALID; }
+  RaySrc S{};
+  S.cam = make_cam_args(cam->eye, cam->focus, cam->up, cam->fov, cam->width, cam->height, cam->samples, cam->depth, cam->jitter_window_size, tile);
+  S.from_cam = 1;
+  return shuffle_async_src(T, S, n, nullptr, nullptr, -1, queues, keep_mask, nullptr, d_overflow, nullptr);
+}
+static int shuffle_async_src(gvt_hip_top *T, const RaySrc &S, size_t n_ub, const unsigned *n_dev, const int *from_arr, int from, gvt_hip_queue *const *queues,
+                             const uint8_t *keep_mask, gvt_hip_fb *fb, unsigned *d_overflow, const void *d_qdesc) {
   Ctx &C = gctx();
   if (!n_ub) return 0;
   hipStream_t st = C.stream;
@@ -508,17 +527,14 @@ int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *f
     if (nI) HIPCHK(hipMemcpyAsync(T->d_qdesc, desc, sizeof(QueueDesc) * nI, hipMemcpyHostToDevice, st));
     qd = (const QueueDesc *)T->d_qdesc;
   }
-  RaySrc S{};
-  S.q = make_planes(q_in->d_planes, q_in->cap);
-  S.from_cam = 0;
   {
     ProfScope ps(KC_SHUFFLE);
     k_top_classify<<<n_blk, TOP_BLOCK, use_lds ? sizeof(unsigned) * nI : 0, st>>>(S, (unsigned)n_ub, T->dev(), (int)nI, from, d_next, d_t, nullptr, use_lds, d_blk,
-                                                                                q_in->d_count, from_arr);
+                                                                                n_dev, from_arr);
     if (d_blk) k_top_scan<<<(unsigned)nI, TOP_BLOCK, 0, st>>>(d_blk, n_blk, qd, nullptr);
     const size_t lds = d_blk ? sizeof(unsigned) * nI * (TOP_BLOCK / 64) : (use_lds ? 2 * sizeof(unsigned) * nI : 0);
     k_top_scatter<<<n_blk, TOP_BLOCK, lds, st>>>(S, (unsigned)n_ub, d_next, d_t, qd, (int)nI, fb ? fb->d_rgba : nullptr,
-                                               fb ? (unsigned)(fb->w * fb->h) : 0u, use_lds, d_blk, q_in->d_count, d_overflow);
+                                               fb ? (unsigned)(fb->w * fb->h) : 0u, use_lds, d_blk, n_dev, d_overflow);
   }
   HIPCHK(hipGetLastError());
   return 0; // q_in's count word is left as it is: the caller's next launch chain resets it (k_wave_pass_begin)

@@ -1568,11 +1568,11 @@ extern "C" int gvt_hip_math_probe(int kind, const float *in, size_t n, float *ou
 // (closest, any) accumulated over the frame and read back with the queue sizes.
 // ------------------------------------------------------------------------------------------------
 namespace {
-__global__ void k_wave_pass_begin(unsigned *c, int pass, unsigned n_host, unsigned *out_count) {
+__global__ void k_wave_pass_begin(unsigned *c, int pass, unsigned n_host, unsigned *out_count, const unsigned *n_dev0 = nullptr) {
   if (blockIdx.x || threadIdx.x) return;
   unsigned long long *tot = (unsigned long long *)(c + 16);
   const int cur = (pass & 1) ? 5 : 2, prev = (pass & 1) ? 2 : 5;
-  if (pass == 0) { *out_count = 0u; c[2] = 0u; c[5] = 0u; tot[0] += n_host; }
+  if (pass == 0) { *out_count = 0u; c[2] = 0u; c[5] = 0u; tot[0] += n_dev0 ? *n_dev0 : n_host; }
   else { tot[1] += c[1]; tot[0] += c[prev]; c[cur] = 0u; }
   c[0] = 0u; c[1] = 0u; c[3] = 0u; c[4] = 0u; c[6] = 0u;
 }
@@ -1621,11 +1621,11 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
   const bool small = n <= (size_t)C.small_rays; // a wave per ray (see k_long_seed)
   const int small_grid = (int)std::min<size_t>((n + 3) / 4, (size_t)C.n_cu * 3);
   for (int pass = 0; pass < passes; pass++) {
-    const unsigned *n_dev = pass ? c + ((pass & 1) ? 2 : 5) : nullptr;          // count written by the previous pass's k_shade
+    const unsigned *n_dev = pass ? c + ((pass & 1) ? 2 : 5) : ((single && single->n_dev) ? single->n_dev : nullptr); // count written by the previous pass's k_shade
     const unsigned *idx = pass ? ((pass & 1) ? d_idx_a : d_idx_b) : nullptr;    // its bounce list
     unsigned *next = (pass & 1) ? d_idx_b : d_idx_a;
     unsigned *c_next = c + ((pass & 1) ? 5 : 2);
-    k_wave_pass_begin<<<1, 64, 0, st>>>(c, pass, (unsigned)n, out->d_count);
+    k_wave_pass_begin<<<1, 64, 0, st>>>(c, pass, (unsigned)n, out->d_count, (single && single->n_dev) ? single->n_dev : nullptr);
     if (single) {
       // one segment (a single non-empty local queue, e.g. the one-domain benchmark): the single-mesh kernels -- no segment lookup and
       // no per-ray table loads at a refill -- with the same device-side counts
@@ -1640,7 +1640,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       if (pkt) {
         ProfScope ps(KC_CLOSEST);
         LongQ LP{ d_long, c + 3, 0 };
-        k_packet<false><<<blocks_for(n), 256, 0, st>>>(single->planes, (unsigned)n, nullptr, single->minv, TS, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
+        k_packet<false><<<blocks_for(n), 256, 0, st>>>(single->planes, (unsigned)n, n_dev, single->minv, TS, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
                                                      TermSink{}, LP, nullptr, nullptr, nullptr, c + 9);
         k_long_closest<true><<<C.n_cu * 3, 256, 0, st>>>(single->planes, d_long, c + 3, single->minv, TS, GVT_RAY_EPSILON, d_hits, c + 4); // packets that bailed out
       } else if (small1) {

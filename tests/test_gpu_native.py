@@ -46,7 +46,7 @@ def test_rounds_equal_the_reference_order_loop(hip, name, mode, exact):
         assert np.abs(fb[..., :3] - ref[..., :3]).max() <= 1e-5
     assert np.array_equal(fb[..., 3], ref[..., 3])
     assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any
-    assert tr.stats["host_syncs"] == tr.stats["chains"] + 1  # one per round + the camera filter
+    assert tr.stats["host_syncs"] <= tr.stats["chains"] + 1  # one per round (+ the camera filter unless its counts stay on the device)
     # a second frame of the same tracer: same image (queues, scratch and counters are reused)
     fb2 = tr().framebuffer(True)
     assert np.abs(fb2 - fb).max() <= (0.0 if exact else 1e-5)
@@ -236,7 +236,7 @@ def test_top_level_bvh_with_1056_instances(hip):
     assert np.array_equal(it().framebuffer(True)[..., :3], ref[..., :3]) and it.adapter_calls == st.adapter_calls
 
 
-@pytest.mark.parametrize("opts", [dict(packet=0), dict(packet=1, camera_tile=0), dict(small_rays=0), dict(small_rays=1 << 30), dict(wave_single=0), dict(shadow_direct=0), dict(fused=1),
+@pytest.mark.parametrize("opts", [dict(packet=1), dict(packet=1, camera_tile=0), dict(first_round_async=0), dict(first_round_async=1, packet=1), dict(small_rays=0), dict(small_rays=1 << 30), dict(wave_single=0), dict(shadow_direct=0), dict(fused=1),
                                   dict(small_rays=1 << 30, wave_single=0), dict(blocks_per_cu_closest=0, term_sink=0)])
 def test_round_results_do_not_depend_on_knobs(hip, opts):
     """The round chain's variants -- a wave per ray for small rounds, single-mesh kernels for one-queue rounds, direct-mapped shadow
