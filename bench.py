@@ -341,7 +341,7 @@ def main():
             n_launch = max(1, st["launches_%s" % dom])
             rays_dom = {"closest": sums["rays_closest"], "any": sums["rays_any"]}[dom]  # this rank's
             achieved = (rays_dom * b_ray / n_launch) / (ms_dom / n_launch / 1e3) / 1e9 if ms_dom > 0 else 0.0
-            merged = args.harness == "native"
+            merged = args.harness == "native" and n_dom > 1  # a one-queue round runs the single-mesh kernels
             symbol = ("k_trace<%s, true, %d, false, true, %s>" % ("false" if dom == "closest" else "true", 0 if dom == "closest" else 1, "true" if merged else "false"))
             traffic, traffic_src = None, None
             tf = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch, committed with its provenance

@@ -254,3 +254,29 @@ def test_round_results_do_not_depend_on_knobs(hip, opts):
             tr.close()
         finally:
             hip.set_option("defaults", 0)
+
+
+def test_degenerate_scenes_through_the_native_tracer(hip):
+    """No lights (nothing is shaded into the frame), an instance whose mesh has no triangles, a camera that sees nothing: frames
+    finish, are black where they must be, and a later normal frame of the same process is unaffected."""
+    sc = scenes.bunny_grid_scene(width=160, height=90)
+    sc.lights = sc.lights[:0]
+    tr = NativeTracer(sc, NORMALS_SMOOTH)
+    fb = tr().framebuffer(True)
+    assert float(np.abs(fb).max()) == 0.0 and tr.stats["rays_closest"] > 1000 and tr.stats["rays_any"] == 0
+    tr.close()
+    one = scenes.soup_scene(1000, 96, 54)
+    one.meshes[0] = scenes.MeshData(np.zeros((3, 3), np.float32), np.zeros((0, 3), np.int32), one.meshes[0].material)
+    tr = NativeTracer(one, NORMALS_FLAT)
+    assert float(np.abs(tr().framebuffer(True)).max()) == 0.0
+    tr.close()
+    away = scenes.soup_scene(20_000, 96, 54)
+    away.camera.focus = (0.5, 0.5, 9.0)  # looks away from the soup
+    tr = NativeTracer(away, NORMALS_FLAT)
+    assert float(np.abs(tr().framebuffer(True)).max()) == 0.0 and tr.stats["rays_closest"] == 0
+    tr.close()
+    ok = scenes.soup_scene(20_000, 96, 54)
+    tr = NativeTracer(ok, NORMALS_FLAT)
+    ref, _ = oracle_render(ok, NORMALS_FLAT)
+    assert np.array_equal(tr().framebuffer(True)[..., :3], ref[..., :3])
+    tr.close()
