@@ -91,14 +91,17 @@ void HipMeshAdapter::trace(gvt::render::actor::RayVector &rayList, gvt::render::
   }
   const size_t n = end > begin ? end - begin : 0;
   const size_t cap = n * (1 + pods.size()) + 16;
-  if (out_.size() < cap) out_.resize(cap);
   size_t n_out = 0;
-  int rc = gvt_hip_trace(mesh_, reinterpret_cast<gvt_hip_ray *>(rayList.data()), rayList.size(), begin, end,
-                         reinterpret_cast<gvt_hip_ray *>(out_.data()), cap, &n_out, &(*m)[0][0], &(*minv)[0][0], &(*normi)[0][0],
-                         pods.empty() ? nullptr : pods.data(), pods.size(), normal_mode_, trace_calls_++);
-  if (rc != GVT_HIP_OK) fail("gvt_hip_trace");
-  // copy to the outgoing ray queue under the adapter's lock, like EmbreeMeshAdapter.cpp:619-621
+  // The moved rays are written straight behind moved_rays' current contents, under the adapter's lock like the append of
+  // EmbreeMeshAdapter.cpp:619-621 (Ray() constructs nothing, so growing the vector touches no memory; the schedulers reserve
+  // 10x the input, ImageTracer.h:240): no intermediate buffer, no second copy of 80 bytes per moved ray.
   std::unique_lock<std::mutex> moved(_outqueue);
-  moved_rays.insert(moved_rays.end(), out_.begin(), out_.begin() + n_out);
+  const size_t old = moved_rays.size();
+  moved_rays.resize(old + cap);
+  int rc = gvt_hip_trace(mesh_, reinterpret_cast<gvt_hip_ray *>(rayList.data()), rayList.size(), begin, end,
+                         reinterpret_cast<gvt_hip_ray *>(moved_rays.data() + old), cap, &n_out, &(*m)[0][0], &(*minv)[0][0], &(*normi)[0][0],
+                         pods.empty() ? nullptr : pods.data(), pods.size(), normal_mode_, trace_calls_++);
+  moved_rays.resize(old + (rc == GVT_HIP_OK ? n_out : 0));
   moved.unlock();
+  if (rc != GVT_HIP_OK) fail("gvt_hip_trace");
 }

@@ -42,7 +42,6 @@ private:
   gvt_hip_mesh *mesh_;
   int normal_mode_;
   unsigned trace_calls_;
-  gvt::render::actor::RayVector out_; // staging for moved rays, reused across calls
 };
 
 } // namespace data
