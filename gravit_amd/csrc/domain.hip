@@ -594,9 +594,7 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
     std::memcpy(one.normi.n, R->normi.data() + 9 * (size_t)i0, 36);
   }
   const bool single = one.mesh != nullptr;
-  if ((rc = wave_trace_chain(W, N, passes, R->q_moved, d_from, P, R->lights.data(), single ? &one : nullptr))) return rc;
-  k_zero_counts<<<(unsigned)((nI + 255) / 256), 256, 0, st>>>(R->d_count_ptr, R->d_mask, (int)nI); // queue[instTarget].clear()
-  HIPCHK(hipGetLastError());
+  if ((rc = wave_trace_chain(W, N, passes, R->q_moved, d_from, P, R->lights.data(), single ? &one : nullptr, R->d_count_ptr, R->d_mask, (int)nI))) return rc;
   // one instance in the whole scene and the terminal rule applied inside the kernels: nothing can have moved
   if (!(nI == 1 && P.sink.fb) &&
       (rc = shuffle_async(R->top, R->q_moved, bound, single ? nullptr : d_from, single ? one.inst : -1, R->queues.data(), nullptr, R->fb, R->d_overflow, R->d_qdesc))) return rc;
@@ -610,9 +608,10 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs) {
   const size_t nI = R->n_inst, row = ANN_HEAD + nI;
   hipStream_t st = C.stream;
   int *d_bbox = (int *)(R->d_overflow + 4);
-  k_bbox_init<<<1, 64, 0, st>>>(d_bbox, R->fb->w, R->fb->h);
-  if (exchange && R->world > 1) // the rectangle this rank's deposits lie in, for the composite: carried by the announce
+  if (exchange && R->world > 1) { // the rectangle this rank's deposits lie in, for the composite: carried by the announce
+    k_bbox_init<<<1, 64, 0, st>>>(d_bbox, R->fb->w, R->fb->h);
     k_fb_bbox<<<(unsigned)(((size_t)R->fb->w * R->fb->h + 255) / 256), 256, 0, st>>>((const float4 *)R->fb->d_rgba, R->fb->w, R->fb->h, d_bbox);
+  }
   k_round_report<<<1, 256, 0, st>>>(R->d_count_ptr, R->d_owner, (int)nI, R->rank, R->world, R->d_report, R->d_ann_out, C.d_counters, R->d_overflow,
                                     R->d_report + nI, d_bbox);
   HIPCHK(hipGetLastError());

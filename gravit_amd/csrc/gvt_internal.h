@@ -236,7 +236,7 @@ struct WaveSingle { // the launch has ONE segment: its queue planes and instance
   const unsigned *n_dev; // the first pass's ray count lives in device memory (the queue's count word; n_total is only its bound)
 };
 int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
-                     const gvt_hip_light *lights_host, const WaveSingle *single);
+                     const gvt_hip_light *lights_host, const WaveSingle *single, unsigned *const *d_count_ptr, const unsigned char *d_mask, int n_inst);
 int convert_aos_to_planes(const gvt_hip_ray *d_src, size_t n, RayPlanes dst, size_t dst_off);
 int convert_planes_to_aos(RayPlanes src, size_t src_off, size_t n, gvt_hip_ray *d_dst);
 int convert_od_to_planes(const float *d_org, const float *d_dir, size_t n, RayPlanes dst);

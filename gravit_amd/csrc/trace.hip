@@ -1576,15 +1576,17 @@ __global__ void k_wave_pass_begin(unsigned *c, int pass, unsigned n_host, unsign
   else { tot[1] += c[1]; tot[0] += c[prev]; c[cur] = 0u; }
   c[0] = 0u; c[1] = 0u; c[3] = 0u; c[4] = 0u; c[6] = 0u;
 }
-__global__ void k_wave_end(unsigned *c) {
-  if (blockIdx.x || threadIdx.x) return;
-  unsigned long long *tot = (unsigned long long *)(c + 16);
-  tot[1] += c[1];
+// end of a round's chain: the last pass's shadow rays into the frame total; and the traced queues' clear() (count words of the
+// queues whose mask byte is set) in the same launch
+__global__ void k_wave_end(unsigned *c, unsigned *const *__restrict__ count_ptr, const unsigned char *__restrict__ mask, int n_inst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { unsigned long long *tot = (unsigned long long *)(c + 16); tot[1] += c[1]; }
+  if (count_ptr && i < n_inst && mask[i]) *count_ptr[i] = 0u;
 }
 } // namespace
 
 int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
-                     const gvt_hip_light *lights_host, const WaveSingle *single) {
+                     const gvt_hip_light *lights_host, const WaveSingle *single, unsigned *const *d_count_ptr, const unsigned char *d_mask, int n_inst) {
   Ctx &C = gctx();
   if (!n_total) return 0;
   hipStream_t st = C.stream;
@@ -1760,7 +1762,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     C.stats.launches_closest++;
     C.stats.launches_any++;
   }
-  k_wave_end<<<1, 64, 0, st>>>(c);
+  k_wave_end<<<(unsigned)((std::max(n_inst, 1) + 255) / 256), 256, 0, st>>>(c, d_count_ptr, d_mask, n_inst); // + queue[instTarget].clear()
   HIPCHK(hipGetLastError());
   C.stats.trace_calls++;
   return 0;
