@@ -12,6 +12,9 @@ Fixtures are DATA (inputs and expected outputs), never reference source text:
                                  RayPacketIntersection, RandEngine, Mesh::addFace, struct sizes) through oracle/ref_shim.cpp
   oracle_vectors.npz             outputs of the pinned CPU oracle on seeded inputs (per-ray hits on bunny.obj, framebuffer
                                  hashes of the golden scenes in flat and smooth mode) for the GPU parity tests
+  round2_vectors.json            (python tests/golden/make_fixtures.py --round2; needs no reference tree) regression pins of what
+                                 the oracle DEFINES where the reference is schedule dependent: gvt_math known answers, camera stream
+                                 words, bounce directions, and the hash / ray counts of a depth-2, 4-rays-per-pixel config-5 frame
 """
 import ctypes as C
 import hashlib
@@ -39,7 +42,39 @@ def f3(*v):
     return np.array(v, np.float32)
 
 
+def round2():
+    """Pins of the oracle's own definitions (no reference involved): written once, checked by tests/test_oracle_pinning.py."""
+    from tests.helpers import oracle_render, oracle_render_domain
+
+    out = {}
+    xs = np.array([0.0, 1e-7, 0.25, 0.5, 0.999999, 1.0, 3.14159274, 6.28318548, 2.5, 5.75], np.float32)
+    out["math"] = {"x": xs.view(np.uint32).tolist(), "sin": orc.math_probe(0, xs).view(np.uint32).tolist(),
+                   "cos": orc.math_probe(1, xs).view(np.uint32).tolist(),
+                   "theta_of_xi": orc.math_probe(2, np.clip(xs, 0, 0.99999994)).view(np.uint32).tolist()}
+    sc = scenes.cathedral_scene(5, 3, samples=2, depth=2)
+    r = orc.camera_rays(sc.camera.eye, sc.camera.focus, sc.camera.up, sc.camera.fov, 5, 3, 2, 2, 0.0)
+    out["camera_stream_words"] = r["rng"].tolist()
+    dirs = []
+    for k, n in enumerate(([0, 0, 1], [0.6, 0.0, 0.8], [-0.57735026, 0.57735026, 0.57735026])):
+        d, s2 = orc.cos_weighted_dir(np.array(n, np.float32), 1000 + k)
+        dirs.append({"n": np.array(n, np.float32).view(np.uint32).tolist(), "seed": 1000 + k, "dir": d.view(np.uint32).tolist(), "seed_after": int(s2)})
+    out["bounce_dirs"] = dirs
+    one = scenes.cathedral_scene(96, 96, samples=2, depth=2, eye=(0.0, 1.5, 13.0), light=(0.0, 2.5, 12.0))
+    fb, st = oracle_render(one, 0, nthreads=1)
+    out["config5_image_96"] = {"rgb_sha256": hashlib.sha256(np.ascontiguousarray(fb[..., :3]).tobytes()).hexdigest(),
+                               "alpha_sha256": hashlib.sha256(np.ascontiguousarray(fb[..., 3]).tobytes()).hexdigest(),
+                               "rays_closest": int(st.rays_closest), "rays_any": int(st.rays_any)}
+    dom = scenes.split_into_domains(one, 4)
+    fb, st = oracle_render_domain(dom, [0, 1, 0, 1], 2, 0, nthreads=1)
+    out["config5_domain_96"] = {"alpha_sha256": hashlib.sha256(np.ascontiguousarray(fb[..., 3]).tobytes()).hexdigest(),
+                                "rays_closest": int(st.rays_closest), "rays_any": int(st.rays_any), "rays_sent": int(st.rays_sent), "rounds": int(st.rounds)}
+    json.dump(out, open(os.path.join(HERE, "round2_vectors.json"), "w"), indent=1, sort_keys=True)
+    print("wrote round2_vectors.json")
+
+
 def main():
+    if "--round2" in sys.argv:
+        return round2()
     assert os.path.isdir(REF), "needs /root/reference"
     ref = orc.ref()
     assert ref is not None, "build oracle/_ref first (make -C oracle)"

@@ -274,3 +274,32 @@ def test_depth2_frame_does_not_depend_on_rank_count():
     assert np.abs(f1 - f2).max() < 1e-6 and np.abs(f1 - f4).max() < 1e-6
     assert np.array_equal(f1[..., 3], f4[..., 3]) and s1.rays_closest == s4.rays_closest and s2.rays_any == s4.rays_any
     assert s1.rays_sent == 0 and s4.rays_sent >= s2.rays_sent > 0
+
+
+def test_round2_definitions_are_stable():
+    """tests/golden/round2_vectors.json pins what the oracle DEFINES where the reference is schedule dependent or calls libm: the
+    written-out sin / cos / acos, the camera's stream words, bounce directions, and a depth-2, 4-rays-per-pixel config-5 frame through
+    both restated schedulers (image bits, deposit counts, ray counts, rays sent, rounds)."""
+    import json
+
+    v = json.load(open(os.path.join(GOLDEN, "round2_vectors.json")))
+    xs = np.array(v["math"]["x"], np.uint32).view(np.float32)
+    assert orc.math_probe(0, xs).view(np.uint32).tolist() == v["math"]["sin"]
+    assert orc.math_probe(1, xs).view(np.uint32).tolist() == v["math"]["cos"]
+    assert orc.math_probe(2, np.clip(xs, 0, 0.99999994)).view(np.uint32).tolist() == v["math"]["theta_of_xi"]
+    sc = scenes.cathedral_scene(5, 3, samples=2, depth=2)
+    r = orc.camera_rays(sc.camera.eye, sc.camera.focus, sc.camera.up, sc.camera.fov, 5, 3, 2, 2, 0.0)
+    assert r["rng"].tolist() == v["camera_stream_words"] and len(set(v["camera_stream_words"])) == 60
+    for b in v["bounce_dirs"]:
+        d, s2 = orc.cos_weighted_dir(np.array(b["n"], np.uint32).view(np.float32), b["seed"])
+        assert d.view(np.uint32).tolist() == b["dir"] and s2 == b["seed_after"]
+    one = scenes.cathedral_scene(96, 96, samples=2, depth=2, eye=(0.0, 1.5, 13.0), light=(0.0, 2.5, 12.0))
+    fb, st = oracle_render(one, 0, nthreads=1)
+    rec = v["config5_image_96"]
+    assert hashlib.sha256(np.ascontiguousarray(fb[..., :3]).tobytes()).hexdigest() == rec["rgb_sha256"]
+    assert hashlib.sha256(np.ascontiguousarray(fb[..., 3]).tobytes()).hexdigest() == rec["alpha_sha256"]
+    assert (st.rays_closest, st.rays_any) == (rec["rays_closest"], rec["rays_any"])
+    fb, st = oracle_render_domain(scenes.split_into_domains(one, 4), [0, 1, 0, 1], 2, 0, nthreads=1)
+    rec = v["config5_domain_96"]
+    assert hashlib.sha256(np.ascontiguousarray(fb[..., 3]).tobytes()).hexdigest() == rec["alpha_sha256"]
+    assert (st.rays_closest, st.rays_any, st.rays_sent, st.rounds) == (rec["rays_closest"], rec["rays_any"], rec["rays_sent"], rec["rounds"])
