@@ -268,7 +268,7 @@ def main():
     barrier()
     if on_gpu:
         capi.stats_reset()
-        capi.profile(True)  # HIP events around every kernel, on the launch stream
+        capi.profile(2)  # HIP events on the launch stream around the traversal kernels (closest hit, long rays, any hit)
     else:
         tracer.backend.rays_closest = tracer.backend.rays_any = 0
     per_frame, sums = [], {"rays_closest": 0, "rays_any": 0, "rays_sent": 0, "rounds": 0, "chains": 0, "host_syncs": 0}

@@ -121,7 +121,7 @@ void *scratch_get(int slot, size_t bytes) {
 // ---- profiling: HIP events on the launch stream ----
 ProfScope::ProfScope(int c) : cls(c) {
   Ctx &C = g_ctx;
-  if (!C.profile) return;
+  if (!C.profile || (C.profile == 2 && c != KC_CLOSEST && c != KC_ANY && c != KC_LONG)) return;
   auto take = [&]() {
     hipEvent_t e;
     if (!C.event_pool.empty()) { e = C.event_pool.back(); C.event_pool.pop_back(); }
@@ -154,7 +154,7 @@ static void drain_events() {
 extern "C" int gvt_hip_profile(int enable) {
   if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
   drain_events();
-  g_ctx.profile = enable != 0;
+  g_ctx.profile = enable < 0 ? 0 : enable;
   return 0;
 }
 extern "C" int gvt_hip_stats_read(gvt_hip_stats *out) {

@@ -54,7 +54,7 @@ struct Ctx : Knobs {
   int device = -1;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  bool profile = false;
+  int profile = 0; // 0 off, 1 every kernel class, 2 the traversal kernels only (closest, long, any)
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;
   gvt_hip_stats stats{};
