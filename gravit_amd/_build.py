@@ -37,6 +37,9 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
+    extra = os.environ.get("GVT_EXTRA_HIPCC_FLAGS", "").split()  # experiments only (e.g. -DTRAV_STACK=16); forces a rebuild
+    if extra:
+        force = True
     cc = hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
@@ -46,7 +49,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(OBJ, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [cc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [cc] + FLAGS + extra + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -39,7 +39,7 @@ static int ctx_setup(Ctx &C, int device) {
   HIPCHK(hipStreamCreateWithFlags(&C.own_stream, hipStreamNonBlocking));
   C.stream = C.own_stream;
   // traversal kernels: 24 KiB LDS per 256-thread block -> 6 blocks/CU; grid = resident blocks, waves pull work
-  C.trav_blocks = C.n_cu * 6;
+  C.trav_blocks = C.n_cu * 8;
   const size_t spill_ints = (size_t)C.trav_blocks * trav_block_threads() * trav_spill_ints_per_thread();
   HIPCHK(hipMalloc((void **)&C.d_spill, spill_ints * sizeof(int)));
   HIPCHK(hipMalloc((void **)&C.d_counters, 64 * sizeof(unsigned)));
@@ -195,8 +195,8 @@ extern "C" int gvt_hip_set_option(const char *name, int value) {
   if (!std::strcmp(name, "coop_fetch")) { g_ctx.coop_fetch = value; return 0; }
   if (!std::strcmp(name, "top_lds")) { g_ctx.top_lds = value; return 0; }
   if (!std::strcmp(name, "trav_kernel")) { g_ctx.trav_kernel = value; return 0; }
-  if (!std::strcmp(name, "blocks_per_cu_closest")) { if (value < 0 || value > 6) { set_error("blocks_per_cu_closest must be 0..6"); return GVT_HIP_ERR_INVALID; } g_ctx.blocks_per_cu_closest = value; return 0; }
-  if (!std::strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 6) { set_error("blocks_per_cu must be 1..6"); return GVT_HIP_ERR_INVALID; } g_ctx.blocks_per_cu = value; return 0; }
+  if (!std::strcmp(name, "blocks_per_cu_closest")) { if (value < 0 || value > 8) { set_error("blocks_per_cu_closest must be 0..8"); return GVT_HIP_ERR_INVALID; } g_ctx.blocks_per_cu_closest = value; return 0; }
+  if (!std::strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 8) { set_error("blocks_per_cu must be 1..8"); return GVT_HIP_ERR_INVALID; } g_ctx.blocks_per_cu = value; return 0; }
   if (!std::strcmp(name, "inner_min")) { if (value < 1 || value > 64) { set_error("inner_min must be 1..64"); return GVT_HIP_ERR_INVALID; } g_ctx.inner_min = value; return 0; }
   if (!std::strcmp(name, "refill_min")) { if (value < 1 || value > 64) { set_error("refill_min must be 1..64"); return GVT_HIP_ERR_INVALID; } g_ctx.refill_min = value; return 0; }
   set_error("set_option: unknown option '%s'", name);

@@ -20,7 +20,9 @@
 #include "gvt_internal.h"
 
 #define TRAV_BLOCK 256
+#ifndef TRAV_STACK
 #define TRAV_STACK 24   // LDS entries per lane; deeper levels spill to a per-thread global area
+#endif
 #define TRAV_SPILL 128  // 24 + 128 = 152 pending entries: > 63 + 24 levels of a 63-bit Karras tree with index tie-breaks, and > 3 x 44, the
                         // worst case of its 4-wide collapse; k_trace reports an error beyond that instead of losing entries
 
