@@ -171,6 +171,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--domains", type=int, default=0, help="N=1 only: cut the soup into this many domains (one rank owns them all)")
+    ap.add_argument("--scheduler", choices=["domain", "image"], default="domain",
+                    help="N>1: domain (default; north_star: the scene cut into one domain per GPU, rays exchanged over RCCL) or image "
+                         "(Tracer<ImageScheduler> under several ranks, ImageTracer.h:111-125: scene replicated, camera rays split; the scaling upper bound)")
     ap.add_argument("--bsp", action="store_true", help="N>1: trace until dry before every exchange (Tracer<DomainScheduler>) instead of asynchronous ticks")
     ap.add_argument("--harness", choices=["native", "python", "checker"], default="native",
                     help="native: gvt_hip_tracer (the product path).  python: the Python scheduler loops over the same C ABI (test harness).  "
@@ -224,7 +227,8 @@ def main():
         from gravit_amd.scheduler import DomainTracer, ImageTracer
         from tests.oracle_backend import OracleBackend
 
-    n_dom = world if world > 1 else max(1, args.domains)
+    image_split = world > 1 and args.scheduler == "image" and args.harness == "native"
+    n_dom = (world if not image_split else 1) if world > 1 else max(1, args.domains)
     scene = scenes.soup_scene(args.tris, args.width, args.height) if n_dom == 1 else scenes.soup_domains_scene(args.tris, n_dom, args.width, args.height)
     owner = [i % world for i in range(scene.n_inst)]
     comm = None
@@ -233,7 +237,7 @@ def main():
             uid = [Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             comm = Comm.rccl(uid[0], rank, world)
-        tracer = NativeTracer(scene, NORMALS_FLAT, owner, comm)
+        tracer = NativeTracer(scene, NORMALS_FLAT, owner, comm, replicate=image_split)
         frame_stats = lambda: tracer.stats  # noqa: E731
     else:
         backend = None if on_gpu else OracleBackend(scene, NORMALS_FLAT, [o == rank for o in owner])
@@ -257,7 +261,7 @@ def main():
 
     def frame():
         if args.harness == "native":
-            tracer(bsp=args.bsp)  # includes IceTComposite::composite (the reduce to rank 0); the PPM download is not part of the frame
+            tracer(bsp=args.bsp, image=image_split)  # includes IceTComposite::composite (to rank 0); the PPM download is not part of the frame
         else:
             tracer()
             if world > 1:
@@ -322,6 +326,7 @@ def main():
                             "fov 30deg, 1 point light at the eye, depth 1 (primary + 1 shadow ray), AO off"
                             % (args.tris, args.tris, args.width, args.height),
                 "scheduler": ("image, 1 domain" if n_dom == 1 else "domain, %d spatial domains on 1 GPU" % n_dom) if world == 1
+                             else ("image, scene replicated on %d GPUs, camera rays split (ImageTracer.h:111-125), composite over RCCL" % world) if image_split
                              else "domain, %d spatial domains, 1 per GPU, %s, ray exchange = RCCL p2p issued by libgvt_hip.so"
                                   % (world, "BSP rounds" if args.bsp else "asynchronous ticks"),
                 "harness": args.harness,

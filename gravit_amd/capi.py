@@ -55,7 +55,7 @@ class FrameStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
-FRAME_BSP, FRAME_NO_COMPOSITE, FRAME_FULL_REDUCE = 1, 2, 4
+FRAME_BSP, FRAME_NO_COMPOSITE, FRAME_FULL_REDUCE, FRAME_IMAGE = 1, 2, 4, 8
 
 
 class Stats(C.Structure):

@@ -33,7 +33,8 @@
 
 int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *from_arr, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
                   gvt_hip_fb *fb, unsigned *d_overflow, const void *d_qdesc);
-int camera_filter_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *const *queues, const uint8_t *keep_mask, unsigned *d_overflow);
+int camera_filter_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *const *queues, const uint8_t *keep_mask, unsigned *d_overflow,
+                        size_t first, size_t count);
 
 // ------------------------------------------------------------------------------------------------
 // RCCL, resolved at first use (a single-GPU process never loads it)
@@ -653,6 +654,18 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   hipStream_t st = C.stream;
   const size_t nI = R->n_inst, row = ANN_HEAD + nI;
   const bool bsp = (flags & GVT_HIP_FRAME_BSP) != 0;
+  // Tracer<ImageScheduler> on several ranks (ImageTracer.h:111-125): the scene is replicated, every rank takes a contiguous portion of
+  // the camera's ray list and traces it to the end on its own; no ray ever changes rank; the frame ends with the composite.
+  const bool image_split = (flags & GVT_HIP_FRAME_IMAGE) != 0 && R->world > 1;
+  if (image_split)
+    for (size_t i = 0; i < nI; i++)
+      if (!R->meshes[i]) { set_error("tracer_frame: GVT_HIP_FRAME_IMAGE needs every instance's mesh on every rank (instance %zu has none)", i); return GVT_HIP_ERR_INVALID; }
+  const int world_saved = R->world;
+  std::vector<uint8_t> owned_saved = R->owned;
+  struct Restore { // whatever path leaves this function: the tracer is a rank of its communicator again
+    gvt_hip_tracer *R; int world; const std::vector<uint8_t> *owned;
+    ~Restore() { R->world = world; R->owned = *owned; }
+  } restore{ R, world_saved, &owned_saved };
   gvt_hip_frame_stats S{};
   int rc;
   // clearBuffer + generateRays + FilterRaysLocally / shuffleDropRays (ImageTracer.h:137-146, DomainTracer.h:148-183, 204-211)
@@ -668,10 +681,19 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     const size_t n_cam = (size_t)R->cam.width * R->cam.height * R->cam.samples * R->cam.samples;
     const int passes0 = R->cam.depth > 1 ? R->cam.depth : 1;
     if ((rc = queue_reserve(R->queues[0], n_cam * (size_t)(1 + (int)R->lights.size() * passes0)))) return rc; // what local_chain will ask for: no move later
-    if ((rc = camera_filter_async(R->top, &R->cam, C.camera_tile, R->queues.data(), nullptr, R->d_overflow))) return rc;
+    if ((rc = camera_filter_async(R->top, &R->cam, C.camera_tile, R->queues.data(), nullptr, R->d_overflow, 0, 0))) return rc;
     R->present[0] = n_cam;
     R->queues[0]->size = n_cam; // bound of what the device holds (a reallocation would copy at least that)
     if ((rc = local_chain(R, nullptr, &S.chains, true, true))) return rc;
+    if ((rc = round_report(R, false, &S.host_syncs))) return rc;
+  } else if (image_split) {
+    const size_t n_cam = (size_t)R->cam.width * R->cam.height * R->cam.samples * R->cam.samples;
+    const size_t portion = n_cam / (size_t)R->world, first = (size_t)R->rank * portion;
+    const size_t count = (R->rank + 1 == R->world) ? n_cam - first : portion; // "tack on any odd rays to last proc" (:116)
+    for (size_t i = 0; i < nI; i++) if ((rc = queue_reserve(R->queues[i], count))) return rc;
+    if ((rc = camera_filter_async(R->top, &R->cam, C.camera_tile, R->queues.data(), nullptr, R->d_overflow, first, count))) return rc;
+    std::fill(R->owned.begin(), R->owned.end(), (uint8_t)1);
+    R->world = 1; // the rounds below are a one-rank frame
     if ((rc = round_report(R, false, &S.host_syncs))) return rc;
   } else {
     if ((rc = gvt_hip_camera_filter(R->top, &R->cam, C.camera_tile, R->queues.data(), R->world > 1 ? R->owned.data() : nullptr))) return rc;
@@ -717,7 +739,13 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
         if ((rc = local_chain(R, nullptr, &S.chains, S.chains == 0))) return rc;
         if ((rc = round_report(R, false, &S.host_syncs))) return rc;
       }
-      if (R->world == 1) break;
+      if (R->world == 1) {
+        if (image_split) { // back among the ranks: one exchange, so that rank 0 learns every rank's deposit rectangle
+          R->world = world_saved; R->owned = owned_saved;
+          if ((rc = round_report(R, true, &S.host_syncs))) return rc;
+        }
+        break;
+      }
     } else {
       bool have_local = false;
       for (size_t i = 0; i < nI; i++) have_local = have_local || (R->owned[i] && R->present[i]);

@@ -14,6 +14,7 @@ struct CamArgs {
   float vert, horz, wmult, hmult, half_sample, offset, contri;
   int W, H, samples, depth;
   int tile; // 0: rays in the reference's order (pixel-major); 8: pixels enumerated in 8x8 tiles (one wave of rays = one tile)
+  unsigned first; // the kernels' ray i is ray `first + i` of the generated list (a rank's portion, ImageTracer.h:112-120)
 };
 
 // position in the generated list -> pixel.  tile == 8: the W8 x H8 part of the image that whole 8x8 tiles cover comes first, tile
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RaySrc S, unsigned n
   if (i < n) {
     float ret_t;
     float4 a, b;
-    if (S.from_cam) { const RayRec r = camera_ray(S.cam, i); a = make_float4(r.o.x, r.o.y, r.o.z, r.t_min); b = make_float4(r.d.x, r.d.y, r.d.z, r.t_max); }
+    if (S.from_cam) { const RayRec r = camera_ray(S.cam, (unsigned long long)S.cam.first + i); a = make_float4(r.o.x, r.o.y, r.o.z, r.t_min); b = make_float4(r.d.x, r.d.y, r.d.z, r.t_max); }
     else { a = S.q.p0[i]; b = S.q.p1[i]; }
     next = top_nearest(a, b, top, from_arr ? from_arr[i] : from, ret_t);
     next_out[i] = next;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_scatter(RaySrc S, unsigned n,
   RayRec r;
   if (i < n) {
     next = next_in[i];
-    r = S.from_cam ? camera_ray(S.cam, i) : load_ray(S.q, i);
+    r = S.from_cam ? camera_ray(S.cam, (unsigned long long)S.cam.first + i) : load_ray(S.q, i);
     if (next >= 0) {
       r.o = add3(r.o, scl3(r.d, t_in[i] * 0.95f)); // TracerBase.h:393
     } else if (fb && r.type == 1 && len3(r.c) > 0.f) { // TracerBase.h:396-400 -> localAdd
@@ -266,7 +267,7 @@ static CamArgs make_cam_args(const float eye[3], const float focus[3], const flo
   A.hmult = 2.f / (float)(H - 1);
   A.half_sample = samples * 0.5f;
   A.contri = 1.f / (samples * samples);
-  A.W = W; A.H = H; A.samples = samples; A.depth = depth; A.tile = tile;
+  A.W = W; A.H = H; A.samples = samples; A.depth = depth; A.tile = tile; A.first = 0u;
   return A;
 }
 
@@ -493,13 +494,17 @@ int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *f
 }
 // generateRays + FilterRaysLocally without a read-back: every kept queue must have room for all W*H*samples^2 rays; the queue counts
 // advance on the device only (the caller's first launch chain reads its ray count from there)
-int camera_filter_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *const *queues, const uint8_t *keep_mask, unsigned *d_overflow) {
-  const size_t n = (size_t)cam->width * cam->height * cam->samples * cam->samples;
-  if (n > 0xffffffffull) { set_error("camera_filter: more than 2^32 rays"); return GVT_HIP_ERR_INVALID; }
+// [first, first + count) of the generated list (count == 0: all of it): a rank's portion under the multi-rank Image scheduler
+int camera_filter_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *const *queues, const uint8_t *keep_mask, unsigned *d_overflow,
+                        size_t first, size_t count) {
+  const size_t n_all = (size_t)cam->width * cam->height * cam->samples * cam->samples;
+  if (n_all > 0xffffffffull) { set_error("camera_filter: more than 2^32 rays"); return GVT_HIP_ERR_INVALID; }
+  if (!count) count = n_all - first;
   RaySrc S{};
   S.cam = make_cam_args(cam->eye, cam->focus, cam->up, cam->fov, cam->width, cam->height, cam->samples, cam->depth, cam->jitter_window_size, tile);
+  S.cam.first = (unsigned)first;
   S.from_cam = 1;
-  return shuffle_async_src(T, S, n, nullptr, nullptr, -1, queues, keep_mask, nullptr, d_overflow, nullptr);
+  return shuffle_async_src(T, S, count, nullptr, nullptr, -1, queues, keep_mask, nullptr, d_overflow, nullptr);
 }
 static int shuffle_async_src(gvt_hip_top *T, const RaySrc &S, size_t n_ub, const unsigned *n_dev, const int *from_arr, int from, gvt_hip_queue *const *queues,
                              const uint8_t *keep_mask, gvt_hip_fb *fb, unsigned *d_overflow, const void *d_qdesc) {

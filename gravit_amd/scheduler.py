@@ -196,7 +196,7 @@ class NativeTracer:
     of one merged launch chain over all local queues, one host synchronisation per round, ray exchange over RCCL (or the in-process
     transport).  owner[i] = rank of instance i (mpiInstanceMap); comm=None: one rank."""
 
-    def __init__(self, scene, normal_mode=NORMALS_FLAT, owner=None, comm=None, backend=None):
+    def __init__(self, scene, normal_mode=NORMALS_FLAT, owner=None, comm=None, backend=None, replicate=False):
         import ctypes as C
 
         self.lib = capi.load()
@@ -204,7 +204,7 @@ class NativeTracer:
         self.comm = comm
         rank = comm.rank if comm is not None else 0
         self.owner = [0] * scene.n_inst if owner is None else list(owner)
-        owned = [o == rank for o in self.owner]
+        owned = [True] * scene.n_inst if replicate else [o == rank for o in self.owner]  # replicate: every mesh on every rank (Image scheduler)
         self.backend = backend or HipBackend(scene, normal_mode, owned)
         B = self.backend
         cam = scene.camera
@@ -221,11 +221,12 @@ class NativeTracer:
         capi.check(self.lib.gvt_hip_tracer_set_domains(self.h, capi.ptr(own), comm.h if comm is not None else None), "gvt_hip_tracer_set_domains")
         self.stats = {}
 
-    def __call__(self, bsp=False, composite=True, full_reduce=False):
+    def __call__(self, bsp=False, composite=True, full_reduce=False, image=False):
         import ctypes as C
 
         st = capi.FrameStats()
-        flags = (capi.FRAME_BSP if bsp else 0) | (0 if composite else capi.FRAME_NO_COMPOSITE) | (capi.FRAME_FULL_REDUCE if full_reduce else 0)
+        flags = ((capi.FRAME_BSP if bsp else 0) | (0 if composite else capi.FRAME_NO_COMPOSITE) | (capi.FRAME_FULL_REDUCE if full_reduce else 0) |
+                 (capi.FRAME_IMAGE if image else 0))
         capi.check(self.lib.gvt_hip_tracer_frame(self.h, C.c_int(flags), C.byref(st)), "gvt_hip_tracer_frame")
         self.stats = st.as_dict()
         return self.backend

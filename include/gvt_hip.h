@@ -237,6 +237,8 @@ int gvt_hip_tracer_set_domains(gvt_hip_tracer *, const int32_t *owner /* n_inst 
 #define GVT_HIP_FRAME_BSP 1          /* Domain: trace until the local queues are dry, then exchange (Tracer<DomainScheduler>); default:
                                         one local chain per exchange, the payload moving while the next chain runs (asynchronous tracer) */
 #define GVT_HIP_FRAME_NO_COMPOSITE 2 /* leave the per-rank framebuffers un-reduced */
+#define GVT_HIP_FRAME_IMAGE 8        /* several ranks, Image scheduler (ImageTracer.h:111-125): the scene is replicated (every instance's mesh on every
+                                        rank), each rank traces its contiguous portion of the camera's rays to the end, then the composite */
 #define GVT_HIP_FRAME_FULL_REDUCE 4  /* composite by a sum-reduce of whole frames (ncclReduce) instead of each rank's written rectangle */
 typedef struct gvt_hip_frame_stats {
   uint64_t rounds;       /* exchanges (Domain) */

@@ -53,7 +53,7 @@ def test_rounds_equal_the_reference_order_loop(hip, name, mode, exact):
     tr.close()
 
 
-def run_native_ranks(scene, owner, world, mode, bsp, full_reduce=False):
+def run_native_ranks(scene, owner, world, mode, bsp, full_reduce=False, image=False):
     hub = capi.load().gvt_hip_hub_create(world)
     out, errs = {}, []
 
@@ -62,8 +62,8 @@ def run_native_ranks(scene, owner, world, mode, bsp, full_reduce=False):
         try:
             ctx = Context(0)
             comm = Comm.local(hub, rank)
-            tr = NativeTracer(scene, mode, owner, comm)
-            B = tr(bsp=bsp, full_reduce=full_reduce)
+            tr = NativeTracer(scene, mode, owner, comm, replicate=image)
+            B = tr(bsp=bsp, full_reduce=full_reduce, image=image)
             out[rank] = (B.framebuffer(True) if rank == 0 else None, dict(tr.stats))
             tr.close()
             comm.close()
@@ -141,6 +141,20 @@ def test_composite_rectangles_equal_the_full_reduce(hip):
     a = run_native_ranks(sc, owner, 3, NORMALS_FLAT, False)[0][0]
     b = run_native_ranks(sc, owner, 3, NORMALS_FLAT, False, full_reduce=True)[0][0]
     assert np.abs(a - b).max() <= 1e-5 and np.array_equal(a[..., 3], b[..., 3]) and (a[..., 3] > 0).mean() > 0.2
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_image_scheduler_on_several_ranks(hip, world):
+    """Tracer<ImageScheduler> under several ranks (ImageTracer.h:111-125): the scene replicated, each rank traces its contiguous
+    portion of the camera's rays, no ray changes rank, composite on rank 0.  The image is the one-rank image; the ranks' ray
+    counts add up to the one-rank counts."""
+    for sc, mode, tol in ((scenes.bunny_grid_scene(width=380, height=216), NORMALS_SMOOTH, 0.0), (config5(192, 4), NORMALS_FLAT, 1e-5)):
+        res = run_native_ranks(sc, [0] * sc.n_inst, world, mode, False, image=True)
+        ref, st = oracle_render(sc, mode, nthreads=8)
+        fb = res[0][0]
+        assert np.abs(fb[..., :3] - ref[..., :3]).max() <= tol and np.array_equal(fb[..., 3], ref[..., 3])
+        assert sum(r[1]["rays_closest"] for r in res.values()) == st.rays_closest and sum(r[1]["rays_any"] for r in res.values()) == st.rays_any
+        assert all(r[1]["rays_sent"] == 0 for r in res.values())  # (a portion of the film may see nothing at all)
 
 
 def test_rccl_communicator_of_one_rank(hip):
