@@ -393,6 +393,7 @@ struct gvt_hip_tracer {
   // per-round tables in ONE pinned block / ONE device block (a single host-to-device copy per round): segments, queue descriptors, mask
   void *d_round = nullptr, *h_round = nullptr;
   size_t round_bytes = 0;
+  std::vector<unsigned char> round_uploaded; // what d_round holds (a round whose tables equal the last upload needs no copy)
   WaveSeg *d_segs = nullptr, *h_segs = nullptr;
   QueueDesc *d_qdesc = nullptr, *h_qdesc = nullptr;
   unsigned **d_count_ptr = nullptr;
@@ -573,7 +574,13 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
     gvt_hip_queue *Q = R->queues[i];
     R->h_qdesc[i].planes = Q->d_planes; R->h_qdesc[i].cap = Q->cap; R->h_qdesc[i].count = Q->d_count; R->h_qdesc[i].keep = 1u;
   }
-  HIPCHK(hipMemcpyAsync(R->d_round, R->h_round, R->round_bytes, hipMemcpyHostToDevice, st)); // segments + descriptors + mask in one copy
+  // segments + descriptors + mask in one copy -- skipped when they equal what the device already holds (steady-state frames of a
+  // one-queue scene: same pointers, same bound)
+  for (size_t k = (size_t)n_seg; k < (nI ? nI : 1); k++) std::memset(&R->h_segs[k], 0, sizeof(WaveSeg));
+  if (R->round_uploaded.size() != R->round_bytes || std::memcmp(R->round_uploaded.data(), R->h_round, R->round_bytes) != 0) {
+    HIPCHK(hipMemcpyAsync(R->d_round, R->h_round, R->round_bytes, hipMemcpyHostToDevice, st));
+    R->round_uploaded.assign((const unsigned char *)R->h_round, (const unsigned char *)R->h_round + R->round_bytes);
+  }
   int *d_from = (int *)scratch_get(17, sizeof(int) * bound);
   if (!d_from) return GVT_HIP_ERR_DEVICE;
   TraceParams P{};

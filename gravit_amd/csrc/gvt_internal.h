@@ -139,6 +139,7 @@ struct gvt_hip_top {
   void **d_qdesc = nullptr;   // device array of queue descriptors
   unsigned *h_hist = nullptr; // pinned staging for the two (asynchronous copies, no pageable bounce)
   void *h_qdesc = nullptr;
+  std::vector<unsigned char> qdesc_uploaded; // what d_qdesc holds when the asynchronous shuffle last uploaded it
 };
 
 struct gvt_hip_fb {

@@ -463,6 +463,7 @@ static int shuffle_impl(gvt_hip_top *T, const RaySrc &in, size_t n, int from, gv
     desc[i].planes = Q->d_planes; desc[i].cap = Q->cap; desc[i].count = Q->d_count; desc[i].keep = keep ? 1u : 0u;
   }
   if (nI) HIPCHK(hipMemcpyAsync(T->d_qdesc, desc, sizeof(QueueDesc) * nI, hipMemcpyHostToDevice, st));
+  T->qdesc_uploaded.clear(); // (the asynchronous shuffle's upload cache no longer describes d_qdesc)
   {
     ProfScope ps(KC_SHUFFLE);
     if (d_blk) k_top_scan<<<(unsigned)nI, TOP_BLOCK, 0, st>>>(d_blk, n_blk, (const QueueDesc *)T->d_qdesc, scan_totals ? T->d_hist : nullptr);
@@ -529,7 +530,11 @@ static int shuffle_async_src(gvt_hip_top *T, const RaySrc &S, size_t n_ub, const
       gvt_hip_queue *Q = queues[i];
       desc[i].planes = Q->d_planes; desc[i].cap = Q->cap; desc[i].count = Q->d_count; desc[i].keep = (!keep_mask || keep_mask[i]) ? 1u : 0u;
     }
-    if (nI) HIPCHK(hipMemcpyAsync(T->d_qdesc, desc, sizeof(QueueDesc) * nI, hipMemcpyHostToDevice, st));
+    // (the descriptors rarely change between frames: copy only when they differ from what the device holds)
+    if (nI && (T->qdesc_uploaded.size() != sizeof(QueueDesc) * nI || std::memcmp(T->qdesc_uploaded.data(), desc, sizeof(QueueDesc) * nI) != 0)) {
+      HIPCHK(hipMemcpyAsync(T->d_qdesc, desc, sizeof(QueueDesc) * nI, hipMemcpyHostToDevice, st));
+      T->qdesc_uploaded.assign((const unsigned char *)desc, (const unsigned char *)desc + sizeof(QueueDesc) * nI);
+    }
     qd = (const QueueDesc *)T->d_qdesc;
   }
   {
