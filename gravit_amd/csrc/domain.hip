@@ -268,6 +268,40 @@ int comm_reduce_sum(gvt_hip_comm *K, float *buf, size_t n_floats, int root) {
 }
 } // namespace
 
+// Loop-back check of the transport on THIS rank: a grouped send-to-self / receive-from-self of `bytes` bytes and an in-place reduce,
+// through exactly the calls the frame loop makes (ncclSend / ncclRecv / ncclReduce on the communication stream, or the in-process
+// transport's copies).  Lets a one-GPU machine exercise the RCCL entry points' signatures, datatypes and stream ordering.
+extern "C" int gvt_hip_comm_selftest(gvt_hip_comm *K, size_t bytes) {
+  if (!K || bytes < 16) { set_error("comm_selftest: null communicator or fewer than 16 bytes"); return GVT_HIP_ERR_INVALID; }
+  bytes &= ~(size_t)15;
+  unsigned char *a = nullptr, *b = nullptr;
+  HIPCHK(hipMalloc((void **)&a, bytes));
+  HIPCHK(hipMalloc((void **)&b, bytes));
+  std::vector<unsigned char> h(bytes), g(bytes, 0);
+  for (size_t i = 0; i < bytes; i++) h[i] = (unsigned char)(i * 131u + 7u);
+  int rc = 0;
+  hipError_t e = hipMemcpyAsync(a, h.data(), bytes, hipMemcpyHostToDevice, K->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(b, 0, bytes, K->stream);
+  if (e != hipSuccess) rc = GVT_HIP_ERR_DEVICE;
+  if (!rc) {
+    comm_group_begin(K);
+    comm_send(K, a, bytes, K->rank);
+    comm_recv(K, b, bytes, K->rank);
+    rc = comm_group_end(K);
+  }
+  if (!rc && hipMemcpyAsync(g.data(), b, bytes, hipMemcpyDeviceToHost, K->stream) != hipSuccess) rc = GVT_HIP_ERR_DEVICE;
+  if (!rc && hipStreamSynchronize(K->stream) != hipSuccess) rc = GVT_HIP_ERR_DEVICE;
+  if (!rc && std::memcmp(g.data(), h.data(), bytes) != 0) { set_error("comm_selftest: the loop-back payload differs"); rc = GVT_HIP_ERR_DEVICE; }
+  if (!rc && K->nccl) { // ncclReduce in place over one rank: the identity
+    ncclResult_t r = g_rccl.Reduce(b, b, bytes / 4, ncclFloat, ncclSum, 0, K->nccl, K->stream);
+    if (r != ncclSuccess) { set_error("comm_selftest: ncclReduce failed: %s", g_rccl.GetErrorString(r)); rc = GVT_HIP_ERR_DEVICE; }
+    if (!rc && (hipMemcpyAsync(g.data(), b, bytes, hipMemcpyDeviceToHost, K->stream) != hipSuccess || hipStreamSynchronize(K->stream) != hipSuccess)) rc = GVT_HIP_ERR_DEVICE;
+  }
+  hipFree(a); hipFree(b);
+  if (rc == GVT_HIP_ERR_DEVICE && !*gvt_hip_last_error()) set_error("comm_selftest: HIP error");
+  return rc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // device helpers of the scheduler loop
 // ------------------------------------------------------------------------------------------------

@@ -185,6 +185,11 @@ class Comm:
             raise capi.GvtHipError("gvt_hip_comm_create_local: " + capi.last_error())
         return cls(h)
 
+    def selftest(self, nbytes=1 << 20):
+        import ctypes as C
+
+        capi.check(self.lib.gvt_hip_comm_selftest(self.h, C.c_size_t(nbytes)), "gvt_hip_comm_selftest")
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.gvt_hip_comm_destroy(self.h)

@@ -223,6 +223,9 @@ void gvt_hip_hub_abort(gvt_hip_hub *);        /* a rank failed: wake the ranks b
 void gvt_hip_hub_destroy(gvt_hip_hub *);
 gvt_hip_comm *gvt_hip_comm_create_local(gvt_hip_hub *, int rank);
 void gvt_hip_comm_destroy(gvt_hip_comm *);
+/* loop-back check on this rank: grouped send-to-self / receive-from-self of `bytes` bytes (+ an in-place ncclReduce under RCCL) through the
+ * very calls the frame loop makes; 0 = the payload came back intact */
+int gvt_hip_comm_selftest(gvt_hip_comm *, size_t bytes);
 int gvt_hip_comm_rank(const gvt_hip_comm *);
 int gvt_hip_comm_world(const gvt_hip_comm *);
 

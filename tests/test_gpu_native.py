@@ -164,6 +164,8 @@ def test_rccl_communicator_of_one_rank(hip):
     assert len(uid) == 128 and any(uid)
     comm = Comm.rccl(uid, 0, 1)
     assert comm.rank == 0 and comm.world == 1
+    comm.selftest(1 << 20)  # ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd to self + ncclReduce, on the communication stream
+    comm.selftest(80 * 1000 + 8 * 3)  # a payload-shaped size (three queues' headers + 1000 rays)
     sc = scenes.bunny_grid_scene(width=190, height=108)
     tr = NativeTracer(sc, NORMALS_SMOOTH, [0] * sc.n_inst, comm)
     fb = tr(bsp=True).framebuffer(True)
