@@ -296,3 +296,35 @@ def test_degenerate_scenes_through_the_native_tracer(hip):
     ref, _ = oracle_render(ok, NORMALS_FLAT)
     assert np.array_equal(tr().framebuffer(True)[..., :3], ref[..., :3])
     tr.close()
+
+
+def test_rounds_with_materials_several_lights_and_vertex_colours(hip):
+    """The merged kernels take every instance's shading attributes from the per-instance table: per-face Phong / Blinn materials on
+    one mesh, vertex colours on another, three lights (point, area: RNG stream per ray, ambient), depth 2, 4 rays per pixel, 6
+    instances on one rank and on 3 in-process ranks -- against the oracle's schedulers (1e-5: powf and float-add order)."""
+    from gravit_amd import layouts
+
+    base = scenes.bunny_scene(64, 64).meshes[0]
+    rng = np.random.default_rng(11)
+    mats = np.concatenate([layouts.default_material(kd=rng.random(3), mtype=(layouts.PHONG if k % 2 else layouts.BLINN), ks=rng.random(3),
+                                                    alpha=1 + 4 * rng.random()) for k in range(4)])
+    face_mat = (np.arange(len(base.tris)) % 5 - 1).astype(np.int32)
+    m_a = scenes.MeshData(base.verts, base.tris, layouts.default_material(kd=(0.7, 0.6, 0.5)), None, None, mats, face_mat)
+    m_b = scenes.MeshData(base.verts, base.tris, layouts.default_material(), None, rng.random(base.verts.shape).astype(np.float32))
+    grid = scenes.bunny_grid_scene(nx=3, ny=2, pitch=0.25, width=300, height=200)
+    lights = np.concatenate([layouts.point_light((0.0, 0.4, 1.0)), layouts.area_light((0.3, 0.9, 0.6), (0.8, 0.8, 1.0), (0.0, -1.0, 0.1), 0.3, 0.2),
+                             layouts.ambient_light((0.03, 0.03, 0.05))])
+    sc = scenes._assemble([m_a, m_b], [i % 2 for i in range(grid.n_inst)], [grid.m[i].reshape(16) for i in range(grid.n_inst)], lights, grid.camera, "materials-grid")
+    sc.camera.samples, sc.camera.depth = 2, 2
+    ref, st = oracle_render(sc, NORMALS_SMOOTH, nthreads=8)
+    assert (ref[..., :3].sum(axis=2) > 0).mean() > 0.02 and st.rays_any > 10_000
+    tr = NativeTracer(sc, NORMALS_SMOOTH)
+    fb = tr().framebuffer(True)
+    assert np.abs(fb[..., :3] - ref[..., :3]).max() <= 1e-5 and np.array_equal(fb[..., 3], ref[..., 3])
+    assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any
+    tr.close()
+    owner = [i % 3 for i in range(sc.n_inst)]
+    res = run_native_ranks(sc, owner, 3, NORMALS_SMOOTH, False)
+    refd, std = oracle_render_domain(sc, owner, 3, 1)
+    assert np.abs(res[0][0][..., :3] - refd[..., :3]).max() <= 1e-5 and np.array_equal(res[0][0][..., 3], refd[..., 3])
+    assert sum(r[1]["rays_sent"] for r in res.values()) == std.rays_sent
