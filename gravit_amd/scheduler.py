@@ -130,7 +130,8 @@ class HipBackend:
 
 
 class Context:
-    """gvt_hip_ctx: a stream + scratch + counters of its own, current for the calling thread (several ranks in one process)."""
+    """gvt_hip_ctx: a stream + scratch + counters of its own, current for the calling thread (several ranks in one process).
+    `with Context(0): ...` in the thread that uses it; close() releases its stream, spill arena and scratch."""
 
     def __init__(self, device=0):
         import ctypes as C
@@ -146,6 +147,16 @@ class Context:
             self.lib.gvt_hip_ctx_make_current(None)
             self.lib.gvt_hip_ctx_destroy(self.h)
             self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+
+        gc.collect()  # wrappers created under this context release their device memory before its stream goes
+        self.close()
+        return False
 
 
 class Comm:

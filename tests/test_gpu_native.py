@@ -67,7 +67,7 @@ def run_native_ranks(scene, owner, world, mode, bsp, full_reduce=False, image=Fa
             out[rank] = (B.framebuffer(True) if rank == 0 else None, dict(tr.stats))
             tr.close()
             comm.close()
-            B = None
+            B = tr = None
         except Exception:  # noqa: BLE001
             import traceback
             errs.append(traceback.format_exc())
@@ -75,6 +75,8 @@ def run_native_ranks(scene, owner, world, mode, bsp, full_reduce=False, image=Fa
         finally:
             import gc
             gc.collect()
+            if ctx is not None:
+                ctx.close()
 
     th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
     [t.start() for t in th]
@@ -183,9 +185,9 @@ def test_two_contexts_trace_concurrently(hip):
 
     def work(k):
         try:
-            Context(0)
-            for _ in range(3):
-                out[k] = ImageTracer(scs[k], NORMALS_SMOOTH)().framebuffer(True)
+            with Context(0):
+                for _ in range(3):
+                    out[k] = ImageTracer(scs[k], NORMALS_SMOOTH)().framebuffer(True)
         except Exception:  # noqa: BLE001
             import traceback
             errs.append(traceback.format_exc())
@@ -328,3 +330,32 @@ def test_rounds_with_materials_several_lights_and_vertex_colours(hip):
     refd, std = oracle_render_domain(sc, owner, 3, 1)
     assert np.abs(res[0][0][..., :3] - refd[..., :3]).max() <= 1e-5 and np.array_equal(res[0][0][..., 3], refd[..., 3])
     assert sum(r[1]["rays_sent"] for r in res.values()) == std.rays_sent
+
+
+def test_tracer_contexts_and_queues_release_their_memory(hip):
+    """Create / render / destroy tracers, communicators and contexts repeatedly: free device memory returns to where it was
+    (scratch arenas of the default context are grow-only and warmed up first)."""
+    import ctypes
+    import gc
+
+    rt = ctypes.CDLL("libamdhip64.so")
+    def free_bytes():
+        hip.synchronize()
+        f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert rt.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+
+    sc = scenes.bunny_grid_scene(width=240, height=136)
+    def cycle():
+        tr = NativeTracer(sc, NORMALS_SMOOTH)
+        tr(); tr()
+        tr.close()
+        res = run_native_ranks(sc, [i % 2 for i in range(sc.n_inst)], 2, NORMALS_SMOOTH, False)
+        assert res[0][0] is not None
+        gc.collect()
+    cycle(); cycle()
+    free0 = free_bytes()
+    for _ in range(6):
+        cycle()
+    free1 = free_bytes()
+    assert free0 - free1 < 64 << 20, "leaked %.1f MiB over 6 create/destroy cycles" % ((free0 - free1) / 2 ** 20)

@@ -17,7 +17,7 @@ for bsp in (False, True):
     bar = threading.Barrier(world)
     res = {}
     def work(rank):
-        Context(0)
+        ctx = Context(0)
         comm = Comm.local(hub, rank)
         tr = NativeTracer(sc, NORMALS_FLAT, owner, comm)
         for _ in range(3):
@@ -27,7 +27,7 @@ for bsp in (False, True):
         for _ in range(10):
             tr(bsp=bsp)
         res[rank] = ((time.perf_counter() - t0) / 10 * 1e3, dict(tr.stats))
-        tr.close(); comm.close()
+        tr.close(); comm.close(); tr = None; ctx.close()
     th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
     [t.start() for t in th]; [t.join() for t in th]
     capi.load().gvt_hip_hub_destroy(hub)

@@ -12,7 +12,7 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 trs, ready, go = [None] * K, threading.Barrier(K + 1), threading.Barrier(K + 1)
 times = [0.0] * K
 def work(k):
-    Context(0)
+    ctx = Context(0)
     tr = NativeTracer(sc, NORMALS_FLAT)
     for _ in range(3):
         tr()
@@ -21,6 +21,7 @@ def work(k):
     for _ in range(20):
         tr()
     times[k] = time.perf_counter() - t0
+    tr.close(); tr = None; ctx.close()
 th = [threading.Thread(target=work, args=(k,)) for k in range(K)]
 [t.start() for t in th]
 ready.wait()

@@ -19,7 +19,7 @@ for name, sc, mode, tol in cases:
         worst, errs = [0.0], []
         def work(rank):
             try:
-                Context(0)
+                ctx = Context(0)
                 comm = Comm.local(hub, rank)
                 tr = NativeTracer(sc, mode, owner, comm)
                 first = None
@@ -32,7 +32,7 @@ for name, sc, mode, tol in cases:
                         else:
                             worst[0] = max(worst[0], float(np.abs(fb - first).max()))
                             assert np.array_equal(fb[..., 3], first[..., 3]), "deposit counts changed in frame %d" % f
-                tr.close(); comm.close()
+                tr.close(); comm.close(); tr = B = None; ctx.close()
             except Exception:
                 import traceback
                 errs.append(traceback.format_exc()); capi.load().gvt_hip_hub_abort(hub)
