@@ -181,6 +181,8 @@ extern "C" int gvt_hip_set_option(const char *name, int value) {
   if (!std::strcmp(name, "share_min_rays")) { g_ctx.share_min_rays = value < 0 ? 0 : value; return 0; }
   if (!std::strcmp(name, "defaults")) { static_cast<Knobs &>(g_ctx) = Knobs{}; return 0; }
   if (!std::strcmp(name, "long_steps")) { g_ctx.long_steps = value < 0 ? 0 : value; return 0; }
+  if (!std::strcmp(name, "long_save")) { g_ctx.long_save = value != 0; return 0; }
+  if (!std::strcmp(name, "long_steps_drain")) { g_ctx.long_steps_drain = value < 0 ? 0 : value; return 0; }
   if (!std::strcmp(name, "long_min_rays")) { g_ctx.long_min_rays = value < 0 ? 0 : value; return 0; }
   if (!std::strcmp(name, "fused")) { g_ctx.fused = value; return 0; }
   if (!std::strcmp(name, "packet")) { g_ctx.packet = value; return 0; }

@@ -127,10 +127,11 @@ struct BvhNode {
 // four slots are filled.  Child boxes are quantised to 8 bits per plane on a per-node grid:
 //   plane = origin[a] + q * 2^(exp[a]-127),  q in 0..255, rounded outwards and verified in double at build time, so every
 //   decoded box CONTAINS the (already padded) binary box -- results cannot depend on the layout.
-//   w0 = (origin.x, origin.y, origin.z, exp.x | exp.y<<8 | exp.z<<16)
+//   w0 = (origin.x, origin.y, origin.z, step.x)      step = 2^(exp-127) as a float (no decode in the traversal loop)
 //   w1 = (qlo.x[4], qhi.x[4], qlo.y[4], qhi.y[4])    one byte per child, child c in byte c
-//   w2 = (qlo.z[4], qhi.z[4], ref0, ref1)   w3 = (ref2, ref3, -, -)
-// refs as in the binary node (>= 0: 4-wide node index, < 0: leaf); an unused slot has ref = GVT_EMPTY_REF.
+//   w2 = (qlo.z[4], qhi.z[4], ref0, ref1)   w3 = (ref2, ref3, step.y, step.z)
+// refs as in the binary node (>= 0: 4-wide node index, < 0: leaf); an unused slot has ref = GVT_EMPTY_REF (an empty leaf) and an
+// inverted box (qlo 255, qhi 0), so the slab test itself rejects it.
 #define GVT_NODE4_F4 4
 #define GVT_EMPTY_REF (-1) // == leaf_ref(0, 0)
 __host__ __device__ inline int leaf_ref(uint32_t first, uint32_t count) { return ~(int)((first << 3) | count); }

@@ -33,6 +33,9 @@ struct Knobs {
   int sort_gather = 0;   // after sorting, traverse a contiguous object-space copy (o,d) of the rays
   int sort_bits = 20;    // radix-sorted key width (8 bits per rocPRIM pass)
   int long_steps = 96;   // closest hit: a ray that exceeds this many 4-wide node steps is parked and finished by a whole wave (0: off)
+  int long_steps_drain = 0; // ... after the launch's work counter ran dry (k_trace waves in their drain phase); 0 or >= long_steps: the same limit.
+                         // Measured (10 M soup, 1 M rays): 72 shortens the closest launch 0.519 -> 0.504 ms but k_long_closest grows 0.044 -> 0.094
+  int long_save = 1;     // parked rays carry their pending stack and go on from it (0: they start again at the root with their best hit as the bound)
   int long_min_rays = 65536; // ... only in launches of at least this many rays (small launches have no tail to speak of)
   int fused = 0;         // scheduler rounds: closest hit + shade + first-light shadow rays in one kernel (k_fused) instead of three launches.
                          // Measured 2.4x SLOWER than the three launches: shading inside the persistent kernel is latency-exposed

@@ -293,7 +293,6 @@ __global__ __launch_bounds__(256) void k_collapse4(const BvhNode *__restrict__ n
   // quantise (outwards, verified in double against the very expression the traversal decodes with)
   uint32_t w[16];
   for (int k = 0; k < 16; k++) w[k] = 0u;
-  uint32_t exps = 0;
   for (int a = 0; a < 3; a++) {
     float o = c[0].lo[a], h = c[0].hi[a];
     for (int s = 1; s < n; s++) { o = fminf(o, c[s].lo[a]); h = fmaxf(h, c[s].hi[a]); }
@@ -319,11 +318,11 @@ __global__ __launch_bounds__(256) void k_collapse4(const BvhNode *__restrict__ n
       if (ok || e >= 254) break;
       e++;
     }
+    for (int s = n; s < 4; s++) ql |= 255u << (8 * s); // unused slots: an inverted box (lo plane 255, hi plane 0) that no ray enters
     w[a] = __float_as_uint(o);
-    exps |= (uint32_t)e << (8 * a);
+    w[a == 0 ? 3 : 13 + a] = (uint32_t)e << 23; // the grid step 2^(e-127) as a float: w0.w (x), w3.z (y), w3.w (z)
     w[4 + 2 * a] = ql; w[5 + 2 * a] = qh;
   }
-  w[3] = exps;
   for (int s = 0; s < 4; s++) w[10 + s] = (uint32_t)(s < n ? c[s].ref : GVT_EMPTY_REF);
   uint4 *dst = nodes4 + (size_t)GVT_NODE4_F4 * (base_in + i);
   dst[0] = make_uint4(w[0], w[1], w[2], w[3]); dst[1] = make_uint4(w[4], w[5], w[6], w[7]);

@@ -23,6 +23,12 @@
 #ifndef TRAV_STACK
 #define TRAV_STACK 24   // LDS entries per lane; deeper levels spill to a per-thread global area
 #endif
+#ifndef KT_BLOCKS_CLOSEST
+#define KT_BLOCKS_CLOSEST 5 // resident 256-thread blocks per CU the compiler must leave room for (register budget 512 / waves per SIMD)
+#endif
+#ifndef KT_BLOCKS_ANY
+#define KT_BLOCKS_ANY 4
+#endif
 #define TRAV_SPILL 128  // 24 + 128 = 152 pending entries: > 63 + 24 levels of a 63-bit Karras tree with index tie-breaks, and > 3 x 44, the
                         // worst case of its 4-wide collapse; k_trace reports an error beyond that instead of losing entries
 
@@ -54,7 +60,7 @@ struct Trav {
 #define GVT_STAMP 0
 #endif
 #if GVT_STAMP
-__device__ unsigned long long g_stamp[16];
+__device__ unsigned long long g_stamp[24];
 #endif
 #define TRAV_OVF_WORD 8 // d_counters[8] of the launching context: set by k_trace / k_long_closest when a traversal stack would have exceeded
                         // LDS levels + spill entries (k_trace's `counter` is d_counters + 0, k_long_closest's d_counters + 4)
@@ -68,44 +74,67 @@ __device__ unsigned long long g_stamp[16];
 // rays at 100 steps -- 0.1 % of them -- shortened it by 18 %).  k_trace therefore parks a ray that exceeds `steps` inner steps,
 // with its best hit so far, in `recs`; k_long_closest then traverses each parked ray with a whole wave: 64 pending nodes per step
 // instead of one.  The result is the same minimum over (t, primID) -- it does not depend on the order in which boxes are opened.
-struct LongRec { unsigned j, i; float bt; int bp; float bu, bv, bden; unsigned pad; };
+// LongRec.ns > 0: the record carries the ray's pending stack (LongQ.stk[slot * LONG_SAVE + k], bottom first) and k_long_closest goes
+// on from there; 0: it starts again at the root with the best hit so far as its bound.
+#define LONG_SAVE 48
+#define LONG_STK_CAP 65536u // records that may carry a stack (12 MiB); later ones start again at the root
+struct LongRec { unsigned j, i; float bt; int bp; float bu, bv, bden; unsigned ns; };
 struct LongQ {
   LongRec *recs;
   unsigned *count;
+  int *stk;          // null: no stacks are saved
+  unsigned stk_cap;
   int steps; // 0: off
+  int steps_drain; // ... once the wave's work counter is exhausted (no refills left to hide a long ray behind): the launch then ends
+                   // ~1 us per remaining step of its longest ray, so the few long rays still in flight are parked earlier
 };
 
 // One compressed 4-wide node against one ray: entry distances of the children the ray enters within [0, lim], GVT_FLT_MAX for the
-// others (misses and unused slots), and their references.
+// others (misses and unused slots, whose boxes are stored inverted), and their references.
 //   plane t = (origin + q*scale - O) / d = q * (scale*inv_d) + (origin*inv_d - O*inv_d); scale is a power of two, so scale*inv_d is
 //   exact.  The rounding of the two fused steps is covered by widening every slab by 2^-21 |O*inv_d| (about 5e-7 |O| in space, on
-//   top of the padded boxes).
-__device__ __forceinline__ void node4_test(const uint4 *__restrict__ nd, float ix, float iy, float iz, float ox, float oy, float oz, float lim,
-                                           float tn[4], int rr[4]) {
-  const uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2];
-  const uint2 w3 = *(const uint2 *)(nd + 3);
-  const float sx = __uint_as_float((w0.w & 0xffu) << 23) * ix, sy = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * iy,
-              sz = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * iz;
-  const float bx = __builtin_fmaf(__uint_as_float(w0.x), ix, -ox), by = __builtin_fmaf(__uint_as_float(w0.y), iy, -oy),
-              bz = __builtin_fmaf(__uint_as_float(w0.z), iz, -oz);
+//   top of the padded boxes): RaySlab keeps O*inv_d moved out by that margin for the near planes (.x) and in for the far planes (.y).
+// CDNA packed FP32: the four children are decoded two at a time (v_pk_fma_f32: 12 instead of 24 fused multiply-adds per node).
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct RaySlab {
+  float ix, iy, iz; // 1 / direction
+  f2 ox, oy, oz;    // (O*inv_d + e, O*inv_d - e), e = 2^-21 |O*inv_d|
+};
+__device__ __forceinline__ RaySlab make_slab(float ix, float iy, float iz, float ox, float oy, float oz) {
+  RaySlab S;
+  S.ix = ix; S.iy = iy; S.iz = iz;
   const float ex = fabsf(ox) * 4.76837158e-7f, ey = fabsf(oy) * 4.76837158e-7f, ez = fabsf(oz) * 4.76837158e-7f;
-  const float bxn = bx - ex, bxf = bx + ex, byn = by - ey, byf = by + ey, bzn = bz - ez, bzf = bz + ez;
-  const unsigned qnx = ix >= 0.f ? w1.x : w1.y, qfx = ix >= 0.f ? w1.y : w1.x; // near / far planes by ray direction
-  const unsigned qny = iy >= 0.f ? w1.z : w1.w, qfy = iy >= 0.f ? w1.w : w1.z;
-  const unsigned qnz = iz >= 0.f ? w2.x : w2.y, qfz = iz >= 0.f ? w2.y : w2.x;
+  S.ox = (f2){ ox + ex, ox - ex }; S.oy = (f2){ oy + ey, oy - ey }; S.oz = (f2){ oz + ez, oz - ez };
+  return S;
+}
+__device__ __forceinline__ f2 splat2(float v) { return (f2){ v, v }; }
+__device__ __forceinline__ void node4_test(const uint4 *__restrict__ nd, const RaySlab &S, float lim, float tn[4], int rr[4]) {
+  const uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3];
+  const float sx = __uint_as_float(w0.w) * S.ix, sy = __uint_as_float(w3.z) * S.iy, sz = __uint_as_float(w3.w) * S.iz;
+  const f2 bx = __builtin_elementwise_fma(splat2(__uint_as_float(w0.x)), splat2(S.ix), -S.ox); // (near offset, far offset)
+  const f2 by = __builtin_elementwise_fma(splat2(__uint_as_float(w0.y)), splat2(S.iy), -S.oy);
+  const f2 bz = __builtin_elementwise_fma(splat2(__uint_as_float(w0.z)), splat2(S.iz), -S.oz);
+  const unsigned qnx = S.ix >= 0.f ? w1.x : w1.y, qfx = S.ix >= 0.f ? w1.y : w1.x; // near / far planes by ray direction
+  const unsigned qny = S.iy >= 0.f ? w1.z : w1.w, qfy = S.iy >= 0.f ? w1.w : w1.z;
+  const unsigned qnz = S.iz >= 0.f ? w2.x : w2.y, qfz = S.iz >= 0.f ? w2.y : w2.x;
   rr[0] = (int)w2.z; rr[1] = (int)w2.w; rr[2] = (int)w3.x; rr[3] = (int)w3.y;
-#define GVT_SLAB4(C)                                                                                              \
-  {                                                                                                              \
-    const float n_ = fmaxf(fmaxf(__builtin_fmaf((float)((qnx >> (8 * C)) & 0xffu), sx, bxn),                     \
-                                 __builtin_fmaf((float)((qny >> (8 * C)) & 0xffu), sy, byn)),                    \
-                           fmaxf(__builtin_fmaf((float)((qnz >> (8 * C)) & 0xffu), sz, bzn), 0.f));              \
-    const float f_ = fminf(fminf(__builtin_fmaf((float)((qfx >> (8 * C)) & 0xffu), sx, bxf),                     \
-                                 __builtin_fmaf((float)((qfy >> (8 * C)) & 0xffu), sy, byf)),                    \
-                           __builtin_fmaf((float)((qfz >> (8 * C)) & 0xffu), sz, bzf)) * 1.0000004f;             \
-    tn[C] = ((n_ <= f_) && (n_ <= lim) && (rr[C] != GVT_EMPTY_REF)) ? n_ : GVT_FLT_MAX; /* a miss sorts last */  \
+#define GVT_Q2(Q, SH) ((f2){ (float)(((Q) >> (SH)) & 0xffu), (float)(((Q) >> ((SH) + 8)) & 0xffu) })
+#define GVT_SLAB2(SH, A, B)                                                                                          \
+  {                                                                                                                  \
+    const f2 nx_ = __builtin_elementwise_fma(GVT_Q2(qnx, SH), splat2(sx), splat2(bx.x));                              \
+    const f2 ny_ = __builtin_elementwise_fma(GVT_Q2(qny, SH), splat2(sy), splat2(by.x));                              \
+    const f2 nz_ = __builtin_elementwise_fma(GVT_Q2(qnz, SH), splat2(sz), splat2(bz.x));                              \
+    const f2 fx_ = __builtin_elementwise_fma(GVT_Q2(qfx, SH), splat2(sx), splat2(bx.y));                              \
+    const f2 fy_ = __builtin_elementwise_fma(GVT_Q2(qfy, SH), splat2(sy), splat2(by.y));                              \
+    const f2 fz_ = __builtin_elementwise_fma(GVT_Q2(qfz, SH), splat2(sz), splat2(bz.y));                              \
+    const float na_ = fmaxf(fmaxf(nx_.x, ny_.x), fmaxf(nz_.x, 0.f)), nb_ = fmaxf(fmaxf(nx_.y, ny_.y), fmaxf(nz_.y, 0.f)); \
+    const float fa_ = fminf(fminf(fx_.x, fy_.x), fz_.x) * 1.0000004f, fb_ = fminf(fminf(fx_.y, fy_.y), fz_.y) * 1.0000004f; \
+    tn[A] = (na_ <= fminf(fa_, lim)) ? na_ : GVT_FLT_MAX; /* a miss sorts last */                                    \
+    tn[B] = (nb_ <= fminf(fb_, lim)) ? nb_ : GVT_FLT_MAX;                                                            \
   }
-  GVT_SLAB4(0) GVT_SLAB4(1) GVT_SLAB4(2) GVT_SLAB4(3)
-#undef GVT_SLAB4
+  GVT_SLAB2(0, 0, 1) GVT_SLAB2(16, 2, 3)
+#undef GVT_SLAB2
+#undef GVT_Q2
 }
 
 // merged launches: segment of virtual ray index g (segments sorted by `begin`, n_seg small)
@@ -176,7 +205,7 @@ struct MultiSrc {
   unsigned long long *tot_any;  // any hit over a direct-mapped list: the rays actually traced are added here (one atomic per wave)
 };
 template <bool ANY, bool XFORM, int MODE, bool COOP, bool W4, bool MULTI = false>
-__global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, Trav T, float tnear,
+__global__ __launch_bounds__(TRAV_BLOCK, ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSEST) void k_trace(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, Trav T, float tnear,
                                                        gvt_hip_hit *__restrict__ hits, int *__restrict__ flags, RayPlanes out, unsigned *out_count,
                                                        unsigned *counter, int *spill_base, int refill_min, int inner_min, const unsigned *__restrict__ n_dev, int share, unsigned share_min, TermSink sink, LongQ LQ,
                                                        MultiSrc MS = MultiSrc{}) {
@@ -213,7 +242,8 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
   bool active = false;
   unsigned j = 0;
   V3 O = mk3(0, 0, 0), D = mk3(0, 0, 1);
-  float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0;
+  RaySlab S = make_slab(0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+  float ox = 0, oy = 0, oz = 0; // O * inv_d as such: only the binary-tree variants (W4 false) read it
   float bt = GVT_FLT_MAX, bu = 0.f, bv = 0.f, bden = 1.f; // bu, bv: un-divided U, V of the best hit; bden its |den|
   int bp = -1, sp = 0, cur = TRAV_DONE;
   int sb = 0;           // bottom of this lane's stack window [sb, sp): entries below sb were given away to helper lanes
@@ -228,11 +258,11 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
   unsigned n_started = 0;           // MULTI any hit: rays this wave really traced (wave-uniform)
 #if GVT_STAMP
   unsigned long long st_refill = 0, st_inner = 0, st_leaf = 0, st_retire = 0, n_inner_it = 0, n_outer_it = 0, t_mark = 0, t_begin = __builtin_amdgcn_s_memtime();
-  unsigned long long t_exh = 0, it_exh = 0, out_exh = 0, act_exh = 0;
+  unsigned long long t_exh = 0, it_exh = 0, out_exh = 0, act_exh = 0, n_inner_lanes = 0, n_leaf_lanes = 0;
 #endif
   for (;;) {
     // ---- refill idle lanes from the wave's private index range
-#if GVT_STAMP
+#if GVT_STAMP == 1
     { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (n_outer_it) st_retire += t_ - t_mark; t_mark = t_; }
 #endif
     unsigned long long idle = __ballot(!active);
@@ -295,8 +325,9 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
             const float dx = fabsf(D.x) < 1e-30f ? copysignf(1e-30f, D.x) : D.x;
             const float dy = fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y;
             const float dz = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;
-            ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
+            const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
             ox = O.x * ix; oy = O.y * iy; oz = O.z * iz;
+            S = make_slab(ix, iy, iz, ox, oy, oz);
             bt = GVT_FLT_MAX; bu = 0.f; bv = 0.f; bden = 1.f; bp = -1;
             sp = 0; sb = 0; donor_lane = -1; nsteps = 0; parked = false;
             cur = (MULTI ? (nodes4_l != nullptr) : (T.nodes != nullptr)) ? 0 : TRAV_DONE;
@@ -326,8 +357,10 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
         const unsigned gj = (unsigned)__shfl((int)j, d);
         const float gOx = __shfl(O.x, d), gOy = __shfl(O.y, d), gOz = __shfl(O.z, d);
         const float gDx = __shfl(D.x, d), gDy = __shfl(D.y, d), gDz = __shfl(D.z, d);
-        const float gix = __shfl(ix, d), giy = __shfl(iy, d), giz = __shfl(iz, d);
         const float gox = __shfl(ox, d), goy = __shfl(oy, d), goz = __shfl(oz, d);
+        RaySlab gS;
+        gS.ix = __shfl(S.ix, d); gS.iy = __shfl(S.iy, d); gS.iz = __shfl(S.iz, d);
+        gS.ox = (f2){ __shfl(S.ox.x, d), __shfl(S.ox.y, d) }; gS.oy = (f2){ __shfl(S.oy.x, d), __shfl(S.oy.y, d) }; gS.oz = (f2){ __shfl(S.oz.x, d), __shfl(S.oz.y, d) };
         const float gbt = __shfl(bt, d), gbu = __shfl(bu, d), gbv = __shfl(bv, d), gbden = __shfl(bden, d);
         const int gbp = __shfl(bp, d);
         const int ginst = __shfl(inst_l, d);
@@ -338,7 +371,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
           cur = (sbd < TRAV_STACK) ? stack[sbd * TRAV_BLOCK + tid_d]
                                    : spill_base[((size_t)blockIdx.x * TRAV_BLOCK + tid_d) * TRAV_SPILL + (sbd - TRAV_STACK)];
           j = gj; O = mk3(gOx, gOy, gOz); D = mk3(gDx, gDy, gDz);
-          ix = gix; iy = giy; iz = giz; ox = gox; oy = goy; oz = goz;
+          S = gS; ox = gox; oy = goy; oz = goz;
           bt = gbt; bu = gbu; bv = gbv; bden = gbden; bp = gbp; // the donor's best so far: a pruning bound, merged idempotently later
           sp = 0; sb = 0;
           donor_lane = d;
@@ -351,7 +384,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
         sharing = true;
       }
     }
-#if GVT_STAMP
+#if GVT_STAMP == 1
     { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_refill += t_ - t_mark; t_mark = t_; n_outer_it++; }
 #endif
     if (!ANY && sharing) { // helpers follow their donor's best hit: a closer hit found by the owner prunes the helper's subtree too
@@ -371,7 +404,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
         if (at_inner) { // one 64-byte fetch decides four children (8-bit boxes on the node's own grid)
           float tn[4];
           int rr[4];
-          node4_test((MULTI ? nodes4_l : T.nodes4) + (size_t)GVT_NODE4_F4 * cur, ix, iy, iz, ox, oy, oz, ANY ? GVT_FLT_MAX : bt, tn, rr);
+          node4_test((MULTI ? nodes4_l : T.nodes4) + (size_t)GVT_NODE4_F4 * cur, S, ANY ? GVT_FLT_MAX : bt, tn, rr);
           if (!ANY) { // nearest first; for any-hit the order does not matter
 #define GVT_CE(A, B) { const bool sw_ = tn[B] < tn[A]; const float ta_ = sw_ ? tn[B] : tn[A], tb_ = sw_ ? tn[A] : tn[B]; \
                        const int ra_ = sw_ ? rr[B] : rr[A], rb_ = sw_ ? rr[A] : rr[B]; tn[A] = ta_; tn[B] = tb_; rr[A] = ra_; rr[B] = rb_; }
@@ -393,6 +426,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
         }
       } else {
       float4 n0, n1, n2, n3;
+      const float ix = S.ix, iy = S.iy, iz = S.iz;
       if (COOP) quad_fetch64((const float4 *)T.nodes, (unsigned)cur, at_inner, n0, n1, n2, n3);
       if (at_inner) {
         if (!COOP) { const BvhNode *nd = T.nodes + cur; n0 = nd->n0; n1 = nd->n1; n2 = nd->n2; n3 = nd->n3; }
@@ -420,14 +454,14 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
         } else KT_POP()
       }
       }
-#if GVT_STAMP
-      n_inner_it++;
+#if GVT_STAMP == 1
+      n_inner_it++; n_inner_lanes += (unsigned long long)__popcll(__ballot(at_inner));
 #endif
-      if (!ANY && at_inner && LQ.steps && ++nsteps > LQ.steps && cur != TRAV_DONE) { cur = TRAV_DONE; parked = true; }
+      if (!ANY && at_inner && LQ.steps && ++nsteps > (exhausted ? LQ.steps_drain : LQ.steps) && cur != TRAV_DONE) { KT_PUSH(cur) cur = TRAV_DONE; parked = true; } // the pending stack, `cur` on top, goes into the record
       im = __ballot(active && cur >= 0);
       if (__popcll(im) < inner_min) break;
     }
-#if GVT_STAMP
+#if GVT_STAMP == 1
     { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_inner += t_ - t_mark; t_mark = t_; }
 #endif
     // ---- leaves: every lane waiting at one intersects its triangles (64-byte slots: v0|prim, e1, e2, Ng).
@@ -437,6 +471,9 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
     //      a wave per SIMD).
     {
       const bool at_leaf = active && cur < 0 && cur != TRAV_DONE;
+#if GVT_STAMP == 1
+      n_leaf_lanes += (unsigned long long)__popcll(__ballot(at_leaf));
+#endif
       if (COOP) {
         const unsigned code = at_leaf ? (unsigned)~cur : 0u;
         const unsigned first = code >> 3, ntri = code & 7u;
@@ -496,7 +533,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
         else KT_POP()
       }
     }
-#if GVT_STAMP
+#if GVT_STAMP == 1
     { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_leaf += t_ - t_mark; t_mark = t_; }
 #endif
     // ---- retire finished rays
@@ -546,8 +583,15 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
         if ((int)lane_id() == __ffsll((long long)pm) - 1) base = atomicAdd(LQ.count, (unsigned)__popcll(pm));
         base = __shfl(base, __ffsll((long long)pm) - 1);
         if (fin && parked) {
-          LongRec R; R.j = j; R.i = MULTI ? gidx : (idx ? idx[j] : j); R.bt = bt; R.bp = bp; R.bu = bu; R.bv = bv; R.bden = bden; R.pad = 0u;
-          LQ.recs[base + lanes_below(pm)] = R;
+          const unsigned slot = base + lanes_below(pm);
+          LongRec R; R.j = j; R.i = MULTI ? gidx : (idx ? idx[j] : j); R.bt = bt; R.bp = bp; R.bu = bu; R.bv = bv; R.bden = bden; R.ns = 0u;
+          const int depth = sp - sb;
+          if (LQ.stk && !sharing && depth > 0 && depth <= LONG_SAVE && slot < LQ.stk_cap) { // a shared ray's windows are not one stack: it starts again
+            int *dst = LQ.stk + (size_t)slot * LONG_SAVE;
+            for (int k = 0; k < depth; k++) dst[k] = (sb + k < TRAV_STACK) ? lds[(sb + k) * TRAV_BLOCK] : spill[sb + k - TRAV_STACK];
+            R.ns = (unsigned)depth;
+          }
+          LQ.recs[slot] = R;
         }
       }
     }
@@ -558,7 +602,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
     }
   }
 #if GVT_STAMP
-  if (lane_id() == 0) { atomicAdd(&g_stamp[0], st_refill); atomicAdd(&g_stamp[1], st_inner); atomicAdd(&g_stamp[2], st_leaf); atomicAdd(&g_stamp[3], st_retire); atomicAdd(&g_stamp[4], n_inner_it); atomicAdd(&g_stamp[5], n_outer_it); atomicAdd(&g_stamp[6], 1ull); atomicAdd(&g_stamp[7], (unsigned long long)__builtin_amdgcn_s_memtime() - t_begin);
+  if (lane_id() == 0) { atomicAdd(&g_stamp[0], st_refill); atomicAdd(&g_stamp[1], st_inner); atomicAdd(&g_stamp[2], st_leaf); atomicAdd(&g_stamp[3], st_retire); atomicAdd(&g_stamp[4], n_inner_it); atomicAdd(&g_stamp[5], n_outer_it); atomicAdd(&g_stamp[6], 1ull); atomicAdd(&g_stamp[7], (unsigned long long)__builtin_amdgcn_s_memtime() - t_begin); atomicAdd(&g_stamp[14], n_inner_lanes); atomicAdd(&g_stamp[15], n_leaf_lanes); atomicMax(&g_stamp[16], ~t_begin); atomicMax(&g_stamp[17], (unsigned long long)__builtin_amdgcn_s_memtime()); atomicMax(&g_stamp[18], t_exh); atomicAdd(&g_stamp[19], t_exh ? t_exh - t_begin : 0ull); atomicMax(&g_stamp[20], (unsigned long long)__builtin_amdgcn_s_memtime() - t_begin); atomicMax(&g_stamp[21], t_exh ? t_exh - t_begin : 0ull); atomicMax(&g_stamp[22], ~(t_exh ? t_exh - t_begin : ~0ull));
     if (t_exh) { atomicAdd(&g_stamp[8], (unsigned long long)__builtin_amdgcn_s_memtime() - t_exh); atomicAdd(&g_stamp[9], n_inner_it - it_exh); atomicAdd(&g_stamp[10], n_outer_it - out_exh); atomicAdd(&g_stamp[11], act_exh); atomicMax(&g_stamp[12], (unsigned long long)__builtin_amdgcn_s_memtime() - t_exh); atomicMax(&g_stamp[13], n_inner_it - it_exh); } }
 #endif
   if (ANY && MODE == 1) { if (n_pend) flush_pending(pend, n_pend, q, out, out_count, sink, MULTI ? MS.ray_inst : nullptr, MULTI ? MS.out_from : nullptr); }
@@ -576,7 +620,8 @@ __global__ __launch_bounds__(TRAV_BLOCK) void k_trace(RayPlanes q, const unsigne
 #define LONG_PHYS (LONG_CAP + 256)
 template <bool XFORM, bool MULTI = false>
 __global__ __launch_bounds__(256) void k_long_closest(RayPlanes q, const LongRec *__restrict__ recs, const unsigned *__restrict__ n_recs, Mat4 minv,
-                                                       Trav T, float tnear, gvt_hip_hit *__restrict__ hits, unsigned *counter, WaveSet W = WaveSet{}) {
+                                                       Trav T, float tnear, gvt_hip_hit *__restrict__ hits, unsigned *counter, WaveSet W = WaveSet{},
+                                                       const int *__restrict__ stk = nullptr) {
   __shared__ int s_ref_all[4][LONG_PHYS];
   __shared__ float s_tn_all[4][LONG_PHYS];
   __shared__ int l_ref_all[4][LONG_PHYS];
@@ -618,11 +663,18 @@ __global__ __launch_bounds__(256) void k_long_closest(RayPlanes q, const LongRec
     const float dy = fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y;
     const float dz = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-    const float ox = O.x * ix, oy = O.y * iy, oz = O.z * iz;
+    const RaySlab S = make_slab(ix, iy, iz, O.x * ix, O.y * iy, O.z * iz);
     float bt = R.bt, bu = R.bu, bv = R.bv, bden = R.bden; // the same in every lane
     int bp = R.bp;
     int ns = 1, nl = 0;                                   // wave-uniform
-    if (lane == 0) { s_ref[0] = 0; s_tn[0] = 0.f; }
+    if (stk && R.ns) { // go on from the parked ray's pending stack (bottom first, so the nearest entries are taken first); entry distances unknown: 0
+      const int e = lane < (int)R.ns ? stk[(size_t)r * LONG_SAVE + lane] : TRAV_DONE;
+      const bool is_node = lane < (int)R.ns && e >= 0, is_leaf = lane < (int)R.ns && e < 0 && e != TRAV_DONE;
+      const unsigned long long mi = __ballot(is_node), ml = __ballot(is_leaf);
+      if (is_node) { s_ref[lanes_below(mi)] = e; s_tn[lanes_below(mi)] = 0.f; }
+      if (is_leaf) { l_ref[lanes_below(ml)] = e; l_tn[lanes_below(ml)] = 0.f; }
+      ns = __popcll(mi); nl = __popcll(ml);
+    } else if (lane == 0) { s_ref[0] = 0; s_tn[0] = 0.f; }
     __builtin_amdgcn_wave_barrier();
     while (ns > 0 || nl > 0) {
       const bool do_leaf = nl > 0 && (ns == 0 || nl >= 64 || nl > LONG_CAP - 256);
@@ -639,7 +691,7 @@ __global__ __launch_bounds__(256) void k_long_closest(RayPlanes q, const LongRec
         int rr[4];
         const bool open = mine && etn <= bt;
         if (open) {
-          node4_test(T.nodes4 + (size_t)GVT_NODE4_F4 * ref, ix, iy, iz, ox, oy, oz, bt, tn, rr);
+          node4_test(T.nodes4 + (size_t)GVT_NODE4_F4 * ref, S, bt, tn, rr);
           // nearest child last: the lists are taken from their end, so the wave keeps descending along the nearest pending nodes
 #define GVT_CE(A, B) { const bool sw_ = tn[B] < tn[A]; const float ta_ = sw_ ? tn[B] : tn[A], tb_ = sw_ ? tn[A] : tn[B]; \
                        const int ra_ = sw_ ? rr[B] : rr[A], rb_ = sw_ ? rr[A] : rr[B]; tn[A] = ta_; tn[B] = tb_; rr[A] = ra_; rr[B] = rb_; }
@@ -710,7 +762,7 @@ __global__ __launch_bounds__(256) void k_long_seed(LongRec *__restrict__ recs, u
   const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j == 0) *count = n;
   if (j >= n) return;
-  LongRec R; R.j = j; R.i = idx ? idx[j] : j; R.bt = GVT_FLT_MAX; R.bp = -1; R.bu = 0.f; R.bv = 0.f; R.bden = 1.f; R.pad = 0u;
+  LongRec R; R.j = j; R.i = idx ? idx[j] : j; R.bt = GVT_FLT_MAX; R.bp = -1; R.bu = 0.f; R.bv = 0.f; R.bden = 1.f; R.ns = 0u;
   recs[j] = R;
 }
 
@@ -748,7 +800,7 @@ __global__ __launch_bounds__(256) void k_wave_any(RayPlanes q, const unsigned *_
     const float dy = fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y;
     const float dz = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-    const float ox = O.x * ix, oy = O.y * iy, oz = O.z * iz;
+    const RaySlab S = make_slab(ix, iy, iz, O.x * ix, O.y * iy, O.z * iz);
     int ns = T.nodes4 ? 1 : 0, nl = 0; // wave-uniform
     bool occluded = false;             // wave-uniform
     if (lane == 0) s_ref[0] = 0;
@@ -765,7 +817,7 @@ __global__ __launch_bounds__(256) void k_wave_any(RayPlanes q, const unsigned *_
         ns -= take;
         float tn[4];
         int rr[4];
-        if (mine) node4_test(T.nodes4 + (size_t)GVT_NODE4_F4 * ref, ix, iy, iz, ox, oy, oz, GVT_FLT_MAX, tn, rr);
+        if (mine) node4_test(T.nodes4 + (size_t)GVT_NODE4_F4 * ref, S, GVT_FLT_MAX, tn, rr);
 #pragma unroll
         for (int c = 3; c >= 0; c--) {
           const bool hit = mine && tn[c] < GVT_FLT_MAX;
@@ -1267,6 +1319,16 @@ template <bool ANY, bool XFORM, int MODE, typename... Args> void launch_trace(bo
 }
 
 // persistent-wave kernel: fewer, longer-lived waves so that every lane is refilled several times
+// scratch of a closest-hit launch's parked rays: n records, then LONG_SAVE stack entries for each of the first LONG_STK_CAP of them
+static size_t long_scratch_bytes(size_t n) { return sizeof(LongRec) * n + sizeof(int) * LONG_SAVE * (size_t)LONG_STK_CAP; }
+static void long_limits(LongQ &LQ, size_t n) {
+  Ctx &C = gctx();
+  LQ.steps = C.long_steps;
+  LQ.steps_drain = C.long_steps_drain > 0 && C.long_steps_drain < C.long_steps ? C.long_steps_drain : C.long_steps;
+  LQ.stk = C.long_save ? (int *)(LQ.recs + n) : nullptr;
+  LQ.stk_cap = LONG_STK_CAP;
+}
+
 int trav_grid2(size_t n, bool closest = false) {
   Ctx &C = gctx();
   size_t want = (size_t)C.n_cu * (size_t)((closest && C.blocks_per_cu_closest) ? C.blocks_per_cu_closest : C.blocks_per_cu);
@@ -1280,11 +1342,11 @@ int trav_grid2(size_t n, bool closest = false) {
 int debug_stamps(unsigned long long *out, int reset) {
 #if GVT_STAMP
   hipDeviceSynchronize();
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 16);
-  if (reset) { unsigned long long z[16] = { 0 }; hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof z); }
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 24);
+  if (reset) { unsigned long long z[24] = { 0 }; hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof z); }
   return 0;
 #else
-  for (int i = 0; i < 16; i++) out[i] = 0;
+  for (int i = 0; i < 24; i++) out[i] = 0;
   return -1;
 #endif
 }
@@ -1338,10 +1400,10 @@ int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, 
   if (!counter_is_zero) HIPCHK(hipMemsetAsync(C.d_counters, 0, 5 * sizeof(unsigned), C.stream));
   LongQ LQ{};
   if (C.trav_kernel == 1 && C.wide4 && have_nodes4 && C.long_steps > 0 && n >= (size_t)C.long_min_rays) { // long rays are parked and traversed a wave per ray
-    LQ.recs = (LongRec *)scratch_get(15, sizeof(LongRec) * n);
+    LQ.recs = (LongRec *)scratch_get(15, long_scratch_bytes(n));
     if (!LQ.recs) return GVT_HIP_ERR_DEVICE;
     LQ.count = C.d_counters + 3;
-    LQ.steps = C.long_steps;
+    long_limits(LQ, n);
   }
   {
     ProfScope ps(KC_CLOSEST);
@@ -1359,8 +1421,8 @@ int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, 
       ProfScope ps(KC_LONG);
       {
         const int grid = C.n_cu * 3; // 48 KiB of LDS per block
-        if (xform) k_long_closest<true><<<grid, 256, 0, C.stream>>>(q, LQ.recs, LQ.count, minv, T, tnear, d_hits, C.d_counters + 4);
-        else k_long_closest<false><<<grid, 256, 0, C.stream>>>(q, LQ.recs, LQ.count, minv, T, tnear, d_hits, C.d_counters + 4);
+        if (xform) k_long_closest<true><<<grid, 256, 0, C.stream>>>(q, LQ.recs, LQ.count, minv, T, tnear, d_hits, C.d_counters + 4, WaveSet{}, LQ.stk);
+        else k_long_closest<false><<<grid, 256, 0, C.stream>>>(q, LQ.recs, LQ.count, minv, T, tnear, d_hits, C.d_counters + 4, WaveSet{}, LQ.stk);
       }
     }
   }
@@ -1601,7 +1663,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
   unsigned *d_idx_b = (unsigned *)scratch_get(4, sizeof(unsigned) * n);
   gvt_hip_light *d_lights = (gvt_hip_light *)scratch_get(5, sizeof(gvt_hip_light) * (nL > 0 ? nL : 1));
   int *d_shadow_inst = (int *)scratch_get(16, sizeof(int) * shadow_cap);
-  LongRec *d_long = (LongRec *)scratch_get(15, sizeof(LongRec) * n);
+  LongRec *d_long = (LongRec *)scratch_get(15, long_scratch_bytes(n));
   if (!d_hits || !d_shadow || !d_idx_a || !d_idx_b || !d_lights || !d_shadow_inst || !d_long) return GVT_HIP_ERR_DEVICE;
   {
     std::vector<unsigned char> &cached = C.lights_cached;
@@ -1637,13 +1699,13 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       const bool have4 = M->d_nodes4 != nullptr;
       Trav TS{ M->d_nodes, M->d_tri, M->d_nodes4 };
       LongQ LQ{};
-      if (use_long && have4) { LQ.recs = d_long; LQ.count = c + 3; LQ.steps = C.long_steps; }
+      if (use_long && have4) { LQ.recs = d_long; LQ.count = c + 3; long_limits(LQ, n); }
       const bool small1 = small && have4;
       // a coherent list (camera rays in 8x8 tiles, straight from the filter): a wave walks the tree for 64 rays at once (k_packet)
       const bool pkt = C.packet && single->coherent && pass == 0 && have4 && !small1;
       if (pkt) {
         ProfScope ps(KC_CLOSEST);
-        LongQ LP{ d_long, c + 3, 0 };
+        LongQ LP{ d_long, c + 3, nullptr, 0u, 0, 0 };
         k_packet<false><<<blocks_for(n), 256, 0, st>>>(single->planes, (unsigned)n, n_dev, single->minv, TS, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
                                                      TermSink{}, LP, nullptr, nullptr, nullptr, c + 9);
         k_long_closest<true><<<C.n_cu * 3, 256, 0, st>>>(single->planes, d_long, c + 3, single->minv, TS, GVT_RAY_EPSILON, d_hits, c + 4); // packets that bailed out
@@ -1658,7 +1720,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       }
       if (LQ.steps && !small1 && !pkt) {
         ProfScope ps(KC_LONG);
-        k_long_closest<true><<<C.n_cu * 3, 256, 0, st>>>(single->planes, d_long, c + 3, single->minv, TS, GVT_RAY_EPSILON, d_hits, c + 4);
+        k_long_closest<true><<<C.n_cu * 3, 256, 0, st>>>(single->planes, d_long, c + 3, single->minv, TS, GVT_RAY_EPSILON, d_hits, c + 4, WaveSet{}, LQ.stk);
       }
       ShadeArgs A;
       A.in = single->planes; A.idx = idx; A.n = (unsigned)n; A.index_base = 0; A.hits = d_hits;
@@ -1722,7 +1784,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       continue;
     }
     LongQ LQ{};
-    if (use_long) { LQ.recs = d_long; LQ.count = c + 3; LQ.steps = C.long_steps; }
+    if (use_long) { LQ.recs = d_long; LQ.count = c + 3; long_limits(LQ, n); }
     MultiSrc MS{ W, nullptr, nullptr, nullptr };
     if (small) {
       ProfScope ps(KC_CLOSEST);
@@ -1736,7 +1798,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     }
     if (use_long && !small) {
       ProfScope ps(KC_LONG);
-      k_long_closest<true, true><<<C.n_cu * 3, 256, 0, st>>>(none, d_long, c + 3, id, T, GVT_RAY_EPSILON, d_hits, c + 4, W);
+      k_long_closest<true, true><<<C.n_cu * 3, 256, 0, st>>>(none, d_long, c + 3, id, T, GVT_RAY_EPSILON, d_hits, c + 4, W, LQ.stk);
     }
     ShadeArgs A;
     A.in = none; A.idx = idx; A.n = (unsigned)n; A.index_base = 0; A.hits = d_hits;

@@ -468,7 +468,8 @@ def test_shuffle_keeps_list_order_and_fused_camera_filter(hip):
 
 def test_long_ray_path_is_bit_exact(hip):
     """Rays that exceed `long_steps` node steps are parked by k_trace and finished by k_long_closest, a wave per ray.  Forced onto
-    (nearly) every ray here -- threshold 1..8 steps, no minimum launch size -- hits and whole frames must not change by a bit."""
+    (nearly) every ray here -- threshold 1..24 steps, no minimum launch size, with and without the saved stack -- hits and whole
+    frames must not change by a bit."""
     from gravit_amd import capi
 
     v, t = scenes.load_mesh_file(os.path.join(GOLDEN, "bun_zipper.npz"))
@@ -488,12 +489,16 @@ def test_long_ray_path_is_bit_exact(hip):
         ref_fb = ImageTracer(sc, NORMALS_SMOOTH)().framebuffer(False).copy()
         assert (ref_hits["prim"] >= 0).sum() > 1000
         capi.set_option("long_min_rays", 0)
-        for steps in (1, 3, 8):
+        # long_save: the record carries the ray's pending stack (k_long_closest goes on from it) or not (it starts again at the root);
+        # long_steps_drain: the lower threshold of waves whose work counter has run dry
+        for steps, save, drain in ((1, 1, 0), (3, 1, 0), (8, 1, 0), (3, 0, 0), (8, 0, 0), (24, 1, 4), (24, 0, 2)):
             capi.set_option("long_steps", steps)
+            capi.set_option("long_save", save)
+            capi.set_option("long_steps_drain", drain)
             h = ad.intersect(org, d.astype(np.float32))
-            assert h.tobytes() == ref_hits.tobytes(), "hits differ with long_steps=%d" % steps
+            assert h.tobytes() == ref_hits.tobytes(), "hits differ with long_steps=%d long_save=%d long_steps_drain=%d" % (steps, save, drain)
             fb = ImageTracer(sc, NORMALS_SMOOTH)().framebuffer(False)
-            assert np.array_equal(fb, ref_fb), "frame differs with long_steps=%d" % steps
+            assert np.array_equal(fb, ref_fb), "frame differs with long_steps=%d long_save=%d long_steps_drain=%d" % (steps, save, drain)
     finally:
         capi.set_option("defaults", 0)
 

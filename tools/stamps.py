@@ -8,7 +8,8 @@ from gravit_amd import capi, scenes, _build
 STAMP_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgvt_hip_stamp.so")
 if "--build" in sys.argv:
     srcs = [os.path.join(_build.CSRC, s) for s in _build.SOURCES]
-    subprocess.check_call([_build.hipcc()] + _build.FLAGS + ["-DGVT_STAMP=1", "-shared", "-o", STAMP_LIB] + srcs)
+    level = [a for a in sys.argv if a.startswith("--level=")]
+    subprocess.check_call([_build.hipcc()] + _build.FLAGS + ["-DGVT_STAMP=" + (level[0][8:] if level else "1"), "-shared", "-o", STAMP_LIB] + srcs)
     print(STAMP_LIB); sys.exit(0)
 capi.LIB_PATH = STAMP_LIB
 from gravit_amd.scheduler import ImageTracer
@@ -19,7 +20,7 @@ for a in sys.argv[2:]:
 sc = scenes.soup_scene(N)
 tr = ImageTracer(sc, 0)
 tr(); capi.synchronize()
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 24)()
 lib = capi.load()
 lib.gvt_hip_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 lib.gvt_hip_debug_stamps(buf, 1)
