@@ -106,21 +106,26 @@ class HipMeshAdapter:
         return out
 
     # -- Adapter::trace (Adapter.h:82-84) ------------------------------------------------------------
-    def trace(self, rayList, m, minv, normi, lights, begin=0, end=0, seed=0):
+    def trace(self, rayList, m, minv, normi, lights, begin=0, end=0, seed=0, write_back=True, out=None):
         """Traces rayList[begin:end) (end==0 -> all, EmbreeMeshAdapter.cpp:642).  rayList (RAY_DTYPE, C-contiguous)
-        is updated in place; returns moved_rays (misses + un-occluded shadow rays, order unspecified)."""
+        is updated in place (write_back=False: only read, GVT_HIP_TRACE_NO_WRITEBACK); returns moved_rays (misses + un-occluded
+        shadow rays, order unspecified), a view of `out` when the caller brings its own buffer (like a re-used RayVector)."""
         if rayList.dtype != RAY_DTYPE or not rayList.flags.c_contiguous:
             raise ValueError("rayList must be a C-contiguous array of RAY_DTYPE (80-byte gvt Ray)")
         lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
         n = len(rayList)
         e = n if end == 0 else end
         cap = max(16, (e - begin) * (1 + len(lights)))
-        out = np.zeros(cap, RAY_DTYPE)
+        if out is None:
+            out = np.zeros(cap, RAY_DTYPE)
+        elif out.dtype != RAY_DTYPE or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous array of RAY_DTYPE")
+        cap = len(out)
         n_out = C.c_size_t(0)
-        capi.check(self.lib.gvt_hip_trace(
+        capi.check(self.lib.gvt_hip_trace_ex(
             self.h, capi.ptr(rayList), C.c_size_t(n), C.c_size_t(begin), C.c_size_t(end), capi.ptr(out), C.c_size_t(cap),
             C.byref(n_out), capi.ptr(capi.f32(m, 16)), capi.ptr(capi.f32(minv, 16)), capi.ptr(capi.f32(normi, 9)), capi.ptr(lights),
-            C.c_size_t(len(lights)), C.c_int(self.normal_mode), C.c_uint32(seed)), "gvt_hip_trace")
+            C.c_size_t(len(lights)), C.c_int(self.normal_mode), C.c_uint32(seed), C.c_uint32(0 if write_back else 1)), "gvt_hip_trace_ex")
         return out[: n_out.value]
 
     def trace_queue(self, q_in, q_out, m, minv, normi, lights, seed=0, sink=None):

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("GVT_HIP_LIB") or os.path.join(HERE, "libgvt_hip.so") 
 # every symbol include/gvt_hip.h declares
 SYMBOLS = [
     "gvt_hip_init", "gvt_hip_set_stream", "gvt_hip_synchronize", "gvt_hip_last_error",
-    "gvt_hip_mesh_create", "gvt_hip_mesh_destroy", "gvt_hip_mesh_get_info", "gvt_hip_mesh_get_normals",
+    "gvt_hip_mesh_create", "gvt_hip_mesh_destroy", "gvt_hip_trace_ex", "gvt_hip_mesh_get_info", "gvt_hip_mesh_get_normals",
     "gvt_hip_trace", "gvt_hip_intersect", "gvt_hip_occluded",
     "gvt_hip_queue_create", "gvt_hip_queue_destroy", "gvt_hip_queue_reserve", "gvt_hip_queue_clear", "gvt_hip_queue_size",
     "gvt_hip_queue_append", "gvt_hip_queue_export", "gvt_hip_trace_queue", "gvt_hip_trace_queue_sink",

@@ -438,7 +438,15 @@ extern "C" int gvt_hip_trace_queue_sink(gvt_hip_mesh *M, gvt_hip_queue *q_in, gv
 extern "C" int gvt_hip_trace(gvt_hip_mesh *M, gvt_hip_ray *rays, size_t n_rays, size_t begin, size_t end, gvt_hip_ray *rays_out, size_t cap,
                              size_t *n_out, const float m[16], const float minv[16], const float normi[9], const gvt_hip_light *lights,
                              size_t n_lights, int normal_mode, uint32_t seed) {
+  return gvt_hip_trace_ex(M, rays, n_rays, begin, end, rays_out, cap, n_out, m, minv, normi, lights, n_lights, normal_mode, seed, 0u);
+}
+
+extern "C" int gvt_hip_trace_ex(gvt_hip_mesh *M, gvt_hip_ray *rays, size_t n_rays, size_t begin, size_t end, gvt_hip_ray *rays_out, size_t cap,
+                                size_t *n_out, const float m[16], const float minv[16], const float normi[9], const gvt_hip_light *lights,
+                                size_t n_lights, int normal_mode, uint32_t seed, uint32_t flags) {
   if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (flags & ~GVT_HIP_TRACE_NO_WRITEBACK) { set_error("trace: unknown flags 0x%x", flags); return GVT_HIP_ERR_INVALID; }
+  const bool write_back = !(flags & GVT_HIP_TRACE_NO_WRITEBACK);
   if (!M || !n_out || (n_rays && !rays)) { set_error("trace: null argument"); return GVT_HIP_ERR_INVALID; }
   if (end == 0) end = n_rays; // EmbreeMeshAdapter.cpp:642
   if (begin > end || end > n_rays) { set_error("trace: bad range [%zu,%zu) of %zu", begin, end, n_rays); return GVT_HIP_ERR_INVALID; }
@@ -455,12 +463,13 @@ extern "C" int gvt_hip_trace(gvt_hip_mesh *M, gvt_hip_ray *rays, size_t n_rays, 
   if ((rc = gvt_hip_queue_clear(qin)) || (rc = gvt_hip_queue_clear(qout))) return rc;
   if ((rc = gvt_hip_queue_append(qin, rays + begin, n, 0))) return rc;
   if ((rc = queue_reserve(qout, n * (1 + n_lights)))) return rc;
+  P.update_in_place = write_back ? 1 : 0;
   if ((rc = trace_core(M, make_planes(qin->d_planes, qin->cap), n, begin, qout, P, lights))) return rc;
   *n_out = qout->size;
   if (qout->size > cap) { set_error("trace: %zu outgoing rays, capacity %zu", qout->size, cap); return GVT_HIP_ERR_CAPACITY; }
   // rayList is updated in place (r.mice.t, bounce state)
   size_t got = 0;
-  if ((rc = gvt_hip_queue_export(qin, rays + begin, n, &got, 0))) return rc;
+  if (write_back && (rc = gvt_hip_queue_export(qin, rays + begin, n, &got, 0))) return rc;
   if (qout->size) {
     if (!rays_out) { set_error("trace: null rays_out"); return GVT_HIP_ERR_INVALID; }
     if ((rc = gvt_hip_queue_export(qout, rays_out, cap, &got, 0))) return rc;

@@ -98,9 +98,10 @@ void HipMeshAdapter::trace(gvt::render::actor::RayVector &rayList, gvt::render::
   std::unique_lock<std::mutex> moved(_outqueue);
   const size_t old = moved_rays.size();
   moved_rays.resize(old + cap);
-  int rc = gvt_hip_trace(mesh_, reinterpret_cast<gvt_hip_ray *>(rayList.data()), rayList.size(), begin, end,
-                         reinterpret_cast<gvt_hip_ray *>(moved_rays.data() + old), cap, &n_out, &(*m)[0][0], &(*minv)[0][0], &(*normi)[0][0],
-                         pods.empty() ? nullptr : pods.data(), pods.size(), normal_mode_, trace_calls_++);
+  int rc = gvt_hip_trace_ex(mesh_, reinterpret_cast<gvt_hip_ray *>(rayList.data()), rayList.size(), begin, end,
+                            reinterpret_cast<gvt_hip_ray *>(moved_rays.data() + old), cap, &n_out, &(*m)[0][0], &(*minv)[0][0], &(*normi)[0][0],
+                            pods.empty() ? nullptr : pods.data(), pods.size(), normal_mode_, trace_calls_++,
+                            write_back_ ? 0u : GVT_HIP_TRACE_NO_WRITEBACK);
   moved_rays.resize(old + (rc == GVT_HIP_OK ? n_out : 0));
   moved.unlock();
   if (rc != GVT_HIP_OK) fail("gvt_hip_trace");

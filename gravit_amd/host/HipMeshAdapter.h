@@ -38,10 +38,16 @@ public:
 
   gvt_hip_mesh *handle() const { return mesh_; }
 
+  /** false: trace() leaves rayList as it is (GVT_HIP_TRACE_NO_WRITEBACK).  Tracer<ImageScheduler> and Tracer<DomainScheduler> clear
+   *  the traced queue right after the call (ImageTracer.h:248, DomainTracer.h:316), so under them the in-place update is never read
+   *  and a third of the call's PCIe traffic can go.  Default true: the literal contract of EmbreeMeshAdapter::trace. */
+  void setWriteBack(bool on) { write_back_ = on; }
+
 private:
   gvt_hip_mesh *mesh_;
   int normal_mode_;
   unsigned trace_calls_;
+  bool write_back_ = true;
 };
 
 } // namespace data

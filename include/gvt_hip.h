@@ -129,6 +129,13 @@ int gvt_hip_mesh_get_normals(const gvt_hip_mesh *, float *out);
 int gvt_hip_trace(gvt_hip_mesh *, gvt_hip_ray *rays, size_t n_rays, size_t begin, size_t end, gvt_hip_ray *rays_out,
                   size_t cap, size_t *n_out, const float m[16], const float minv[16], const float normi[9],
                   const gvt_hip_light *lights, size_t n_lights, int normal_mode, uint32_t seed);
+/* The same call with flags.  GVT_HIP_TRACE_NO_WRITEBACK: `rays` is only read.  Both of the reference's schedulers clear the traced
+ * queue right after the call (ImageTracer.h:248, DomainTracer.h:316), so the rayList's in-place update is never observed there;
+ * skipping it saves a third of the call's PCIe traffic (80 B per ray back to the host). */
+#define GVT_HIP_TRACE_NO_WRITEBACK 1u
+int gvt_hip_trace_ex(gvt_hip_mesh *, gvt_hip_ray *rays, size_t n_rays, size_t begin, size_t end, gvt_hip_ray *rays_out,
+                     size_t cap, size_t *n_out, const float m[16], const float minv[16], const float normi[9],
+                     const gvt_hip_light *lights, size_t n_lights, int normal_mode, uint32_t seed, uint32_t flags);
 
 /* ---- the Embree queries the adapter is built on (rtcIntersect / rtcOccluded,
  *      EmbreeMeshAdapter.cpp:474,375): object-space rays, t in (tnear, FLT_MAX) ---- */

@@ -622,3 +622,18 @@ def test_multisample_frame_within_tolerance(hip):
     B = ImageTracer(sc, NORMALS_SMOOTH)()
     ref, _ = oracle_render(sc, 1)
     assert np.abs(B.framebuffer(True)[..., :3] - ref[..., :3]).max() <= RADIANCE_TOL
+
+
+def test_trace_without_write_back_leaves_the_ray_list_alone(hip):
+    """GVT_HIP_TRACE_NO_WRITEBACK (gvt_hip_trace_ex): the same moved rays, rayList untouched -- what the reference's schedulers need,
+    which clear the traced queue right after Adapter::trace (ImageTracer.h:248, DomainTracer.h:316)."""
+    sc = scenes.bunny_grid_scene(width=96, height=54)
+    ad = HipMeshAdapter(sc.meshes[sc.inst_mesh[0]], NORMALS_SMOOTH)
+    c = sc.camera
+    rays = orc.camera_rays(c.eye, c.focus, c.up, c.fov, c.width, c.height)
+    a, b = rays.copy(), rays.copy()
+    moved_a = ad.trace(a, sc.m[0], sc.minv[0], sc.normi[0], sc.lights, seed=3)
+    moved_b = ad.trace(b, sc.m[0], sc.minv[0], sc.normi[0], sc.lights, seed=3, write_back=False)
+    assert rays_equal_bits(b, rays) and not rays_equal_bits(a, rays)  # the 68 defined bytes of every ray (numpy leaves the padding of a copy undefined)
+    assert len(moved_a) == len(moved_b) and len(moved_a) > 0
+    assert rays_equal_bits(sort_rays(moved_a), sort_rays(moved_b))
