@@ -171,6 +171,52 @@ def abi_path(scene, tracer, capi, np):
     return out
 
 
+def two_frames_in_flight(scene, steps, rays_per_frame):
+    """Throughput of a STREAM of frames: two tracers, each with its own library context (stream, scratch, counters, queues,
+    framebuffer), render alternate frames from two host threads; one frame's launch tails overlap the other's bulk.  Reported
+    beside the line, never as `value` (which keeps one frame in flight, like the reference's frame loop)."""
+    import threading
+
+    from gravit_amd.layouts import NORMALS_FLAT
+    from gravit_amd.scheduler import Context, NativeTracer
+
+    ready, go = threading.Barrier(3), threading.Barrier(3)
+    spans, errs = [None, None], []
+
+    def work(k):
+        try:
+            with Context(0):
+                tr = NativeTracer(scene, NORMALS_FLAT)
+                for _ in range(3):
+                    tr()
+                ready.wait(); go.wait()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    tr()
+                spans[k] = (t0, time.perf_counter())
+                tr.close()
+                tr = None
+        except Exception:  # noqa: BLE001
+            import traceback
+            errs.append(traceback.format_exc())
+            for b in (ready, go):
+                b.abort()
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    try:
+        ready.wait(); go.wait()
+    except threading.BrokenBarrierError:
+        pass
+    [t.join() for t in th]
+    if errs:
+        raise RuntimeError(errs[0])
+    span = max(e for _, e in spans) - min(b for b, _ in spans)
+    return {"ms_per_frame": span / (2 * steps) * 1e3, "Mrays/s": rays_per_frame * 2 * steps / span / 1e6, "frames": 2 * steps,
+            "note": "two library contexts on two host threads, each rendering %d frames of the same workload concurrently; first start "
+                    "to last end; never `value`" % steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -387,6 +433,11 @@ def main():
                                                                   "triangle_tests": vs["tri_tests_per_ray"], "sample_rays": int(len(rr))}
                 except Exception as e:
                     out["roofline"]["visits_per_primary_ray"] = "failed: %r" % (e,)
+        if on_gpu and world == 1 and n_dom == 1 and args.harness == "native" and not args.no_abi_path:
+            try:
+                out["two_frames_in_flight"] = two_frames_in_flight(scene, args.steps, rays_total / args.steps)
+            except Exception as e:
+                out["two_frames_in_flight"] = {"failed": repr(e)}
         if on_gpu and world == 1 and n_dom == 1 and not args.no_abi_path:
             try:
                 out["abi_path"] = abi_path(scene, tracer, capi, np)

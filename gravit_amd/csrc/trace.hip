@@ -19,7 +19,10 @@
 // diagnostic) and fused_kernel.inc (k_fused, measured slower); DESIGN.md 4.1 lists what was measured on the way.
 #include "gvt_internal.h"
 
-#define TRAV_BLOCK 256
+#ifndef TRAV_BLOCK
+#define TRAV_BLOCK 256   // threads per traversal block (64: every wave is its own block and gives its registers / LDS back when IT ends)
+#endif
+#define TRAV_BLOCK_SCALE (256 / TRAV_BLOCK) // blocks-per-CU knobs count 256-thread blocks
 #ifndef TRAV_STACK
 #define TRAV_STACK 24   // LDS entries per lane; deeper levels spill to a per-thread global area
 #endif
@@ -205,7 +208,7 @@ struct MultiSrc {
   unsigned long long *tot_any;  // any hit over a direct-mapped list: the rays actually traced are added here (one atomic per wave)
 };
 template <bool ANY, bool XFORM, int MODE, bool COOP, bool W4, bool MULTI = false>
-__global__ __launch_bounds__(TRAV_BLOCK, ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSEST) void k_trace(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, Trav T, float tnear,
+__global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSEST) * TRAV_BLOCK_SCALE) void k_trace(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, Trav T, float tnear,
                                                        gvt_hip_hit *__restrict__ hits, int *__restrict__ flags, RayPlanes out, unsigned *out_count,
                                                        unsigned *counter, int *spill_base, int refill_min, int inner_min, const unsigned *__restrict__ n_dev, int share, unsigned share_min, TermSink sink, LongQ LQ,
                                                        MultiSrc MS = MultiSrc{}) {
@@ -1318,7 +1321,6 @@ template <bool ANY, bool XFORM, int MODE, typename... Args> void launch_trace(bo
   else k_trace<ANY, XFORM, MODE, false, false><<<grid, TRAV_BLOCK, 0, st>>>(args...);
 }
 
-// persistent-wave kernel: fewer, longer-lived waves so that every lane is refilled several times
 // scratch of a closest-hit launch's parked rays: n records, then LONG_SAVE stack entries for each of the first LONG_STK_CAP of them
 static size_t long_scratch_bytes(size_t n) { return sizeof(LongRec) * n + sizeof(int) * LONG_SAVE * (size_t)LONG_STK_CAP; }
 static void long_limits(LongQ &LQ, size_t n) {
@@ -1329,9 +1331,10 @@ static void long_limits(LongQ &LQ, size_t n) {
   LQ.stk_cap = LONG_STK_CAP;
 }
 
+// persistent-wave kernel: fewer, longer-lived waves so that every lane is refilled several times
 int trav_grid2(size_t n, bool closest = false) {
   Ctx &C = gctx();
-  size_t want = (size_t)C.n_cu * (size_t)((closest && C.blocks_per_cu_closest) ? C.blocks_per_cu_closest : C.blocks_per_cu);
+  size_t want = (size_t)C.n_cu * (size_t)((closest && C.blocks_per_cu_closest) ? C.blocks_per_cu_closest : C.blocks_per_cu) * TRAV_BLOCK_SCALE;
   size_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
   if (want > (size_t)C.trav_blocks) want = (size_t)C.trav_blocks;
   return (int)(need < want ? (need ? need : 1) : want);
