@@ -1,4 +1,5 @@
-"""Build libgvt_hip.so (the C-ABI adapter library) for gfx950 with hipcc, in-tree.
+"""Build libgvt_hip.so (the C-ABI adapter library) and libgvt_hip_exp.so (the same sources with -DGVT_EXPERIMENTS: every
+variant that was measured and lost behind its knob, for the knob sweeps and probes) for gfx950 with hipcc, in-tree.
 
 hipcc cross-compiles without a GPU; the built .so is git-ignored but travels with the tree to
 the GPU box.  -ffp-contract=off is part of the contract: the parity-critical arithmetic must not
@@ -13,9 +14,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libgvt_hip.so")
+LIB_EXP = os.path.join(HERE, "libgvt_hip_exp.so")
 SOURCES = ["api.hip", "lbvh.hip", "trace.hip", "sched.hip", "domain.hip"]
-HEADERS = ["gvt_device.h", "gvt_internal.h", "diag_kernels.inc", "fused_kernel.inc", "packet_kernel.inc", os.path.join("..", "..", "include", "gvt_hip.h"),
+HEADERS = ["gvt_device.h", "gvt_internal.h", "diag_kernels.inc", os.path.join("..", "..", "include", "gvt_hip.h"),
            os.path.join("..", "..", "include", "gvt_math.h")]
+EXP_HEADERS = [os.path.join("experiments", f) for f in ("fused_kernel.inc", "packet_kernel.inc", "quad_kernel.inc", "binary_node_arm.inc", "coop_leaf_arm.inc")]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 
@@ -35,18 +38,23 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, verbose=False, experiments=False):
+    """The shipped library, or with experiments=True the experiments build (objects in csrc/build/exp)."""
+    obj_dir = os.path.join(OBJ, "exp") if experiments else OBJ
+    lib_path = LIB_EXP if experiments else LIB
+    os.makedirs(obj_dir, exist_ok=True)
     extra = os.environ.get("GVT_EXTRA_HIPCC_FLAGS", "").split()  # experiments only (e.g. -DTRAV_STACK=16); forces a rebuild
     if extra:
         force = True
+    if experiments:
+        extra = extra + ["-DGVT_EXPERIMENTS"]
     cc = hipcc()
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS + (EXP_HEADERS if experiments else [])]
     objs = []
     procs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        obj = os.path.join(obj_dir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
             cmd = [cc] + FLAGS + extra + ["-c", src, "-o", obj]
@@ -59,13 +67,14 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s:\n%s" % (s, out.decode(errors="replace")))
         if verbose and out:
             print(out.decode(errors="replace"), file=sys.stderr)
-    if force or _stale(LIB, objs):
-        cmd = [cc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+    if force or _stale(lib_path, objs):
+        cmd = [cc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib_path] + objs
         out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if out.returncode != 0:
             raise RuntimeError("link failed:\n%s" % out.stdout.decode(errors="replace"))
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, experiments=True))

@@ -174,6 +174,16 @@ extern "C" int gvt_hip_stats_reset(void) {
 
 extern "C" int gvt_hip_set_option(const char *name, int value) {
   if (!name) { set_error("set_option: null name"); return GVT_HIP_ERR_INVALID; }
+#ifndef GVT_EXPERIMENTS
+  { // the variants behind these knobs live in the experiments build only (libgvt_hip_exp.so, -DGVT_EXPERIMENTS)
+    static const struct { const char *name; int shipped; } exp_only[] = { { "trav_kernel", 1 }, { "wide4", 1 }, { "coop_fetch", 0 }, { "fused", 0 }, { "packet", 0 }, { "quad", 0 } };
+    for (const auto &e : exp_only)
+      if (!std::strcmp(name, e.name) && value != e.shipped) {
+        set_error("set_option: %s=%d needs the experiments build of the library (libgvt_hip_exp.so)", name, value);
+        return GVT_HIP_ERR_INVALID;
+      }
+  }
+#endif
   if (!std::strcmp(name, "sort_rays")) { g_ctx.sort_rays = value; return 0; }
   if (!std::strcmp(name, "sort_gather")) { g_ctx.sort_gather = value; return 0; }
   if (!std::strcmp(name, "sort_bits")) { if (value < 8 || value > 32) { set_error("sort_bits must be 8..32"); return GVT_HIP_ERR_INVALID; } g_ctx.sort_bits = value; return 0; }
@@ -196,6 +206,11 @@ extern "C" int gvt_hip_set_option(const char *name, int value) {
   if (!std::strcmp(name, "wide4")) { g_ctx.wide4 = value; return 0; }
   if (!std::strcmp(name, "coop_fetch")) { g_ctx.coop_fetch = value; return 0; }
   if (!std::strcmp(name, "top_lds")) { g_ctx.top_lds = value; return 0; }
+  if (!std::strcmp(name, "quad")) { g_ctx.quad = value; return 0; }
+  if (!std::strcmp(name, "leaf_max")) { if (value < 1 || value > 4) { set_error("leaf_max must be 1..4"); return GVT_HIP_ERR_INVALID; } g_ctx.leaf_max = value; return 0; }
+  if (!std::strcmp(name, "quad_inner_min")) { if (value < 1 || value > 16) { set_error("quad_inner_min must be 1..16"); return GVT_HIP_ERR_INVALID; } g_ctx.quad_inner_min = value; return 0; }
+  if (!std::strcmp(name, "quad_refill_min")) { if (value < 1 || value > 16) { set_error("quad_refill_min must be 1..16"); return GVT_HIP_ERR_INVALID; } g_ctx.quad_refill_min = value; return 0; }
+  if (!std::strcmp(name, "blocks_per_cu_quad")) { if (value < 1 || value > 8) { set_error("blocks_per_cu_quad must be 1..8"); return GVT_HIP_ERR_INVALID; } g_ctx.blocks_per_cu_quad = value; return 0; }
   if (!std::strcmp(name, "trav_kernel")) { g_ctx.trav_kernel = value; return 0; }
   if (!std::strcmp(name, "blocks_per_cu_closest")) { if (value < 0 || value > 8) { set_error("blocks_per_cu_closest must be 0..8"); return GVT_HIP_ERR_INVALID; } g_ctx.blocks_per_cu_closest = value; return 0; }
   if (!std::strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 8) { set_error("blocks_per_cu must be 1..8"); return GVT_HIP_ERR_INVALID; } g_ctx.blocks_per_cu = value; return 0; }
@@ -278,7 +293,7 @@ extern "C" void gvt_hip_mesh_destroy(gvt_hip_mesh *M) {
   if (!M) return;
   if (g_ctx.ready) hipStreamSynchronize(g_ctx.stream);
   hipFree(M->d_verts); hipFree(M->d_tris); hipFree(M->d_normals); hipFree(M->d_vcolors); hipFree(M->d_materials);
-  hipFree(M->d_face_mat); hipFree(M->d_nodes); hipFree(M->d_tri); hipFree(M->d_nodes4);
+  hipFree(M->d_face_mat); hipFree(M->d_nodes); hipFree(M->d_tri); hipFree(M->d_nodes4); hipFree(M->d_nodes4q); hipFree(M->d_triq);
   delete M;
 }
 
@@ -287,7 +302,7 @@ extern "C" int gvt_hip_mesh_get_info(const gvt_hip_mesh *M, gvt_hip_mesh_info *o
   std::memset(o, 0, sizeof *o);
   o->n_tris = M->nT; o->n_verts = M->nV; o->n_nodes = M->nNodes; o->n_leaves = M->nLeaves;
   for (int k = 0; k < 3; k++) { o->bbox_lo[k] = M->lo[k]; o->bbox_hi[k] = M->hi[k]; }
-  o->build_ms = M->build_ms; o->max_leaf = GVT_LEAF_MAX;
+  o->build_ms = M->build_ms; o->max_leaf = M->leaf_max;
   o->bytes_nodes = M->nNodes * sizeof(BvhNode) + M->nNodes4 * 64; o->bytes_tris = M->nT * 64;
   return 0;
 }
@@ -544,4 +559,11 @@ extern "C" int gvt_hip_visit_stats(gvt_hip_mesh *M, const float *org, const floa
 }
 
 int debug_stamps(unsigned long long *out, int reset);
+extern "C" int gvt_hip_is_experiments_build(void) {
+#ifdef GVT_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
 extern "C" int gvt_hip_debug_stamps(unsigned long long *out, int reset) { return debug_stamps(out, reset); }

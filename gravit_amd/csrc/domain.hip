@@ -422,6 +422,7 @@ struct gvt_hip_tracer {
   std::vector<uint8_t> owned;
   gvt_hip_comm *comm = nullptr; // borrowed
   int rank = 0, world = 1;
+  bool all_quad = true; // every local mesh carries the quad-per-ray layouts
   // device tables
   WaveInst *d_insts = nullptr;
   // per-round tables in ONE pinned block / ONE device block (a single host-to-device copy per round): segments, queue descriptors, mask
@@ -506,7 +507,8 @@ extern "C" gvt_hip_tracer *gvt_hip_tracer_create(gvt_hip_top *T, gvt_hip_mesh *c
     cptr[i] = R->queues[i]->d_count;
     if (!M) continue; // an instance whose data lives on another rank (Domain scheduler): never traced here
     if (!M->d_nodes4 && M->nNodes) ok = build_nodes4(M) == 0; // the merged kernels traverse the 4-wide layout
-    I.nodes4 = M->d_nodes4; I.tris = M->d_tri;
+    I.nodes4 = M->d_nodes4; I.tris = M->d_tri; I.nodes4q = M->d_nodes4q; I.trisq = M->d_triq;
+    if (M->nNodes && !(M->d_nodes4q && M->d_triq)) R->all_quad = false;
     I.mv.verts = M->d_verts; I.mv.tris = M->d_tris; I.mv.normals = M->d_normals; I.mv.vcolors = M->d_vcolors;
     I.mv.materials = M->d_materials; I.mv.n_mat = (unsigned)M->nMat; I.mv.face_mat = M->d_face_mat; I.mv.mat = M->mesh_mat;
   }
@@ -624,7 +626,7 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
     P.sink.top = R->top->dev(); P.sink.from = -1;
     P.sink.fb = R->fb->d_rgba; P.sink.n_pix = (unsigned)(R->fb->w * R->fb->h);
   }
-  WaveSet W{ R->d_segs, R->d_insts, n_seg };
+  WaveSet W{ R->d_segs, R->d_insts, n_seg, R->all_quad ? 1 : 0 };
   WaveSingle one{};
   if (n_seg == 1 && R->meshes[R->h_segs[0].inst] && C.wave_single) {
     const int i0 = R->h_segs[0].inst;

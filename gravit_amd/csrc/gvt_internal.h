@@ -50,6 +50,12 @@ struct Knobs {
   int camera_tile = 8;   // gvt_hip_image_frame: camera rays listed in 8x8-pixel tiles (0: pixel-major like generateRays)
   int top_ordered = 1;   // shuffle: order-preserving, deterministic slots (<= 64 destinations) instead of arrival-order atomics
   int top_lds = 1;       // shuffle kernels: aggregate destination counters in LDS per 1024-thread block
+  int quad = 0;          // experiments build: four lanes per ray (k_traceq, experiments/quad_kernel.inc) instead of one (k_trace); meshes created while it
+                         // is set carry the quad layouts.  Measured 1.5x slower on the 10 M soup (VALU bound: 16 rays per wave), DESIGN.md 4.1
+  int leaf_max = 2;      // triangles per leaf at mesh build (1..4): closest hit on the 10 M soup 0.51 ms (2) vs 0.57 ms (4)
+  int quad_inner_min = 8; // k_traceq: the node loop is left once fewer quads than this still descend
+  int quad_refill_min = 4; // k_traceq: idle quads needed before a refill
+  int blocks_per_cu_quad = 8; // k_traceq grid: resident 256-thread blocks per CU
 };
 
 struct Ctx : Knobs {
@@ -118,6 +124,9 @@ struct gvt_hip_mesh {
   float4 *d_tri = nullptr; // 4 float4 per slot, leaf order
   uint4 *d_nodes4 = nullptr;  // compressed 4-wide collapse: 4 x 16 B (64 B) per node
   size_t nNodes4 = 0;
+  uint4 *d_nodes4q = nullptr; // the same nodes laid out for the quad-per-ray traversal: piece s = child s (quad_kernel.inc)
+  float4 *d_triq = nullptr;   // leaf blocks, transposed (lbvh.hip k_emit_trisq)
+  int leaf_max = 2;           // triangles per leaf this mesh was built with
   size_t nLeaves = 0;
   float lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
   float build_ms = 0.f;
@@ -205,12 +214,15 @@ struct WaveInst { // per instance (Adapter::trace arguments m / minv / normi + t
   int pad[3];
   const uint4 *nodes4;
   const float4 *tris;
+  const uint4 *nodes4q;  // quad layouts (null: the mesh was built without them)
+  const float4 *trisq;
   MeshView mv;
 };
 struct WaveSet {
   const WaveSeg *segs;
   const WaveInst *insts;
   int n_seg;
+  int quad_ok; // every instance that can be traced here carries the quad layouts (nodes4q / trisq)
 };
 
 // lbvh.hip

@@ -174,16 +174,16 @@ __global__ __launch_bounds__(256) void k_node_boxes(int n_inner, const int *__re
 }
 
 __global__ __launch_bounds__(256) void k_mark_live(int n_inner, const int *__restrict__ rfirst, const int *__restrict__ rlast,
-                                                   unsigned *__restrict__ live) {
+                                                   unsigned *__restrict__ live, int leaf_max) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_inner) return;
-  live[i] = (rlast[i] - rfirst[i] + 1 > GVT_LEAF_MAX) ? 1u : 0u;
+  live[i] = (rlast[i] - rfirst[i] + 1 > leaf_max) ? 1u : 0u;
 }
 
-__device__ inline int final_ref(int c, const int *__restrict__ rfirst, const int *__restrict__ rlast, const unsigned *__restrict__ newidx) {
+__device__ inline int final_ref(int c, const int *__restrict__ rfirst, const int *__restrict__ rlast, const unsigned *__restrict__ newidx, int leaf_max) {
   if (c < 0) return leaf_ref((unsigned)(~c), 1u);
   int cnt = rlast[c] - rfirst[c] + 1;
-  if (cnt <= GVT_LEAF_MAX) return leaf_ref((unsigned)rfirst[c], (unsigned)cnt);
+  if (cnt <= leaf_max) return leaf_ref((unsigned)rfirst[c], (unsigned)cnt);
   return (int)newidx[c];
 }
 
@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256) void k_emit_nodes(int n_inner, const unsigned 
                                                     const float4 *__restrict__ slo, const float4 *__restrict__ shi,
                                                     const float4 *__restrict__ ilo, const float4 *__restrict__ ihi,
                                                     const int *__restrict__ child_l, const int *__restrict__ child_r, const int *__restrict__ rfirst,
-                                                    const int *__restrict__ rlast, float pad, BvhNode *__restrict__ nodes, unsigned *n_leaves) {
+                                                    const int *__restrict__ rlast, float pad, BvhNode *__restrict__ nodes, unsigned *n_leaves, int leaf_max,
+                                                    unsigned *__restrict__ leaf_of) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_inner || !live[i]) return;
   int cl = child_l[i], cr = child_r[i];
@@ -202,11 +203,14 @@ __global__ __launch_bounds__(256) void k_emit_nodes(int n_inner, const unsigned 
   nd.n0 = make_float4(al.x - pad, ah.x + pad, al.y - pad, ah.y + pad);
   nd.n1 = make_float4(bl.x - pad, bh.x + pad, bl.y - pad, bh.y + pad);
   nd.n2 = make_float4(al.z - pad, ah.z + pad, bl.z - pad, bh.z + pad);
-  int r0 = final_ref(cl, rfirst, rlast, newidx), r1 = final_ref(cr, rfirst, rlast, newidx);
+  int r0 = final_ref(cl, rfirst, rlast, newidx, leaf_max), r1 = final_ref(cr, rfirst, rlast, newidx, leaf_max);
   nd.n3 = make_float4(__int_as_float(r0), __int_as_float(r1), 0.f, 0.f);
   nodes[newidx[i]] = nd;
   unsigned nl = (r0 < 0) + (r1 < 0);
   if (nl) atomicAdd(n_leaves, nl);
+  // every sorted triangle learns its leaf (first slot, count): the transposed leaf blocks of k_emit_trisq are laid out per leaf
+  if (r0 < 0) { const unsigned code = (unsigned)~r0; for (unsigned k = 0; k < (code & 7u); k++) leaf_of[(code >> 3) + k] = code; }
+  if (r1 < 0) { const unsigned code = (unsigned)~r1; for (unsigned k = 0; k < (code & 7u); k++) leaf_of[(code >> 3) + k] = code; }
 }
 
 __global__ __launch_bounds__(256) void k_emit_tris(const float *__restrict__ verts, const int *__restrict__ tris, const unsigned *__restrict__ sorted,
@@ -224,7 +228,28 @@ __global__ __launch_bounds__(256) void k_emit_tris(const float *__restrict__ ver
   out[4 * s + 3] = make_float4(Ng.x, Ng.y, Ng.z, 0.f);
 }
 
-// n <= GVT_LEAF_MAX: one node, child0 = the only leaf, child1 = empty leaf behind an inverted box
+// Leaf blocks for the quad-per-ray traversal (quad_kernel.inc): the n <= 4 triangles of a leaf occupy n x 64 B starting at slot
+// `first`, TRANSPOSED -- piece i (0: v0|prim, 1: e1, 2: e2, 3: Ng) of triangle k at float4 index 4*first + i*n + k -- so that the
+// lanes of a quad, lane k testing triangle k, read n consecutive 16-byte pieces (one or two cache lines) per load instruction
+// instead of n different lines.  Same float operations as k_emit_tris: bit-identical operands.
+__global__ __launch_bounds__(256) void k_emit_trisq(const float *__restrict__ verts, const int *__restrict__ tris, const unsigned *__restrict__ sorted,
+                                                    const unsigned *__restrict__ leaf_of, unsigned n, float4 *__restrict__ out) {
+  unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const unsigned code = leaf_of[s], first = code >> 3, cnt = code & 7u, k = s - first;
+  unsigned p = sorted[s];
+  int a = tris[3 * p], b = tris[3 * p + 1], c = tris[3 * p + 2];
+  V3 v0 = ld3(verts + 3 * a), v1 = ld3(verts + 3 * b), v2 = ld3(verts + 3 * c);
+  V3 e1 = sub3(v0, v1), e2 = sub3(v2, v0);
+  V3 Ng = cross3(e1, e2);
+  float4 *blk = out + (size_t)4 * first;
+  blk[0 * cnt + k] = make_float4(v0.x, v0.y, v0.z, __int_as_float((int)p));
+  blk[1 * cnt + k] = make_float4(e1.x, e1.y, e1.z, 0.f);
+  blk[2 * cnt + k] = make_float4(e2.x, e2.y, e2.z, 0.f);
+  blk[3 * cnt + k] = make_float4(Ng.x, Ng.y, Ng.z, 0.f);
+}
+
+// n <= leaf_max: one node, child0 = the only leaf, child1 = empty leaf behind an inverted box
 __global__ void k_single_node(const float4 *__restrict__ plo, const float4 *__restrict__ phi, unsigned n, float pad, BvhNode *nodes) {
   if (threadIdx.x || blockIdx.x) return;
   float lo[3] = { GVT_FLT_MAX, GVT_FLT_MAX, GVT_FLT_MAX }, hi[3] = { -GVT_FLT_MAX, -GVT_FLT_MAX, -GVT_FLT_MAX };
@@ -256,7 +281,8 @@ __device__ inline float slot_area(const Slot4 &c) {
   return dx * dy + dy * dz + dz * dx;
 }
 __global__ __launch_bounds__(256) void k_collapse4(const BvhNode *__restrict__ nodes, const int *__restrict__ fin, unsigned n_in, unsigned base_in,
-                                                   int *__restrict__ fout, unsigned *__restrict__ next_count, uint4 *__restrict__ nodes4) {
+                                                   int *__restrict__ fout, unsigned *__restrict__ next_count, uint4 *__restrict__ nodes4,
+                                                   uint4 *__restrict__ nodes4q) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n_in;
   Slot4 c[4];
@@ -327,6 +353,18 @@ __global__ __launch_bounds__(256) void k_collapse4(const BvhNode *__restrict__ n
   uint4 *dst = nodes4 + (size_t)GVT_NODE4_F4 * (base_in + i);
   dst[0] = make_uint4(w[0], w[1], w[2], w[3]); dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
   dst[2] = make_uint4(w[8], w[9], w[10], w[11]); dst[3] = make_uint4(w[12], w[13], w[14], w[15]);
+  if (nodes4q) {
+    // the same node for the quad-per-ray traversal: piece s (16 B) is all lane s of a quad needs of child s --
+    //   x = ref_s, y = (lo.x, lo.y, lo.z, hi.x) bytes, z = (hi.y, hi.z) bytes | grid step of axis s as the upper half of its float
+    //   (a power of two: the lower 16 bits are zero), w = grid origin of axis s (s < 3)
+    const uint32_t step[3] = { w[3], w[14], w[15] };
+    uint4 *dq = nodes4q + (size_t)GVT_NODE4_F4 * (base_in + i);
+    for (int s = 0; s < 4; s++) {
+      const uint32_t lx = (w[4] >> (8 * s)) & 0xffu, hx = (w[5] >> (8 * s)) & 0xffu, ly = (w[6] >> (8 * s)) & 0xffu, hy = (w[7] >> (8 * s)) & 0xffu,
+                     lz = (w[8] >> (8 * s)) & 0xffu, hz = (w[9] >> (8 * s)) & 0xffu;
+      dq[s] = make_uint4(w[10 + s], lx | (ly << 8) | (lz << 16) | (hx << 24), hy | (hz << 8) | (s < 3 ? (step[s] & 0xffff0000u) : 0u), s < 3 ? w[s] : 0u);
+    }
+  }
 }
 
 template <typename T> int dalloc(T **p, size_t n) {
@@ -371,7 +409,10 @@ int build_lbvh(gvt_hip_mesh *M) {
 
   float4 *plo = nullptr, *phi = nullptr, *slo = nullptr, *shi = nullptr, *ilo = nullptr, *ihi = nullptr;
   unsigned long long *keys = nullptr, *keys2 = nullptr;
-  unsigned *vals = nullptr, *sorted = nullptr, *live = nullptr, *newidx = nullptr, *nleaves = nullptr;
+  unsigned *vals = nullptr, *sorted = nullptr, *live = nullptr, *newidx = nullptr, *nleaves = nullptr, *leaf_of = nullptr;
+  const int leaf_max = C.leaf_max < 1 ? 1 : (C.leaf_max > 4 ? 4 : C.leaf_max);
+  const bool want_q = C.quad != 0; // the quad-per-ray layouts (nodes4q + transposed leaf blocks)
+  M->leaf_max = leaf_max;
   int *cl = nullptr, *cr = nullptr, *rf = nullptr, *rl = nullptr;
   void *tmp = nullptr;
   std::vector<float4 *> lvl_a, lvl_b; // device arrays of the two range-union tables
@@ -404,8 +445,10 @@ int build_lbvh(gvt_hip_mesh *M) {
     pad = ext * 1e-5f; // keeps the slab test conservative w.r.t. the triangle test's rounding
   }
   OK(dalloc(&M->d_tri, (size_t)4 * n));
+  OK(dalloc(&leaf_of, n));
+  if (want_q) OK(dalloc(&M->d_triq, (size_t)4 * n));
 
-  if (n <= GVT_LEAF_MAX) {
+  if ((int)n <= leaf_max) {
     OK(dalloc(&M->d_nodes, 1));
     M->nNodes = 1; M->nLeaves = 1;
     OK(dalloc(&sorted, n));
@@ -417,6 +460,12 @@ int build_lbvh(gvt_hip_mesh *M) {
     }
     k_single_node<<<1, 64, 0, st>>>(plo, phi, n, pad, M->d_nodes);
     k_emit_tris<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, n, M->d_tri);
+    if (want_q) {
+      std::vector<unsigned> lo_(n, (unsigned)~leaf_ref(0u, n));
+      HOK(hipMemcpyAsync(leaf_of, lo_.data(), sizeof(unsigned) * n, hipMemcpyHostToDevice, st));
+      HOK(hipStreamSynchronize(st));
+      k_emit_trisq<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, leaf_of, n, M->d_triq);
+    }
   } else {
     OK(dalloc(&keys, n)); OK(dalloc(&keys2, n)); OK(dalloc(&vals, n)); OK(dalloc(&sorted, n));
     {
@@ -442,7 +491,7 @@ int build_lbvh(gvt_hip_mesh *M) {
       OK(build_box_levels(slo, shi, n, lvl_b, T, st));
       k_node_boxes<<<(n_inner + B - 1) / B, B, 0, st>>>(n_inner, rf, rl, T, ilo, ihi);
     }
-    k_mark_live<<<(n_inner + B - 1) / B, B, 0, st>>>(n_inner, rf, rl, live);
+    k_mark_live<<<(n_inner + B - 1) / B, B, 0, st>>>(n_inner, rf, rl, live, leaf_max);
     {
       size_t tb = 0;
       HOK(hipFree(tmp)); tmp = nullptr;
@@ -456,14 +505,15 @@ int build_lbvh(gvt_hip_mesh *M) {
     HOK(hipStreamSynchronize(st));
     M->nNodes = (size_t)last_idx + last_live;
     OK(dalloc(&M->d_nodes, M->nNodes));
-    k_emit_nodes<<<(n_inner + B - 1) / B, B, 0, st>>>(n_inner, live, newidx, slo, shi, ilo, ihi, cl, cr, rf, rl, pad, M->d_nodes, nleaves);
+    k_emit_nodes<<<(n_inner + B - 1) / B, B, 0, st>>>(n_inner, live, newidx, slo, shi, ilo, ihi, cl, cr, rf, rl, pad, M->d_nodes, nleaves, leaf_max, leaf_of);
     k_emit_tris<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, n, M->d_tri);
+    if (want_q) k_emit_trisq<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, leaf_of, n, M->d_triq);
     unsigned nl = 0;
     HOK(hipMemcpyAsync(&nl, nleaves, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HOK(hipStreamSynchronize(st));
     M->nLeaves = nl;
   }
-  if (gctx().wide4) OK(build_nodes4(M)); // the traversal layout; counted in the build time
+  if (gctx().wide4 || want_q) OK(build_nodes4(M)); // the traversal layout; counted in the build time
   HOK(hipEventRecord(e1, st));
   HOK(hipEventSynchronize(e1));
   HOK(hipEventElapsedTime(&M->build_ms, e0, e1));
@@ -471,7 +521,7 @@ int build_lbvh(gvt_hip_mesh *M) {
 done:
   hipStreamSynchronize(st);
   hipFree(plo); hipFree(phi); hipFree(slo); hipFree(shi); hipFree(ilo); hipFree(ihi); hipFree(keys); hipFree(keys2); hipFree(vals);
-  hipFree(sorted); hipFree(live); hipFree(newidx); hipFree(nleaves); hipFree(cl); hipFree(cr); hipFree(rf); hipFree(rl); hipFree(tmp);
+  hipFree(sorted); hipFree(live); hipFree(newidx); hipFree(nleaves); hipFree(leaf_of); hipFree(cl); hipFree(cr); hipFree(rf); hipFree(rl); hipFree(tmp);
   for (float4 *p : lvl_a) hipFree(p);
   for (float4 *p : lvl_b) hipFree(p);
   hipEventDestroy(e0); hipEventDestroy(e1);
@@ -499,6 +549,7 @@ int build_nodes4(gvt_hip_mesh *M) {
   int *fa = nullptr, *fb = nullptr;
   unsigned *cnt = nullptr;
   int rc = dalloc(&M->d_nodes4, (size_t)GVT_NODE4_F4 * M->nNodes);
+  if (!rc && M->d_triq) rc = dalloc(&M->d_nodes4q, (size_t)GVT_NODE4_F4 * M->nNodes);
   if (!rc) rc = dalloc(&fa, M->nNodes);
   if (!rc) rc = dalloc(&fb, M->nNodes);
   if (!rc) rc = dalloc(&cnt, 1);
@@ -509,7 +560,7 @@ int build_nodes4(gvt_hip_mesh *M) {
     while (e == hipSuccess && n_in) {
       e = hipMemsetAsync(cnt, 0, sizeof(unsigned), st);
       if (e != hipSuccess) break;
-      k_collapse4<<<(n_in + 255) / 256, 256, 0, st>>>(M->d_nodes, fa, n_in, base, fb, cnt, M->d_nodes4);
+      k_collapse4<<<(n_in + 255) / 256, 256, 0, st>>>(M->d_nodes, fa, n_in, base, fb, cnt, M->d_nodes4, M->d_nodes4q);
       unsigned n_next = 0;
       e = hipMemcpyAsync(&n_next, cnt, sizeof n_next, hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -521,6 +572,6 @@ int build_nodes4(gvt_hip_mesh *M) {
     if (e != hipSuccess) { set_error("4-wide collapse: %s", hipGetErrorString(e)); rc = GVT_HIP_ERR_DEVICE; }
   }
   hipFree(fa); hipFree(fb); hipFree(cnt);
-  if (rc) { hipFree(M->d_nodes4); M->d_nodes4 = nullptr; }
+  if (rc) { hipFree(M->d_nodes4); M->d_nodes4 = nullptr; hipFree(M->d_nodes4q); M->d_nodes4q = nullptr; }
   return rc;
 }

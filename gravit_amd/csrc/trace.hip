@@ -14,9 +14,11 @@
 // One lane per ray.  k_trace runs persistent waves: a wave pulls index ranges from a device counter (an exit every wave
 // reaches), refills lanes whose ray has finished while the others go on, alternates a tight loop over the compressed 4-wide
 // nodes with a leaf phase, keeps its traversal stacks in LDS (stack[level][lane]: lane-contiguous, bank conflict free) and
-// compacts survivors per wave (__ballot + mbcnt, one atomic per >= 64 rays).  Not in this file: diag_kernels.inc (the first
-// version -- one 64-ray batch per wave over the binary tree -- kept as the trav_kernel=0 baseline and for the visit-count
-// diagnostic) and fused_kernel.inc (k_fused, measured slower); DESIGN.md 4.1 lists what was measured on the way.
+// compacts survivors per wave (__ballot + mbcnt, one atomic per >= 64 rays).  Not in this file: diag_kernels.inc (the visit-count
+// diagnostic) and, compiled only with -DGVT_EXPERIMENTS (libgvt_hip_exp.so, the library the knob sweeps and probes run against),
+// the variants that were measured and lost -- experiments/: the first-version kernels (trav_kernel=0), the binary-node and
+// quad-cooperative-fetch arms of k_trace (wide4=0, coop_fetch=1), k_fused, k_packet, k_traceq (four lanes per ray).  DESIGN.md 4.1
+// lists what was measured on the way.
 #include "gvt_internal.h"
 
 #ifndef TRAV_BLOCK
@@ -43,7 +45,7 @@ struct Trav {
   const uint4 *__restrict__ nodes4;  // compressed 4-wide collapse (64 B per node) or null
 };
 
-#include "diag_kernels.inc" // the first-version kernels (one 64-ray batch per wave over the binary tree): trav_kernel=0 baseline + visit counts
+#include "diag_kernels.inc" // visit counts (+ the first-version kernels in the experiments build)
 
 // ------------------------------------------------------------------------------------------------
 // Persistent-wave traversal with lane refill ("wavefront compaction of active rays").
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
             S = make_slab(ix, iy, iz, ox, oy, oz);
             bt = GVT_FLT_MAX; bu = 0.f; bv = 0.f; bden = 1.f; bp = -1;
             sp = 0; sb = 0; donor_lane = -1; nsteps = 0; parked = false;
-            cur = (MULTI ? (nodes4_l != nullptr) : (T.nodes != nullptr)) ? 0 : TRAV_DONE;
+            cur = (MULTI ? (nodes4_l != nullptr) : (W4 ? (T.nodes4 != nullptr) : (T.nodes != nullptr))) ? 0 : TRAV_DONE;
             active = true;
           }
         }
@@ -427,36 +429,12 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
           if (have) cur = nxt;
           else KT_POP()
         }
-      } else {
-      float4 n0, n1, n2, n3;
-      const float ix = S.ix, iy = S.iy, iz = S.iz;
-      if (COOP) quad_fetch64((const float4 *)T.nodes, (unsigned)cur, at_inner, n0, n1, n2, n3);
-      if (at_inner) {
-        if (!COOP) { const BvhNode *nd = T.nodes + cur; n0 = nd->n0; n1 = nd->n1; n2 = nd->n2; n3 = nd->n3; }
-        float a0 = __builtin_fmaf(n0.x, ix, -ox), a1 = __builtin_fmaf(n0.y, ix, -ox);
-        float b0 = __builtin_fmaf(n0.z, iy, -oy), b1 = __builtin_fmaf(n0.w, iy, -oy);
-        float c0 = __builtin_fmaf(n2.x, iz, -oz), c1 = __builtin_fmaf(n2.y, iz, -oz);
-        const float tn0 = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.f));
-        const float tf0 = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1)) * 1.0000004f;
-        a0 = __builtin_fmaf(n1.x, ix, -ox); a1 = __builtin_fmaf(n1.y, ix, -ox);
-        b0 = __builtin_fmaf(n1.z, iy, -oy); b1 = __builtin_fmaf(n1.w, iy, -oy);
-        c0 = __builtin_fmaf(n2.z, iz, -oz); c1 = __builtin_fmaf(n2.w, iz, -oz);
-        const float tn1 = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.f));
-        const float tf1 = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1)) * 1.0000004f;
-        const float lim = ANY ? GVT_FLT_MAX : bt;
-        const bool h0 = (tn0 <= tf0) && (tn0 <= lim);
-        const bool h1 = (tn1 <= tf1) && (tn1 <= lim);
-        const int r0 = __float_as_int(n3.x), r1 = __float_as_int(n3.y);
-        if (h0 && h1) {
-          const bool swap = tn1 < tn0;
-          const int farc = swap ? r0 : r1;
-          KT_PUSH(farc)
-          cur = swap ? r1 : r0;
-        } else if (h0 || h1) {
-          cur = h0 ? r0 : r1;
-        } else KT_POP()
       }
+#ifdef GVT_EXPERIMENTS
+      else {
+#include "experiments/binary_node_arm.inc"
       }
+#endif
 #if GVT_STAMP == 1
       n_inner_it++; n_inner_lanes += (unsigned long long)__popcll(__ballot(at_inner));
 #endif
@@ -477,31 +455,12 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
 #if GVT_STAMP == 1
       n_leaf_lanes += (unsigned long long)__popcll(__ballot(at_leaf));
 #endif
+#ifdef GVT_EXPERIMENTS
       if (COOP) {
-        const unsigned code = at_leaf ? (unsigned)~cur : 0u;
-        const unsigned first = code >> 3, ntri = code & 7u;
-        bool occluded = false;
-        for (unsigned k = 0; k < GVT_LEAF_MAX; k++) {
-          const bool want = at_leaf && k < ntri && !occluded;
-          if (!__ballot(want)) break;
-          float4 t0, t1, t2, t3;
-          quad_fetch64(T.tris, first + k, want, t0, t1, t2, t3);
-          if (want) {
-            float TT, U, V, aden;
-            if (tri_test_raw(O, D, mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), mk3(t3.x, t3.y, t3.z), tnear, TT, U, V, aden)) {
-              const float t = TT / aden;
-              if (t <= GVT_FLT_MAX) {
-                if (ANY) occluded = true;
-                else {
-                  const int prim = __float_as_int(t0.w);
-                  if (bp < 0 || t < bt || (t == bt && prim < bp)) { bt = t; bp = prim; bu = U; bv = V; bden = aden; }
-                }
-              }
-            }
-          }
-        }
-        if (at_leaf && ANY && occluded) bp = 0;
-      } else if (at_leaf) {
+#include "experiments/coop_leaf_arm.inc"
+      } else
+#endif
+      if (at_leaf) {
         const unsigned code = (unsigned)~cur;
         const unsigned first = code >> 3, ntri = code & 7u;
         const float4 *ts = (MULTI ? tris_l : T.tris) + 4 * (size_t)first;
@@ -614,6 +573,10 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
 #undef KT_PUSH
 #undef KT_POP
 }
+
+#ifdef GVT_EXPERIMENTS
+#include "experiments/quad_kernel.inc" // k_traceq: four lanes per ray (measured slower: VALU bound)
+#endif
 
 // A whole wave per parked ray.  The pending nodes live in a per-wave LDS list; each step the 64 lanes open up to 64 of them (newest
 // first), append the children the ray enters to the node list or the leaf list, and when enough leaves have gathered (or no node is
@@ -883,7 +846,9 @@ __global__ __launch_bounds__(256) void k_wave_any(RayPlanes q, const unsigned *_
   if (overflow) atomicOr(counter + TRAV_OVF_WORD, 1u);
 }
 
-#include "packet_kernel.inc" // k_packet: a wave walks the BVH for a packet of 64 coherent rays
+#ifdef GVT_EXPERIMENTS
+#include "experiments/packet_kernel.inc" // k_packet: a wave walks the BVH for a packet of 64 coherent rays
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Shading (Material.cpp:50-139, Light.cpp:58-133), in the oracle's evaluation order
@@ -1017,11 +982,13 @@ __device__ inline bool shade(const MatEval &m, const RayRec &ray, V3 N, const gv
   return true;
 }
 
+#ifdef GVT_EXPERIMENTS
 // out-of-line copies for k_fused: the shading code runs once per ray, the traversal loop thousands of times -- keeping it a call
 // keeps its registers out of the loop's allocation
 __device__ __attribute__((noinline)) bool shade_call(const MatEval &m, const RayRec &ray, V3 N, const gvt_hip_light &L, V3 lightPos, V3 &out) {
   return shade(m, ray, N, L, lightPos, out);
 }
+#endif
 
 // CosWeightedRandomHemisphereDirection2 (EmbreeMeshAdapter.cpp:289-318)
 __device__ inline V3 cos_weighted_dir(V3 n, uint32_t &seed) {
@@ -1215,7 +1182,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M1)
   }
 }
 
-#include "fused_kernel.inc" // k_fused: the one-kernel closest + shade + shadow variant (measured slower; knob `fused`)
+#ifdef GVT_EXPERIMENTS
+#include "experiments/fused_kernel.inc" // k_fused: the one-kernel closest + shade + shadow variant (measured slower; knob `fused`)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // layout conversions at the ABI boundary: 80-byte Ray AoS <-> planes
@@ -1316,9 +1285,14 @@ int trav_grid(size_t n) {
 }
 
 template <bool ANY, bool XFORM, int MODE, typename... Args> void launch_trace(bool have_nodes4, int grid, hipStream_t st, Args... args) {
-  if (gctx().wide4 && have_nodes4) k_trace<ANY, XFORM, MODE, false, true><<<grid, TRAV_BLOCK, 0, st>>>(args...);
-  else if (gctx().coop_fetch) k_trace<ANY, XFORM, MODE, true, false><<<grid, TRAV_BLOCK, 0, st>>>(args...);
-  else k_trace<ANY, XFORM, MODE, false, false><<<grid, TRAV_BLOCK, 0, st>>>(args...);
+#ifdef GVT_EXPERIMENTS
+  if (!(gctx().wide4 && have_nodes4)) { // the uncompressed binary nodes
+    if (gctx().coop_fetch) k_trace<ANY, XFORM, MODE, true, false><<<grid, TRAV_BLOCK, 0, st>>>(args...);
+    else k_trace<ANY, XFORM, MODE, false, false><<<grid, TRAV_BLOCK, 0, st>>>(args...);
+    return;
+  }
+#endif
+  k_trace<ANY, XFORM, MODE, false, true><<<grid, TRAV_BLOCK, 0, st>>>(args...); // a mesh without 4-wide nodes has no triangles: every ray retires as a miss
 }
 
 // scratch of a closest-hit launch's parked rays: n records, then LONG_SAVE stack entries for each of the first LONG_STK_CAP of them
@@ -1339,6 +1313,19 @@ int trav_grid2(size_t n, bool closest = false) {
   if (want > (size_t)C.trav_blocks) want = (size_t)C.trav_blocks;
   return (int)(need < want ? (need ? need : 1) : want);
 }
+
+#ifdef GVT_EXPERIMENTS
+// k_traceq: 64 rays in flight per 256-thread block
+int quad_grid(size_t n) {
+  Ctx &C = gctx();
+  size_t want = (size_t)C.n_cu * (size_t)C.blocks_per_cu_quad;
+  size_t need = (n + 63) / 64;
+  if (want > (size_t)C.trav_blocks) want = (size_t)C.trav_blocks;
+  return (int)(need < want ? (need ? need : 1) : want);
+}
+// (32-bit byte offsets into the node and leaf-block arrays: meshes beyond 2^26 triangles keep the one-lane-per-ray kernels)
+inline bool quad_usable(const gvt_hip_mesh *M) { return gctx().quad && gctx().trav_kernel == 1 && M->d_nodes4q && M->d_triq && M->nT < ((size_t)1 << 26) && M->nNodes4 < ((size_t)1 << 26); }
+#endif
 
 } // namespace
 
@@ -1411,12 +1398,19 @@ int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, 
   {
     ProfScope ps(KC_CLOSEST);
     RayPlanes none{};
-    if (C.trav_kernel == 1) {
-      if (xform) launch_trace<false, true, 0>(have_nodes4, trav_grid2(n, true), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
-      else launch_trace<false, false, 0>(have_nodes4, trav_grid2(n, true), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
-    } else {
+#ifdef GVT_EXPERIMENTS
+    if (quad_usable(M)) {
+      TravQ TQ{ M->d_nodes4q, M->d_triq };
+      if (xform) k_traceq<false, true, 0><<<quad_grid(n), 256, 0, C.stream>>>(q, idx, (unsigned)n, minv, TQ, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.quad_refill_min, C.quad_inner_min, nullptr, TermSink{}, LQ);
+      else k_traceq<false, false, 0><<<quad_grid(n), 256, 0, C.stream>>>(q, idx, (unsigned)n, minv, TQ, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.quad_refill_min, C.quad_inner_min, nullptr, TermSink{}, LQ);
+    } else if (C.trav_kernel != 1) {
       if (xform) k_closest<true><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
       else k_closest<false><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, idx, (unsigned)n, minv, T, tnear, d_hits, counter, C.d_spill);
+    } else
+#endif
+    {
+      if (xform) launch_trace<false, true, 0>(have_nodes4, trav_grid2(n, true), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
+      else launch_trace<false, false, 0>(have_nodes4, trav_grid2(n, true), C.stream, q, idx, (unsigned)n, minv, T, tnear, d_hits, nullptr, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
     }
   }
   if (LQ.steps) {
@@ -1458,12 +1452,19 @@ int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const M
   RayPlanes none{};
   {
     ProfScope ps(KC_ANY);
-    if (C.trav_kernel == 1) {
-      if (xform) launch_trace<true, true, 0>(have_nodes4, trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LongQ{});
-      else launch_trace<true, false, 0>(have_nodes4, trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LongQ{});
-    } else {
+#ifdef GVT_EXPERIMENTS
+    if (quad_usable(M)) {
+      TravQ TQ{ M->d_nodes4q, M->d_triq };
+      if (xform) k_traceq<true, true, 0><<<quad_grid(n), 256, 0, C.stream>>>(q, nullptr, (unsigned)n, minv, TQ, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.quad_refill_min, C.quad_inner_min, nullptr, TermSink{}, LongQ{});
+      else k_traceq<true, false, 0><<<quad_grid(n), 256, 0, C.stream>>>(q, nullptr, (unsigned)n, minv, TQ, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.quad_refill_min, C.quad_inner_min, nullptr, TermSink{}, LongQ{});
+    } else if (C.trav_kernel != 1) {
       if (xform) k_any<true, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
       else k_any<false, 0><<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, minv, T, tnear, d_flags, none, nullptr, counter, C.d_spill);
+    } else
+#endif
+    {
+      if (xform) launch_trace<true, true, 0>(have_nodes4, trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LongQ{});
+      else launch_trace<true, false, 0>(have_nodes4, trav_grid2(n), C.stream, q, nullptr, (unsigned)n, minv, T, tnear, nullptr, d_flags, none, nullptr, counter, C.d_spill, C.refill_min, C.inner_min, nullptr, C.share, (unsigned)C.share_min_rays, TermSink{}, LongQ{});
     }
   }
   HIPCHK(hipGetLastError());
@@ -1515,6 +1516,11 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
   const unsigned *idx = nullptr;
   unsigned *next = d_idx_a;
   int pass = 0;
+#ifdef GVT_EXPERIMENTS
+  const bool persistent = C.trav_kernel == 1;
+#else
+  const bool persistent = true;
+#endif
   while (n_active) { // while (validRayLeft) :465
     int rc;
     if (C.sort_rays && n_active >= 8192) { // ray sorting: traverse in Morton order of the object-space origin
@@ -1550,7 +1556,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
     A.in = in; A.idx = idx; A.n = (unsigned)n_active; A.index_base = index_base; A.hits = d_hits;
     A.first_pass = (pass == 0); A.carried_rng = P.carried_rng; A.out = outp; A.out_count = out->d_count; A.shadow = shadow; A.shadow_count = c_shadow;
     A.next_idx = next; A.next_count = c_next; A.lights = d_lights; A.normi = P.normi; A.normal_mode = P.normal_mode;
-    A.n_lights = nL; A.seed = P.seed; A.zero_word = (C.trav_kernel == 1) ? C.d_counters + 0 : nullptr;
+    A.n_lights = nL; A.seed = P.seed; A.zero_word = persistent ? C.d_counters + 0 : nullptr;
     A.sink = P.sink; A.update_in_place = P.update_in_place;
     A.n_dev = nullptr; A.W = WaveSet{}; A.out_from = nullptr; A.shadow_inst = nullptr; A.shadow_stride = 0;
     {
@@ -1563,12 +1569,18 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
     // it, the grid does not depend on it); the host learns the counts of the pass in ONE read-back afterwards.
     unsigned n_shadow = 0, n_next = 0;
     const size_t shadow_ub = n_active * (size_t)nL;
-    if (C.trav_kernel == 1) {
+    if (persistent) {
       if (shadow_ub) {
         Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
         unsigned *counter = C.d_counters + 0; // zeroed by k_shade
         {
           ProfScope ps(KC_ANY);
+#ifdef GVT_EXPERIMENTS
+          if (quad_usable(M))
+            k_traceq<true, true, 1><<<quad_grid(shadow_ub), 256, 0, st>>>(shadow, nullptr, 0u, P.minv, TravQ{ M->d_nodes4q, M->d_triq }, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count, counter,
+                                                                          C.d_spill, C.quad_refill_min, C.quad_inner_min, c_shadow, P.sink, LongQ{});
+          else
+#endif
           launch_trace<true, true, 1>(M->d_nodes4 != nullptr, trav_grid2(shadow_ub), st, shadow, nullptr, 0u, P.minv, T, GVT_RAY_EPSILON, nullptr, nullptr, outp,
                                                                                out->d_count, counter, C.d_spill, C.refill_min, C.inner_min, c_shadow, C.share, (unsigned)C.share_min_rays, P.sink, LongQ{});
         }
@@ -1582,7 +1594,9 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
       if ((rc = trav_overflow_result())) return rc;
       n_shadow = C.h_pinned[0]; n_next = C.h_pinned[1];
       C.stats.rays_any += n_shadow;
-    } else {
+    }
+#ifdef GVT_EXPERIMENTS
+    else { // trav_kernel=0: the first-version kernels size their grid from the host-known count
       HIPCHK(hipMemcpyAsync(C.h_pinned, c_shadow, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
       n_shadow = C.h_pinned[0]; n_next = C.h_pinned[1];
@@ -1602,6 +1616,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
       HIPCHK(hipMemcpyAsync(C.h_pinned + 2, out->d_count, sizeof(unsigned), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
     }
+#endif
     n_active = n_next;
     idx = next;
     next = (next == d_idx_a) ? d_idx_b : d_idx_a;
@@ -1704,6 +1719,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       LongQ LQ{};
       if (use_long && have4) { LQ.recs = d_long; LQ.count = c + 3; long_limits(LQ, n); }
       const bool small1 = small && have4;
+#ifdef GVT_EXPERIMENTS
       // a coherent list (camera rays in 8x8 tiles, straight from the filter): a wave walks the tree for 64 rays at once (k_packet)
       const bool pkt = C.packet && single->coherent && pass == 0 && have4 && !small1;
       if (pkt) {
@@ -1712,11 +1728,23 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
         k_packet<false><<<blocks_for(n), 256, 0, st>>>(single->planes, (unsigned)n, n_dev, single->minv, TS, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
                                                      TermSink{}, LP, nullptr, nullptr, nullptr, c + 9);
         k_long_closest<true><<<C.n_cu * 3, 256, 0, st>>>(single->planes, d_long, c + 3, single->minv, TS, GVT_RAY_EPSILON, d_hits, c + 4); // packets that bailed out
-      } else if (small1) {
+      } else
+#else
+      const bool pkt = false;
+#endif
+      if (small1) {
         ProfScope ps(KC_CLOSEST);
         k_long_seed<<<blocks_for(n), 256, 0, st>>>(d_long, c + 3, idx, (unsigned)n, n_dev);
         k_long_closest<true><<<small_grid, 256, 0, st>>>(single->planes, d_long, c + 3, single->minv, TS, GVT_RAY_EPSILON, d_hits, c + 4);
-      } else {
+      }
+#ifdef GVT_EXPERIMENTS
+      else if (quad_usable(M)) {
+        ProfScope ps(KC_CLOSEST);
+        k_traceq<false, true, 0><<<quad_grid(n), 256, 0, st>>>(single->planes, idx, (unsigned)n, single->minv, TravQ{ M->d_nodes4q, M->d_triq }, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
+                                                             c + 0, C.d_spill, C.quad_refill_min, C.quad_inner_min, n_dev, TermSink{}, LQ);
+      }
+#endif
+      else {
         ProfScope ps(KC_CLOSEST);
         launch_trace<false, true, 0>(have4, trav_grid2(n, true), st, single->planes, idx, (unsigned)n, single->minv, TS, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
                                      c + 0, C.d_spill, C.refill_min, C.inner_min, n_dev, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
@@ -1744,6 +1772,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
         ProfScope ps(KC_ANY);
         TermSink sk = P.sink;
         sk.from = single->inst;
+#ifdef GVT_EXPERIMENTS
         if (pkt) {
           unsigned *d_retry = (unsigned *)scratch_get(18, sizeof(unsigned) * shadow_cap);
           if (!d_retry) return GVT_HIP_ERR_DEVICE;
@@ -1752,7 +1781,12 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
           // rays of packets that bailed out: one lane per ray (an empty list costs a few microseconds)
           launch_trace<true, true, 1>(have4, trav_grid2(4096), st, shadow, d_retry, 0u, single->minv, TS, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
                                       c + 0, C.d_spill, C.refill_min, C.inner_min, c + 6, C.share, (unsigned)C.share_min_rays, sk, LongQ{});
-        } else if (small1) k_wave_any<false><<<(int)std::min<size_t>((shadow_cap + 3) / 4, (size_t)C.n_cu * 3), 256, 0, st>>>(shadow, c + 1, single->minv, TS, GVT_RAY_EPSILON, outp, out->d_count, c + 0, sk, MultiSrc{});
+        } else if (quad_usable(M) && !small1)
+          k_traceq<true, true, 1><<<quad_grid(shadow_cap), 256, 0, st>>>(shadow, nullptr, 0u, single->minv, TravQ{ M->d_nodes4q, M->d_triq }, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
+                                                                       c + 0, C.d_spill, C.quad_refill_min, C.quad_inner_min, c + 1, sk, LongQ{});
+        else
+#endif
+        if (small1) k_wave_any<false><<<(int)std::min<size_t>((shadow_cap + 3) / 4, (size_t)C.n_cu * 3), 256, 0, st>>>(shadow, c + 1, single->minv, TS, GVT_RAY_EPSILON, outp, out->d_count, c + 0, sk, MultiSrc{});
         else launch_trace<true, true, 1>(have4, trav_grid2(shadow_cap), st, shadow, nullptr, 0u, single->minv, TS, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
                                          c + 0, C.d_spill, C.refill_min, C.inner_min, c + 1, C.share, (unsigned)C.share_min_rays, sk, LongQ{});
       }
@@ -1761,6 +1795,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       C.stats.launches_any++;
       continue;
     }
+#ifdef GVT_EXPERIMENTS
     if (C.fused && P.sink.fb) {
       // one launch: closest hit, shade, the first light's shadow rays, terminal rule (k_fused); lights 1.. through the list
       FusedArgs F;
@@ -1786,6 +1821,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       C.stats.launches_closest++;
       continue;
     }
+#endif
     LongQ LQ{};
     if (use_long) { LQ.recs = d_long; LQ.count = c + 3; long_limits(LQ, n); }
     MultiSrc MS{ W, nullptr, nullptr, nullptr };
@@ -1793,7 +1829,15 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       ProfScope ps(KC_CLOSEST);
       k_long_seed<<<blocks_for(n), 256, 0, st>>>(d_long, c + 3, idx, (unsigned)n, n_dev);
       k_long_closest<true, true><<<small_grid, 256, 0, st>>>(none, d_long, c + 3, id, T, GVT_RAY_EPSILON, d_hits, c + 4, W);
-    } else {
+    }
+#ifdef GVT_EXPERIMENTS
+    else if (C.quad && W.quad_ok) {
+      ProfScope ps(KC_CLOSEST);
+      k_traceq<false, true, 0, true><<<quad_grid(n), 256, 0, st>>>(none, idx, (unsigned)n, id, TravQ{}, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
+                                                                 c + 0, C.d_spill, C.quad_refill_min, C.quad_inner_min, n_dev, TermSink{}, LQ, MS);
+    }
+#endif
+    else {
       ProfScope ps(KC_CLOSEST);
       k_trace<false, true, 0, false, true, true><<<trav_grid2(n, true), TRAV_BLOCK, 0, st>>>(none, idx, (unsigned)n, id, T, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
                                                                                       c + 0, C.d_spill, C.refill_min, C.inner_min, n_dev, C.share, (unsigned)C.share_min_rays,
@@ -1820,6 +1864,11 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       ProfScope ps(KC_ANY);
       MultiSrc MA{ W, d_shadow_inst, d_out_from, direct ? (unsigned long long *)(c + 18) : nullptr };
       if (small) k_wave_any<true><<<(int)std::min<size_t>((shadow_cap + 3) / 4, (size_t)C.n_cu * 3), 256, 0, st>>>(shadow, c + 1, id, T, GVT_RAY_EPSILON, outp, out->d_count, c + 0, P.sink, MA);
+#ifdef GVT_EXPERIMENTS
+      else if (C.quad && W.quad_ok)
+        k_traceq<true, true, 1, true><<<quad_grid(shadow_cap), 256, 0, st>>>(shadow, nullptr, direct ? (unsigned)shadow_cap : 0u, id, TravQ{}, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
+                                                                           c + 0, C.d_spill, C.quad_refill_min, C.quad_inner_min, direct ? nullptr : c + 1, P.sink, LongQ{}, MA);
+#endif
       else
       k_trace<true, true, 1, false, true, true><<<trav_grid2(shadow_cap), TRAV_BLOCK, 0, st>>>(shadow, nullptr, direct ? (unsigned)shadow_cap : 0u, id, T, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
                                                                                               c + 0, C.d_spill, C.refill_min, C.inner_min, direct ? nullptr : c + 1, C.share, (unsigned)C.share_min_rays,

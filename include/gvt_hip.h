@@ -293,9 +293,14 @@ int gvt_hip_visit_stats(gvt_hip_mesh *, const float *org, const float *dir, size
  * functions the bounce path (EmbreeMeshAdapter.cpp:289-318) is built on. */
 int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
 /* adapter-internal tuning knobs (results never depend on them; gvt_internal.h `struct Knobs` lists them with their defaults):
- * "wide4", "blocks_per_cu", "refill_min", "inner_min", "share", "share_min_rays", "long_steps", "long_steps_drain", "long_save", "long_min_rays", "sort_rays", "sort_bits",
- * "top_ordered", "top_lds", "fused", "packet", "small_rays", "first_round_async", "wave_single", "shadow_direct", "blocks_per_cu_closest", "term_sink", "camera_tile", "trav_kernel", "coop_fetch"; ("defaults", 0) restores all of them. */
+ * "blocks_per_cu", "blocks_per_cu_closest", "refill_min", "inner_min", "share", "share_min_rays", "long_steps", "long_steps_drain", "long_save", "long_min_rays",
+ * "sort_rays", "sort_bits", "top_ordered", "top_lds", "small_rays", "first_round_async", "wave_single", "shadow_direct", "term_sink", "camera_tile", "leaf_max";
+ * ("defaults", 0) restores all of them.  The variants that were measured and lost -- "trav_kernel" = 0, "wide4" = 0, "coop_fetch", "fused", "packet", "quad"
+ * -- are compiled only into the experiments build of the library (libgvt_hip_exp.so, -DGVT_EXPERIMENTS); the shipped library answers
+ * GVT_HIP_ERR_INVALID when one of them is switched away from its default. */
 int gvt_hip_set_option(const char *name, int value);
+/* 1 in the experiments build (every variant behind its knob), 0 in the shipped library */
+int gvt_hip_is_experiments_build(void);
 
 #ifdef __cplusplus
 }

@@ -254,11 +254,12 @@ def test_top_level_bvh_with_1056_instances(hip):
     assert np.array_equal(it().framebuffer(True)[..., :3], ref[..., :3]) and it.adapter_calls == st.adapter_calls
 
 
-@pytest.mark.parametrize("opts", [dict(packet=1), dict(packet=1, camera_tile=0), dict(first_round_async=0), dict(first_round_async=1, packet=1), dict(small_rays=0), dict(small_rays=1 << 30), dict(wave_single=0), dict(shadow_direct=0), dict(fused=1),
-                                  dict(small_rays=1 << 30, wave_single=0), dict(blocks_per_cu_closest=0, term_sink=0)])
+@pytest.mark.parametrize("opts", [dict(first_round_async=0), dict(small_rays=0), dict(small_rays=1 << 30), dict(wave_single=0), dict(shadow_direct=0),
+                                  dict(small_rays=1 << 30, wave_single=0), dict(blocks_per_cu_closest=0, term_sink=0), dict(leaf_max=4, small_rays=0)])
 def test_round_results_do_not_depend_on_knobs(hip, opts):
     """The round chain's variants -- a wave per ray for small rounds, single-mesh kernels for one-queue rounds, direct-mapped shadow
-    slots, the one-kernel k_fused, no terminal sink -- return the oracle's image on a multi-domain depth-2 frame and on config 4."""
+    slots, no terminal sink -- return the oracle's image on a multi-domain depth-2 frame and on config 4 (k_fused / k_packet /
+    k_traceq: tests/experiment_cases.py, against the experiments build)."""
     for sc, mode, tol in ((config5(192, 4), NORMALS_FLAT, 1e-5), (scenes.bunny_grid_scene(width=380, height=216), NORMALS_SMOOTH, 0.0),
                           (scenes.soup_scene(100_000, 160, 90), NORMALS_FLAT, 0.0)):
         ref, st = oracle_render(sc, mode, nthreads=8)

@@ -64,23 +64,26 @@ def test_closest_and_any_hit_match_oracle(hip, name):
     assert info["n_tris"] == len(mesh.tris) and np.allclose(info["bbox_lo"], lo) and np.allclose(info["bbox_hi"], hi)
 
 
-@pytest.mark.parametrize("opts", [dict(trav_kernel=0), dict(refill_min=1, inner_min=1), dict(refill_min=64, inner_min=64),
+@pytest.mark.parametrize("opts", [dict(refill_min=1, inner_min=1), dict(refill_min=64, inner_min=64),
                                   dict(blocks_per_cu=1, refill_min=8, inner_min=16), dict(sort_rays=0, top_lds=0), dict(sort_rays=1, sort_bits=32),
-                                  dict(wide4=0, coop_fetch=0), dict(wide4=0, coop_fetch=1, refill_min=3, inner_min=5), dict(wide4=0, sort_rays=1),
-                                  dict(wide4=1, refill_min=2, inner_min=60), dict(share=0), dict(share=3, blocks_per_cu=6, refill_min=64, share_min_rays=0), dict(share=3, share_min_rays=0),
+                                  dict(refill_min=2, inner_min=60), dict(share=0), dict(share=3, blocks_per_cu=6, refill_min=64, share_min_rays=0), dict(share=3, share_min_rays=0),
                                   dict(share=3, share_min_rays=0, long_steps=3, long_min_rays=0), dict(share=1, share_min_rays=0, blocks_per_cu=1),
-                                  dict(long_steps=2, long_min_rays=0), dict(long_steps=0), dict(top_ordered=0), dict(term_sink=0, camera_tile=0)])
+                                  dict(long_steps=2, long_min_rays=0), dict(long_steps=0), dict(top_ordered=0), dict(term_sink=0, camera_tile=0),
+                                  dict(leaf_max=1), dict(leaf_max=4, long_steps=4, long_min_rays=0), dict(leaf_max=3, share=3, share_min_rays=0)])
 def test_results_do_not_depend_on_tuning_knobs(hip, opts):
-    """Both traversal kernels and every refill / phase / grid / sorting setting return the same bits."""
+    """Every refill / phase / grid / sorting / leaf-size setting of the shipped kernels returns the same bits (the variants that live
+    in the experiments build only: tests/experiment_cases.py)."""
     sc = scenes.soup_scene(150_000, 160, 90)
     mesh = sc.meshes[0]
-    ad, om = HipMeshAdapter(mesh), orc.Mesh(mesh.verts, mesh.tris, mesh_mat=mesh.material)
+    om = orc.Mesh(mesh.verts, mesh.tris, mesh_mat=mesh.material)
     lo, hi = om.bbox()
     org, d = seeded_rays_at(lo, hi, 30_001, 21)
     rays = oracle_camera_rays(sc)
     try:
         for k, v in opts.items():
             hip.set_option(k, v)
+        ad = HipMeshAdapter(mesh)  # after the options: leaf_max is a build-time knob of the mesh
+        assert ad.info()["max_leaf"] == opts.get("leaf_max", 2)
         assert_hits_equal(ad.intersect(org, d), om.intersect(org, d))
         assert (ad.occluded(org, d) == om.occluded(org, d)).all()
         rg, rc = rays.copy(), rays.copy()

@@ -9,7 +9,7 @@ STAMP_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgvt_hip
 if "--build" in sys.argv:
     srcs = [os.path.join(_build.CSRC, s) for s in _build.SOURCES]
     level = [a for a in sys.argv if a.startswith("--level=")]
-    subprocess.check_call([_build.hipcc()] + _build.FLAGS + ["-DGVT_STAMP=" + (level[0][8:] if level else "1"), "-shared", "-o", STAMP_LIB] + srcs)
+    subprocess.check_call([_build.hipcc()] + _build.FLAGS + ["-DGVT_STAMP=" + (level[0][8:] if level else "1"), "-DGVT_EXPERIMENTS", "-shared", "-o", STAMP_LIB] + srcs)
     print(STAMP_LIB); sys.exit(0)
 capi.LIB_PATH = STAMP_LIB
 from gravit_amd.scheduler import ImageTracer
