@@ -198,6 +198,7 @@ extern "C" int gvt_hip_set_option(const char *name, int value) {
   if (!std::strcmp(name, "packet")) { g_ctx.packet = value; return 0; }
   if (!std::strcmp(name, "small_rays")) { g_ctx.small_rays = value < 0 ? 0 : value; return 0; }
   if (!std::strcmp(name, "first_round_async")) { g_ctx.first_round_async = value; return 0; }
+  if (!std::strcmp(name, "lean_frame")) { g_ctx.lean_frame = value; return 0; }
   if (!std::strcmp(name, "wave_single")) { g_ctx.wave_single = value; return 0; }
   if (!std::strcmp(name, "shadow_direct")) { g_ctx.shadow_direct = value; return 0; }
   if (!std::strcmp(name, "term_sink")) { g_ctx.term_sink = value; return 0; }
@@ -293,7 +294,7 @@ extern "C" void gvt_hip_mesh_destroy(gvt_hip_mesh *M) {
   if (!M) return;
   if (g_ctx.ready) hipStreamSynchronize(g_ctx.stream);
   hipFree(M->d_verts); hipFree(M->d_tris); hipFree(M->d_normals); hipFree(M->d_vcolors); hipFree(M->d_materials);
-  hipFree(M->d_face_mat); hipFree(M->d_nodes); hipFree(M->d_tri); hipFree(M->d_nodes4); hipFree(M->d_nodes4q); hipFree(M->d_triq);
+  hipFree(M->d_face_mat); hipFree(M->d_nodes); hipFree(M->d_tri); hipFree(M->d_slot_of); hipFree(M->d_nodes4); hipFree(M->d_nodes4q); hipFree(M->d_triq);
   delete M;
 }
 

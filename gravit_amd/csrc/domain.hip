@@ -33,6 +33,7 @@
 
 int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *from_arr, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
                   gvt_hip_fb *fb, unsigned *d_overflow, const void *d_qdesc);
+int camera_one_instance_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *q, gvt_hip_fb *fb, unsigned *d_overflow, unsigned *d_moved_count);
 int camera_filter_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *const *queues, const uint8_t *keep_mask, unsigned *d_overflow,
                         size_t first, size_t count);
 
@@ -313,11 +314,16 @@ namespace {
 // sizes[i] = *count_ptr[i]; the announce row for every peer; totals (2 x u64) and flags copied next to them so that ONE device-to-host
 // copy carries everything the host needs from a round
 __global__ void k_round_report(unsigned *const *__restrict__ count_ptr, const int *__restrict__ owner, int n_inst, int rank, int world,
-                               unsigned *__restrict__ sizes, int *__restrict__ ann /* [world][ANN_HEAD + n_inst] */, const unsigned *__restrict__ counters,
+                               unsigned *__restrict__ sizes, int *__restrict__ ann /* [world][ANN_HEAD + n_inst] */, unsigned *counters,
                                const unsigned *__restrict__ overflow, unsigned *__restrict__ tail /* sizes + n_inst: tot[4], ovf trav, ovf queue, bbox[4] */,
-                               const int *__restrict__ bbox) {
+                               const int *__restrict__ bbox, int chain_end = 0, const unsigned char *__restrict__ chain_mask = nullptr) {
   __shared__ unsigned long long sh_out, sh_local;
   if (threadIdx.x == 0) { sh_out = 0; sh_local = 0; }
+  if (chain_end) { // the launch chain in front left its k_wave_end to this kernel: last pass's shadow rays into the frame total, traced queues cleared
+    if (threadIdx.x == 0) { unsigned long long *tot = (unsigned long long *)(counters + 16); tot[1] += counters[1]; }
+    for (int i = threadIdx.x; i < n_inst; i += blockDim.x)
+      if (chain_mask[i]) *count_ptr[i] = 0u;
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < n_inst; i += blockDim.x) {
     const unsigned s = *count_ptr[i];
@@ -509,7 +515,7 @@ extern "C" gvt_hip_tracer *gvt_hip_tracer_create(gvt_hip_top *T, gvt_hip_mesh *c
     if (!M->d_nodes4 && M->nNodes) ok = build_nodes4(M) == 0; // the merged kernels traverse the 4-wide layout
     I.nodes4 = M->d_nodes4; I.tris = M->d_tri; I.nodes4q = M->d_nodes4q; I.trisq = M->d_triq;
     if (M->nNodes && !(M->d_nodes4q && M->d_triq)) R->all_quad = false;
-    I.mv.verts = M->d_verts; I.mv.tris = M->d_tris; I.mv.normals = M->d_normals; I.mv.vcolors = M->d_vcolors;
+    I.mv.slots = M->d_tri; I.mv.slot_of = M->d_slot_of; I.mv.verts = M->d_verts; I.mv.tris = M->d_tris; I.mv.normals = M->d_normals; I.mv.vcolors = M->d_vcolors;
     I.mv.materials = M->d_materials; I.mv.n_mat = (unsigned)M->nMat; I.mv.face_mat = M->d_face_mat; I.mv.mat = M->mesh_mat;
   }
   R->round_bytes = (sizeof(WaveSeg) + sizeof(QueueDesc)) * n1 + ((n1 + 15) & ~(size_t)15);
@@ -577,7 +583,8 @@ int grow(void **buf, size_t *cap, size_t bytes) {
 // (1) of a round: the merged launch chain over this rank's non-empty queues + the shuffle of everything that moved.  Host-known
 // sizes in R->present; on return they are stale until the next report.  extra_in[i]: rays about to be appended to queue i by a
 // pending unpack (room is reserved for them too).
-int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t *chains, bool fresh_from_camera, bool count_on_device = false) {
+int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t *chains, bool fresh_from_camera, bool count_on_device = false,
+                bool pass0_begun = false, bool defer_end = false) {
   Ctx &C = gctx();
   const size_t nI = R->n_inst;
   const int nL = (int)R->lights.size();
@@ -634,11 +641,12 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
     one.mesh = R->meshes[i0]; one.inst = i0;
     one.coherent = (fresh_from_camera && C.camera_tile == 8) ? 1 : 0;
     one.n_dev = count_on_device ? R->queues[i0]->d_count : nullptr; // present[i0] is then only the bound (the whole camera list)
+    one.pass0_begun = pass0_begun ? 1 : 0;
     std::memcpy(one.minv.m, R->minv.data() + 16 * (size_t)i0, 64);
     std::memcpy(one.normi.n, R->normi.data() + 9 * (size_t)i0, 36);
   }
   const bool single = one.mesh != nullptr;
-  if ((rc = wave_trace_chain(W, N, passes, R->q_moved, d_from, P, R->lights.data(), single ? &one : nullptr, R->d_count_ptr, R->d_mask, (int)nI))) return rc;
+  if ((rc = wave_trace_chain(W, N, passes, R->q_moved, d_from, P, R->lights.data(), single ? &one : nullptr, R->d_count_ptr, R->d_mask, (int)nI, defer_end && single))) return rc;
   // one instance in the whole scene and the terminal rule applied inside the kernels: nothing can have moved
   if (!(nI == 1 && P.sink.fb) &&
       (rc = shuffle_async(R->top, R->q_moved, bound, single ? nullptr : d_from, single ? one.inst : -1, R->queues.data(), nullptr, R->fb, R->d_overflow, R->d_qdesc))) return rc;
@@ -647,7 +655,7 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
 }
 
 // (3)+(4)+(5): report kernel -> [announce exchange] -> ONE device-to-host copy -> ONE host synchronisation
-int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs) {
+int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_end = false) {
   Ctx &C = gctx();
   const size_t nI = R->n_inst, row = ANN_HEAD + nI;
   hipStream_t st = C.stream;
@@ -657,7 +665,7 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs) {
     k_fb_bbox<<<(unsigned)(((size_t)R->fb->w * R->fb->h + 255) / 256), 256, 0, st>>>((const float4 *)R->fb->d_rgba, R->fb->w, R->fb->h, d_bbox);
   }
   k_round_report<<<1, 256, 0, st>>>(R->d_count_ptr, R->d_owner, (int)nI, R->rank, R->world, R->d_report, R->d_ann_out, C.d_counters, R->d_overflow,
-                                    R->d_report + nI, d_bbox);
+                                    R->d_report + nI, d_bbox, chain_end ? 1 : 0, R->d_mask);
   HIPCHK(hipGetLastError());
   if (exchange && R->world > 1) {
     gvt_hip_comm *K = R->comm;
@@ -712,23 +720,29 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   gvt_hip_frame_stats S{};
   int rc;
   // clearBuffer + generateRays + FilterRaysLocally / shuffleDropRays (ImageTracer.h:137-146, DomainTracer.h:148-183, 204-211)
-  if ((rc = gvt_hip_fb_clear(R->fb))) return rc;
-  for (size_t i = 0; i < nI; i++) R->queues[i]->size = 0;
-  R->q_moved->size = 0;
-  if (nI) k_zero_counts<<<(unsigned)((nI + 255) / 256), 256, 0, st>>>(R->d_count_ptr, nullptr, (int)nI); // every queue.clear() in one launch
-  k_zero_totals<<<1, 64, 0, st>>>(C.d_counters, R->d_overflow);
   // One instance, one rank, terminal rule inside the kernels: the first (and only) launch chain takes its ray count from the queue's
   // count word on the device -- the camera filter needs no read-back and the frame has ONE host synchronisation.
   const bool one_shot = nI == 1 && R->world == 1 && C.term_sink && C.wave_single && R->meshes[0] && C.first_round_async;
+  // ... and in eight launches: the camera filter's two kernels also clear the framebuffer and do the resets (k_zero_counts,
+  // k_zero_totals, k_wave_pass_begin), the round's report does k_wave_end's work
+  const bool lean = one_shot && C.lean_frame;
+  for (size_t i = 0; i < nI; i++) R->queues[i]->size = 0;
+  R->q_moved->size = 0;
+  if (!lean) {
+    if ((rc = gvt_hip_fb_clear(R->fb))) return rc;
+    if (nI) k_zero_counts<<<(unsigned)((nI + 255) / 256), 256, 0, st>>>(R->d_count_ptr, nullptr, (int)nI); // every queue.clear() in one launch
+    k_zero_totals<<<1, 64, 0, st>>>(C.d_counters, R->d_overflow);
+  }
   if (one_shot) {
     const size_t n_cam = (size_t)R->cam.width * R->cam.height * R->cam.samples * R->cam.samples;
     const int passes0 = R->cam.depth > 1 ? R->cam.depth : 1;
     if ((rc = queue_reserve(R->queues[0], n_cam * (size_t)(1 + (int)R->lights.size() * passes0)))) return rc; // what local_chain will ask for: no move later
-    if ((rc = camera_filter_async(R->top, &R->cam, C.camera_tile, R->queues.data(), nullptr, R->d_overflow, 0, 0))) return rc;
+    if (lean) { if ((rc = camera_one_instance_async(R->top, &R->cam, C.camera_tile, R->queues[0], R->fb, R->d_overflow, R->q_moved->d_count))) return rc; }
+    else if ((rc = camera_filter_async(R->top, &R->cam, C.camera_tile, R->queues.data(), nullptr, R->d_overflow, 0, 0))) return rc;
     R->present[0] = n_cam;
     R->queues[0]->size = n_cam; // bound of what the device holds (a reallocation would copy at least that)
-    if ((rc = local_chain(R, nullptr, &S.chains, true, true))) return rc;
-    if ((rc = round_report(R, false, &S.host_syncs))) return rc;
+    if ((rc = local_chain(R, nullptr, &S.chains, true, true, lean, lean))) return rc;
+    if ((rc = round_report(R, false, &S.host_syncs, lean))) return rc;
   } else if (image_split) {
     const size_t n_cam = (size_t)R->cam.width * R->cam.height * R->cam.samples * R->cam.samples;
     const size_t portion = n_cam / (size_t)R->world, first = (size_t)R->rank * portion;

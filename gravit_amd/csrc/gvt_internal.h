@@ -43,6 +43,8 @@ struct Knobs {
                          // Off: 8 % faster on a surface mesh (bun_zipper), 2.5x-20x SLOWER on the random soups
   int small_rays = 4096; // scheduler rounds holding at most this many rays give every ray a whole wave (k_long_closest / k_wave_any): ~40 us
                          // per traversal launch instead of the ~150 us latency floor of a one-lane-per-ray launch
+  int lean_frame = 1;    // one-instance scenes on one rank: framebuffer clear, counter resets and the chain's begin / end folded into the camera filter's
+                         // two kernels and the round's report (8 launches per frame instead of 14)
   int first_round_async = 1; // one-instance scenes on one rank: no read-back after the camera filter (the chain reads its ray count on the device)
   int wave_single = 1;   // scheduler rounds: a round with ONE non-empty local queue uses the single-mesh kernels (no per-ray segment / instance lookups)
   int shadow_direct = 1; // scheduler rounds: shadow rays in direct-mapped slots (the order of the traced list) instead of block-arrival order
@@ -121,7 +123,8 @@ struct gvt_hip_mesh {
   // acceleration structure
   BvhNode *d_nodes = nullptr;
   size_t nNodes = 0;
-  float4 *d_tri = nullptr; // 4 float4 per slot, leaf order
+  float4 *d_tri = nullptr; // 4 float4 per slot, leaf order: (v0 | prim), (e1 | v1.x), (e2 | v1.y), (v1.z, v2)
+  unsigned *d_slot_of = nullptr; // primID -> slot (the shading kernel reads the triangle from the slot the traversal touched)
   uint4 *d_nodes4 = nullptr;  // compressed 4-wide collapse: 4 x 16 B (64 B) per node
   size_t nNodes4 = 0;
   uint4 *d_nodes4q = nullptr; // the same nodes laid out for the quad-per-ray traversal: piece s = child s (quad_kernel.inc)
@@ -187,6 +190,8 @@ struct TraceParams {
 
 // what k_shade needs of a mesh (shading attributes in their reference shapes)
 struct MeshView {
+  const float4 *slots;      // triangle slots in leaf order (gvt_hip_mesh::d_tri) and primID -> slot
+  const unsigned *slot_of;
   const float *verts;
   const int *tris;
   const float *normals;
@@ -250,9 +255,12 @@ struct WaveSingle { // the launch has ONE segment: its queue planes and instance
   int inst;
   int coherent; // the queue holds camera rays in tile order, straight from the filter: packet traversal (k_packet)
   const unsigned *n_dev; // the first pass's ray count lives in device memory (the queue's count word; n_total is only its bound)
+  int pass0_begun;       // the producer of the queue (k_cam1_scatter) has already done k_wave_pass_begin's pass-0 resets
 };
+// defer_end: the caller's next kernel (k_round_report) does k_wave_end's work
 int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
-                     const gvt_hip_light *lights_host, const WaveSingle *single, unsigned *const *d_count_ptr, const unsigned char *d_mask, int n_inst);
+                     const gvt_hip_light *lights_host, const WaveSingle *single, unsigned *const *d_count_ptr, const unsigned char *d_mask, int n_inst,
+                     bool defer_end = false);
 int convert_aos_to_planes(const gvt_hip_ray *d_src, size_t n, RayPlanes dst, size_t dst_off);
 int convert_planes_to_aos(RayPlanes src, size_t src_off, size_t n, gvt_hip_ray *d_dst);
 int convert_od_to_planes(const float *d_org, const float *d_dir, size_t n, RayPlanes dst);

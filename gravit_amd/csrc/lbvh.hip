@@ -214,18 +214,21 @@ __global__ __launch_bounds__(256) void k_emit_nodes(int n_inner, const unsigned 
 }
 
 __global__ __launch_bounds__(256) void k_emit_tris(const float *__restrict__ verts, const int *__restrict__ tris, const unsigned *__restrict__ sorted,
-                                                   unsigned n, float4 *__restrict__ out) {
+                                                   unsigned n, float4 *__restrict__ out, unsigned *__restrict__ slot_of) {
   unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   unsigned p = sorted[s];
   int a = tris[3 * p], b = tris[3 * p + 1], c = tris[3 * p + 2];
   V3 v0 = ld3(verts + 3 * a), v1 = ld3(verts + 3 * b), v2 = ld3(verts + 3 * c);
-  V3 e1 = sub3(v0, v1), e2 = sub3(v2, v0);
-  V3 Ng = cross3(e1, e2); // same float ops as evaluating it per test (no contraction): bit-identical
+  V3 e1 = sub3(v0, v1), e2 = sub3(v2, v0); // same float ops as evaluating them per test (no contraction): bit-identical
+  // the traversal reads (v0 | prim), e1, e2 (48 of the 64 bytes); the remaining six floats carry v1 and v2 as they are, so that the
+  // shading kernel finds the whole triangle in the one line the traversal has just touched (EmbreeMeshAdapter.cpp:503-504 needs
+  // cross(v1 - v0, v2 - v0) of the ORIGINAL vertices: -(e1 x e2) differs from it in the signs of zeros)
   out[4 * s + 0] = make_float4(v0.x, v0.y, v0.z, __int_as_float((int)p));
-  out[4 * s + 1] = make_float4(e1.x, e1.y, e1.z, 0.f);
-  out[4 * s + 2] = make_float4(e2.x, e2.y, e2.z, 0.f);
-  out[4 * s + 3] = make_float4(Ng.x, Ng.y, Ng.z, 0.f);
+  out[4 * s + 1] = make_float4(e1.x, e1.y, e1.z, v1.x);
+  out[4 * s + 2] = make_float4(e2.x, e2.y, e2.z, v1.y);
+  out[4 * s + 3] = make_float4(v1.z, v2.x, v2.y, v2.z);
+  slot_of[p] = s;
 }
 
 // Leaf blocks for the quad-per-ray traversal (quad_kernel.inc): the n <= 4 triangles of a leaf occupy n x 64 B starting at slot
@@ -445,6 +448,7 @@ int build_lbvh(gvt_hip_mesh *M) {
     pad = ext * 1e-5f; // keeps the slab test conservative w.r.t. the triangle test's rounding
   }
   OK(dalloc(&M->d_tri, (size_t)4 * n));
+  OK(dalloc(&M->d_slot_of, n));
   OK(dalloc(&leaf_of, n));
   if (want_q) OK(dalloc(&M->d_triq, (size_t)4 * n));
 
@@ -459,7 +463,7 @@ int build_lbvh(gvt_hip_mesh *M) {
       HOK(hipStreamSynchronize(st));
     }
     k_single_node<<<1, 64, 0, st>>>(plo, phi, n, pad, M->d_nodes);
-    k_emit_tris<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, n, M->d_tri);
+    k_emit_tris<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, n, M->d_tri, M->d_slot_of);
     if (want_q) {
       std::vector<unsigned> lo_(n, (unsigned)~leaf_ref(0u, n));
       HOK(hipMemcpyAsync(leaf_of, lo_.data(), sizeof(unsigned) * n, hipMemcpyHostToDevice, st));
@@ -506,7 +510,7 @@ int build_lbvh(gvt_hip_mesh *M) {
     M->nNodes = (size_t)last_idx + last_live;
     OK(dalloc(&M->d_nodes, M->nNodes));
     k_emit_nodes<<<(n_inner + B - 1) / B, B, 0, st>>>(n_inner, live, newidx, slo, shi, ilo, ihi, cl, cr, rf, rl, pad, M->d_nodes, nleaves, leaf_max, leaf_of);
-    k_emit_tris<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, n, M->d_tri);
+    k_emit_tris<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, n, M->d_tri, M->d_slot_of);
     if (want_q) k_emit_trisq<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, leaf_of, n, M->d_triq);
     unsigned nl = 0;
     HOK(hipMemcpyAsync(&nl, nleaves, sizeof(unsigned), hipMemcpyDeviceToHost, st));

@@ -224,6 +224,69 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_scatter(RaySrc S, unsigned n,
   }
 }
 
+// ---- ONE instance on ONE rank (the one-domain frame): clearBuffer + generateRays + FilterRaysLocally + the counter resets the
+// round's launch chain starts from, in two launches and without the classify / scatter hand-over arrays.  k_cam1_count: every thread
+// generates its ray, tests it against the instance box and zeroes its pixel of the framebuffer; a block leaves its number of
+// entering rays.  k_cam1_scatter: a block's first slot is the sum of the counts in front of it (a few thousand words from L2), its
+// rays are generated again and stored in list order -- the queue keeps the camera's (tile) order exactly as the three-kernel
+// shuffle did -- and the last block publishes the total and performs k_wave_pass_begin's pass-0 resets.
+__global__ __launch_bounds__(TOP_BLOCK) void k_cam1_count(CamArgs A, unsigned n, TopDev top, unsigned *__restrict__ blk_cnt, float4 *__restrict__ fb, unsigned n_pix,
+                                                          unsigned *__restrict__ c, unsigned *__restrict__ ovf) {
+  __shared__ unsigned sh_w[TOP_BLOCK / 64];
+  const unsigned i = blockIdx.x * TOP_BLOCK + threadIdx.x;
+  bool hit = false;
+  if (i < n) {
+    const RayRec r = camera_ray(A, (unsigned long long)i);
+    float ret_t;
+    hit = top_nearest(make_float4(r.o.x, r.o.y, r.o.z, r.t_min), make_float4(r.d.x, r.d.y, r.d.z, r.t_max), top, -1, ret_t) >= 0;
+    if (fb && i % (unsigned)(A.samples * A.samples) == 0u && (unsigned)r.id < n_pix) fb[(unsigned)r.id] = make_float4(0.f, 0.f, 0.f, 0.f); // clearBuffer
+  }
+  const unsigned long long m = __ballot(hit);
+  if (lane_id() == 0) sh_w[threadIdx.x >> 6] = (unsigned)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned tot = 0;
+    for (int w = 0; w < TOP_BLOCK / 64; w++) tot += sh_w[w];
+    blk_cnt[blockIdx.x] = tot;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 4) c[16 + threadIdx.x] = 0u; // the frame's ray totals (k_zero_totals)
+  if (blockIdx.x == 0 && threadIdx.x == 4) { *ovf = 0u; c[9] = 0u; }
+}
+__global__ __launch_bounds__(TOP_BLOCK) void k_cam1_scatter(CamArgs A, unsigned n, TopDev top, const unsigned *__restrict__ blk_cnt, QueueDesc Q,
+                                                            unsigned *__restrict__ overflow, unsigned *__restrict__ c, unsigned *__restrict__ moved_count) {
+  __shared__ unsigned sh_w[TOP_BLOCK / 64], sh_p[TOP_BLOCK / 64];
+  unsigned part = 0;
+  for (unsigned b = threadIdx.x; b < blockIdx.x; b += TOP_BLOCK) part += blk_cnt[b];
+  for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+  const unsigned i = blockIdx.x * TOP_BLOCK + threadIdx.x;
+  bool hit = false;
+  RayRec r;
+  if (i < n) {
+    r = camera_ray(A, (unsigned long long)i);
+    float ret_t;
+    hit = top_nearest(make_float4(r.o.x, r.o.y, r.o.z, r.t_min), make_float4(r.d.x, r.d.y, r.d.z, r.t_max), top, -1, ret_t) >= 0;
+    if (hit) r.o = add3(r.o, scl3(r.d, ret_t * 0.95f)); // TracerBase.h:393
+  }
+  const unsigned long long m = __ballot(hit);
+  if (lane_id() == 0) { sh_w[threadIdx.x >> 6] = (unsigned)__popcll(m); sh_p[threadIdx.x >> 6] = part; }
+  __syncthreads();
+  unsigned base = 0, mine = 0;
+  for (int w = 0; w < TOP_BLOCK / 64; w++) { base += sh_p[w]; if (w < (int)(threadIdx.x >> 6)) mine += sh_w[w]; }
+  if (hit) {
+    const unsigned slot = base + mine + lanes_below(m);
+    if (slot < Q.cap) store_ray(make_planes(Q.planes, Q.cap), slot, r);
+    else atomicOr(overflow, 1u);
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { // the list is complete behind this block
+    unsigned total = base;
+    for (int w = 0; w < TOP_BLOCK / 64; w++) total += sh_w[w];
+    *Q.count = total;
+    unsigned long long *tot = (unsigned long long *)(c + 16); // k_wave_pass_begin, pass 0 (trace.hip)
+    *moved_count = 0u; c[2] = 0u; c[5] = 0u; tot[0] += total;
+    c[0] = 0u; c[1] = 0u; c[3] = 0u; c[4] = 0u; c[6] = 0u;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_fb_clamp(const float *__restrict__ src, float *__restrict__ dst, unsigned long long n4, int clamp) {
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
@@ -507,6 +570,26 @@ int camera_filter_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt
   S.from_cam = 1;
   return shuffle_async_src(T, S, count, nullptr, nullptr, -1, queues, keep_mask, nullptr, d_overflow, nullptr);
 }
+// clearBuffer + generateRays + FilterRaysLocally for a ONE-instance scene on one rank, with the launch chain's pass-0 resets folded
+// in (k_cam1_count / k_cam1_scatter).  q must have room for all W*H*samples^2 rays; its count lives on the device only.
+int camera_one_instance_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *q, gvt_hip_fb *fb, unsigned *d_overflow, unsigned *d_moved_count) {
+  Ctx &C = gctx();
+  const size_t n = (size_t)cam->width * cam->height * cam->samples * cam->samples;
+  if (!n || n > 0xffffffffull || T->n != 1) { set_error("camera_one_instance: bad arguments"); return GVT_HIP_ERR_INVALID; }
+  const CamArgs A = make_cam_args(cam->eye, cam->focus, cam->up, cam->fov, cam->width, cam->height, cam->samples, cam->depth, cam->jitter_window_size, tile);
+  const unsigned n_blk = blocks_for(n, TOP_BLOCK);
+  unsigned *d_blk = (unsigned *)scratch_get(14, sizeof(unsigned) * n_blk);
+  if (!d_blk) return GVT_HIP_ERR_DEVICE;
+  QueueDesc Q{ q->d_planes, q->cap, q->d_count, 1u };
+  {
+    ProfScope ps(KC_SHUFFLE);
+    k_cam1_count<<<n_blk, TOP_BLOCK, 0, C.stream>>>(A, (unsigned)n, T->dev(), d_blk, fb ? (float4 *)fb->d_rgba : nullptr, fb ? (unsigned)(fb->w * fb->h) : 0u, C.d_counters, d_overflow);
+    k_cam1_scatter<<<n_blk, TOP_BLOCK, 0, C.stream>>>(A, (unsigned)n, T->dev(), d_blk, Q, d_overflow, C.d_counters, d_moved_count);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 static int shuffle_async_src(gvt_hip_top *T, const RaySrc &S, size_t n_ub, const unsigned *n_dev, const int *from_arr, int from, gvt_hip_queue *const *queues,
                              const uint8_t *keep_mask, gvt_hip_fb *fb, unsigned *d_overflow, const void *d_qdesc) {
   Ctx &C = gctx();

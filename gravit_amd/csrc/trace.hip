@@ -1079,8 +1079,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M1)
       shaded = true;
       float t = h.t;
       r.t = t; // :491
-      const int ia = M->tris[3 * h.prim], ib = M->tris[3 * h.prim + 1], ic = M->tris[3 * h.prim + 2];
-      const V3 v0 = ld3(M->verts + 3 * ia), v1 = ld3(M->verts + 3 * ib), v2 = ld3(M->verts + 3 * ic);
+      // the triangle's vertices from the 64-byte slot the traversal has just intersected (one line, usually still in L2) instead of
+      // three index words and three vertices gathered from the mesh's own arrays; the indices only where per-vertex attributes are used
+      const float4 *sl = M->slots + 4 * (size_t)M->slot_of[h.prim];
+      const float4 s0 = sl[0], s1 = sl[1], s2 = sl[2], s3 = sl[3];
+      const V3 v0 = mk3(s0.x, s0.y, s0.z), v1 = mk3(s1.w, s2.w, s3.x), v2 = mk3(s3.y, s3.z, s3.w);
+      int ia = 0, ib = 0, ic = 0;
+      if (A.normal_mode == GVT_HIP_NORMALS_SMOOTH || M->vcolors) { ia = M->tris[3 * h.prim]; ib = M->tris[3 * h.prim + 1]; ic = M->tris[3 * h.prim + 2]; }
       const V3 negNg = cross3(sub3(v1, v0), sub3(v2, v0)); // -Ng of Embree (cf. OptixMeshAdapter.cu:280-287)
       const V3 normalflat = norm3(mat3_mul(normi, negNg)); // :504
       if (A.normal_mode == GVT_HIP_NORMALS_SMOOTH) { // :505-518
@@ -1508,7 +1513,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
   k_trace_begin<<<1, 64, 0, st>>>(out->d_count, (unsigned)out->size, C.d_counters); // c_shadow, c_next, work counter
 
   MeshView mv;
-  mv.verts = M->d_verts; mv.tris = M->d_tris; mv.normals = M->d_normals; mv.vcolors = M->d_vcolors;
+  mv.slots = M->d_tri; mv.slot_of = M->d_slot_of; mv.verts = M->d_verts; mv.tris = M->d_tris; mv.normals = M->d_normals; mv.vcolors = M->d_vcolors;
   mv.materials = M->d_materials; mv.n_mat = (unsigned)M->nMat; mv.face_mat = M->d_face_mat;
   mv.mat = M->mesh_mat;
 
@@ -1668,7 +1673,8 @@ __global__ void k_wave_end(unsigned *c, unsigned *const *__restrict__ count_ptr,
 } // namespace
 
 int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
-                     const gvt_hip_light *lights_host, const WaveSingle *single, unsigned *const *d_count_ptr, const unsigned char *d_mask, int n_inst) {
+                     const gvt_hip_light *lights_host, const WaveSingle *single, unsigned *const *d_count_ptr, const unsigned char *d_mask, int n_inst,
+                     bool defer_end) {
   Ctx &C = gctx();
   if (!n_total) return 0;
   hipStream_t st = C.stream;
@@ -1709,7 +1715,8 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     const unsigned *idx = pass ? ((pass & 1) ? d_idx_a : d_idx_b) : nullptr;    // its bounce list
     unsigned *next = (pass & 1) ? d_idx_b : d_idx_a;
     unsigned *c_next = c + ((pass & 1) ? 5 : 2);
-    k_wave_pass_begin<<<1, 64, 0, st>>>(c, pass, (unsigned)n, out->d_count, (single && single->n_dev) ? single->n_dev : nullptr);
+    if (!(pass == 0 && single && single->pass0_begun))
+      k_wave_pass_begin<<<1, 64, 0, st>>>(c, pass, (unsigned)n, out->d_count, (single && single->n_dev) ? single->n_dev : nullptr);
     if (single) {
       // one segment (a single non-empty local queue, e.g. the one-domain benchmark): the single-mesh kernels -- no segment lookup and
       // no per-ray table loads at a refill -- with the same device-side counts
@@ -1762,7 +1769,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       A.n_dev = n_dev; A.W = WaveSet{}; A.out_from = nullptr; A.shadow_inst = nullptr; A.shadow_stride = 0;
       if (pkt) { A.shadow_inst = d_shadow_inst; A.shadow_stride = (unsigned)n; } // shadow rays in the primaries' order: packets again
       MeshView mv;
-      mv.verts = M->d_verts; mv.tris = M->d_tris; mv.normals = M->d_normals; mv.vcolors = M->d_vcolors;
+      mv.slots = M->d_tri; mv.slot_of = M->d_slot_of; mv.verts = M->d_verts; mv.tris = M->d_tris; mv.normals = M->d_normals; mv.vcolors = M->d_vcolors;
       mv.materials = M->d_materials; mv.n_mat = (unsigned)M->nMat; mv.face_mat = M->d_face_mat; mv.mat = M->mesh_mat;
       {
         ProfScope ps(KC_SHADE);
@@ -1878,7 +1885,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     C.stats.launches_closest++;
     C.stats.launches_any++;
   }
-  k_wave_end<<<(unsigned)((std::max(n_inst, 1) + 255) / 256), 256, 0, st>>>(c, d_count_ptr, d_mask, n_inst); // + queue[instTarget].clear()
+  if (!defer_end) k_wave_end<<<(unsigned)((std::max(n_inst, 1) + 255) / 256), 256, 0, st>>>(c, d_count_ptr, d_mask, n_inst); // + queue[instTarget].clear()
   HIPCHK(hipGetLastError());
   C.stats.trace_calls++;
   return 0;

@@ -24,7 +24,7 @@ else:
     def name(r):
         m = re.search(r"(k_[a-z_0-9]+)", r["Kernel_Name"])
         return m.group(1) if m else r["Kernel_Name"][:32]
-    idx = [i for i, r in enumerate(rows) if name(r) == "k_top_classify"]
+    idx = [i for i, r in enumerate(rows) if name(r) in ("k_top_classify", "k_cam1_count")]
     a = idx[-1]
     while a > 0 and int(rows[a]["Start_Timestamp"]) - int(rows[a - 1]["End_Timestamp"]) < 60000 and name(rows[a - 1]) != "k_round_report":
         a -= 1
