@@ -199,6 +199,8 @@ extern "C" int gvt_hip_set_option(const char *name, int value) {
   if (!std::strcmp(name, "small_rays")) { g_ctx.small_rays = value < 0 ? 0 : value; return 0; }
   if (!std::strcmp(name, "first_round_async")) { g_ctx.first_round_async = value; return 0; }
   if (!std::strcmp(name, "lean_frame")) { g_ctx.lean_frame = value; return 0; }
+  if (!std::strcmp(name, "report_poll")) { g_ctx.report_poll = value; return 0; }
+  if (!std::strcmp(name, "inject_fail_tick")) { g_ctx.inject_fail_tick = value; return 0; }
   if (!std::strcmp(name, "wave_single")) { g_ctx.wave_single = value; return 0; }
   if (!std::strcmp(name, "shadow_direct")) { g_ctx.shadow_direct = value; return 0; }
   if (!std::strcmp(name, "term_sink")) { g_ctx.term_sink = value; return 0; }

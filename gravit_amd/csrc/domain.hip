@@ -29,6 +29,9 @@
 #include <memory>
 #include <mutex>
 
+#include <chrono>
+#include <thread>
+
 #include "gvt_internal.h"
 
 int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *from_arr, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
@@ -52,6 +55,8 @@ struct Rccl {
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr; // optional
 };
 Rccl g_rccl;
 std::mutex g_rccl_mu;
@@ -68,8 +73,9 @@ int rccl_load() {
   if (!g_rccl.field) { set_error("RCCL symbol %s missing", name); dlclose(h); return GVT_HIP_ERR_DEVICE; }
   GVT_SYM(GetUniqueId, "ncclGetUniqueId") GVT_SYM(CommInitRank, "ncclCommInitRank") GVT_SYM(CommDestroy, "ncclCommDestroy")
   GVT_SYM(GroupStart, "ncclGroupStart") GVT_SYM(GroupEnd, "ncclGroupEnd") GVT_SYM(Send, "ncclSend") GVT_SYM(Recv, "ncclRecv")
-  GVT_SYM(Reduce, "ncclReduce") GVT_SYM(GetErrorString, "ncclGetErrorString")
+  GVT_SYM(Reduce, "ncclReduce") GVT_SYM(GetErrorString, "ncclGetErrorString") GVT_SYM(CommCount, "ncclCommCount")
 #undef GVT_SYM
+  *(void **)(&g_rccl.CommAbort) = dlsym(h, "ncclCommAbort");
   g_rccl.lib = h;
   return 0;
 }
@@ -120,6 +126,11 @@ struct gvt_hip_comm {
   gvt_hip_hub *hub = nullptr;
   struct Op { int send; void *ptr; size_t bytes; int peer; int accumulate; };
   std::vector<Op> ops; // the open group
+  int count = 1;          // ranks the transport itself reports (ncclCommCount / the hub's world)
+  int deadline_ms = 20000; // every blocking point of an exchange gives up after this long (GVT_HIP_ERR_TIMEOUT)
+  bool dead = false;      // a deadline passed: the communicator was aborted
+  hipEvent_t ev_wait = nullptr;
+  double ms_host_wait = 0.0; // host time spent in bounded waits since the frame began
 };
 
 extern "C" gvt_hip_hub *gvt_hip_hub_create(int world) {
@@ -157,6 +168,9 @@ static gvt_hip_comm *comm_new(int rank, int world) {
   gvt_hip_comm *K = new gvt_hip_comm();
   K->rank = rank; K->world = world;
   if (hipStreamCreateWithFlags(&K->stream, hipStreamNonBlocking) != hipSuccess) { set_error("comm_create: stream"); delete K; return nullptr; }
+  if (hipEventCreateWithFlags(&K->ev_wait, hipEventDisableTiming) != hipSuccess) { set_error("comm_create: event"); hipStreamDestroy(K->stream); delete K; return nullptr; }
+  if (const char *e = getenv("GVT_HIP_EXCHANGE_TIMEOUT_MS")) { const int v = atoi(e); if (v > 0) K->deadline_ms = v; }
+  K->count = world;
   return K;
 }
 extern "C" gvt_hip_comm *gvt_hip_comm_create(const unsigned char id[128], int rank, int world) {
@@ -167,7 +181,14 @@ extern "C" gvt_hip_comm *gvt_hip_comm_create(const unsigned char id[128], int ra
   ncclUniqueId u;
   std::memcpy(&u, id, 128);
   ncclResult_t r = g_rccl.CommInitRank(&K->nccl, world, u, rank);
-  if (r != ncclSuccess) { set_error("ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); hipStreamDestroy(K->stream); delete K; return nullptr; }
+  if (r != ncclSuccess) { set_error("ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); hipEventDestroy(K->ev_wait); hipStreamDestroy(K->stream); delete K; return nullptr; }
+  int cnt = -1;
+  r = g_rccl.CommCount(K->nccl, &cnt);
+  if (r != ncclSuccess || cnt != world) { // the communicator RCCL built is not the one the launcher asked for
+    set_error("gvt_hip_comm_create: ncclCommCount = %d, expected the world size %d (%s)", cnt, world, r != ncclSuccess ? g_rccl.GetErrorString(r) : "ok");
+    g_rccl.CommDestroy(K->nccl); hipEventDestroy(K->ev_wait); hipStreamDestroy(K->stream); delete K; return nullptr;
+  }
+  K->count = cnt;
   return K;
 }
 extern "C" gvt_hip_comm *gvt_hip_comm_create_local(gvt_hip_hub *hub, int rank) {
@@ -178,15 +199,54 @@ extern "C" gvt_hip_comm *gvt_hip_comm_create_local(gvt_hip_hub *hub, int rank) {
 }
 extern "C" void gvt_hip_comm_destroy(gvt_hip_comm *K) {
   if (!K) return;
-  hipStreamSynchronize(K->stream);
+  if (!K->dead) hipStreamSynchronize(K->stream); // (a dead communicator's stream may hold an exchange that never completes)
   if (K->nccl) g_rccl.CommDestroy(K->nccl);
-  hipStreamDestroy(K->stream);
+  if (K->ev_wait) hipEventDestroy(K->ev_wait);
+  if (!K->dead) hipStreamDestroy(K->stream);
   delete K;
+}
+extern "C" int gvt_hip_comm_count(const gvt_hip_comm *K) { return K ? K->count : 1; }
+extern "C" int gvt_hip_comm_set_deadline_ms(gvt_hip_comm *K, int ms) {
+  if (!K || ms <= 0) { set_error("comm_set_deadline_ms: null communicator or ms <= 0"); return GVT_HIP_ERR_INVALID; }
+  K->deadline_ms = ms;
+  return 0;
 }
 extern "C" int gvt_hip_comm_rank(const gvt_hip_comm *K) { return K ? K->rank : 0; }
 extern "C" int gvt_hip_comm_world(const gvt_hip_comm *K) { return K ? K->world : 1; }
 
 namespace {
+// A deadline passed: nothing this rank still has in flight on the communicator can be trusted to complete.  The RCCL communicator is
+// aborted (its kernels leave the stream), the in-process hub wakes every rank; the caller returns GVT_HIP_ERR_TIMEOUT and the process
+// is expected to report and exit non-zero -- never to re-exec itself.
+int comm_timed_out(gvt_hip_comm *K, const char *what, const char *diag) {
+  K->dead = true;
+  if (K->hub) gvt_hip_hub_abort(K->hub);
+  else if (K->nccl && g_rccl.CommAbort) { g_rccl.CommAbort(K->nccl); K->nccl = nullptr; }
+  set_error("ray exchange: rank %d of %d waited more than %d ms for %s%s%s -- a peer has stopped taking part; the communicator is aborted", K->rank, K->world,
+            K->deadline_ms, what, diag && *diag ? "; " : "", diag ? diag : "");
+  return GVT_HIP_ERR_TIMEOUT;
+}
+// host wait for an event with the communicator's deadline (hipEventSynchronize would wait for ever on an exchange a peer never joins)
+int bounded_event_wait(gvt_hip_comm *K, hipEvent_t ev, const char *what, const char *diag = nullptr) {
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = 0;
+  for (unsigned spins = 0;; spins++) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) break;
+    if (e != hipErrorNotReady) { set_error("hipEventQuery while waiting for %s: %s", what, hipGetErrorString(e)); rc = GVT_HIP_ERR_DEVICE; break; }
+    if ((spins & 63u) == 63u) {
+      if (K->hub && K->hub->aborted) { set_error("hub: aborted while waiting for %s", what); K->dead = true; rc = GVT_HIP_ERR_TIMEOUT; break; }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(K->deadline_ms)) { rc = comm_timed_out(K, what, diag); break; }
+      if (spins > 4096u) std::this_thread::yield();
+    }
+  }
+  K->ms_host_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
+}
+int bounded_stream_wait(gvt_hip_comm *K, hipStream_t st, const char *what, const char *diag = nullptr) {
+  HIPCHK(hipEventRecord(K->ev_wait, st));
+  return bounded_event_wait(K, K->ev_wait, what, diag);
+}
 void comm_group_begin(gvt_hip_comm *K) { K->ops.clear(); }
 void comm_send(gvt_hip_comm *K, const void *p, size_t bytes, int peer) { K->ops.push_back({ 1, (void *)p, bytes, peer, 0 }); }
 void comm_recv(gvt_hip_comm *K, void *p, size_t bytes, int peer, int accumulate = 0) { K->ops.push_back({ 0, p, bytes, peer, accumulate }); }
@@ -199,8 +259,8 @@ int hub_group_end(gvt_hip_comm *K) {
     if (!o.send) continue;
     std::unique_lock<std::mutex> lk(H->mu);
     gvt_hip_hub::Slot &s = H->slots[(size_t)o.peer * W + me];
-    H->cv.wait(lk, [&] { return s.state == 0 || H->aborted; });
-    if (H->aborted) { set_error("hub: aborted"); return GVT_HIP_ERR_DEVICE; }
+    if (!H->cv.wait_for(lk, std::chrono::milliseconds(K->deadline_ms), [&] { return s.state == 0 || H->aborted; })) { lk.unlock(); return comm_timed_out(K, "a free send slot (in-process transport)", nullptr); }
+    if (H->aborted) { set_error("hub: aborted"); K->dead = true; return GVT_HIP_ERR_TIMEOUT; }
     if (!s.ready) { hipEventCreateWithFlags(&s.ready, hipEventDisableTiming); hipEventCreateWithFlags(&s.copied, hipEventDisableTiming); }
     HIPCHK(hipEventRecord(s.ready, K->stream));
     s.ptr = o.ptr; s.bytes = o.bytes; s.state = 1;
@@ -212,8 +272,8 @@ int hub_group_end(gvt_hip_comm *K) {
     if (o.send) continue;
     std::unique_lock<std::mutex> lk(H->mu);
     gvt_hip_hub::Slot &s = H->slots[(size_t)me * W + o.peer];
-    H->cv.wait(lk, [&] { return s.state == 1 || H->aborted; });
-    if (H->aborted) { set_error("hub: aborted"); return GVT_HIP_ERR_DEVICE; }
+    if (!H->cv.wait_for(lk, std::chrono::milliseconds(K->deadline_ms), [&] { return s.state == 1 || H->aborted; })) { lk.unlock(); return comm_timed_out(K, "a peer's matching send (in-process transport)", nullptr); }
+    if (H->aborted) { set_error("hub: aborted"); K->dead = true; return GVT_HIP_ERR_TIMEOUT; }
     if (s.bytes != o.bytes) { set_error("hub: rank %d expects %zu bytes from %d, which sends %zu", me, o.bytes, o.peer, s.bytes); H->aborted = true; H->cv.notify_all(); return GVT_HIP_ERR_INVALID; }
     HIPCHK(hipStreamWaitEvent(K->stream, s.ready, 0));
     if (o.bytes) {
@@ -230,8 +290,8 @@ int hub_group_end(gvt_hip_comm *K) {
     if (!o.send) continue;
     std::unique_lock<std::mutex> lk(H->mu);
     gvt_hip_hub::Slot &s = H->slots[(size_t)o.peer * W + me];
-    H->cv.wait(lk, [&] { return s.state == 2 || H->aborted; });
-    if (H->aborted) { set_error("hub: aborted"); return GVT_HIP_ERR_DEVICE; }
+    if (!H->cv.wait_for(lk, std::chrono::milliseconds(K->deadline_ms), [&] { return s.state == 2 || H->aborted; })) { lk.unlock(); return comm_timed_out(K, "a peer to take a send (in-process transport)", nullptr); }
+    if (H->aborted) { set_error("hub: aborted"); K->dead = true; return GVT_HIP_ERR_TIMEOUT; }
     HIPCHK(hipStreamWaitEvent(K->stream, s.copied, 0));
     s.state = 0;
     lk.unlock();
@@ -242,6 +302,7 @@ int hub_group_end(gvt_hip_comm *K) {
 }
 
 int comm_group_end(gvt_hip_comm *K) {
+  if (K->dead) { set_error("ray exchange: the communicator of rank %d was aborted after a deadline passed", K->rank); return GVT_HIP_ERR_TIMEOUT; }
   if (K->hub) return hub_group_end(K);
   if (K->ops.empty()) return 0;
   NCCLCHK(g_rccl.GroupStart());
@@ -307,16 +368,19 @@ extern "C" int gvt_hip_comm_selftest(gvt_hip_comm *K, size_t bytes) {
 // device helpers of the scheduler loop
 // ------------------------------------------------------------------------------------------------
 namespace {
-#define ANN_HEAD 8 // announce row: {rays to you, bytes to you, my total outgoing rays, my local pending rays, the bounding rectangle of the
-                   // pixels my framebuffer holds deposits in (x0, y0, x1, y1; for the composite), rays per queue [n_inst]}
+#define ANN_HEAD 10 // announce row: {rays to you, bytes to you, my total outgoing rays, my local pending rays, the bounding rectangle of the
+                    // pixels my framebuffer holds deposits in (x0, y0, x1, y1; for the composite), my error code (0: none -- a rank whose
+                    // local work failed still takes part in the exchange, so that EVERY rank leaves the frame, with the same error),
+                    // my exchange number (ranks out of step are a protocol error, not a hang), rays per queue [n_inst]}
 #define REPORT_TAIL 12 // words behind the queue sizes in the round's report
 
 // sizes[i] = *count_ptr[i]; the announce row for every peer; totals (2 x u64) and flags copied next to them so that ONE device-to-host
 // copy carries everything the host needs from a round
 __global__ void k_round_report(unsigned *const *__restrict__ count_ptr, const int *__restrict__ owner, int n_inst, int rank, int world,
-                               unsigned *__restrict__ sizes, int *__restrict__ ann /* [world][ANN_HEAD + n_inst] */, unsigned *counters,
-                               const unsigned *__restrict__ overflow, unsigned *__restrict__ tail /* sizes + n_inst: tot[4], ovf trav, ovf queue, bbox[4] */,
-                               const int *__restrict__ bbox, int chain_end = 0, const unsigned char *__restrict__ chain_mask = nullptr) {
+                               unsigned *sizes, int *__restrict__ ann /* [world][ANN_HEAD + n_inst] */, unsigned *counters,
+                               const unsigned *__restrict__ overflow, unsigned *tail /* sizes + n_inst: tot[4], ovf trav, ovf queue, bbox[4] */,
+                               const int *__restrict__ bbox, int chain_end = 0, const unsigned char *__restrict__ chain_mask = nullptr,
+                               unsigned *host_report = nullptr, unsigned host_seq = 0u, int err_code = 0, int tick = 0) {
   __shared__ unsigned long long sh_out, sh_local;
   if (threadIdx.x == 0) { sh_out = 0; sh_local = 0; }
   if (chain_end) { // the launch chain in front left its k_wave_end to this kernel: last pass's shadow rays into the frame total, traced queues cleared
@@ -344,12 +408,22 @@ __global__ void k_round_report(unsigned *const *__restrict__ count_ptr, const in
     ann[p * row + 2] = (int)sh_out;
     ann[p * row + 3] = (int)sh_local;
     for (int k = 0; k < 4; k++) ann[p * row + 4 + k] = bbox[k];
+    ann[p * row + 8] = err_code;
+    ann[p * row + 9] = tick;
   }
   if (threadIdx.x == 0) {
     tail[0] = counters[16]; tail[1] = counters[17]; tail[2] = counters[18]; tail[3] = counters[19];
     tail[4] = counters[8]; tail[5] = *overflow;
     for (int k = 0; k < 4; k++) tail[6 + k] = (unsigned)bbox[k];
     tail[10] = counters[9]; // packets handed over by k_packet
+  }
+  if (host_report) { // one rank: the report goes straight into the host's pinned copy, the sequence word last -- the host polls it
+    __syncthreads(); // instead of a device-to-host copy + a stream synchronisation (an interrupt and a wake-up per round)
+    for (int i = threadIdx.x; i < n_inst; i += blockDim.x) host_report[i] = sizes[i];
+    for (int k = threadIdx.x; k < REPORT_TAIL - 1; k += blockDim.x) host_report[n_inst + k] = tail[k];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { __hip_atomic_store(host_report + n_inst + REPORT_TAIL - 1, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
   }
 }
 
@@ -440,19 +514,23 @@ struct gvt_hip_tracer {
   unsigned **d_count_ptr = nullptr;
   int *d_owner = nullptr;
   unsigned char *d_mask = nullptr, *h_mask = nullptr;
-  unsigned *d_report = nullptr, *h_report = nullptr; // sizes[n_inst] + tail[8]
+  unsigned *d_report = nullptr, *h_report = nullptr; // sizes[n_inst] + tail[REPORT_TAIL]; the tail's last word: sequence number of a polled report
+  unsigned report_seq = 0;
   int *d_ann_out = nullptr, *d_ann_in = nullptr, *h_ann_in = nullptr; // [world][ANN_HEAD + n_inst]
   unsigned *d_overflow = nullptr;
   std::vector<void *> send_buf, recv_buf;
   std::vector<size_t> send_cap, recv_cap;
   hipEvent_t ev_compute = nullptr, ev_report = nullptr, ev_pack = nullptr, ev_recv = nullptr, ev_comm = nullptr;
+  hipEvent_t ev_chain0 = nullptr, ev_ann0 = nullptr, ev_pay0 = nullptr, ev_comp0 = nullptr; // phase timing (multi-rank frames)
+  bool chain_timed = false, payload_timed = false;
+  uint64_t last_local_pending = 0;
   std::vector<size_t> present; // host-known queue sizes as of the last report
 };
 
 extern "C" void gvt_hip_tracer_destroy(gvt_hip_tracer *R) {
   if (!R) return;
   if (gctx().ready) hipStreamSynchronize(gctx().stream);
-  if (R->comm) hipStreamSynchronize(R->comm->stream);
+  if (R->comm && !R->comm->dead) hipStreamSynchronize(R->comm->stream);
   for (auto q : R->queues) gvt_hip_queue_destroy(q);
   gvt_hip_queue_destroy(R->q_moved);
   hipFree(R->d_insts); hipFree(R->d_round); hipHostFree(R->h_round); hipFree(R->d_count_ptr); hipFree(R->d_owner);
@@ -460,7 +538,7 @@ extern "C" void gvt_hip_tracer_destroy(gvt_hip_tracer *R) {
   hipFree(R->d_overflow);
   for (void *p : R->send_buf) hipFree(p);
   for (void *p : R->recv_buf) hipFree(p);
-  for (hipEvent_t e : { R->ev_compute, R->ev_report, R->ev_pack, R->ev_recv, R->ev_comm }) if (e) hipEventDestroy(e);
+  for (hipEvent_t e : { R->ev_compute, R->ev_report, R->ev_pack, R->ev_recv, R->ev_comm, R->ev_chain0, R->ev_ann0, R->ev_pay0, R->ev_comp0 }) if (e) hipEventDestroy(e);
   delete R;
 }
 
@@ -523,7 +601,7 @@ extern "C" gvt_hip_tracer *gvt_hip_tracer_create(gvt_hip_top *T, gvt_hip_mesh *c
        hipHostMalloc(&R->h_round, R->round_bytes, hipHostMallocDefault) == hipSuccess &&
        hipMalloc((void **)&R->d_count_ptr, sizeof(unsigned *) * n1) == hipSuccess && hipMalloc((void **)&R->d_owner, sizeof(int) * n1) == hipSuccess &&
        hipMalloc((void **)&R->d_report, sizeof(unsigned) * (n1 + REPORT_TAIL)) == hipSuccess &&
-       hipHostMalloc((void **)&R->h_report, sizeof(unsigned) * (n1 + REPORT_TAIL), hipHostMallocDefault) == hipSuccess &&
+       hipHostMalloc((void **)&R->h_report, sizeof(unsigned) * (n1 + REPORT_TAIL), hipHostMallocDefault) == hipSuccess && std::memset(R->h_report, 0, sizeof(unsigned) * (n1 + REPORT_TAIL)) &&
        hipMalloc((void **)&R->d_overflow, 64) == hipSuccess;
   if (ok) {
     R->h_segs = (WaveSeg *)R->h_round; R->d_segs = (WaveSeg *)R->d_round;
@@ -533,8 +611,10 @@ extern "C" gvt_hip_tracer *gvt_hip_tracer_create(gvt_hip_top *T, gvt_hip_mesh *c
          hipMemcpy(R->d_count_ptr, cptr.data(), sizeof(unsigned *) * n1, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemset(R->d_owner, 0, sizeof(int) * n1) == hipSuccess && hipMemset(R->d_overflow, 0, 64) == hipSuccess;
   }
-  for (hipEvent_t *e : { &R->ev_compute, &R->ev_report, &R->ev_pack, &R->ev_recv, &R->ev_comm })
+  for (hipEvent_t *e : { &R->ev_pack })
     ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+  for (hipEvent_t *e : { &R->ev_compute, &R->ev_report, &R->ev_recv, &R->ev_comm, &R->ev_chain0, &R->ev_ann0, &R->ev_pay0, &R->ev_comp0 }) // timed: the frame's phase breakdown
+    ok = ok && hipEventCreate(e) == hipSuccess;
   if (ok) ok = tracer_alloc_tables(R) == 0;
   if (!ok) { if (!*gvt_hip_last_error()) set_error("tracer_create: device allocation failed"); gvt_hip_tracer_destroy(R); return nullptr; }
   (void)C;
@@ -655,22 +735,25 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
 }
 
 // (3)+(4)+(5): report kernel -> [announce exchange] -> ONE device-to-host copy -> ONE host synchronisation
-int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_end = false) {
+int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_end = false, int err_code = 0, int tick = 0, gvt_hip_frame_stats *S = nullptr) {
   Ctx &C = gctx();
   const size_t nI = R->n_inst, row = ANN_HEAD + nI;
   hipStream_t st = C.stream;
   int *d_bbox = (int *)(R->d_overflow + 4);
+  const bool poll = !(exchange && R->world > 1) && C.report_poll;
+  int rc_wait = 0;
   if (exchange && R->world > 1) { // the rectangle this rank's deposits lie in, for the composite: carried by the announce
     k_bbox_init<<<1, 64, 0, st>>>(d_bbox, R->fb->w, R->fb->h);
     k_fb_bbox<<<(unsigned)(((size_t)R->fb->w * R->fb->h + 255) / 256), 256, 0, st>>>((const float4 *)R->fb->d_rgba, R->fb->w, R->fb->h, d_bbox);
   }
   k_round_report<<<1, 256, 0, st>>>(R->d_count_ptr, R->d_owner, (int)nI, R->rank, R->world, R->d_report, R->d_ann_out, C.d_counters, R->d_overflow,
-                                    R->d_report + nI, d_bbox, chain_end ? 1 : 0, R->d_mask);
+                                    R->d_report + nI, d_bbox, chain_end ? 1 : 0, R->d_mask, poll ? R->h_report : nullptr, poll ? ++R->report_seq : 0u, err_code, tick);
   HIPCHK(hipGetLastError());
   if (exchange && R->world > 1) {
     gvt_hip_comm *K = R->comm;
-    HIPCHK(hipEventRecord(R->ev_compute, st));
+    HIPCHK(hipEventRecord(R->ev_compute, st)); // (timing event: the end of this tick's local chain)
     HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0));
+    HIPCHK(hipEventRecord(R->ev_ann0, K->stream));
     comm_group_begin(K);
     for (int p = 0; p < R->world; p++) {
       if (p == R->rank) continue;
@@ -680,11 +763,37 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_e
     int rc = comm_group_end(K);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(R->h_ann_in, R->d_ann_in, sizeof(int) * R->world * row, hipMemcpyDeviceToHost, K->stream));
-    HIPCHK(hipMemcpyAsync(R->h_report, R->d_report, sizeof(unsigned) * (nI + REPORT_TAIL), hipMemcpyDeviceToHost, K->stream));
+    HIPCHK(hipMemcpyAsync(R->h_report, R->d_report, sizeof(unsigned) * (nI + REPORT_TAIL - 1), hipMemcpyDeviceToHost, K->stream)); // (the last word is the polled reports' sequence number)
     HIPCHK(hipEventRecord(R->ev_report, K->stream));
-    HIPCHK(hipEventSynchronize(R->ev_report));
+    { // bounded: a peer that never joins the exchange must not hang this rank
+      char diag[256];
+      std::snprintf(diag, sizeof diag, "exchange %d, this rank's announce: %zu local rays pending, error word %d; last report: %u rays in the first queue", tick,
+                    (size_t)R->last_local_pending, err_code, nI ? R->h_report[0] : 0u);
+      if ((rc_wait = bounded_event_wait(K, R->ev_report, "the announce exchange", diag))) return rc_wait;
+    }
+    if (S) { // phase times of this tick (all three events are complete now)
+      float ms = 0.f;
+      if (R->chain_timed && hipEventElapsedTime(&ms, R->ev_chain0, R->ev_compute) == hipSuccess) S->ms_chain += ms;
+      if (hipEventElapsedTime(&ms, R->ev_ann0, R->ev_report) == hipSuccess) S->ms_announce += ms;
+      if (R->payload_timed && hipEventElapsedTime(&ms, R->ev_pay0, R->ev_recv) == hipSuccess) S->ms_payload += ms;
+      R->chain_timed = false; R->payload_timed = false;
+    }
+  } else if (poll) {
+    // k_round_report wrote the report into pinned host memory and released the sequence word last: wait for it with loads (no
+    // interrupt, no wake-up latency); a device that stops answering is caught by the stream synchronisation behind the deadline
+    volatile unsigned *flag = R->h_report + nI + REPORT_TAIL - 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (unsigned spins = 0;; spins++) {
+      if (__atomic_load_n((const unsigned *)flag, __ATOMIC_ACQUIRE) == R->report_seq) { seen = true; break; }
+      if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+    }
+    if (!seen) {
+      HIPCHK(hipStreamSynchronize(st));
+      if (__atomic_load_n((const unsigned *)flag, __ATOMIC_ACQUIRE) != R->report_seq) { set_error("round report: the device finished without publishing report %u", R->report_seq); return GVT_HIP_ERR_DEVICE; }
+    }
   } else {
-    HIPCHK(hipMemcpyAsync(R->h_report, R->d_report, sizeof(unsigned) * (nI + REPORT_TAIL), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(R->h_report, R->d_report, sizeof(unsigned) * (nI + REPORT_TAIL - 1), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
   }
   if (syncs) (*syncs)++;
@@ -785,34 +894,61 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     return 0;
   };
 
-  for (;;) {
+  int local_err = 0;
+  std::string local_msg;
+  // after an announce exchange: did every rank arrive at the same exchange number without an error?
+  auto peers_ok = [&](int tick_) -> int {
+    int bad_rank = -1, bad_code = 0;
+    for (int p = 0; p < R->world; p++) {
+      if (p == R->rank) continue;
+      const int *a = R->h_ann_in + (size_t)p * row;
+      if (a[9] != tick_) { set_error("ray exchange: rank %d is at exchange %d while rank %d is at %d (ranks out of step)", p, a[9], R->rank, tick_); return GVT_HIP_ERR_DEVICE; }
+      if (a[8] && bad_rank < 0) { bad_rank = p; bad_code = a[8]; }
+    }
+    if (local_err) { set_error("%s", local_msg.c_str()); return local_err; } // (the peers leave with GVT_HIP_ERR_PEER)
+    if (bad_rank >= 0) { set_error("ray exchange: rank %d reported error %d in its announce of exchange %d; this frame is abandoned on every rank", bad_rank, bad_code, tick_); return GVT_HIP_ERR_PEER; }
+    return 0;
+  };
+  // Under several ranks a failure of this rank's LOCAL work (a reservation, a launch, a capacity error) must not leave the peers inside
+  // an exchange this rank never joins: the error is remembered, the rank still takes part in the tick's announce with its error word
+  // set, and every rank leaves the frame after that exchange -- the failing one with its own error, the others with GVT_HIP_ERR_PEER.
+  // (A rank that cannot even run the exchange -- a device fault, a dead process -- is what the deadlines are for.)
+  auto failed = [&](int rc_) { if (rc_ && !local_err) { local_err = rc_; local_msg = gvt_hip_last_error(); } return rc_ != 0; };
+  const bool multi = world_saved > 1;
+  if (R->comm) R->comm->ms_host_wait = 0.0;
+  int tick = 0;
+  for (;; tick++) {
     // (1) local work: one merged chain (asynchronous ticks), or chains until the local queues are dry (BSP rounds / one rank)
+    if (multi && R->world > 1) { HIPCHK(hipEventRecord(R->ev_chain0, st)); R->chain_timed = true; }
+    if (C.inject_fail_tick == tick && multi) { set_error("injected failure at exchange %d (test knob inject_fail_tick)", tick); failed(GVT_HIP_ERR_CAPACITY); }
     if (R->world == 1 || bsp) {
-      if ((rc = unpack_pending())) return rc;
-      for (;;) {
+      if (!local_err && failed(unpack_pending()) && !multi) return local_err;
+      for (; !local_err;) {
         bool any = false;
         for (size_t i = 0; i < nI; i++) any = any || (R->owned[i] && R->present[i]);
         if (!any) break;
-        if ((rc = local_chain(R, nullptr, &S.chains, S.chains == 0))) return rc;
-        if ((rc = round_report(R, false, &S.host_syncs))) return rc;
+        if (failed(local_chain(R, nullptr, &S.chains, S.chains == 0)) || failed(round_report(R, false, &S.host_syncs))) { if (!multi) return local_err; break; }
       }
       if (R->world == 1) {
         if (image_split) { // back among the ranks: one exchange, so that rank 0 learns every rank's deposit rectangle
           R->world = world_saved; R->owned = owned_saved;
-          if ((rc = round_report(R, true, &S.host_syncs))) return rc;
-        }
+          if ((rc = round_report(R, true, &S.host_syncs, false, local_err, tick, &S))) return rc;
+          if ((rc = peers_ok(tick))) return rc;
+        } else if (local_err) return local_err;
         break;
       }
-    } else {
+    } else if (!local_err) {
       bool have_local = false;
       for (size_t i = 0; i < nI; i++) have_local = have_local || (R->owned[i] && R->present[i]);
-      if (!have_local && (rc = unpack_pending())) return rc; // nothing to overlap the transfer with: take what arrived first
-      if ((rc = local_chain(R, &incoming, &S.chains, S.chains == 0))) return rc;
-      if ((rc = unpack_pending())) return rc;
+      if (!have_local) failed(unpack_pending()); // nothing to overlap the transfer with: take what arrived first
+      if (!local_err) failed(local_chain(R, &incoming, &S.chains, S.chains == 0));
+      if (!local_err) failed(unpack_pending());
     }
-    // (3)-(5) sizes + announce exchange, one synchronisation
-    if ((rc = round_report(R, true, &S.host_syncs))) return rc;
+    // (3)-(5) sizes + announce exchange (carrying this rank's error word), one bounded synchronisation
+    { uint64_t lp = 0; for (size_t i = 0; i < nI; i++) if (R->owned[i]) lp += R->present[i]; R->last_local_pending = lp; }
+    if ((rc = round_report(R, true, &S.host_syncs, false, local_err, tick, &S))) return rc;
     S.rounds++;
+    if ((rc = peers_ok(tick))) return rc;
     // (6) the vote: every rank reads the same ballots
     uint64_t not_done = 0;
     for (size_t i = 0; i < nI; i++) not_done += R->present[i];
@@ -827,8 +963,11 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
       if (p == R->rank) continue;
       for (size_t i = 0; i < nI; i++) if (R->owner[i] == p && R->present[i]) bytes_out[p] += 8 + 80 * R->present[i];
       bytes_in[p] = (size_t)(unsigned)R->h_ann_in[(size_t)p * row + 1];
+      // (a failure from here on -- after the announce promised these bytes -- cannot be reported before the peers have posted their
+      // matching operations: it ends this rank's frame at once and the peers run into the exchange deadline)
       if ((rc = grow(&R->send_buf[p], &R->send_cap[p], bytes_out[p]))) return rc;
       if ((rc = grow(&R->recv_buf[p], &R->recv_cap[p], bytes_in[p]))) return rc;
+      S.bytes_sent += bytes_out[p];
       size_t off = 0;
       for (size_t i = 0; i < nI; i++) {
         if (R->owner[i] != p || !R->present[i]) continue;
@@ -854,6 +993,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
         if (incoming[i] && (rc = queue_reserve(R->queues[i], R->present[i] + incoming[i]))) return rc;
       HIPCHK(hipEventRecord(R->ev_pack, st));
       HIPCHK(hipStreamWaitEvent(K->stream, R->ev_pack, 0));
+      HIPCHK(hipEventRecord(R->ev_pay0, K->stream)); R->payload_timed = true;
       comm_group_begin(K); // sizes are known on both sides from the announces: no size handshake on the wire
       for (int p = 0; p < R->world; p++) {
         if (p == R->rank) continue;
@@ -873,6 +1013,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   if (R->world > 1 && !(flags & GVT_HIP_FRAME_NO_COMPOSITE)) {
     gvt_hip_comm *K = R->comm;
     const int W = R->fb->w;
+    HIPCHK(hipEventRecord(R->ev_comp0, st));
     if (flags & GVT_HIP_FRAME_FULL_REDUCE) {
       HIPCHK(hipEventRecord(R->ev_compute, st));
       HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0));
@@ -914,9 +1055,11 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     }
     HIPCHK(hipEventRecord(R->ev_comm, K->stream));
     HIPCHK(hipStreamWaitEvent(st, R->ev_comm, 0));
-    HIPCHK(hipStreamSynchronize(K->stream));
+    if ((rc = bounded_event_wait(K, R->ev_comm, "the framebuffer composite"))) return rc;
     S.host_syncs++;
+    { float ms = 0.f; if (hipEventElapsedTime(&ms, R->ev_comp0, R->ev_comm) == hipSuccess) S.ms_composite += ms; }
   }
+  if (R->comm) S.ms_host_wait = R->comm->ms_host_wait;
   const unsigned *tail = R->h_report + nI;
   S.rays_closest = (uint64_t)tail[0] | ((uint64_t)tail[1] << 32);
   S.rays_any = (uint64_t)tail[2] | ((uint64_t)tail[3] << 32);

@@ -45,6 +45,8 @@ struct Knobs {
                          // per traversal launch instead of the ~150 us latency floor of a one-lane-per-ray launch
   int lean_frame = 1;    // one-instance scenes on one rank: framebuffer clear, counter resets and the chain's begin / end folded into the camera filter's
                          // two kernels and the round's report (8 launches per frame instead of 14)
+  int inject_fail_tick = -1; // tests: this rank's local work "fails" at that exchange of a multi-rank frame (the announce carries the error to every rank)
+  int report_poll = 1;   // one rank: a round's report is written into pinned host memory by the kernel and polled (no copy, no stream synchronisation)
   int first_round_async = 1; // one-instance scenes on one rank: no read-back after the camera filter (the chain reads its ray count on the device)
   int wave_single = 1;   // scheduler rounds: a round with ONE non-empty local queue uses the single-mesh kernels (no per-ray segment / instance lookups)
   int shadow_direct = 1; // scheduler rounds: shadow rays in direct-mapped slots (the order of the traced list) instead of block-arrival order

@@ -196,6 +196,16 @@ class Comm:
             raise capi.GvtHipError("gvt_hip_comm_create_local: " + capi.last_error())
         return cls(h)
 
+    @property
+    def count(self):
+        """ranks the transport itself reports (ncclCommCount; the hub's world)"""
+        return self.lib.gvt_hip_comm_count(self.h)
+
+    def set_deadline_ms(self, ms):
+        import ctypes as C
+
+        capi.check(self.lib.gvt_hip_comm_set_deadline_ms(self.h, C.c_int(int(ms))), "gvt_hip_comm_set_deadline_ms")
+
     def selftest(self, nbytes=1 << 20):
         import ctypes as C
 

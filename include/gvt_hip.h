@@ -36,6 +36,8 @@ extern "C" {
 #define GVT_HIP_ERR_DEVICE (-2)   /* HIP runtime error */
 #define GVT_HIP_ERR_CAPACITY (-3) /* output buffer / queue too small; nothing lost, see call */
 #define GVT_HIP_ERR_NODEVICE (-4) /* no gfx950 device visible */
+#define GVT_HIP_ERR_TIMEOUT (-5)  /* ray exchange: a peer did not answer within the communicator's deadline; the communicator is dead */
+#define GVT_HIP_ERR_PEER (-6)     /* ray exchange: another rank reported an error in its announce; every rank leaves the frame with this */
 
 #define GVT_HIP_NORMALS_FLAT 0   /* EmbreeMeshAdapter.cpp:75,520-522 (FLAT_SHADING) */
 #define GVT_HIP_NORMALS_SMOOTH 1 /* EmbreeMeshAdapter.cpp:505-518, EmbreeStreamMeshAdapter.cpp:708, OptixMeshAdapter.cu:298 */
@@ -234,6 +236,12 @@ void gvt_hip_comm_destroy(gvt_hip_comm *);
  * very calls the frame loop makes; 0 = the payload came back intact */
 int gvt_hip_comm_selftest(gvt_hip_comm *, size_t bytes);
 int gvt_hip_comm_rank(const gvt_hip_comm *);
+/* ranks the transport itself counts (ncclCommCount; the hub's world): gvt_hip_comm_create fails unless it equals `world` */
+int gvt_hip_comm_count(const gvt_hip_comm *);
+/* deadline of every blocking point of an exchange, in milliseconds (default: GVT_HIP_EXCHANGE_TIMEOUT_MS or 20000).  A rank that waits
+ * longer returns GVT_HIP_ERR_TIMEOUT with its last announce in gvt_hip_last_error(), aborts the communicator (ncclCommAbort / hub
+ * abort) and must not use it again: the process reports and exits non-zero. */
+int gvt_hip_comm_set_deadline_ms(gvt_hip_comm *, int ms);
 int gvt_hip_comm_world(const gvt_hip_comm *);
 
 /* The tracer copies matrices, lights and camera, creates its own per-instance queues, and borrows top, meshes and fb. */
@@ -258,6 +266,13 @@ typedef struct gvt_hip_frame_stats {
   uint64_t rays_closest; /* rays this rank pushed through the closest-hit kernel */
   uint64_t rays_any;     /* ... through the any-hit kernel */
   uint64_t packets_bailed; /* 64-ray packets the packet traversal handed to the one-lane-per-ray kernels (stack / step budget) */
+  uint64_t bytes_sent;   /* payload bytes this rank sent to other ranks (wire format, DomainTracer.h:441-455), composite excluded */
+  /* where a multi-rank frame's time goes (HIP events on the compute / communication streams, host clock for the waits); 0 on one rank */
+  double ms_chain;       /* local launch chains (incl. unpacking what arrived) */
+  double ms_announce;    /* announce exchanges: group of sends / receives + the report's device-to-host copy */
+  double ms_payload;     /* payload exchanges, posting to arrival (overlaps the next chain) */
+  double ms_composite;   /* framebuffer composite on rank 0 */
+  double ms_host_wait;   /* host time blocked in the exchanges' bounded waits */
 } gvt_hip_frame_stats;
 /* One frame: clearBuffer, generateRays + FilterRaysLocally / shuffleDropRays, rounds until every queue of every rank is empty, then
  * (Domain) the composite: the sum of the ranks' float framebuffers on rank 0 (IceTComposite.cpp:84-101).  Collective under a comm. */

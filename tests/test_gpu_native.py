@@ -159,13 +159,105 @@ def test_image_scheduler_on_several_ranks(hip, world):
         assert all(r[1]["rays_sent"] == 0 for r in res.values())  # (a portion of the film may see nothing at all)
 
 
+def test_a_failing_rank_ends_the_frame_on_every_rank_and_the_next_frame_works(hip):
+    """A rank whose local work fails (test knob: at its second exchange) still joins the announce with its error word: it leaves with
+    its own error, every other rank with GVT_HIP_ERR_PEER naming it -- nobody hangs -- and the ranks are still in step: the next
+    frame of the same tracers gives the oracle's image."""
+    world = 3
+    sc = config5(192, 6)
+    owner = [i % world for i in range(sc.n_inst)]
+    hub = capi.load().gvt_hip_hub_create(world)
+    msgs, fbs, errs = {}, {}, []
+    sync = threading.Barrier(world)
+
+    def rank_main(rank):
+        ctx = None
+        try:
+            ctx = Context(0)
+            comm = Comm.local(hub, rank)
+            comm.set_deadline_ms(20000)
+            assert comm.count == world
+            tr = NativeTracer(sc, NORMALS_FLAT, owner, comm)
+            if rank == 1:
+                capi.set_option("inject_fail_tick", 1)
+            try:
+                tr()
+                msgs[rank] = "no error"
+            except capi.GvtHipError as e:
+                msgs[rank] = str(e)
+            capi.set_option("defaults", 0)
+            sync.wait(timeout=60)
+            B = tr()
+            fbs[rank] = B.framebuffer(True) if rank == 0 else None
+            tr.close(); comm.close()
+            B = tr = None
+        except Exception:  # noqa: BLE001
+            import traceback
+            errs.append(traceback.format_exc())
+            capi.load().gvt_hip_hub_abort(hub)
+        finally:
+            import gc
+            gc.collect()
+            if ctx is not None:
+                ctx.close()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    capi.load().gvt_hip_hub_destroy(hub)
+    assert not errs, errs[0]
+    assert "injected failure" in msgs[1], msgs
+    assert all("rank 1 reported error" in msgs[r] for r in (0, 2)), msgs
+    ref, _ = oracle_render_domain(sc, owner, world, 0)
+    assert np.abs(fbs[0][..., :3] - ref[..., :3]).max() <= 1e-5 and np.array_equal(fbs[0][..., 3], ref[..., 3])
+
+
+def test_a_rank_that_never_joins_runs_its_peer_into_the_deadline(hip):
+    """Rank 1 never calls the frame: rank 0 must come back from its first announce with GVT_HIP_ERR_TIMEOUT after the communicator's
+    deadline (here 400 ms), not hang."""
+    import time
+
+    sc = scenes.bunny_grid_scene(width=190, height=108)
+    owner = [i % 2 for i in range(sc.n_inst)]
+    hub = capi.load().gvt_hip_hub_create(2)
+    res = {}
+
+    def rank0():
+        ctx = Context(0)
+        try:
+            comm = Comm.local(hub, 0)
+            comm.set_deadline_ms(400)
+            tr = NativeTracer(sc, NORMALS_SMOOTH, owner, comm)
+            t0 = time.perf_counter()
+            try:
+                tr()
+                res["msg"] = "no error"
+            except capi.GvtHipError as e:
+                res["msg"] = str(e)
+            res["s"] = time.perf_counter() - t0
+            tr.close(); comm.close()
+            tr = None
+        finally:
+            import gc
+            gc.collect()
+            ctx.close()
+
+    t = threading.Thread(target=rank0)
+    t.start()
+    t.join(timeout=120)
+    assert not t.is_alive(), "rank 0 hangs in an exchange its peer never joined"
+    capi.load().gvt_hip_hub_destroy(hub)
+    assert "waited more than 400 ms" in res["msg"] and "a peer has stopped taking part" in res["msg"], res
+    assert res["s"] < 30.0
+
+
 def test_rccl_communicator_of_one_rank(hip):
     """RCCL itself, as far as one GPU allows: the library resolves librccl, creates a communicator from a unique id and runs a
     Domain frame on it (no peers: no sends; the composite reduce is skipped for one rank)."""
     uid = Comm.unique_id()
     assert len(uid) == 128 and any(uid)
     comm = Comm.rccl(uid, 0, 1)
-    assert comm.rank == 0 and comm.world == 1
+    assert comm.rank == 0 and comm.world == 1 and comm.count == 1  # ncclCommCount agrees with the world the launcher asked for
     comm.selftest(1 << 20)  # ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd to self + ncclReduce, on the communication stream
     comm.selftest(80 * 1000 + 8 * 3)  # a payload-shaped size (three queues' headers + 1000 rays)
     sc = scenes.bunny_grid_scene(width=190, height=108)
@@ -255,7 +347,7 @@ def test_top_level_bvh_with_1056_instances(hip):
 
 
 @pytest.mark.parametrize("opts", [dict(first_round_async=0), dict(small_rays=0), dict(small_rays=1 << 30), dict(wave_single=0), dict(shadow_direct=0),
-                                  dict(small_rays=1 << 30, wave_single=0), dict(blocks_per_cu_closest=0, term_sink=0), dict(leaf_max=4, small_rays=0), dict(lean_frame=0)])
+                                  dict(small_rays=1 << 30, wave_single=0), dict(blocks_per_cu_closest=0, term_sink=0), dict(leaf_max=4, small_rays=0), dict(lean_frame=0), dict(report_poll=0), dict(lean_frame=0, report_poll=0, first_round_async=0)])
 def test_round_results_do_not_depend_on_knobs(hip, opts):
     """The round chain's variants -- a wave per ray for small rounds, single-mesh kernels for one-queue rounds, direct-mapped shadow
     slots, no terminal sink -- return the oracle's image on a multi-domain depth-2 frame and on config 4 (k_fused / k_packet /
