@@ -217,6 +217,130 @@ def two_frames_in_flight(scene, steps, rays_per_frame):
                     "to last end; never `value`" % steps}
 
 
+PHASES = ("ms_chain", "ms_announce", "ms_payload", "ms_composite", "ms_host_wait")
+
+
+def die_on_exchange_error(rank, world, what, err, stats):
+    """A frame failed under several ranks (a deadline passed, a peer reported an error): say what this rank knows and leave with a
+    non-zero status -- a fresh launch is the launcher's business, this process never re-executes itself."""
+    print("bench.py: rank %d of %d: %s failed: %s\n  last frame stats of this rank: %s" % (rank, world, what, err, stats), file=sys.stderr, flush=True)
+    os._exit(1)
+
+
+def measure_variant(run_frame, frame_stats, steps, warmup, barrier, reduce_sum, reduce_max, rank, world, name):
+    """W untimed + K timed frames of one scheduler variant; rays and bytes summed over the ranks, wall time and the per-phase times
+    as the maximum over the ranks.  run_frame() renders one frame, frame_stats() returns that frame's counters on this rank."""
+    def frame():
+        try:
+            run_frame()
+        except Exception as e:  # noqa: BLE001 -- GvtHipError: a deadline passed or a peer reported an error
+            if type(e).__name__ != "GvtHipError":
+                raise
+            die_on_exchange_error(rank, world, name, e, frame_stats())
+
+    for _ in range(warmup):
+        frame()
+    barrier()
+    sums = {}
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        frame()
+        for k, v in frame_stats().items():
+            sums[k] = sums.get(k, 0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tot = reduce_sum([float(sums.get(k, 0)) for k in ("rays_closest", "rays_any", "rays_sent", "bytes_sent")])
+    mx = reduce_max([elapsed] + [float(sums.get(k, 0.0)) for k in PHASES] + [float(sums.get(k, 0)) for k in ("rounds", "chains", "host_syncs")])
+    ticks = mx[1 + len(PHASES)] / steps
+    res = {"value": (tot[0] + tot[1]) / mx[0] / 1e6, "unit": "Mrays/s", "ms_per_step": mx[0] / steps * 1e3,
+           "ticks_per_step": ticks, "ms_per_tick": (mx[0] / steps * 1e3 / ticks) if ticks else None,
+           "launch_chains_per_step": mx[2 + len(PHASES)] / steps, "host_syncs_per_step": mx[3 + len(PHASES)] / steps,
+           "rays_sent_per_step": tot[2] / steps, "bytes_sent_per_step": tot[3] / steps,
+           "phase_ms_per_step_max_over_ranks": {k[3:]: mx[1 + i] / steps for i, k in enumerate(PHASES)}}
+    return res, sums, mx[0], tot
+
+
+def inproc_ranks(args):
+    """--inproc-ranks N: the native multi-rank frame loop (announces, wire packing, payload, vote, composite) with the N ranks as
+    threads of THIS process on ONE GPU, joined by the library's in-process transport: the same control flow and the same keys as a
+    --gpus N run, for looking at tick counts and per-tick cost where only one GPU is at hand.  Not a scaling number."""
+    import threading
+
+    import numpy as np
+
+    from gravit_amd import capi, scenes
+    from gravit_amd.layouts import NORMALS_FLAT
+    from gravit_amd.scheduler import Comm, Context, NativeTracer
+
+    N = args.inproc_ranks
+    capi.init(0)
+    variants = [("domain_async", "domain", dict(bsp=False)), ("domain_bsp", "domain", dict(bsp=True)), ("image_replicated", "image", dict(image=True))]
+    scene_dom = scenes.soup_domains_scene(args.tris, N, args.width, args.height)
+    scene_img = scenes.soup_scene(args.tris, args.width, args.height)
+    out = {"metric": "Mrays/s (primary+shadow) at 1080p, 10M-tri scene", "n_gpus": 1, "inproc_ranks": N, "steps": args.steps, "warmup": args.warmup,
+           "note": "N in-process ranks share ONE GPU (hub transport): tick counts, bytes and per-phase times of the Domain scheduler's frame loop; not a scaling number",
+           "variants": {}}
+    for name, kind, call in variants:
+        scene = scene_dom if kind == "domain" else scene_img
+        owner = [i % N for i in range(scene.n_inst)] if kind == "domain" else [0] * scene.n_inst
+        hub = capi.load().gvt_hip_hub_create(N)
+        bar = threading.Barrier(N)
+        per_rank, errs = {}, []
+
+        def rank_main(r):
+            ctx = None
+            try:
+                ctx = Context(0)
+                for o in args.opt:
+                    k, v = o.split("=")
+                    capi.set_option(k, int(v))
+                comm = Comm.local(hub, r)
+                tr = NativeTracer(scene, NORMALS_FLAT, owner, comm, replicate=(kind == "image"))
+                for _ in range(args.warmup):
+                    tr(**call)
+                capi.synchronize(); bar.wait()
+                sums = {}
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    tr(**call)
+                    for k, v in tr.stats.items():
+                        sums[k] = sums.get(k, 0) + v
+                capi.synchronize(); bar.wait()
+                per_rank[r] = (sums, time.perf_counter() - t0)
+                tr.close(); comm.close()
+                tr = None
+            except Exception:  # noqa: BLE001
+                import traceback
+                errs.append(traceback.format_exc())
+                capi.load().gvt_hip_hub_abort(hub)
+                bar.abort()
+            finally:
+                import gc
+                gc.collect()
+                if ctx is not None:
+                    ctx.close()
+
+        th = [threading.Thread(target=rank_main, args=(r,)) for r in range(N)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        capi.load().gvt_hip_hub_destroy(hub)
+        if errs:
+            print(errs[0], file=sys.stderr)
+            sys.exit(1)
+        el = max(v[1] for v in per_rank.values())
+        tot = lambda k: float(sum(v[0].get(k, 0) for v in per_rank.values()))  # noqa: E731
+        mx = lambda k: float(max(v[0].get(k, 0) for v in per_rank.values()))  # noqa: E731
+        ticks = mx("rounds") / args.steps
+        out["variants"][name] = {"value": (tot("rays_closest") + tot("rays_any")) / el / 1e6, "unit": "Mrays/s", "ms_per_step": el / args.steps * 1e3,
+                                 "ticks_per_step": ticks, "ms_per_tick": el / args.steps * 1e3 / ticks if ticks else None,
+                                 "launch_chains_per_step": mx("chains") / args.steps, "host_syncs_per_step": mx("host_syncs") / args.steps,
+                                 "rays_sent_per_step": tot("rays_sent") / args.steps, "bytes_sent_per_step": tot("bytes_sent") / args.steps,
+                                 "phase_ms_per_step_max_over_ranks": {k[3:]: mx(k) / args.steps for k in PHASES}}
+    out["value"] = out["variants"]["domain_async"]["value"]
+    out["unit"] = "Mrays/s"
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,7 +362,17 @@ def main():
     ap.add_argument("--no-abi-path", action="store_true")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal only: every rank uses device 0 (needs an RCCL that tolerates it)")
+    ap.add_argument("--single-variant", action="store_true", help="N>1: only the variant --scheduler / --bsp select (default: Domain asynchronous = `value`, "
+                                                                    "plus Domain BSP and the replicated Image scheduler as extra keys of the same line)")
+    ap.add_argument("--inproc-ranks", type=int, default=0, help="N=1 only: run the native multi-rank frame loop with this many in-process ranks on ONE GPU "
+                                                                 "(hub transport) and print the per-variant tick / byte / phase table; a diagnostic, not a scaling run")
+    ap.add_argument("--exchange-timeout-ms", type=int, default=0, help="N>1: deadline of every blocking point of the ray exchange (default: the library's 20 s)")
     args = ap.parse_args()
+    if args.inproc_ranks > 1:
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+            print("bench.py: --inproc-ranks is a one-process, one-GPU mode", file=sys.stderr)
+            sys.exit(2)
+        return inproc_ranks(args)
 
     import numpy as np
     import torch
@@ -291,7 +425,9 @@ def main():
         if world > 1:
             uid = [Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
-            comm = Comm.rccl(uid[0], rank, world)
+            comm = Comm.rccl(uid[0], rank, world)  # fails unless ncclCommCount == world
+            if args.exchange_timeout_ms > 0:
+                comm.set_deadline_ms(args.exchange_timeout_ms)
         tracer = NativeTracer(scene, NORMALS_FLAT, owner, comm, replicate=image_split)
         frame_stats = lambda: tracer.stats  # noqa: E731
     else:
@@ -316,7 +452,12 @@ def main():
 
     def frame():
         if args.harness == "native":
-            tracer(bsp=args.bsp, image=image_split)  # includes IceTComposite::composite (to rank 0); the PPM download is not part of the frame
+            try:
+                tracer(bsp=args.bsp, image=image_split)  # includes IceTComposite::composite (to rank 0); the PPM download is not part of the frame
+            except capi.GvtHipError as e:
+                if world == 1:
+                    raise
+                die_on_exchange_error(rank, world, "the primary variant", e, tracer.stats)
         else:
             tracer()
             if world > 1:
@@ -330,7 +471,7 @@ def main():
         capi.profile(2)  # HIP events on the launch stream around the traversal kernels (closest hit, long rays, any hit)
     else:
         tracer.backend.rays_closest = tracer.backend.rays_any = 0
-    per_frame, sums = [], {"rays_closest": 0, "rays_any": 0, "rays_sent": 0, "rounds": 0, "chains": 0, "host_syncs": 0}
+    per_frame, sums = [], {"rays_closest": 0, "rays_any": 0, "rays_sent": 0, "rounds": 0, "chains": 0, "host_syncs": 0, "bytes_sent": 0}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         f0 = time.perf_counter()
@@ -357,6 +498,53 @@ def main():
         elapsed = float(mx[3].item())
     rays_closest, rays_any, rays_sent = float(tot[0].item()), float(tot[1].item()), float(tot[2].item())
     rays_total = rays_closest + rays_any
+
+    # N > 1: the scheduler variants in ONE invocation -- Domain asynchronous, Domain BSP and (native harness) the replicated Image
+    # scheduler -- as extra keys of the line; `value` stays the primary variant measured above
+    variants = None
+    if world > 1 and not args.single_variant:
+        def reduce_sum(v):
+            t = torch.tensor(v, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return [float(x) for x in t]
+
+        def reduce_max(v):
+            t = torch.tensor(v, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return [float(x) for x in t]
+
+        variants = {}
+        primary = "image_replicated" if image_split else ("domain_bsp" if args.bsp else "domain_async")
+        todo = [("domain_async", "domain", False), ("domain_bsp", "domain", True)] + ([("image_replicated", "image", False)] if args.harness == "native" else [])
+        for name, kind, bsp_v in todo:
+            made = None
+            if args.harness == "native":
+                if (kind == "image") == image_split:
+                    tr_v = tracer  # same scene and tracer as the primary variant
+                else:
+                    sc_v = scenes.soup_scene(args.tris, args.width, args.height) if kind == "image" else scenes.soup_domains_scene(args.tris, world, args.width, args.height)
+                    tr_v = made = NativeTracer(sc_v, NORMALS_FLAT, [i % world for i in range(sc_v.n_inst)], comm, replicate=(kind == "image"))
+                run_v = (lambda t=tr_v, b=bsp_v, im=(kind == "image"): t(bsp=b, image=im))
+                stats_v = (lambda t=tr_v: t.stats)
+            else:  # the Python scheduler loops (harness / CPU rehearsal): a tracer per variant, counters through the backend
+                be_v = None if on_gpu else OracleBackend(scene, NORMALS_FLAT, [o == rank for o in owner])
+                tr_v = made = DomainTracer(scene, owner, dist, torch, dev, NORMALS_FLAT, backend=be_v, overlap=not bsp_v)
+                last = {"c": 0, "a": 0}
+
+                def run_v(t=tr_v):
+                    t()
+                    t.composite(download=False)
+
+                def stats_v(t=tr_v, last=last):
+                    c, a = getattr(t.backend, "rays_closest", 0), getattr(t.backend, "rays_any", 0)
+                    d = {"rays_closest": c - last["c"], "rays_any": a - last["a"], "rays_sent": getattr(t, "rays_sent", 0), "rounds": getattr(t, "rounds", 0)}
+                    last["c"], last["a"] = c, a
+                    return d
+            res_v, _, _, _ = measure_variant(run_v, stats_v, args.steps, args.warmup, barrier, reduce_sum, reduce_max, rank, world, name)
+            res_v["is_value"] = name == primary
+            variants[name] = res_v
+            if made is not None and hasattr(made, "close"):
+                made.close()
 
     if rank == 0:
         gpu_fb = tracer.backend.framebuffer(False) if (on_gpu and world == 1 and n_dom == 1) else None  # before the extra legs reuse the backend
@@ -395,6 +583,12 @@ def main():
                 "normal_mode": "flat",
             },
         }
+        if world > 1 and args.harness == "native":
+            out["config"]["rccl_comm_count"] = comm.count  # == WORLD_SIZE (gvt_hip_comm_create refuses anything else)
+        if variants is not None:
+            out["config"]["bytes_sent_per_step"] = ([v for v in variants.values() if v["is_value"]] or [{}])[0].get("bytes_sent_per_step")
+        if variants is not None:
+            out["variants"] = variants  # Domain asynchronous / Domain BSP / replicated Image, each: ticks, ms per tick, rays and bytes sent, per-phase ms
         if on_gpu:
             dom = "closest" if st["ms_closest"] >= st["ms_any"] else "any"
             ms_dom = st["ms_%s" % dom]

@@ -127,3 +127,8 @@ def test_bench_script_multi_rank_branch_under_gloo(tmp_path):
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "strong" and j["value"] > 0
     assert j["config"]["primary_traced_per_step"] > 1000 and j["config"]["shadow_traced_per_step"] > 100
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")], "only rank 0 prints the line"
+    # the scheduler variants measured in the same invocation (the native harness adds the replicated Image scheduler)
+    v = j["variants"]
+    assert set(v) == {"domain_async", "domain_bsp"} and v["domain_async"]["is_value"] and not v["domain_bsp"]["is_value"]
+    for r in v.values():
+        assert r["value"] > 0 and r["ms_per_step"] > 0 and set(r["phase_ms_per_step_max_over_ranks"]) == {"chain", "announce", "payload", "composite", "host_wait"}
