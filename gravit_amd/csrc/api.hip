@@ -1,6 +1,8 @@
 // api.hip -- C ABI glue of include/gvt_hip.h: context, meshes, device ray queues, Adapter::trace.
+#include <atomic>
 #include <cmath>
 #include <mutex>
+#include <thread>
 
 #include "gvt_internal.h"
 
@@ -81,6 +83,9 @@ extern "C" void gvt_hip_ctx_destroy(gvt_hip_ctx *c) {
     for (auto e : C->event_pool) hipEventDestroy(e);
     if (C->abi_qin) gvt_hip_queue_destroy(C->abi_qin);
     if (C->abi_qout) gvt_hip_queue_destroy(C->abi_qout);
+    for (Ctx *L : C->abi_lanes) gvt_hip_ctx_destroy((gvt_hip_ctx *)L);
+    C->abi_lanes.clear();
+    hipSetDevice(C->device);
     for (int k = 0; k < 24; k++) if (C->scratch[k]) hipFree(C->scratch[k]);
     hipFree(C->d_spill); hipFree(C->d_counters); hipHostFree(C->h_pinned);
     hipStreamDestroy(C->own_stream);
@@ -199,6 +204,9 @@ extern "C" int gvt_hip_set_option(const char *name, int value) {
   if (!std::strcmp(name, "small_rays")) { g_ctx.small_rays = value < 0 ? 0 : value; return 0; }
   if (!std::strcmp(name, "first_round_async")) { g_ctx.first_round_async = value; return 0; }
   if (!std::strcmp(name, "lean_frame")) { g_ctx.lean_frame = value; return 0; }
+  if (!std::strcmp(name, "abi_lanes")) { if (value < 0 || value > 8) { set_error("abi_lanes must be 0..8"); return GVT_HIP_ERR_INVALID; } g_ctx.abi_lanes_n = value; return 0; }
+  if (!std::strcmp(name, "abi_chunk")) { if (value < 16384) { set_error("abi_chunk must be >= 16384"); return GVT_HIP_ERR_INVALID; } g_ctx.abi_chunk = value; return 0; }
+  if (!std::strcmp(name, "abi_pipe_min")) { g_ctx.abi_pipe_min = value < 0 ? 0 : value; return 0; }
   if (!std::strcmp(name, "report_poll")) { g_ctx.report_poll = value; return 0; }
   if (!std::strcmp(name, "inject_fail_tick")) { g_ctx.inject_fail_tick = value; return 0; }
   if (!std::strcmp(name, "wave_single")) { g_ctx.wave_single = value; return 0; }
@@ -459,6 +467,77 @@ extern "C" int gvt_hip_trace(gvt_hip_mesh *M, gvt_hip_ray *rays, size_t n_rays, 
   return gvt_hip_trace_ex(M, rays, n_rays, begin, end, rays_out, cap, n_out, m, minv, normi, lights, n_lights, normal_mode, seed, 0u);
 }
 
+// Adapter::trace on a HOST RayVector, pipelined like the reference's own GPU adapter (adapter/optix/OptixMeshAdapter.cpp:622-684: the
+// list cut into packets on two streams so that upload, trace and download overlap).  The list is cut into chunks; `abi_lanes` host
+// threads, each with a context of its own (stream, scratch, counters, staging queues), take chunks in turn: upload of the 80-byte rays
+// + conversion to planes, the closest / shade / any chain, download of the updated rayList slice and of the chunk's moved rays to
+// their place behind the moved rays of the chunks before it (a running offset; the order of moved_rays is unspecified in the
+// reference too, EmbreeMeshAdapter.cpp:619-621).  While one lane waits for its chain or its download, another uploads: the two
+// directions of the link and the kernels overlap.  Results do not depend on the cut: a ray's RNG stream is keyed on its index in
+// rayList (trace_core's index_base).  Used when rays_out has room for the worst case n * (1 + n_lights), so that a capacity error
+// cannot arise after the rayList has begun to change; smaller buffers take the one-shot path below.
+static int trace_pipelined(Ctx &C, gvt_hip_mesh *M, gvt_hip_ray *rays, size_t begin, size_t n, gvt_hip_ray *rays_out, size_t *n_out, const TraceParams &P,
+                           const gvt_hip_light *lights, size_t n_lights, bool write_back) {
+  const int L = C.abi_lanes_n < 1 ? 1 : (C.abi_lanes_n > 8 ? 8 : C.abi_lanes_n);
+  while ((int)C.abi_lanes.size() < L) {
+    Ctx *LC = (Ctx *)gvt_hip_ctx_create(C.device);
+    if (!LC) return GVT_HIP_ERR_DEVICE;
+    C.abi_lanes.push_back(LC);
+  }
+  const size_t chunk = (size_t)(C.abi_chunk < 16384 ? 16384 : C.abi_chunk);
+  const size_t n_chunks = (n + chunk - 1) / chunk;
+  std::atomic<size_t> next{ 0 }, out_pos{ 0 };
+  std::atomic<int> err{ 0 };
+  std::mutex mu;
+  std::string err_msg;
+  Ctx *caller_ctx = &C;
+  auto work = [&](int li) {
+    Ctx *LC = C.abi_lanes[(size_t)li];
+    gvt_hip_ctx_make_current((gvt_hip_ctx *)LC);
+    static_cast<Knobs &>(*LC) = static_cast<const Knobs &>(*caller_ctx); // the caller's tuning knobs
+    LC->profile = 0;
+    const gvt_hip_stats before = LC->stats;
+    int rc = 0;
+    if (!LC->abi_qin) { LC->abi_qin = gvt_hip_queue_create(0); LC->abi_qout = gvt_hip_queue_create(0); }
+    gvt_hip_queue *qin = LC->abi_qin, *qout = LC->abi_qout;
+    if (!qin || !qout) rc = GVT_HIP_ERR_DEVICE;
+    while (!rc && !err.load()) {
+      const size_t k = next.fetch_add(1);
+      if (k >= n_chunks) break;
+      const size_t off = k * chunk, cn = std::min(chunk, n - off);
+      size_t got = 0;
+      if ((rc = gvt_hip_queue_clear(qin)) || (rc = gvt_hip_queue_clear(qout))) break;
+      if ((rc = gvt_hip_queue_append(qin, rays + begin + off, cn, 0))) break;
+      if ((rc = queue_reserve(qout, cn * (1 + n_lights)))) break;
+      if ((rc = trace_core(M, make_planes(qin->d_planes, qin->cap), cn, begin + off, qout, P, lights))) break;
+      const size_t moved = qout->size, pos = out_pos.fetch_add(moved);
+      if (write_back && (rc = gvt_hip_queue_export(qin, rays + begin + off, cn, &got, 0))) break; // rayList is updated in place (r.mice.t, bounce state)
+      if (moved && (rc = gvt_hip_queue_export(qout, rays_out + pos, moved, &got, 0))) break;
+    }
+    if (rc) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!err.load()) { err.store(rc); err_msg = gvt_hip_last_error(); }
+    }
+    { // the lane's counters belong to the caller's context
+      std::lock_guard<std::mutex> lk(mu);
+      gvt_hip_stats &S = caller_ctx->stats;
+      const gvt_hip_stats &A = LC->stats;
+      S.rays_closest += A.rays_closest - before.rays_closest; S.rays_any += A.rays_any - before.rays_any; S.rays_shaded += A.rays_shaded - before.rays_shaded;
+      S.rays_forwarded += A.rays_forwarded - before.rays_forwarded; S.launches_closest += A.launches_closest - before.launches_closest;
+      S.launches_any += A.launches_any - before.launches_any; S.trace_calls += A.trace_calls - before.trace_calls;
+    }
+    gvt_hip_ctx_make_current(nullptr);
+  };
+  std::vector<std::thread> th;
+  const int n_thr = (int)std::min<size_t>((size_t)L, n_chunks);
+  for (int li = 0; li < n_thr; li++) th.emplace_back(work, li);
+  for (auto &t : th) t.join();
+  C.stats.trace_calls -= (uint64_t)(n_chunks ? n_chunks - 1 : 0); // ONE Adapter::trace call
+  if (err.load()) { set_error("%s", err_msg.c_str()); return err.load(); }
+  *n_out = out_pos.load();
+  return 0;
+}
+
 extern "C" int gvt_hip_trace_ex(gvt_hip_mesh *M, gvt_hip_ray *rays, size_t n_rays, size_t begin, size_t end, gvt_hip_ray *rays_out, size_t cap,
                                 size_t *n_out, const float m[16], const float minv[16], const float normi[9], const gvt_hip_light *lights,
                                 size_t n_lights, int normal_mode, uint32_t seed, uint32_t flags) {
@@ -475,6 +554,10 @@ extern "C" int gvt_hip_trace_ex(gvt_hip_mesh *M, gvt_hip_ray *rays, size_t n_ray
   const size_t n = end - begin;
   *n_out = 0;
   if (!n) return 0;
+  if (C.abi_lanes_n > 0 && n >= (size_t)C.abi_pipe_min && rays_out && cap >= n * (1 + n_lights)) {
+    P.update_in_place = write_back ? 1 : 0;
+    return trace_pipelined(C, M, rays, begin, n, rays_out, n_out, P, lights, n_lights, write_back);
+  }
   if (!C.abi_qin) { C.abi_qin = gvt_hip_queue_create(0); C.abi_qout = gvt_hip_queue_create(0); }
   gvt_hip_queue *qin = C.abi_qin, *qout = C.abi_qout;
   if (!qin || !qout) return GVT_HIP_ERR_DEVICE;

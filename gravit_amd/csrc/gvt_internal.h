@@ -43,6 +43,9 @@ struct Knobs {
                          // Off: 8 % faster on a surface mesh (bun_zipper), 2.5x-20x SLOWER on the random soups
   int small_rays = 4096; // scheduler rounds holding at most this many rays give every ray a whole wave (k_long_closest / k_wave_any): ~40 us
                          // per traversal launch instead of the ~150 us latency floor of a one-lane-per-ray launch
+  int abi_lanes_n = 4;   // gvt_hip_trace on a host RayVector: host threads (each with a context of its own) that pipeline the list's chunks (0: one shot)
+  int abi_chunk = 262144; // ... rays per chunk
+  int abi_pipe_min = 131072; // ... lists shorter than this take the one-shot path
   int lean_frame = 1;    // one-instance scenes on one rank: framebuffer clear, counter resets and the chain's begin / end folded into the camera filter's
                          // two kernels and the round's report (8 launches per frame instead of 14)
   int inject_fail_tick = -1; // tests: this rank's local work "fails" at that exchange of a multi-rank frame (the announce carries the error to every rank)
@@ -86,6 +89,7 @@ struct Ctx : Knobs {
   const void *lights_cached_dst = nullptr;
   // staging queues of gvt_hip_trace (host RayVector in / out)
   gvt_hip_queue *abi_qin = nullptr, *abi_qout = nullptr;
+  std::vector<Ctx *> abi_lanes; // contexts of the pipelined host path's lanes (api.hip trace_pipelined), created on first use
 };
 // The context API calls run on: the calling thread's current context (gvt_hip_ctx_make_current), else the process default one
 // (gvt_hip_init).  A context owns a stream, scratch arenas, counters, statistics and knobs; meshes / queues / framebuffers are plain

@@ -95,6 +95,11 @@ void HipMeshAdapter::trace(gvt::render::actor::RayVector &rayList, gvt::render::
   // The moved rays are written straight behind moved_rays' current contents, under the adapter's lock like the append of
   // EmbreeMeshAdapter.cpp:619-621 (Ray() constructs nothing, so growing the vector touches no memory; the schedulers reserve
   // 10x the input, ImageTracer.h:240): no intermediate buffer, no second copy of 80 bytes per moved ray.
+  // One call at a time per adapter, like the reference (its trace() writes the members begin / end / global_scene,
+  // EmbreeMeshAdapter.cpp:633-645, and both schedulers call an adapter from their single scheduler thread): the lock is held across
+  // the device call because the library writes into moved_rays' own storage -- a second caller would otherwise see the vector
+  // grown by the worst case.  Concurrency inside the call is the library's (gvt_hip_trace_ex pipelines the list over several
+  // host threads and streams).  cap is the worst case n * (1 + lights), which is also what lets the library take that path.
   std::unique_lock<std::mutex> moved(_outqueue);
   const size_t old = moved_rays.size();
   moved_rays.resize(old + cap);

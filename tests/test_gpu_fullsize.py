@@ -6,9 +6,9 @@ import pytest
 from gravit_amd import scenes
 from gravit_amd.adapter import HipMeshAdapter
 from gravit_amd.layouts import NORMALS_FLAT
-from gravit_amd.scheduler import ImageTracer
+from gravit_amd.scheduler import ImageTracer, NativeTracer
 from oracle import orc
-from tests.helpers import bits, oracle_camera_rays
+from tests.helpers import bits, oracle_camera_rays, oracle_render
 
 pytestmark = pytest.mark.gpu
 
@@ -99,3 +99,43 @@ def test_traversal_layouts_agree_at_full_size(soup, hip):
     hip.set_option("defaults", 0)
     assert a.tobytes() == b.tobytes(), "parking long rays changed a hit record"
     assert parked_ms > 0.0 and (a["prim"] >= 0).sum() > 900_000
+
+
+def test_whole_config3_frame_of_the_native_tracer_is_bit_exact(soup, hip):
+    """The benchmark's own frame -- 10 M triangles, 1920x1080, the native tracer the bench times -- against a multi-threaded pass of
+    the CPU oracle over the same rays: the WHOLE float framebuffer bit for bit, the ray counts equal (the comparison bench.py
+    prints as `parity`, inside the test-suite)."""
+    sc, _ = soup
+    tr = NativeTracer(sc, NORMALS_FLAT)
+    fb = tr().framebuffer(True).copy()
+    stats = dict(tr.stats)
+    fb2 = tr().framebuffer(True)
+    assert np.array_equal(fb, fb2)
+    ref, st = oracle_render(sc, NORMALS_FLAT, nthreads=16)
+    assert fb.shape == ref.shape == (1080, 1920, 4)
+    assert np.array_equal(fb.view(np.uint32), ref.view(np.uint32)), "max |diff| %g in %d pixels" % (np.abs(fb - ref).max(), (fb != ref).any(axis=2).sum())
+    assert stats["rays_closest"] == st.rays_closest == 1_040_400 and stats["rays_any"] == st.rays_any > 1_000_000
+    assert stats["host_syncs"] == 1 and stats["chains"] == 1
+    tr.close()
+
+
+def test_config1_bunny_conf_at_its_full_film(hip):
+    """BASELINE config 1 at the film size data/bunny.conf states (1900 x 1080, :8): three bunny instances through the native tracer
+    and through the reference-order loop, whole float framebuffer against the oracle's restated Image scheduler (smooth normals,
+    the mode of the reference's golden images)."""
+    import os
+
+    from gravit_amd.layouts import NORMALS_SMOOTH
+    from tests.conftest import GOLDEN
+    sc = scenes.load_conf(os.path.join(GOLDEN, "bunny.conf"))
+    assert (sc.camera.width, sc.camera.height) == (1900, 1080)
+    ref, st = oracle_render(sc, NORMALS_SMOOTH, nthreads=16)
+    assert (ref[..., 3] > 0).sum() > 50_000
+    tr = NativeTracer(sc, NORMALS_SMOOTH)
+    fb = tr().framebuffer(True)
+    assert np.array_equal(fb[..., :3].view(np.uint32), ref[..., :3].view(np.uint32)) and np.array_equal(fb[..., 3], ref[..., 3])
+    assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any
+    tr.close()
+    it = ImageTracer(sc, NORMALS_SMOOTH)
+    fb = it().framebuffer(True)
+    assert np.array_equal(fb[..., :3].view(np.uint32), ref[..., :3].view(np.uint32)) and it.adapter_calls == st.adapter_calls
