@@ -147,6 +147,16 @@ class HipMeshAdapter:
                    "gvt_hip_intersect")
         return out
 
+    def wide_visit_stats(self, org, dirs, width, tnear=1e-6):
+        """Diagnostic: nodes a `width`-wide collapse of the tree would make each ray visit (mean), and the collapse's node count."""
+        org = capi.f32(org, (-1, 3))
+        dirs = capi.f32(dirs, (-1, 3))
+        cnt = np.zeros(len(org), np.uint32)
+        nw = C.c_uint64(0)
+        capi.check(self.lib.gvt_hip_wide_visit_stats(self.h, capi.ptr(org), capi.ptr(dirs), C.c_size_t(len(org)), C.c_float(tnear), C.c_int(width),
+                                                     capi.ptr(cnt), C.byref(nw)), "gvt_hip_wide_visit_stats")
+        return {"width": width, "nodes_per_ray": float(cnt.mean()), "p99": float(np.percentile(cnt, 99)), "max": int(cnt.max()), "wide_nodes": int(nw.value)}
+
     def visit_stats(self, org, dirs, tnear=1e-6):
         """Diagnostic: per-ray (inner-node visits, leaf visits, triangle tests) of the closest-hit traversal, plus the
         number of steps a 64-lane wave executes per batch (the slowest lane's inner + leaf steps)."""

@@ -644,6 +644,28 @@ extern "C" int gvt_hip_visit_stats(gvt_hip_mesh *M, const float *org, const floa
   return 0;
 }
 
+extern "C" int gvt_hip_wide_visit_stats(gvt_hip_mesh *M, const float *org, const float *dir, size_t n, float tnear, int width, uint32_t *counts /* n */,
+                                        uint64_t *n_wide_nodes) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!M || (n && (!org || !dir || !counts)) || width < 2 || width > 8) { set_error("wide_visit_stats: null argument or width outside 2..8"); return GVT_HIP_ERR_INVALID; }
+  if (!n || !M->nNodes) { for (size_t i = 0; i < n; i++) counts[i] = 0; if (n_wide_nodes) *n_wide_nodes = 0; return 0; }
+  Ctx &C = g_ctx;
+  unsigned char *d_marks = nullptr;
+  HIPCHK(hipMalloc((void **)&d_marks, M->nNodes));
+  size_t nw = 0;
+  int rc = wide_root_marks(M, width, d_marks, &nw);
+  RayPlanes pl;
+  if (!rc) rc = stage_od(org, dir, n, pl);
+  unsigned *d_out = rc ? nullptr : (unsigned *)scratch_get(0, n * sizeof(unsigned));
+  if (!rc && !d_out) rc = GVT_HIP_ERR_DEVICE;
+  if (!rc) rc = launch_wide_visit_stats(M, pl, n, tnear, d_marks, d_out);
+  if (!rc && hipMemcpyAsync(counts, d_out, n * sizeof(unsigned), hipMemcpyDeviceToHost, C.stream) != hipSuccess) rc = GVT_HIP_ERR_DEVICE;
+  if (hipStreamSynchronize(C.stream) != hipSuccess && !rc) rc = GVT_HIP_ERR_DEVICE;
+  hipFree(d_marks);
+  if (n_wide_nodes) *n_wide_nodes = nw;
+  return rc;
+}
+
 int debug_stamps(unsigned long long *out, int reset);
 extern "C" int gvt_hip_is_experiments_build(void) {
 #ifdef GVT_EXPERIMENTS

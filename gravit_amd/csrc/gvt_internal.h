@@ -249,6 +249,8 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
 int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, bool xform, const Mat4 &minv, float tnear,
                    gvt_hip_hit *d_hits, bool counter_is_zero = false);
 int launch_visit_stats(gvt_hip_mesh *M, RayPlanes q, size_t n, float tnear, unsigned *d_out);
+int launch_wide_visit_stats(gvt_hip_mesh *M, RayPlanes q, size_t n, float tnear, const unsigned char *d_marks, unsigned *d_out);
+int wide_root_marks(gvt_hip_mesh *M, int width, unsigned char *d_marks, size_t *n_wide); // lbvh.hip
 int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const Mat4 &minv, float tnear, int *d_flags);
 int set_device_u32(unsigned *p, unsigned v); // stream-ordered store of a host-known value
 // one round's merged launch chain (no host round trip inside); `out` must have room for n_total * (1 + n_lights * passes) rays and

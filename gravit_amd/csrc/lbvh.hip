@@ -370,6 +370,33 @@ __global__ __launch_bounds__(256) void k_collapse4(const BvhNode *__restrict__ n
   }
 }
 
+// Marks the binary nodes that become roots of W-wide nodes under k_collapse4's rule (start from the two children, replace the inner
+// child of largest area by its two children until W slots are filled), level by level: the diagnostic behind "how many steps would
+// an 8-wide layout take" (gvt_hip_wide_visit_stats).
+__global__ __launch_bounds__(256) void k_collapse_mark(const BvhNode *__restrict__ nodes, const int *__restrict__ fin, unsigned n_in, int width,
+                                                       int *__restrict__ fout, unsigned *__restrict__ next_count, unsigned char *__restrict__ marks) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_in) return;
+  marks[fin[i]] = 1;
+  Slot4 c[8];
+  int n = 2;
+  const BvhNode nb = nodes[fin[i]];
+  slot_from(nb, 0, c[0]); slot_from(nb, 1, c[1]);
+  if (c[1].ref == GVT_EMPTY_REF) n = 1;
+  while (n < width) {
+    int k = -1;
+    float best = -1.f;
+    for (int s = 0; s < n; s++)
+      if (c[s].ref >= 0) { const float a = slot_area(c[s]); if (a > best) { best = a; k = s; } }
+    if (k < 0) break;
+    const BvhNode nc = nodes[c[k].ref];
+    slot_from(nc, 0, c[k]); slot_from(nc, 1, c[n]);
+    n++;
+  }
+  for (int s = 0; s < n; s++)
+    if (c[s].ref >= 0) fout[atomicAdd(next_count, 1u)] = c[s].ref;
+}
+
 template <typename T> int dalloc(T **p, size_t n) {
   hipError_t e = hipMalloc((void **)p, sizeof(T) * (n ? n : 1));
   if (e != hipSuccess) { set_error("hipMalloc(%zu B) failed: %s", sizeof(T) * n, hipGetErrorString(e)); return GVT_HIP_ERR_DEVICE; }
@@ -577,5 +604,38 @@ int build_nodes4(gvt_hip_mesh *M) {
   }
   hipFree(fa); hipFree(fb); hipFree(cnt);
   if (rc) { hipFree(M->d_nodes4); M->d_nodes4 = nullptr; hipFree(M->d_nodes4q); M->d_nodes4q = nullptr; }
+  return rc;
+}
+
+// diagnostic: marks[k] = 1 where binary node k is the root of a `width`-wide node (width 2..8); *n_wide = number of wide nodes
+int wide_root_marks(gvt_hip_mesh *M, int width, unsigned char *d_marks, size_t *n_wide) {
+  Ctx &C = gctx();
+  hipStream_t st = C.stream;
+  int *fa = nullptr, *fb = nullptr;
+  unsigned *cnt = nullptr;
+  int rc = dalloc(&fa, M->nNodes);
+  if (!rc) rc = dalloc(&fb, M->nNodes);
+  if (!rc) rc = dalloc(&cnt, 1);
+  size_t total = 0;
+  if (!rc) {
+    const int root = 0;
+    hipError_t e = hipMemsetAsync(d_marks, 0, M->nNodes, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(fa, &root, sizeof root, hipMemcpyHostToDevice, st);
+    unsigned n_in = 1;
+    while (e == hipSuccess && n_in) {
+      e = hipMemsetAsync(cnt, 0, sizeof(unsigned), st);
+      if (e != hipSuccess) break;
+      k_collapse_mark<<<(n_in + 255) / 256, 256, 0, st>>>(M->d_nodes, fa, n_in, width, fb, cnt, d_marks);
+      unsigned n_next = 0;
+      e = hipMemcpyAsync(&n_next, cnt, sizeof n_next, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      total += n_in;
+      n_in = n_next;
+      int *t = fa; fa = fb; fb = t;
+    }
+    if (e != hipSuccess) { set_error("wide_root_marks: %s", hipGetErrorString(e)); rc = GVT_HIP_ERR_DEVICE; }
+  }
+  hipFree(fa); hipFree(fb); hipFree(cnt);
+  if (n_wide) *n_wide = total;
   return rc;
 }

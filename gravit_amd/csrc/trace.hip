@@ -1446,6 +1446,17 @@ int launch_visit_stats(gvt_hip_mesh *M, RayPlanes q, size_t n, float tnear, unsi
   return 0;
 }
 
+int launch_wide_visit_stats(gvt_hip_mesh *M, RayPlanes q, size_t n, float tnear, const unsigned char *d_marks, unsigned *d_out) {
+  if (!n) return 0;
+  Ctx &C = gctx();
+  Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
+  unsigned *counter = C.d_counters + 0;
+  HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), C.stream));
+  k_wide_visit_stats<<<trav_grid(n), TRAV_BLOCK, 0, C.stream>>>(q, (unsigned)n, T, tnear, d_marks, d_out, counter, C.d_spill);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const Mat4 &minv, float tnear, int *d_flags) {
   if (!n) return 0;
   Ctx &C = gctx();

@@ -303,6 +303,10 @@ int gvt_hip_stats_reset(void);
 /* diagnostic, not on the hot path: per-ray visit counts of the closest-hit traversal over n object-space rays:
  * counts[3*j + 0..2] = inner-node visits / leaf visits / triangle tests of ray j. */
 int gvt_hip_visit_stats(gvt_hip_mesh *, const float *org, const float *dir, size_t n, float tnear, uint32_t *counts);
+/* diagnostic, not on the hot path: the number of nodes a `width`-wide collapse of the mesh's tree (width 2..8, the collapse rule of the
+ * 4-wide layout the traversal uses) would make each ray visit; *n_wide_nodes (optional) = nodes of that collapse. */
+int gvt_hip_wide_visit_stats(gvt_hip_mesh *, const float *org, const float *dir, size_t n, float tnear, int width, uint32_t *counts /* n */,
+                             uint64_t *n_wide_nodes);
 /* diagnostic, not on the hot path: include/gvt_math.h evaluated on the device, element-wise over n floats -- kind 0 gvt_sinf(x),
  * 1 gvt_cosf(x), 2 (float)gvt_acos(sqrt(1.0 - x)) -- so that a test can compare the device's bits with the host's for the
  * functions the bounce path (EmbreeMeshAdapter.cpp:289-318) is built on. */
