@@ -714,6 +714,14 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
     P.sink.fb = R->fb->d_rgba; P.sink.n_pix = (unsigned)(R->fb->w * R->fb->h);
   }
   WaveSet W{ R->d_segs, R->d_insts, n_seg, R->all_quad ? 1 : 0 };
+  if (C.finish_rays > 0 && N <= (size_t)C.finish_rays && P.sink.fb && !count_on_device) {
+    // a small round: ONE launch follows every ray to its end on this rank (finish_kernel.inc); what remains are rays in other ranks' queues
+    if ((rc = finish_round(W, N, P, R->lights.data(), R->d_qdesc, R->d_owner, R->world > 1 ? R->rank : -1, R->d_overflow))) return rc;
+    k_zero_counts<<<(unsigned)((nI + 255) / 256), 256, 0, st>>>(R->d_count_ptr, R->d_mask, (int)nI); // the traced queues' clear()
+    HIPCHK(hipGetLastError());
+    if (chains) (*chains)++;
+    return 0;
+  }
   WaveSingle one{};
   if (n_seg == 1 && R->meshes[R->h_segs[0].inst] && C.wave_single) {
     const int i0 = R->h_segs[0].inst;

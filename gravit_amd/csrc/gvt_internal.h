@@ -41,6 +41,8 @@ struct Knobs {
                          // Measured 2.4x SLOWER than the three launches: shading inside the persistent kernel is latency-exposed
   int packet = 0;        // scheduler rounds: camera rays in tile order (and their direct-mapped shadow rays) traversed a packet of 64 per wave (k_packet).
                          // Off: 8 % faster on a surface mesh (bun_zipper), 2.5x-20x SLOWER on the random soups
+  int finish_rays = 32768; // scheduler rounds holding at most this many rays are run by ONE kernel that follows every ray to its end on this rank (k_finish):
+                         // no per-hop rounds for the few rays that move between the rank's own domains (0: off)
   int small_rays = 4096; // scheduler rounds holding at most this many rays give every ray a whole wave (k_long_closest / k_wave_any): ~40 us
                          // per traversal launch instead of the ~150 us latency floor of a one-lane-per-ray launch
   int abi_lanes_n = 4;   // gvt_hip_trace on a host RayVector: host threads (each with a context of its own) that pipeline the list's chunks (0: one shot)
@@ -269,6 +271,8 @@ struct WaveSingle { // the launch has ONE segment: its queue planes and instance
 int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
                      const gvt_hip_light *lights_host, const WaveSingle *single, unsigned *const *d_count_ptr, const unsigned char *d_mask, int n_inst,
                      bool defer_end = false);
+int finish_round(const WaveSet &W, size_t n_total, const TraceParams &P, const gvt_hip_light *lights_host, const void *d_qdesc, const int *d_owner, int rank,
+                 unsigned *d_queue_overflow);
 int convert_aos_to_planes(const gvt_hip_ray *d_src, size_t n, RayPlanes dst, size_t dst_off);
 int convert_planes_to_aos(RayPlanes src, size_t src_off, size_t n, gvt_hip_ray *d_dst);
 int convert_od_to_planes(const float *d_org, const float *d_dir, size_t n, RayPlanes dst);

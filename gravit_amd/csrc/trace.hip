@@ -1187,6 +1187,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M1)
   }
 }
 
+#include "finish_kernel.inc" // k_finish: a small round in one launch, every ray followed to its end on this rank
+
 #ifdef GVT_EXPERIMENTS
 #include "experiments/fused_kernel.inc" // k_fused: the one-kernel closest + shade + shadow variant (measured slower; knob `fused`)
 #endif
@@ -1898,6 +1900,45 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
   }
   if (!defer_end) k_wave_end<<<(unsigned)((std::max(n_inst, 1) + 255) / 256), 256, 0, st>>>(c, d_count_ptr, d_mask, n_inst); // + queue[instTarget].clear()
   HIPCHK(hipGetLastError());
+  C.stats.trace_calls++;
+  return 0;
+}
+
+// A small round in ONE launch (finish_kernel.inc): the rays of the segments in W are traced, shaded, their shadow rays traced and
+// everything that moves on is followed through this rank's instances; rays for other ranks' instances are appended to their queues
+// (which must have room: n_total * (1 + n_lights * depth) each), everything else ends in the framebuffer.  No shuffle follows.
+int finish_round(const WaveSet &W, size_t n_total, const TraceParams &P, const gvt_hip_light *lights_host, const void *d_qdesc, const int *d_owner, int rank,
+                 unsigned *d_queue_overflow) {
+  Ctx &C = gctx();
+  if (!n_total) return 0;
+  hipStream_t st = C.stream;
+  const int nL = P.n_lights;
+  gvt_hip_light *d_lights = (gvt_hip_light *)scratch_get(5, sizeof(gvt_hip_light) * (nL > 0 ? nL : 1));
+  if (!d_lights) return GVT_HIP_ERR_DEVICE;
+  {
+    std::vector<unsigned char> &cached = C.lights_cached;
+    const void *&cached_dst = C.lights_cached_dst;
+    const size_t bytes = sizeof(gvt_hip_light) * (size_t)nL;
+    if (nL && (cached_dst != d_lights || cached.size() != bytes || std::memcmp(cached.data(), lights_host, bytes) != 0)) {
+      cached.assign((const unsigned char *)lights_host, (const unsigned char *)lights_host + bytes);
+      cached_dst = d_lights;
+      HIPCHK(hipMemcpyAsync(d_lights, cached.data(), bytes, hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+  }
+  FinishArgs A;
+  A.W = W; A.n = (unsigned)n_total; A.lights = d_lights; A.n_lights = nL; A.normal_mode = P.normal_mode;
+  A.top = P.sink.top; A.fb = P.sink.fb; A.n_pix = P.sink.n_pix;
+  A.queues = (const QueueDesc *)d_qdesc; A.owner = d_owner; A.rank = rank;
+  A.counter = C.d_counters + 0; A.tot = (unsigned long long *)(C.d_counters + 16);
+  A.queue_overflow = d_queue_overflow; A.trav_overflow = C.d_counters + TRAV_OVF_WORD;
+  HIPCHK(hipMemsetAsync(C.d_counters, 0, sizeof(unsigned), st));
+  {
+    ProfScope ps(KC_CLOSEST);
+    k_finish<<<(int)std::min<size_t>((n_total + 3) / 4, (size_t)C.n_cu * 3), 256, 0, st>>>(A);
+  }
+  HIPCHK(hipGetLastError());
+  C.stats.launches_closest++;
   C.stats.trace_calls++;
   return 0;
 }
