@@ -1935,7 +1935,7 @@ int finish_round(const WaveSet &W, size_t n_total, const TraceParams &P, const g
   HIPCHK(hipMemsetAsync(C.d_counters, 0, sizeof(unsigned), st));
   {
     ProfScope ps(KC_CLOSEST);
-    k_finish<<<(int)std::min<size_t>((n_total + 3) / 4, (size_t)C.n_cu * 3), 256, 0, st>>>(A);
+    k_finish<<<(int)std::min<size_t>((n_total + 3) / 4, (size_t)C.n_cu * 3), 256, 0, st>>>(A); // 48 KiB of LDS per block
   }
   HIPCHK(hipGetLastError());
   C.stats.launches_closest++;

@@ -8,9 +8,12 @@ if sys.argv[1] == "run":
     from gravit_amd.layouts import NORMALS_FLAT
     from gravit_amd.scheduler import NativeTracer
     capi.init(0)
+    n_dom = 1
     for a in sys.argv[2:]:
-        k, v = a.split("="); capi.set_option(k, int(v))
-    tr = NativeTracer(scenes.soup_scene(10_000_000), NORMALS_FLAT)
+        k, v = a.split("=")
+        if k == "domains": n_dom = int(v)
+        else: capi.set_option(k, int(v))
+    tr = NativeTracer(scenes.soup_scene(10_000_000) if n_dom == 1 else scenes.soup_domains_scene(10_000_000, n_dom), NORMALS_FLAT)
     for _ in range(6):
         tr()
     capi.synchronize()
@@ -24,13 +27,13 @@ else:
     def name(r):
         m = re.search(r"(k_[a-z_0-9]+)", r["Kernel_Name"])
         return m.group(1) if m else r["Kernel_Name"][:32]
-    idx = [i for i, r in enumerate(rows) if name(r) in ("k_top_classify", "k_cam1_count")]
-    a = idx[-1]
-    while a > 0 and int(rows[a]["Start_Timestamp"]) - int(rows[a - 1]["End_Timestamp"]) < 60000 and name(rows[a - 1]) != "k_round_report":
-        a -= 1
-    b = a
-    while b < len(rows) and name(rows[b]) != "k_round_report":
-        b += 1
+    # a frame starts at the framebuffer clear (fill) or the lean path's k_cam1_count and ends with its last k_round_report
+    starts = [i for i, r in enumerate(rows) if name(r) in ("k_cam1_count", "k_zero_totals")]
+    a = starts[-2] if len(starts) > 1 else starts[-1]
+    nxt = [i for i in starts if i > a]
+    b = (nxt[0] if nxt else len(rows)) - 1
+    while b > a and name(rows[b]) != "k_round_report":
+        b -= 1
     t0 = int(rows[a]["Start_Timestamp"])
     prev_end = t0
     busy = 0
