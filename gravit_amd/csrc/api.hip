@@ -203,6 +203,7 @@ extern "C" int gvt_hip_set_option(const char *name, int value) {
   if (!std::strcmp(name, "packet")) { g_ctx.packet = value; return 0; }
   if (!std::strcmp(name, "small_rays")) { g_ctx.small_rays = value < 0 ? 0 : value; return 0; }
   if (!std::strcmp(name, "finish_rays")) { g_ctx.finish_rays = value < 0 ? 0 : value; return 0; }
+  if (!std::strcmp(name, "round_room_mb")) { g_ctx.round_room_mb = value < 0 ? 0 : value; return 0; }
   if (!std::strcmp(name, "first_round_async")) { g_ctx.first_round_async = value; return 0; }
   if (!std::strcmp(name, "lean_frame")) { g_ctx.lean_frame = value; return 0; }
   if (!std::strcmp(name, "abi_lanes")) { if (value < 0 || value > 8) { set_error("abi_lanes must be 0..8"); return GVT_HIP_ERR_INVALID; } g_ctx.abi_lanes_n = value; return 0; }

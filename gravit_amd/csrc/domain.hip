@@ -36,6 +36,7 @@
 
 int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *from_arr, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
                   gvt_hip_fb *fb, unsigned *d_overflow, const void *d_qdesc);
+int shuffle_exact(gvt_hip_top *T, gvt_hip_queue *q_in, const int *from_arr, int from, gvt_hip_queue *const *queues, gvt_hip_fb *fb);
 int camera_one_instance_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *q, gvt_hip_fb *fb, unsigned *d_overflow, unsigned *d_moved_count);
 int camera_filter_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *const *queues, const uint8_t *keep_mask, unsigned *d_overflow,
                         size_t first, size_t count);
@@ -684,9 +685,18 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
   if (bound >= 0xffffffffull) { set_error("round: %zu rays exceed the 32-bit slot counters", bound); return GVT_HIP_ERR_INVALID; }
   int rc = queue_reserve(R->q_moved, bound);
   if (rc) return rc;
-  for (size_t i = 0; i < nI; i++) { // every destination has room for all of them (288 GB of HBM: worst-case room beats a read-back per shuffle)
+  // Every destination gets room for ALL rays the round can move (288 GB of HBM: worst-case room beats a read-back per shuffle) -- as
+  // long as that fits the round's memory budget.  With hundreds of domains it does not (n_inst x bound x 68 bytes: 86 GB at 256
+  // domains and 1080p): the round then reserves only what is known to arrive and shuffles with exact growth (two synchronisations).
+  size_t growth = 0;
+  for (size_t i = 0; i < nI; i++) {
+    const size_t stay = R->h_mask[i] ? 0 : R->present[i], want = stay + bound + (extra_in ? (*extra_in)[i] : 0);
+    if (want > R->queues[i]->cap) growth += (want - R->queues[i]->cap) * GVT_QUEUE_BYTES_PER_RAY;
+  }
+  const bool exact = growth > ((size_t)(C.round_room_mb > 0 ? C.round_room_mb : 1) << 20) && !count_on_device;
+  for (size_t i = 0; i < nI; i++) {
     const size_t stay = R->h_mask[i] ? 0 : R->present[i];
-    if ((rc = queue_reserve(R->queues[i], stay + bound + (extra_in ? (*extra_in)[i] : 0)))) return rc;
+    if ((rc = queue_reserve(R->queues[i], stay + (exact ? 0 : bound) + (extra_in ? (*extra_in)[i] : 0)))) return rc;
   }
   for (int k = 0; k < n_seg; k++) { // (a reserve above may have moved a traced queue)
     gvt_hip_queue *q = R->queues[R->h_segs[k].inst];
@@ -714,7 +724,7 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
     P.sink.fb = R->fb->d_rgba; P.sink.n_pix = (unsigned)(R->fb->w * R->fb->h);
   }
   WaveSet W{ R->d_segs, R->d_insts, n_seg, R->all_quad ? 1 : 0 };
-  if (C.finish_rays > 0 && N <= (size_t)C.finish_rays && P.sink.fb && !count_on_device) {
+  if (C.finish_rays > 0 && N <= (size_t)C.finish_rays && P.sink.fb && !count_on_device && !exact) {
     // a small round: ONE launch follows every ray to its end on this rank (finish_kernel.inc); what remains are rays in other ranks' queues
     if ((rc = finish_round(W, N, P, R->lights.data(), R->d_qdesc, R->d_owner, R->world > 1 ? R->rank : -1, R->d_overflow))) return rc;
     k_zero_counts<<<(unsigned)((nI + 255) / 256), 256, 0, st>>>(R->d_count_ptr, R->d_mask, (int)nI); // the traced queues' clear()
@@ -736,8 +746,10 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
   const bool single = one.mesh != nullptr;
   if ((rc = wave_trace_chain(W, N, passes, R->q_moved, d_from, P, R->lights.data(), single ? &one : nullptr, R->d_count_ptr, R->d_mask, (int)nI, defer_end && single))) return rc;
   // one instance in the whole scene and the terminal rule applied inside the kernels: nothing can have moved
-  if (!(nI == 1 && P.sink.fb) &&
-      (rc = shuffle_async(R->top, R->q_moved, bound, single ? nullptr : d_from, single ? one.inst : -1, R->queues.data(), nullptr, R->fb, R->d_overflow, R->d_qdesc))) return rc;
+  if (exact) {
+    if ((rc = shuffle_exact(R->top, R->q_moved, single ? nullptr : d_from, single ? one.inst : -1, R->queues.data(), R->fb))) return rc;
+  } else if (!(nI == 1 && P.sink.fb) &&
+             (rc = shuffle_async(R->top, R->q_moved, bound, single ? nullptr : d_from, single ? one.inst : -1, R->queues.data(), nullptr, R->fb, R->d_overflow, R->d_qdesc))) return rc;
   if (chains) (*chains)++;
   return 0;
 }

@@ -41,6 +41,7 @@ struct Knobs {
                          // Measured 2.4x SLOWER than the three launches: shading inside the persistent kernel is latency-exposed
   int packet = 0;        // scheduler rounds: camera rays in tile order (and their direct-mapped shadow rays) traversed a packet of 64 per wave (k_packet).
                          // Off: 8 % faster on a surface mesh (bun_zipper), 2.5x-20x SLOWER on the random soups
+  int round_room_mb = 16384; // scheduler rounds: memory the worst-case reservation of the destination queues may add (MiB); beyond it the round shuffles with exact growth
   int finish_rays = 32768; // scheduler rounds holding at most this many rays are run by ONE kernel that follows every ray to its end on this rank (k_finish):
                          // no per-hop rounds for the few rays that move between the rank's own domains (0: off)
   int small_rays = 4096; // scheduler rounds holding at most this many rays give every ray a whole wave (k_long_closest / k_wave_any): ~40 us

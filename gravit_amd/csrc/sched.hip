@@ -475,7 +475,8 @@ extern "C" int gvt_hip_top_order(const gvt_hip_top *T, int32_t *out) {
 }
 
 // shuffleRays over n rays taken from S (a queue's planes or the camera)
-static int shuffle_impl(gvt_hip_top *T, const RaySrc &in, size_t n, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask, gvt_hip_fb *fb) {
+static int shuffle_impl(gvt_hip_top *T, const RaySrc &in, size_t n, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask, gvt_hip_fb *fb,
+                        const int *from_arr = nullptr) {
   Ctx &C = gctx();
   if (!n) return 0;
   hipStream_t st = C.stream;
@@ -509,7 +510,7 @@ static int shuffle_impl(gvt_hip_top *T, const RaySrc &in, size_t n, int from, gv
   {
     ProfScope ps(KC_SHUFFLE);
     k_top_classify<<<n_blk, TOP_BLOCK, use_lds ? sizeof(unsigned) * nI : 0, st>>>(in, (unsigned)n, T->dev(), (int)nI, from, d_next, d_t,
-                                                                                scan_totals ? nullptr : T->d_hist, use_lds, d_blk);
+                                                                                scan_totals ? nullptr : T->d_hist, use_lds, d_blk, nullptr, from_arr);
   }
   HIPCHK(hipGetLastError());
   if (!roomy) {
@@ -648,6 +649,21 @@ extern "C" int gvt_hip_shuffle(gvt_hip_top *T, gvt_hip_queue *q_in, int from, gv
   q_in->size = 0; // rays.clear(), TracerBase.h:411
   HIPCHK(hipMemsetAsync(q_in->d_count, 0, sizeof(unsigned), gctx().stream));
   return 0;
+}
+
+// shuffleRays of a device-resident list with EXACT growth of the destinations (two host synchronisations: the list's length, then the
+// per-destination counts): the path for rounds whose worst-case reservation -- every destination sized for every moved ray -- would
+// not fit the round's memory budget (hundreds of domains).  from_arr: source instance per ray, else `from` for all.
+int shuffle_exact(gvt_hip_top *T, gvt_hip_queue *q_in, const int *from_arr, int from, gvt_hip_queue *const *queues, gvt_hip_fb *fb) {
+  Ctx &C = gctx();
+  HIPCHK(hipMemcpyAsync(C.h_pinned + 12, q_in->d_count, sizeof(unsigned), hipMemcpyDeviceToHost, C.stream));
+  HIPCHK(hipStreamSynchronize(C.stream));
+  const size_t n = C.h_pinned[12];
+  if (!n) return 0;
+  RaySrc S{};
+  S.q = make_planes(q_in->d_planes, q_in->cap);
+  S.from_cam = 0;
+  return shuffle_impl(T, S, n, from, queues, nullptr, fb, from_arr);
 }
 
 // generateRays + FilterRaysLocally in one step: the camera's rays go straight to the queues of the instances they enter first

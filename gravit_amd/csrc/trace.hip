@@ -632,8 +632,8 @@ __global__ __launch_bounds__(256) void k_long_closest(RayPlanes q, const LongRec
     const RaySlab S = make_slab(ix, iy, iz, O.x * ix, O.y * iy, O.z * iz);
     float bt = R.bt, bu = R.bu, bv = R.bv, bden = R.bden; // the same in every lane
     int bp = R.bp;
-    int ns = 1, nl = 0;                                   // wave-uniform
-    if (stk && R.ns) { // go on from the parked ray's pending stack (bottom first, so the nearest entries are taken first); entry distances unknown: 0
+    int ns = T.nodes4 ? 1 : 0, nl = 0;                    // wave-uniform (an instance whose mesh has no nodes: the ray retires as a miss)
+    if (stk && R.ns && T.nodes4) { // go on from the parked ray's pending stack (bottom first, so the nearest entries are taken first); entry distances unknown: 0
       const int e = lane < (int)R.ns ? stk[(size_t)r * LONG_SAVE + lane] : TRAV_DONE;
       const bool is_node = lane < (int)R.ns && e >= 0, is_leaf = lane < (int)R.ns && e < 0 && e != TRAV_DONE;
       const unsigned long long mi = __ballot(is_node), ml = __ballot(is_leaf);

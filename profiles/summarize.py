@@ -101,7 +101,7 @@ def main():
         if k.startswith("k_trace<true") and "hbm_read_bytes_per_launch_raw" in e and "hbm_write_bytes_per_launch" in e:
             traffic["k_any_bytes_per_launch"] = 2.0 * e["hbm_read_bytes_per_launch_raw"] + e["hbm_write_bytes_per_launch"]
             traffic["k_any_kernel"] = k
-    if len(traffic) > 2:
+    if any(k.endswith("_bytes_per_launch") for k in traffic):  # (a pass without k_trace rows must not overwrite the committed file)
         json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1, sort_keys=True)
     out_pmc = os.path.join(ROOT, "profiles", "%s_pmc.json" % tag)
     json.dump(summary, open(out_pmc, "w"), indent=1, sort_keys=True)

@@ -347,7 +347,7 @@ def test_top_level_bvh_with_1056_instances(hip):
 
 
 @pytest.mark.parametrize("opts", [dict(first_round_async=0), dict(small_rays=0), dict(small_rays=1 << 30), dict(wave_single=0), dict(shadow_direct=0),
-                                  dict(small_rays=1 << 30, wave_single=0), dict(blocks_per_cu_closest=0, term_sink=0), dict(leaf_max=4, small_rays=0), dict(lean_frame=0), dict(report_poll=0), dict(finish_rays=0), dict(finish_rays=1 << 30), dict(finish_rays=1 << 30, leaf_max=4), dict(lean_frame=0, report_poll=0, first_round_async=0)])
+                                  dict(small_rays=1 << 30, wave_single=0), dict(blocks_per_cu_closest=0, term_sink=0), dict(leaf_max=4, small_rays=0), dict(lean_frame=0), dict(report_poll=0), dict(finish_rays=0), dict(round_room_mb=0), dict(round_room_mb=0, finish_rays=0, small_rays=0), dict(finish_rays=1 << 30), dict(finish_rays=1 << 30, leaf_max=4), dict(lean_frame=0, report_poll=0, first_round_async=0)])
 def test_round_results_do_not_depend_on_knobs(hip, opts):
     """The round chain's variants -- a wave per ray for small rounds, single-mesh kernels for one-queue rounds, direct-mapped shadow
     slots, no terminal sink -- return the oracle's image on a multi-domain depth-2 frame and on config 4 (k_fused / k_packet /
