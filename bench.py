@@ -63,6 +63,15 @@ def git_head():
         return None
 
 
+def source_hash():
+    try:
+        from gravit_amd import _build
+
+        return _build.source_hash()
+    except Exception:
+        return None
+
+
 def cpu_baseline(scene, row_stride, nthreads, repeats=3, gpu_fb=None, parity_out=None):
     """The CPU oracle (a port of the reference's Embree adapter path; Embree 2.x itself is not in the tree) timed on a
     bounded sample of the same frame: every row_stride-th scanline of the 1080p camera (default: the whole frame) on all
@@ -603,7 +612,8 @@ def main():
                 try:
                     tj = json.load(open(tf))
                     traffic = tj.get("k_%s_bytes_per_launch" % dom)
-                    traffic_src = {"file": "profiles/traffic.json", "tag": tj.get("tag"), "profiled_commit": tj.get("commit"), "kernel": tj.get("k_%s_kernel" % dom)}
+                    traffic_src = {"file": "profiles/traffic.json", "tag": tj.get("tag"), "profiled_commit": tj.get("commit"),
+                                   "profiled_source_hash": tj.get("source_hash"), "kernel": tj.get("k_%s_kernel" % dom)}
                 except Exception:
                     traffic = None
             peak_meas = measured_stream_peak(torch, dev)
@@ -611,9 +621,11 @@ def main():
                 "bound": "hbm", "kernel": symbol, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "peak_measured_copy": peak_meas, "frac_of_measured_copy": achieved / peak_meas if peak_meas else None,
+                "peak_measured_copy_note": "a 1 GiB torch copy_ (device to device) timed in this run: a floor for the achievable rate, below the guide's 6.29 TB/s float4 copy",
                 "algorithmic_bytes_per_ray": b_ray, "rays_per_launch": rays_dom / n_launch, "avg_launch_ms": ms_dom / n_launch,
                 "kernel_ms": {k: st[k] for k in ("ms_closest", "ms_any", "ms_shade", "ms_shuffle", "ms_camera", "ms_convert", "ms_sort", "ms_long")},
-                "commit": git_head(),
+                "commit": git_head(),  # None on the GPU box (no .git travels); source_hash ties the line to a tree either way
+                "source_hash": source_hash(),
             }
             if world == 1 and n_dom == 1:
                 try:  # mean visits per primary ray (diagnostic kernel over the binary LBVH; the traversal itself walks its 4-wide collapse)

@@ -23,6 +23,24 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=o
          "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 
 
+def source_hash():
+    """Hash of the sources a build is made of (csrc/**, include/*.h, bench.py): ties a bench line or a profile to a tree where no .git travels."""
+    import hashlib
+
+    root = os.path.dirname(HERE)
+    files = [os.path.join(root, "bench.py")]
+    for base in (CSRC, os.path.join(root, "include")):
+        for d, _, fs in os.walk(base):
+            if os.path.basename(d) == "build" or os.sep + "build" + os.sep in d + os.sep:
+                continue
+            files += [os.path.join(d, f) for f in fs if f.endswith((".hip", ".h", ".inc"))]
+    h = hashlib.sha256()
+    for f in sorted(files):
+        h.update(os.path.relpath(f, root).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def hipcc():
     for c in ("hipcc", "/opt/rocm/bin/hipcc"):
         p = shutil.which(c)

@@ -1039,7 +1039,7 @@ struct ShadeArgs {
 
 #define SHADE_BLOCK 512
 template <bool MULTI>
-__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs A, MeshView M1) {
+__global__ __launch_bounds__(SHADE_BLOCK, 4) void k_shade(ShadeArgs A, MeshView M1) { // 128 VGPRs: 4 waves per SIMD (unbounded: 134-148, 3)
   // one LDS (count, base) pair per output list use: moved_rays, next list, one per light
   __shared__ unsigned sh_alloc[2 * (2 + 64)];
   for (int k = threadIdx.x; k < 2 * (2 + 64); k += SHADE_BLOCK) sh_alloc[k] = 0u;

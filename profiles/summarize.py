@@ -90,7 +90,13 @@ def main():
     cf = os.path.join(ROOT, "profiles", ".profiled_commit")  # written by the caller before the tree travels to the GPU box (no .git there)
     if os.path.exists(cf):
         commit = open(cf).read().strip() or None
-    traffic = {"tag": tag, "commit": commit,
+    try:
+        sys.path.insert(0, ROOT)
+        from gravit_amd import _build
+        src_hash = _build.source_hash()
+    except Exception:
+        src_hash = None
+    traffic = {"tag": tag, "commit": commit, "source_hash": src_hash,
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE over `bench.py --steps 5 --warmup 2`, tag %s" % tag,
                "note": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch; x2 on reads: gfx950 tallies 128-byte fabric requests "
                        "as 64 bytes (MI355X guide), confirmed for this kernel's 64-byte gathers by profiles/r01_fetch_calibration.txt"}
