@@ -350,7 +350,12 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
     //      its slowest ray (measured: up to 536 more inner steps at ~2.5 K cycles each while 63 lanes idle -- the fixed ~0.5 ms of
     //      every launch).  Now an idle lane takes the BOTTOM entry (the largest pending subtree) of a busy lane's stack together with a
     //      copy of its ray and best hit, and traverses that subtree as a helper; results are merged when lanes of a ray retire.
-    if ((ANY ? (share & 1) : (share & 2)) && exhausted && nidle > 0 && n >= share_min) { // small launches: the hand-off costs more than the tail it trims (15 K shadow rays: 83 -> 66 us)
+#ifdef GVT_EXPERIMENTS
+    const bool share_on = ANY ? (share & 1) != 0 : (share & 2) != 0;
+#else
+    const bool share_on = ANY && (share & 1) != 0; // sharing for closest hit lost: compiled into the experiments build only
+#endif
+    if (share_on && exhausted && nidle > 0 && n >= share_min) { // small launches: the hand-off costs more than the tail it trims (15 K shadow rays: 83 -> 66 us)
       unsigned long long idle_m = idle;
       unsigned long long don_m = __ballot(active && cur != TRAV_DONE && (sp - sb) >= 2);
       const unsigned wave_tid0 = threadIdx.x & ~63u;
