@@ -723,7 +723,7 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
     P.sink.top = R->top->dev(); P.sink.from = -1;
     P.sink.fb = R->fb->d_rgba; P.sink.n_pix = (unsigned)(R->fb->w * R->fb->h);
   }
-  WaveSet W{ R->d_segs, R->d_insts, n_seg, R->all_quad ? 1 : 0 };
+  WaveSet W{ R->d_segs, R->d_insts, n_seg, R->all_quad ? 1 : 0, (int)nI };
   if (C.finish_rays > 0 && N <= (size_t)C.finish_rays && P.sink.fb && !count_on_device && !exact) {
     // a small round: ONE launch follows every ray to its end on this rank (finish_kernel.inc); what remains are rays in other ranks' queues
     if ((rc = finish_round(W, N, P, R->lights.data(), R->d_qdesc, R->d_owner, R->world > 1 ? R->rank : -1, R->d_overflow))) return rc;

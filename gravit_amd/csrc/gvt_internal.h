@@ -237,6 +237,7 @@ struct WaveSet {
   const WaveInst *insts;
   int n_seg;
   int quad_ok; // every instance that can be traced here carries the quad layouts (nodes4q / trisq)
+  int n_inst;  // rows of `insts` (0: unknown; the kernels then read the tables from global memory)
 };
 
 // lbvh.hip

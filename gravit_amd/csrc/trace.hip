@@ -203,6 +203,11 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
 // MULTI (merged launch, gvt_internal.h): closest hit -- ray j is virtual index (idx ? idx[j] : j) of the segment table MS.W; any hit --
 // ray j of q was generated in instance MS.ray_inst[j]; either way the lane takes transform and acceleration structure from
 // MS.W.insts[instance].  out_from receives the source instance of every survivor appended to `out`.
+// per-block LDS copies of the round's tables (<= KT_TAB segments and instances): a refill then costs one memory round trip -- the
+// ray itself -- instead of a binary search over the segment table plus the segment's and the instance's rows, each a dependent load
+#define KT_TAB 32
+struct KtInst { Mat4 minv; const uint4 *nodes4; const float4 *tris; };
+struct KtSeg { float4 *planes; unsigned long long cap; unsigned begin; int inst; };
 struct MultiSrc {
   WaveSet W;
   const int *ray_inst;          // any hit: instance per ray of q; < 0 = an empty slot of a direct-mapped shadow list (skipped)
@@ -226,6 +231,18 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
   __shared__ int stack[TRAV_STACK * TRAV_BLOCK];
   int *lds = &stack[threadIdx.x];
   int *spill = spill_base + (size_t)(blockIdx.x * TRAV_BLOCK + threadIdx.x) * TRAV_SPILL;
+  __shared__ KtInst s_inst[MULTI ? KT_TAB : 1];
+  __shared__ KtSeg s_seg[(MULTI && !ANY) ? KT_TAB : 1];
+  bool tab = false; // block-uniform
+  if (MULTI) {
+    tab = MS.W.n_inst > 0 && MS.W.n_inst <= KT_TAB && MS.W.n_seg <= KT_TAB;
+    if (tab) {
+      const int t = (int)threadIdx.x;
+      if (t < MS.W.n_inst) { const WaveInst *wi = MS.W.insts + t; s_inst[t].minv = wi->minv; s_inst[t].nodes4 = wi->nodes4; s_inst[t].tris = wi->tris; }
+      if (!ANY && t >= 64 && t - 64 < MS.W.n_seg) { const WaveSeg sg = MS.W.segs[t - 64]; KtSeg k; k.planes = sg.planes; k.cap = sg.cap; k.begin = sg.begin; k.inst = sg.inst; s_seg[t - 64] = k; }
+      __syncthreads();
+    }
+  }
   bool overflow = false;
 #define KT_PUSH(REF)                                                                  \
   {                                                                                   \
@@ -310,13 +327,23 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
               inst_l = MS.ray_inst[i];
               start = inst_l >= 0; // direct-mapped shadow list: a slot whose primary emitted nothing
               if (start) { a = q.p0[i]; b = q.p1[i]; }
+            } else if (tab) {
+              int lo = 0, hi = MS.W.n_seg - 1;
+              while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_seg[mid].begin <= i) lo = mid; else hi = mid - 1; }
+              const unsigned local = i - s_seg[lo].begin;
+              const float4 *pl = s_seg[lo].planes;
+              a = pl[local]; b = pl[s_seg[lo].cap + local];
+              inst_l = s_seg[lo].inst; gidx = i;
             } else {
               const WaveSeg sg = MS.W.segs[wave_find_seg(MS.W, i)];
               const unsigned local = i - sg.begin;
               a = sg.planes[local]; b = sg.planes[sg.cap + local];
               inst_l = sg.inst; gidx = i;
             }
-            if (start) {
+            if (start && tab) {
+              nodes4_l = s_inst[inst_l].nodes4; tris_l = s_inst[inst_l].tris;
+              O = xfm_point(s_inst[inst_l].minv, mk3(a.x, a.y, a.z)); D = xfm_vector(s_inst[inst_l].minv, mk3(b.x, b.y, b.z));
+            } else if (start) {
               const WaveInst *wi = MS.W.insts + inst_l;
               nodes4_l = wi->nodes4; tris_l = wi->tris;
               O = xfm_point(wi->minv, mk3(a.x, a.y, a.z)); D = xfm_vector(wi->minv, mk3(b.x, b.y, b.z));
