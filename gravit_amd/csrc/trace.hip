@@ -243,12 +243,11 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
       __syncthreads();
     }
   }
-  bool overflow = false;
 #define KT_PUSH(REF)                                                                  \
   {                                                                                   \
     if (sp < TRAV_STACK) { lds[sp * TRAV_BLOCK] = (REF); sp++; }                      \
     else if (sp - TRAV_STACK < TRAV_SPILL) { spill[sp - TRAV_STACK] = (REF); sp++; }  \
-    else overflow = true;                                                             \
+    else atomicOr(counter + TRAV_OVF_WORD, 1u); /* reported, never silent */          \
   }
 #define KT_POP()                                                                      \
   {                                                                                   \
@@ -271,8 +270,8 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
   int sb = 0;           // bottom of this lane's stack window [sb, sp): entries below sb were given away to helper lanes
   bool sharing = false; // wave-uniform: some ray of this wave is being traversed by more than one lane
   int donor_lane = -1;  // helper: the lane it took its subtree from (to follow that lane's best hit)
-  int nsteps = 0;       // closest hit: inner steps of this lane's ray; beyond LQ.steps the ray is parked for k_long_closest
-  bool parked = false;
+  int nsteps = 0;       // closest hit: inner steps of this lane's ray; beyond LQ.steps the ray is parked for k_long_closest (nsteps = -1 from then on)
+#define KT_PARKED (nsteps < 0)
   const uint4 *nodes4_l = T.nodes4; // MULTI: this lane's ray's instance
   const float4 *tris_l = T.tris;
   int inst_l = 0;
@@ -361,7 +360,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
             ox = O.x * ix; oy = O.y * iy; oz = O.z * iz;
             S = make_slab(ix, iy, iz, ox, oy, oz);
             bt = GVT_FLT_MAX; bu = 0.f; bv = 0.f; bden = 1.f; bp = -1;
-            sp = 0; sb = 0; donor_lane = -1; nsteps = 0; parked = false;
+            sp = 0; sb = 0; donor_lane = -1; nsteps = 0;
             cur = (MULTI ? (nodes4_l != nullptr) : (W4 ? (T.nodes4 != nullptr) : (T.nodes != nullptr))) ? 0 : TRAV_DONE;
             active = true;
           }
@@ -412,7 +411,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
           bt = gbt; bu = gbu; bv = gbv; bden = gbden; bp = gbp; // the donor's best so far: a pruning bound, merged idempotently later
           sp = 0; sb = 0;
           donor_lane = d;
-          nsteps = 0; parked = false; // a fresh share of the ray: not the step count / parked state of the lane's previous ray
+          nsteps = 0; // a fresh share of the ray: not the step count / parked state of the lane's previous ray
           active = true;
         }
         if ((int)lane_id() == d) sb++;
@@ -451,11 +450,21 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
           // push the hit children farthest first (closest hit: sorted), continue with the first hit one
           int nxt = TRAV_DONE;
           bool have = false;
+          if (sp + 3 <= TRAV_STACK) { // room for three entries in the LDS part: no bounds checks, no spill path
 #pragma unroll
-          for (int c4 = 3; c4 >= 0; c4--) {
-            if (tn[c4] < GVT_FLT_MAX) {
-              if (have) KT_PUSH(nxt)
-              nxt = rr[c4]; have = true;
+            for (int c4 = 3; c4 >= 0; c4--) {
+              if (tn[c4] < GVT_FLT_MAX) {
+                if (have) { lds[sp * TRAV_BLOCK] = nxt; sp++; }
+                nxt = rr[c4]; have = true;
+              }
+            }
+          } else {
+#pragma unroll
+            for (int c4 = 3; c4 >= 0; c4--) {
+              if (tn[c4] < GVT_FLT_MAX) {
+                if (have) KT_PUSH(nxt)
+                nxt = rr[c4]; have = true;
+              }
             }
           }
           if (have) cur = nxt;
@@ -470,7 +479,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
 #if GVT_STAMP == 1
       n_inner_it++; n_inner_lanes += (unsigned long long)__popcll(__ballot(at_inner));
 #endif
-      if (!ANY && at_inner && LQ.steps && ++nsteps > (exhausted ? LQ.steps_drain : LQ.steps) && cur != TRAV_DONE) { KT_PUSH(cur) cur = TRAV_DONE; parked = true; } // the pending stack, `cur` on top, goes into the record
+      if (!ANY && at_inner && LQ.steps && ++nsteps > (exhausted ? LQ.steps_drain : LQ.steps) && cur != TRAV_DONE) { KT_PUSH(cur) cur = TRAV_DONE; nsteps = -1; } // the pending stack, `cur` on top, goes into the record
       im = __ballot(active && cur >= 0);
       if (__popcll(im) < inner_min) break;
     }
@@ -546,8 +555,8 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
           const int sidx = __ffsll((long long)src) - 1;
           const float st = __shfl(bt, sidx), su = __shfl(bu, sidx), sv = __shfl(bv, sidx), sd = __shfl(bden, sidx);
           const int spr = __shfl(bp, sidx);
-          const bool spk = __shfl((int)parked, sidx) != 0;
-          if (!ANY && (int)lane_id() == tgt && spk) parked = true; // a lane that gave up on its share: the whole ray goes to k_long_closest
+          const bool spk = __shfl(nsteps, sidx) < 0;
+          if (!ANY && (int)lane_id() == tgt && spk) nsteps = -1; // a lane that gave up on its share: the whole ray goes to k_long_closest
           if (ANY) { if (spr >= 0) merged_occluded = true; }
           else if ((int)lane_id() == tgt && spr >= 0 && (bp < 0 || st < bt || (st == bt && spr < bp))) { bt = st; bp = spr; bu = su; bv = sv; bden = sd; }
           if ((int)lane_id() == sidx) active = false; // folded into tgt: retires without writing
@@ -571,12 +580,12 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
       if (n_pend >= 64) { flush_pending(pend, n_pend, q, out, out_count, sink, MULTI ? MS.ray_inst : nullptr, MULTI ? MS.out_from : nullptr); n_pend = 0; }
     }
     if (!ANY && LQ.steps) {
-      const unsigned long long pm = __ballot(fin && parked);
+      const unsigned long long pm = __ballot(fin && KT_PARKED);
       if (pm) {
         unsigned base = 0;
         if ((int)lane_id() == __ffsll((long long)pm) - 1) base = atomicAdd(LQ.count, (unsigned)__popcll(pm));
         base = __shfl(base, __ffsll((long long)pm) - 1);
-        if (fin && parked) {
+        if (fin && KT_PARKED) {
           const unsigned slot = base + lanes_below(pm);
           LongRec R; R.j = j; R.i = MULTI ? gidx : (idx ? idx[j] : j); R.bt = bt; R.bp = bp; R.bu = bu; R.bv = bv; R.bden = bden; R.ns = 0u;
           const int depth = sp - sb;
@@ -591,7 +600,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
     }
     if (fin) {
       if (ANY) { if (MODE == 0) flags[j] = (bp >= 0) ? 1 : 0; }
-      else if (!parked) { gvt_hip_hit h; h.t = bt; h.prim = bp; h.u = (bp >= 0) ? bu / bden : 0.f; h.v = (bp >= 0) ? bv / bden : 0.f; hits[j] = h; }
+      else if (!KT_PARKED) { gvt_hip_hit h; h.t = bt; h.prim = bp; h.u = (bp >= 0) ? bu / bden : 0.f; h.v = (bp >= 0) ? bv / bden : 0.f; hits[j] = h; }
       active = false;
     }
   }
@@ -601,9 +610,9 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
 #endif
   if (ANY && MODE == 1) { if (n_pend) flush_pending(pend, n_pend, q, out, out_count, sink, MULTI ? MS.ray_inst : nullptr, MULTI ? MS.out_from : nullptr); }
   if (MULTI && ANY && MS.tot_any && n_started && lane_id() == 0) atomicAdd(MS.tot_any, (unsigned long long)n_started);
-  if (overflow) atomicOr(counter + TRAV_OVF_WORD, 1u);
 #undef KT_PUSH
 #undef KT_POP
+#undef KT_PARKED
 }
 
 #ifdef GVT_EXPERIMENTS
