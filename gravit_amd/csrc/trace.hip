@@ -31,6 +31,9 @@
 #ifndef KT_BLOCKS_CLOSEST
 #define KT_BLOCKS_CLOSEST 5 // resident 256-thread blocks per CU the compiler must leave room for (register budget 512 / waves per SIMD)
 #endif
+#ifndef RETIRE_BATCH
+#define RETIRE_BATCH 1
+#endif
 #ifndef KT_BLOCKS_ANY
 #define KT_BLOCKS_ANY 4
 #endif
@@ -539,7 +542,14 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
 #if GVT_STAMP == 1
     { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_leaf += t_ - t_mark; t_mark = t_; }
 #endif
-    // ---- retire finished rays
+    // ---- retire finished rays.  Retirement is batched: a finished lane costs nothing while it waits, so the block below (result
+    //      stores with their two divisions, the parked-ray and survivor lists) runs only when a refill is due, when nothing is left
+    //      in flight, or -- while lanes of a drained wave share rays -- at once, because a finished helper's result ends its group
+    {
+      const int nfin_w = __popcll(__ballot(active && cur == TRAV_DONE)), nidle_w = __popcll(__ballot(!active));
+      const bool retire_now = RETIRE_BATCH == 0 || (share_on && exhausted) || nfin_w + nidle_w >= (exhausted ? 64 : refill_min);
+      if (!retire_now) continue;
+    }
     if (sharing) { // lanes of one ray: the last one to finish carries the merged result, the others fold theirs into a partner
       const unsigned long long FM = __ballot(active && cur == TRAV_DONE);
       unsigned long long fm = FM;
@@ -625,6 +635,159 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
 // when they are taken.  LONG_CAP throttles the number of nodes opened per step so that the lists cannot outgrow LONG_PHYS.
 #define LONG_CAP 512
 #define LONG_PHYS (LONG_CAP + 256)
+
+// The traversal of ONE ray by a whole wave (every lane holds the same O, D): shared by k_long_closest, k_wave_any and k_finish.
+// The caller has put the pending nodes / leaves into the wave's LDS lists (ns / nl entries).  A node step opens up to 64 nodes and
+// appends the children the ray enters (nearest last: the lists are taken from their end); `take` is throttled so that the lists stay
+// within CAP, and PHYS = CAP + 256 leaves room for the one step that may exceed it -- the bound is checked ONCE per step for the
+// wave (a list that would outgrow PHYS: flag word set, the ray's traversal ends; reported, never silent), not per store.
+template <int CAP, int PHYS>
+__device__ __forceinline__ void wave_closest_run(const uint4 *__restrict__ nodes4, const float4 *__restrict__ tris, V3 O, V3 D, const RaySlab &S, float tnear,
+                                                  volatile int *s_ref, volatile float *s_tn, volatile int *l_ref, volatile float *l_tn, int ns, int nl,
+                                                  float &bt, int &bp, float &bu, float &bv, float &bden, unsigned *ovf_word) {
+  const int lane = (int)lane_id();
+  while (ns > 0 || nl > 0) {
+    const bool do_leaf = nl > 0 && (ns == 0 || nl >= 64 || nl > CAP - 256);
+    if (!do_leaf) {
+      int take = min(min(ns, 64), min((CAP - ns) / 3, (CAP - nl) / 4));
+      take = max(take, 1);
+      if (ns + 3 * take > PHYS || nl + 4 * take > PHYS) { if (lane == 0) atomicOr(ovf_word, 1u); break; }
+      const bool mine = lane < take;
+      int ref = 0;
+      float etn = 0.f;
+      if (mine) { ref = s_ref[ns - 1 - lane]; etn = s_tn[ns - 1 - lane]; }
+      __builtin_amdgcn_wave_barrier();
+      ns -= take;
+      float tn[4];
+      int rr[4];
+      const bool open = mine && etn <= bt;
+      if (open) {
+        node4_test(nodes4 + (size_t)GVT_NODE4_F4 * ref, S, bt, tn, rr);
+#define GVT_CE(A, B) { const bool sw_ = tn[B] < tn[A]; const float ta_ = sw_ ? tn[B] : tn[A], tb_ = sw_ ? tn[A] : tn[B]; \
+                       const int ra_ = sw_ ? rr[B] : rr[A], rb_ = sw_ ? rr[A] : rr[B]; tn[A] = ta_; tn[B] = tb_; rr[A] = ra_; rr[B] = rb_; }
+        GVT_CE(0, 1) GVT_CE(2, 3) GVT_CE(0, 2) GVT_CE(1, 3) GVT_CE(1, 2)
+#undef GVT_CE
+      }
+#pragma unroll
+      for (int c = 3; c >= 0; c--) {
+        const bool hit = open && tn[c] < GVT_FLT_MAX;
+        const bool inner = hit && rr[c] >= 0, leaf = hit && rr[c] < 0;
+        const unsigned long long mi = __ballot(inner), ml = __ballot(leaf);
+        if (inner) { const int pos = ns + (int)lanes_below(mi); s_ref[pos] = rr[c]; s_tn[pos] = tn[c]; }
+        if (leaf) { const int pos = nl + (int)lanes_below(ml); l_ref[pos] = rr[c]; l_tn[pos] = tn[c]; }
+        ns += __popcll(mi);
+        nl += __popcll(ml);
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      const int take = min(nl, 64);
+      const bool mine = lane < take;
+      int ref = -1;
+      float etn = 0.f;
+      if (mine) { ref = l_ref[nl - 1 - lane]; etn = l_tn[nl - 1 - lane]; }
+      __builtin_amdgcn_wave_barrier();
+      nl -= take;
+      float lt = GVT_FLT_MAX, lu = 0.f, lv = 0.f, ld = 1.f;
+      int lp = -1;
+      if (mine && etn <= bt) {
+        const unsigned code = (unsigned)~ref;
+        const unsigned first = code >> 3, ntri = code & 7u;
+        const float4 *ts = tris + 4 * (size_t)first;
+        for (unsigned k = 0; k < ntri; k++) {
+          const float4 s0 = ts[4 * k], s1 = ts[4 * k + 1], s2 = ts[4 * k + 2];
+          const V3 e1 = mk3(s1.x, s1.y, s1.z), e2 = mk3(s2.x, s2.y, s2.z);
+          float TT, U, V, aden;
+          if (tri_test_raw(O, D, mk3(s0.x, s0.y, s0.z), e1, e2, cross3(e1, e2), tnear, TT, U, V, aden)) {
+            const float t = TT / aden;
+            if (t <= GVT_FLT_MAX) {
+              const int prim = __float_as_int(s0.w);
+              if (lp < 0 || t < lt || (t == lt && prim < lp)) { lt = t; lp = prim; lu = U; lv = V; ld = aden; }
+            }
+          }
+        }
+      }
+      if (__ballot(lp >= 0)) { // the wave's best candidate, then against the ray's best so far
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          const float ot = __shfl_xor(lt, off), ou = __shfl_xor(lu, off), ov = __shfl_xor(lv, off), od = __shfl_xor(ld, off);
+          const int op = __shfl_xor(lp, off);
+          if (op >= 0 && (lp < 0 || ot < lt || (ot == lt && op < lp))) { lt = ot; lp = op; lu = ou; lv = ov; ld = od; }
+        }
+        if (lp >= 0 && (bp < 0 || lt < bt || (lt == bt && lp < bp))) { bt = lt; bp = lp; bu = lu; bv = lv; bden = ld; }
+      }
+    }
+  }
+}
+
+// any hit of one ray by a whole wave, from the root: true = occluded
+template <int CAP, int PHYS>
+__device__ __forceinline__ bool wave_any_run(const uint4 *__restrict__ nodes4, const float4 *__restrict__ tris, V3 O, V3 D, const RaySlab &S, float tnear,
+                                              volatile int *s_ref, volatile int *l_ref, unsigned *ovf_word) {
+  const int lane = (int)lane_id();
+  int ns = nodes4 ? 1 : 0, nl = 0; // wave-uniform
+  bool occluded = false;           // wave-uniform
+  if (lane == 0) s_ref[0] = 0;
+  __builtin_amdgcn_wave_barrier();
+  while (!occluded && (ns > 0 || nl > 0)) {
+    const bool do_leaf = nl > 0 && (ns == 0 || nl >= 64 || nl > CAP - 256);
+    if (!do_leaf) {
+      int take = min(min(ns, 64), min((CAP - ns) / 3, (CAP - nl) / 4));
+      take = max(take, 1);
+      if (ns + 3 * take > PHYS || nl + 4 * take > PHYS) { if (lane == 0) atomicOr(ovf_word, 1u); break; }
+      const bool mine = lane < take;
+      int ref = 0;
+      if (mine) ref = s_ref[ns - 1 - lane];
+      __builtin_amdgcn_wave_barrier();
+      ns -= take;
+      float tn[4];
+      int rr[4];
+      if (mine) node4_test(nodes4 + (size_t)GVT_NODE4_F4 * ref, S, GVT_FLT_MAX, tn, rr);
+#pragma unroll
+      for (int c = 3; c >= 0; c--) {
+        const bool hit = mine && tn[c] < GVT_FLT_MAX;
+        const bool inner = hit && rr[c] >= 0, leaf = hit && rr[c] < 0;
+        const unsigned long long mi = __ballot(inner), ml = __ballot(leaf);
+        if (inner) s_ref[ns + (int)lanes_below(mi)] = rr[c];
+        if (leaf) l_ref[nl + (int)lanes_below(ml)] = rr[c];
+        ns += __popcll(mi);
+        nl += __popcll(ml);
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      const int take = min(nl, 64);
+      const bool mine = lane < take;
+      int ref = -1;
+      if (mine) ref = l_ref[nl - 1 - lane];
+      __builtin_amdgcn_wave_barrier();
+      nl -= take;
+      bool hit_any = false;
+      if (mine) {
+        const unsigned code = (unsigned)~ref;
+        const unsigned first_slot = code >> 3, ntri = code & 7u;
+        const float4 *ts = tris + 4 * (size_t)first_slot;
+        for (unsigned k = 0; k < ntri && !hit_any; k++) {
+          const float4 s0 = ts[4 * k], s1 = ts[4 * k + 1], s2 = ts[4 * k + 2];
+          const V3 e1 = mk3(s1.x, s1.y, s1.z), e2 = mk3(s2.x, s2.y, s2.z);
+          float TT, U, V, aden;
+          if (tri_test_raw(O, D, mk3(s0.x, s0.y, s0.z), e1, e2, cross3(e1, e2), tnear, TT, U, V, aden)) {
+            const float t = TT / aden;
+            if (t <= GVT_FLT_MAX) hit_any = true;
+          }
+        }
+      }
+      occluded = __ballot(hit_any) != 0ull;
+    }
+  }
+  return occluded;
+}
+__device__ __forceinline__ RaySlab slab_of(V3 O, V3 D) {
+  const float dx = fabsf(D.x) < 1e-30f ? copysignf(1e-30f, D.x) : D.x;
+  const float dy = fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y;
+  const float dz = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;
+  const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+  return make_slab(ix, iy, iz, O.x * ix, O.y * iy, O.z * iz);
+}
+
 template <bool XFORM, bool MULTI = false>
 __global__ __launch_bounds__(256) void k_long_closest(RayPlanes q, const LongRec *__restrict__ recs, const unsigned *__restrict__ n_recs, Mat4 minv,
                                                        Trav T, float tnear, gvt_hip_hit *__restrict__ hits, unsigned *counter, WaveSet W = WaveSet{},
@@ -640,7 +803,7 @@ __global__ __launch_bounds__(256) void k_long_closest(RayPlanes q, const LongRec
   volatile int *l_ref = l_ref_all[wv];
   volatile float *l_tn = l_tn_all[wv];
   const unsigned n = *n_recs;
-  bool overflow = false, first = true;
+  bool first = true;
   for (;;) {
     unsigned r = 0;
     if (first) { // first ray of a wave: its own number; later ones through the counter, behind those
@@ -666,11 +829,7 @@ __global__ __launch_bounds__(256) void k_long_closest(RayPlanes q, const LongRec
       O = mk3(a.x, a.y, a.z); D = mk3(b.x, b.y, b.z);
       if (XFORM) { O = xfm_point(minv, O); D = xfm_vector(minv, D); }
     }
-    const float dx = fabsf(D.x) < 1e-30f ? copysignf(1e-30f, D.x) : D.x;
-    const float dy = fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y;
-    const float dz = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-    const RaySlab S = make_slab(ix, iy, iz, O.x * ix, O.y * iy, O.z * iz);
+    const RaySlab S = slab_of(O, D);
     float bt = R.bt, bu = R.bu, bv = R.bv, bden = R.bden; // the same in every lane
     int bp = R.bp;
     int ns = T.nodes4 ? 1 : 0, nl = 0;                    // wave-uniform (an instance whose mesh has no nodes: the ray retires as a miss)
@@ -683,79 +842,9 @@ __global__ __launch_bounds__(256) void k_long_closest(RayPlanes q, const LongRec
       ns = __popcll(mi); nl = __popcll(ml);
     } else if (lane == 0) { s_ref[0] = 0; s_tn[0] = 0.f; }
     __builtin_amdgcn_wave_barrier();
-    while (ns > 0 || nl > 0) {
-      const bool do_leaf = nl > 0 && (ns == 0 || nl >= 64 || nl > LONG_CAP - 256);
-      if (!do_leaf) {
-        int take = min(min(ns, 64), min((LONG_CAP - ns) / 3, (LONG_CAP - nl) / 4));
-        take = max(take, 1);
-        const bool mine = lane < take;
-        int ref = 0;
-        float etn = 0.f;
-        if (mine) { ref = s_ref[ns - 1 - lane]; etn = s_tn[ns - 1 - lane]; }
-        __builtin_amdgcn_wave_barrier();
-        ns -= take;
-        float tn[4];
-        int rr[4];
-        const bool open = mine && etn <= bt;
-        if (open) {
-          node4_test(T.nodes4 + (size_t)GVT_NODE4_F4 * ref, S, bt, tn, rr);
-          // nearest child last: the lists are taken from their end, so the wave keeps descending along the nearest pending nodes
-#define GVT_CE(A, B) { const bool sw_ = tn[B] < tn[A]; const float ta_ = sw_ ? tn[B] : tn[A], tb_ = sw_ ? tn[A] : tn[B]; \
-                       const int ra_ = sw_ ? rr[B] : rr[A], rb_ = sw_ ? rr[A] : rr[B]; tn[A] = ta_; tn[B] = tb_; rr[A] = ra_; rr[B] = rb_; }
-          GVT_CE(0, 1) GVT_CE(2, 3) GVT_CE(0, 2) GVT_CE(1, 3) GVT_CE(1, 2)
-#undef GVT_CE
-        }
-#pragma unroll
-        for (int c = 3; c >= 0; c--) {
-          const bool hit = open && tn[c] < GVT_FLT_MAX;
-          const unsigned long long mi = __ballot(hit && rr[c] >= 0), ml = __ballot(hit && rr[c] < 0);
-          if (hit && rr[c] >= 0) { const int pos = ns + (int)lanes_below(mi); if (pos < LONG_PHYS) { s_ref[pos] = rr[c]; s_tn[pos] = tn[c]; } else overflow = true; }
-          if (hit && rr[c] < 0) { const int pos = nl + (int)lanes_below(ml); if (pos < LONG_PHYS) { l_ref[pos] = rr[c]; l_tn[pos] = tn[c]; } else overflow = true; }
-          ns = min(ns + __popcll(mi), LONG_PHYS);
-          nl = min(nl + __popcll(ml), LONG_PHYS);
-        }
-        __builtin_amdgcn_wave_barrier();
-      } else {
-        const int take = min(nl, 64);
-        const bool mine = lane < take;
-        int ref = -1;
-        float etn = 0.f;
-        if (mine) { ref = l_ref[nl - 1 - lane]; etn = l_tn[nl - 1 - lane]; }
-        __builtin_amdgcn_wave_barrier();
-        nl -= take;
-        float lt = GVT_FLT_MAX, lu = 0.f, lv = 0.f, ld = 1.f;
-        int lp = -1;
-        if (mine && etn <= bt) {
-          const unsigned code = (unsigned)~ref;
-          const unsigned first = code >> 3, ntri = code & 7u;
-          const float4 *ts = T.tris + 4 * (size_t)first;
-          for (unsigned k = 0; k < ntri; k++) {
-            const float4 s0 = ts[4 * k], s1 = ts[4 * k + 1], s2 = ts[4 * k + 2];
-            const V3 e1 = mk3(s1.x, s1.y, s1.z), e2 = mk3(s2.x, s2.y, s2.z);
-            float TT, U, V, aden;
-            if (tri_test_raw(O, D, mk3(s0.x, s0.y, s0.z), e1, e2, cross3(e1, e2), tnear, TT, U, V, aden)) {
-              const float t = TT / aden;
-              if (t <= GVT_FLT_MAX) {
-                const int prim = __float_as_int(s0.w);
-                if (lp < 0 || t < lt || (t == lt && prim < lp)) { lt = t; lp = prim; lu = U; lv = V; ld = aden; }
-              }
-            }
-          }
-        }
-        if (__ballot(lp >= 0)) { // the wave's best candidate, then against the ray's best so far
-#pragma unroll
-          for (int off = 32; off >= 1; off >>= 1) {
-            const float ot = __shfl_xor(lt, off), ou = __shfl_xor(lu, off), ov = __shfl_xor(lv, off), od = __shfl_xor(ld, off);
-            const int op = __shfl_xor(lp, off);
-            if (op >= 0 && (lp < 0 || ot < lt || (ot == lt && op < lp))) { lt = ot; lp = op; lu = ou; lv = ov; ld = od; }
-          }
-          if (lp >= 0 && (bp < 0 || lt < bt || (lt == bt && lp < bp))) { bt = lt; bp = lp; bu = lu; bv = lv; bden = ld; }
-        }
-      }
-    }
+    wave_closest_run<LONG_CAP, LONG_PHYS>(T.nodes4, T.tris, O, D, S, tnear, s_ref, s_tn, l_ref, l_tn, ns, nl, bt, bp, bu, bv, bden, counter + (TRAV_OVF_WORD - 4));
     if (lane == 0) { gvt_hip_hit h; h.t = bt; h.prim = bp; h.u = (bp >= 0) ? bu / bden : 0.f; h.v = (bp >= 0) ? bv / bden : 0.f; hits[R.j] = h; }
   }
-  if (overflow) atomicOr(counter + (TRAV_OVF_WORD - 4), 1u);
 }
 
 // Small launches.  A persistent one-lane-per-ray launch cannot be faster than its slowest ray's chain of dependent fetches
@@ -783,7 +872,7 @@ __global__ __launch_bounds__(256) void k_wave_any(RayPlanes q, const unsigned *_
   volatile int *s_ref = s_ref_all[wv];
   volatile int *l_ref = l_ref_all[wv];
   const unsigned n = *n_dev;
-  bool overflow = false, first = true;
+  bool first = true;
   for (;;) {
     unsigned r = 0;
     if (first) { first = false; r = blockIdx.x * 4u + (unsigned)wv; }
@@ -803,63 +892,7 @@ __global__ __launch_bounds__(256) void k_wave_any(RayPlanes q, const unsigned *_
     } else {
       O = xfm_point(minv, mk3(a.x, a.y, a.z)); D = xfm_vector(minv, mk3(b.x, b.y, b.z));
     }
-    const float dx = fabsf(D.x) < 1e-30f ? copysignf(1e-30f, D.x) : D.x;
-    const float dy = fabsf(D.y) < 1e-30f ? copysignf(1e-30f, D.y) : D.y;
-    const float dz = fabsf(D.z) < 1e-30f ? copysignf(1e-30f, D.z) : D.z;
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-    const RaySlab S = make_slab(ix, iy, iz, O.x * ix, O.y * iy, O.z * iz);
-    int ns = T.nodes4 ? 1 : 0, nl = 0; // wave-uniform
-    bool occluded = false;             // wave-uniform
-    if (lane == 0) s_ref[0] = 0;
-    __builtin_amdgcn_wave_barrier();
-    while (!occluded && (ns > 0 || nl > 0)) {
-      const bool do_leaf = nl > 0 && (ns == 0 || nl >= 64 || nl > LONG_CAP - 256);
-      if (!do_leaf) {
-        int take = min(min(ns, 64), min((LONG_CAP - ns) / 3, (LONG_CAP - nl) / 4));
-        take = max(take, 1);
-        const bool mine = lane < take;
-        int ref = 0;
-        if (mine) ref = s_ref[ns - 1 - lane];
-        __builtin_amdgcn_wave_barrier();
-        ns -= take;
-        float tn[4];
-        int rr[4];
-        if (mine) node4_test(T.nodes4 + (size_t)GVT_NODE4_F4 * ref, S, GVT_FLT_MAX, tn, rr);
-#pragma unroll
-        for (int c = 3; c >= 0; c--) {
-          const bool hit = mine && tn[c] < GVT_FLT_MAX;
-          const unsigned long long mi = __ballot(hit && rr[c] >= 0), ml = __ballot(hit && rr[c] < 0);
-          if (hit && rr[c] >= 0) { const int pos = ns + (int)lanes_below(mi); if (pos < LONG_PHYS) s_ref[pos] = rr[c]; else overflow = true; }
-          if (hit && rr[c] < 0) { const int pos = nl + (int)lanes_below(ml); if (pos < LONG_PHYS) l_ref[pos] = rr[c]; else overflow = true; }
-          ns = min(ns + __popcll(mi), LONG_PHYS);
-          nl = min(nl + __popcll(ml), LONG_PHYS);
-        }
-        __builtin_amdgcn_wave_barrier();
-      } else {
-        const int take = min(nl, 64);
-        const bool mine = lane < take;
-        int ref = -1;
-        if (mine) ref = l_ref[nl - 1 - lane];
-        __builtin_amdgcn_wave_barrier();
-        nl -= take;
-        bool hit_any = false;
-        if (mine) {
-          const unsigned code = (unsigned)~ref;
-          const unsigned first_slot = code >> 3, ntri = code & 7u;
-          const float4 *ts = T.tris + 4 * (size_t)first_slot;
-          for (unsigned k = 0; k < ntri && !hit_any; k++) {
-            const float4 s0 = ts[4 * k], s1 = ts[4 * k + 1], s2 = ts[4 * k + 2];
-            const V3 e1 = mk3(s1.x, s1.y, s1.z), e2 = mk3(s2.x, s2.y, s2.z);
-            float TT, U, V, aden;
-            if (tri_test_raw(O, D, mk3(s0.x, s0.y, s0.z), e1, e2, cross3(e1, e2), tnear, TT, U, V, aden)) {
-              const float t = TT / aden;
-              if (t <= GVT_FLT_MAX) hit_any = true;
-            }
-          }
-        }
-        occluded = __ballot(hit_any) != 0ull;
-      }
-    }
+    const bool occluded = wave_any_run<LONG_CAP, LONG_PHYS>(T.nodes4, T.tris, O, D, slab_of(O, D), tnear, s_ref, l_ref, counter + TRAV_OVF_WORD);
     if (!occluded && lane == 0) { // un-occluded: moved on, or ended here by shuffleRays' terminal rule (TracerBase.h:396-400)
       const float4 c = q.p2[r], d = q.p3[r];
       bool go_on = true;
@@ -884,7 +917,6 @@ __global__ __launch_bounds__(256) void k_wave_any(RayPlanes q, const unsigned *_
       }
     }
   }
-  if (overflow) atomicOr(counter + TRAV_OVF_WORD, 1u);
 }
 
 #ifdef GVT_EXPERIMENTS
