@@ -669,6 +669,14 @@ extern "C" int gvt_hip_wide_visit_stats(gvt_hip_mesh *M, const float *org, const
 }
 
 int debug_stamps(unsigned long long *out, int reset);
+// diagnostic: the launching context's counter words (work counters, parked-ray count [3], overflow flags [8]), after a synchronisation
+extern "C" int gvt_hip_counters_peek(uint32_t out[32]) {
+  Ctx &C = gctx();
+  if (!out || !C.d_counters) { set_error("counters_peek: null"); return GVT_HIP_ERR_INVALID; }
+  HIPCHK(hipStreamSynchronize(C.stream));
+  HIPCHK(hipMemcpy(out, C.d_counters, 32 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return 0;
+}
 extern "C" int gvt_hip_is_experiments_build(void) {
 #ifdef GVT_EXPERIMENTS
   return 1;

@@ -215,12 +215,14 @@ __host__ __device__ inline uint32_t camera_stream_word(uint64_t ridx) {
 
 // wave64 helpers
 __device__ inline unsigned lane_id() { return __lane_id(); }
+// the wave's mask of a per-lane condition (bool in, no widening to int as with HIP's __ballot)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ inline unsigned lanes_below(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 // wave-aggregated slot allocation: one atomic per wave for all lanes with `want`
 __device__ inline unsigned wave_alloc(unsigned *counter, bool want) {
-  unsigned long long mask = __ballot(want);
+  unsigned long long mask = ballot64(want);
   if (mask == 0ull) return 0u;
   unsigned base = 0;
   int leader = __ffsll((long long)mask) - 1;
@@ -233,7 +235,7 @@ __device__ inline unsigned wave_alloc(unsigned *counter, bool want) {
 // `sh` points at two LDS words reserved for this call site (count, base), zeroed before the first __syncthreads of the
 // kernel.  Must be reached by every thread of the block.
 __device__ inline unsigned block_alloc(unsigned *counter, bool want, unsigned *sh) {
-  const unsigned long long mask = __ballot(want);
+  const unsigned long long mask = ballot64(want);
   unsigned woff = 0;
   if (mask) {
     const int leader = __ffsll((long long)mask) - 1;

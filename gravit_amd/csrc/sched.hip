@@ -104,11 +104,11 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RaySrc S, unsigned n
     next_out[i] = next;
     t_out[i] = ret_t;
   }
-  unsigned long long todo = __ballot(next >= 0);
+  unsigned long long todo = ballot64(next >= 0);
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;
     const int d = __shfl(next, leader);
-    const unsigned long long m = __ballot(next == d);
+    const unsigned long long m = ballot64(next == d);
     if ((int)lane_id() == leader) {
       if (use_lds) atomicAdd(&sh_cnt[d], (unsigned)__popcll(m)); else atomicAdd(&hist[d], (unsigned)__popcll(m));
     }
@@ -189,11 +189,11 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_scatter(RaySrc S, unsigned n,
     if (next >= 0 && !queues[next].keep) next = -1; // shuffleDropRays: not this rank's domain
   }
   unsigned local = 0; // use_lds: offset inside the block's share of the destination; else: final slot
-  unsigned long long todo = __ballot(next >= 0);
+  unsigned long long todo = ballot64(next >= 0);
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;
     const int d = __shfl(next, leader);
-    const unsigned long long m = __ballot(next == d);
+    const unsigned long long m = ballot64(next == d);
     unsigned base = 0;
     if (blk_base) {
       if ((int)lane_id() == leader) sh[(threadIdx.x >> 6) * n_inst + d] = (unsigned)__popcll(m);
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_cam1_count(CamArgs A, unsigned n,
     hit = top_nearest(make_float4(r.o.x, r.o.y, r.o.z, r.t_min), make_float4(r.d.x, r.d.y, r.d.z, r.t_max), top, -1, ret_t) >= 0;
     if (fb && i % (unsigned)(A.samples * A.samples) == 0u && (unsigned)r.id < n_pix) fb[(unsigned)r.id] = make_float4(0.f, 0.f, 0.f, 0.f); // clearBuffer
   }
-  const unsigned long long m = __ballot(hit);
+  const unsigned long long m = ballot64(hit);
   if (lane_id() == 0) sh_w[threadIdx.x >> 6] = (unsigned)__popcll(m);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_cam1_scatter(CamArgs A, unsigned 
     hit = top_nearest(make_float4(r.o.x, r.o.y, r.o.z, r.t_min), make_float4(r.d.x, r.d.y, r.d.z, r.t_max), top, -1, ret_t) >= 0;
     if (hit) r.o = add3(r.o, scl3(r.d, ret_t * 0.95f)); // TracerBase.h:393
   }
-  const unsigned long long m = __ballot(hit);
+  const unsigned long long m = ballot64(hit);
   if (lane_id() == 0) { sh_w[threadIdx.x >> 6] = (unsigned)__popcll(m); sh_p[threadIdx.x >> 6] = part; }
   __syncthreads();
   unsigned base = 0, mine = 0;

@@ -193,7 +193,7 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
         }
       }
     }
-    const unsigned long long m = __ballot(go_on);
+    const unsigned long long m = ballot64(go_on);
     if (m) {
       unsigned base = 0;
       if (lane_id() == 0) base = atomicAdd(out_count, (unsigned)__popcll(m));
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
 #if GVT_STAMP == 1
     { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (n_outer_it) st_retire += t_ - t_mark; t_mark = t_; }
 #endif
-    unsigned long long idle = __ballot(!active);
+    unsigned long long idle = ballot64(!active);
     int nidle = __popcll(idle);
     if (!exhausted && (nidle >= refill_min || nidle == 64)) {
       while (nidle > 0) {
@@ -368,9 +368,9 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
             active = true;
           }
         }
-        if (MULTI && ANY) n_started += (unsigned)__popcll(__ballot(start));
+        if (MULTI && ANY) n_started += (unsigned)__popcll(ballot64(start));
         c_next += take;
-        idle = __ballot(!active);
+        idle = ballot64(!active);
         nidle = __popcll(idle);
       }
     }
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
 #endif
     if (share_on && exhausted && nidle > 0 && n >= share_min) { // small launches: the hand-off costs more than the tail it trims (15 K shadow rays: 83 -> 66 us)
       unsigned long long idle_m = idle;
-      unsigned long long don_m = __ballot(active && cur != TRAV_DONE && (sp - sb) >= 2);
+      unsigned long long don_m = ballot64(active && cur != TRAV_DONE && (sp - sb) >= 2);
       const unsigned wave_tid0 = threadIdx.x & ~63u;
       for (int pairs = 0; idle_m && don_m && pairs < 16; pairs++) {
         const int h = __ffsll((long long)idle_m) - 1, d = __ffsll((long long)don_m) - 1;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
     // ---- inner nodes: the lanes holding one descend level by level in a tight loop; the loop is left as soon as
     //      fewer than inner_min lanes still descend (the others wait at a leaf, have finished, or are idle), so that
     //      both this loop and the dearer leaf phase below run at high lane utilisation.
-    unsigned long long im = __ballot(active && cur >= 0);
+    unsigned long long im = ballot64(active && cur >= 0);
     while (im) {
       const bool at_inner = active && cur >= 0;
       if (W4) {
@@ -480,10 +480,10 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
       }
 #endif
 #if GVT_STAMP == 1
-      n_inner_it++; n_inner_lanes += (unsigned long long)__popcll(__ballot(at_inner));
+      n_inner_it++; n_inner_lanes += (unsigned long long)__popcll(ballot64(at_inner));
 #endif
       if (!ANY && at_inner && LQ.steps && ++nsteps > (exhausted ? LQ.steps_drain : LQ.steps) && cur != TRAV_DONE) { KT_PUSH(cur) cur = TRAV_DONE; nsteps = -1; } // the pending stack, `cur` on top, goes into the record
-      im = __ballot(active && cur >= 0);
+      im = ballot64(active && cur >= 0);
       if (__popcll(im) < inner_min) break;
     }
 #if GVT_STAMP == 1
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
     {
       const bool at_leaf = active && cur < 0 && cur != TRAV_DONE;
 #if GVT_STAMP == 1
-      n_leaf_lanes += (unsigned long long)__popcll(__ballot(at_leaf));
+      n_leaf_lanes += (unsigned long long)__popcll(ballot64(at_leaf));
 #endif
 #ifdef GVT_EXPERIMENTS
       if (COOP) {
@@ -546,17 +546,17 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
     //      stores with their two divisions, the parked-ray and survivor lists) runs only when a refill is due, when nothing is left
     //      in flight, or -- while lanes of a drained wave share rays -- at once, because a finished helper's result ends its group
     {
-      const int nfin_w = __popcll(__ballot(active && cur == TRAV_DONE)), nidle_w = __popcll(__ballot(!active));
+      const int nfin_w = __popcll(ballot64(active && cur == TRAV_DONE)), nidle_w = __popcll(ballot64(!active));
       const bool retire_now = RETIRE_BATCH == 0 || (share_on && exhausted) || nfin_w + nidle_w >= (exhausted ? 64 : refill_min);
       if (!retire_now) continue;
     }
     if (sharing) { // lanes of one ray: the last one to finish carries the merged result, the others fold theirs into a partner
-      const unsigned long long FM = __ballot(active && cur == TRAV_DONE);
+      const unsigned long long FM = ballot64(active && cur == TRAV_DONE);
       unsigned long long fm = FM;
       while (fm) {
         const int f = __ffsll((long long)fm) - 1;
         const unsigned jf = (unsigned)__shfl((int)j, f);
-        const unsigned long long G = __ballot(active && j == jf);
+        const unsigned long long G = ballot64(active && j == jf);
         const unsigned long long Gf = G & FM, A = G & ~FM;
         const int tgt = A ? __ffsll((long long)A) - 1 : __ffsll((long long)Gf) - 1;
         unsigned long long src = Gf & ~(1ull << tgt);
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
       // at a time: one atomic on the queue counter per flush instead of one per retirement (a single counter
       // word sustains only ~90 atomics/us chip-wide).
       const bool survive = fin && bp < 0;
-      const unsigned long long sm = __ballot(survive);
+      const unsigned long long sm = ballot64(survive);
       if (sm) {
         if (survive) pend[n_pend + lanes_below(sm)] = j;
         n_pend += __popcll(sm);
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
       if (n_pend >= 64) { flush_pending(pend, n_pend, q, out, out_count, sink, MULTI ? MS.ray_inst : nullptr, MULTI ? MS.out_from : nullptr); n_pend = 0; }
     }
     if (!ANY && LQ.steps) {
-      const unsigned long long pm = __ballot(fin && KT_PARKED);
+      const unsigned long long pm = ballot64(fin && KT_PARKED);
       if (pm) {
         unsigned base = 0;
         if ((int)lane_id() == __ffsll((long long)pm) - 1) base = atomicAdd(LQ.count, (unsigned)__popcll(pm));
@@ -672,7 +672,7 @@ __device__ __forceinline__ void wave_closest_run(const uint4 *__restrict__ nodes
       for (int c = 3; c >= 0; c--) {
         const bool hit = open && tn[c] < GVT_FLT_MAX;
         const bool inner = hit && rr[c] >= 0, leaf = hit && rr[c] < 0;
-        const unsigned long long mi = __ballot(inner), ml = __ballot(leaf);
+        const unsigned long long mi = ballot64(inner), ml = ballot64(leaf);
         if (inner) { const int pos = ns + (int)lanes_below(mi); s_ref[pos] = rr[c]; s_tn[pos] = tn[c]; }
         if (leaf) { const int pos = nl + (int)lanes_below(ml); l_ref[pos] = rr[c]; l_tn[pos] = tn[c]; }
         ns += __popcll(mi);
@@ -706,7 +706,7 @@ __device__ __forceinline__ void wave_closest_run(const uint4 *__restrict__ nodes
           }
         }
       }
-      if (__ballot(lp >= 0)) { // the wave's best candidate, then against the ray's best so far
+      if (ballot64(lp >= 0)) { // the wave's best candidate, then against the ray's best so far
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
           const float ot = __shfl_xor(lt, off), ou = __shfl_xor(lu, off), ov = __shfl_xor(lv, off), od = __shfl_xor(ld, off);
@@ -746,7 +746,7 @@ __device__ __forceinline__ bool wave_any_run(const uint4 *__restrict__ nodes4, c
       for (int c = 3; c >= 0; c--) {
         const bool hit = mine && tn[c] < GVT_FLT_MAX;
         const bool inner = hit && rr[c] >= 0, leaf = hit && rr[c] < 0;
-        const unsigned long long mi = __ballot(inner), ml = __ballot(leaf);
+        const unsigned long long mi = ballot64(inner), ml = ballot64(leaf);
         if (inner) s_ref[ns + (int)lanes_below(mi)] = rr[c];
         if (leaf) l_ref[nl + (int)lanes_below(ml)] = rr[c];
         ns += __popcll(mi);
@@ -775,7 +775,7 @@ __device__ __forceinline__ bool wave_any_run(const uint4 *__restrict__ nodes4, c
           }
         }
       }
-      occluded = __ballot(hit_any) != 0ull;
+      occluded = ballot64(hit_any) != 0ull;
     }
   }
   return occluded;
@@ -836,14 +836,17 @@ __global__ __launch_bounds__(256) void k_long_closest(RayPlanes q, const LongRec
     if (stk && R.ns && T.nodes4) { // go on from the parked ray's pending stack (bottom first, so the nearest entries are taken first); entry distances unknown: 0
       const int e = lane < (int)R.ns ? stk[(size_t)r * LONG_SAVE + lane] : TRAV_DONE;
       const bool is_node = lane < (int)R.ns && e >= 0, is_leaf = lane < (int)R.ns && e < 0 && e != TRAV_DONE;
-      const unsigned long long mi = __ballot(is_node), ml = __ballot(is_leaf);
+      const unsigned long long mi = ballot64(is_node), ml = ballot64(is_leaf);
       if (is_node) { s_ref[lanes_below(mi)] = e; s_tn[lanes_below(mi)] = 0.f; }
       if (is_leaf) { l_ref[lanes_below(ml)] = e; l_tn[lanes_below(ml)] = 0.f; }
       ns = __popcll(mi); nl = __popcll(ml);
     } else if (lane == 0) { s_ref[0] = 0; s_tn[0] = 0.f; }
     __builtin_amdgcn_wave_barrier();
     wave_closest_run<LONG_CAP, LONG_PHYS>(T.nodes4, T.tris, O, D, S, tnear, s_ref, s_tn, l_ref, l_tn, ns, nl, bt, bp, bu, bv, bden, counter + (TRAV_OVF_WORD - 4));
-    if (lane == 0) { gvt_hip_hit h; h.t = bt; h.prim = bp; h.u = (bp >= 0) ? bu / bden : 0.f; h.v = (bp >= 0) ? bv / bden : 0.f; hits[R.j] = h; }
+    // Every lane stores the (same) result.  A lane-0-only block as the LAST statement of a loop whose header takes the next ray with
+    // readfirstlane lets hipcc send lane 0 and the other 63 lanes round the loop separately (seen in an experiment that finished the
+    // parked rays inside k_trace: the 63 lanes then read a ticket no lane had taken and traced the same record for ever).
+    { gvt_hip_hit h; h.t = bt; h.prim = bp; h.u = (bp >= 0) ? bu / bden : 0.f; h.v = (bp >= 0) ? bv / bden : 0.f; hits[R.j] = h; }
   }
 }
 
@@ -916,6 +919,7 @@ __global__ __launch_bounds__(256) void k_wave_any(RayPlanes q, const unsigned *_
         if (MULTI && MS.out_from) MS.out_from[slot] = inst;
       }
     }
+    __builtin_amdgcn_wave_barrier(); // (convergent: the lanes meet again here, not at the loop header's readfirstlane -- see k_long_closest)
   }
 }
 

@@ -320,6 +320,9 @@ int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
 int gvt_hip_set_option(const char *name, int value);
 /* 1 in the experiments build (every variant behind its knob), 0 in the shipped library */
 int gvt_hip_is_experiments_build(void);
+/* diagnostic: the calling thread's context counter words (32) after a stream synchronisation; [3] = rays the last closest-hit launch
+   parked for k_long_closest, [8] = traversal overflow flags */
+int gvt_hip_counters_peek(uint32_t out[32]);
 
 #ifdef __cplusplus
 }

@@ -92,6 +92,7 @@ def test_traversal_layouts_agree_at_full_size(soup, hip):
     try:
         a = ad.intersect(o, d)
         parked_ms = hip.stats()["ms_long"]
+        assert 100 < hip.counters_peek()[3] < 100_000  # rays the default launch parked
     finally:
         hip.profile(False)
     hip.set_option("long_steps", 0)
@@ -99,6 +100,7 @@ def test_traversal_layouts_agree_at_full_size(soup, hip):
     hip.set_option("defaults", 0)
     assert a.tobytes() == b.tobytes(), "parking long rays changed a hit record"
     assert parked_ms > 0.0 and (a["prim"] >= 0).sum() > 900_000
+    assert hip.counters_peek()[3] == 0  # (the last launch, long_steps = 0, parked nothing)
 
 
 def test_whole_config3_frame_of_the_native_tracer_is_bit_exact(soup, hip):
