@@ -172,6 +172,8 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
     }
     return;
   }
+  // a scene of ONE instance whose rays these are: there is nothing ahead of any of them -- no origin / direction fetch, no box test
+  const bool alone = K.top.n_inst == 1 && !ray_inst && K.from >= 0;
   for (int k0 = 0; k0 < n_pend; k0 += 64) {
     const int k = k0 + (int)lane_id();
     bool go_on = false;
@@ -179,10 +181,13 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
     int from = K.from;
     if (k < n_pend) {
       const unsigned src = pend[k];
-      a = q.p0[src]; b = q.p1[src]; c = q.p2[src]; d = q.p3[src];
-      if (ray_inst) from = ray_inst[src];
-      float ret_t;
-      go_on = top_nearest(a, b, K.top, from, ret_t) >= 0;
+      c = q.p2[src]; d = q.p3[src];
+      if (!alone) {
+        a = q.p0[src]; b = q.p1[src];
+        if (ray_inst) from = ray_inst[src];
+        float ret_t;
+        go_on = top_nearest(a, b, K.top, from, ret_t) >= 0;
+      }
       if (!go_on) {
         const V3 col = mk3(c.x, c.y, c.z);
         const unsigned id = (unsigned)__float_as_int(d.x);
