@@ -123,6 +123,15 @@ void *scratch_get(int slot, size_t bytes) {
   return C.scratch[slot];
 }
 
+void scratch_release(int slot) {
+  Ctx &C = g_ctx;
+  if (!C.scratch[slot]) return;
+  hipStreamSynchronize(C.stream);
+  hipFree(C.scratch[slot]);
+  C.scratch[slot] = nullptr;
+  C.scratch_bytes[slot] = 0;
+}
+
 // ---- profiling: HIP events on the launch stream ----
 ProfScope::ProfScope(int c) : cls(c) {
   Ctx &C = g_ctx;

@@ -101,6 +101,7 @@ Ctx &gctx();
 void set_error(const char *fmt, ...);
 int ensure_init();
 void *scratch_get(int slot, size_t bytes); // grow-only; contents NOT preserved on growth
+void scratch_release(int slot); // gives a slot's memory back (after a synchronisation of the context's stream)
 
 #define HIPCHK(expr)                                                                              \
   do {                                                                                            \

@@ -16,6 +16,9 @@
 #include <rocprim/rocprim.hpp>
 
 #include "gvt_internal.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -397,26 +400,44 @@ __global__ __launch_bounds__(256) void k_collapse_mark(const BvhNode *__restrict
     if (c[s].ref >= 0) fout[atomicAdd(next_count, 1u)] = c[s].ref;
 }
 
+// The build's temporaries come out of ONE allocation (the context's scratch slot 21; given back when it is larger than 1 GiB) instead
+// of thirty hipMalloc / hipFree pairs.  (GVT_HIP_BUILD_TRACE=1 prints where a build's time goes -- tools/build_trace.py: 10 M triangles
+// take 7 ms, 1.4 Gtris/s; the first build of a process 15-17 ms, of which 8 are the first kernel launches: code objects, rocPRIM.)
+struct BuildArena {
+  char *base = nullptr;
+  size_t off = 0, cap = 0;
+  template <typename T> int take(T **p, size_t n) {
+    const size_t bytes = (sizeof(T) * (n ? n : 1) + 255) & ~(size_t)255;
+    if (!base || off + bytes > cap) { set_error("BVH build: scratch arena too small (%zu + %zu > %zu)", off, bytes, cap); return GVT_HIP_ERR_DEVICE; }
+    *p = (T *)(base + off);
+    off += bytes;
+    return 0;
+  }
+};
+static double g_alloc_ms = 0.0; // (GVT_HIP_BUILD_TRACE: host time spent in hipMalloc during a build)
 template <typename T> int dalloc(T **p, size_t n) {
+  const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc((void **)p, sizeof(T) * (n ? n : 1));
+  g_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (e != hipSuccess) { set_error("hipMalloc(%zu B) failed: %s", sizeof(T) * n, hipGetErrorString(e)); return GVT_HIP_ERR_DEVICE; }
   return 0;
 }
 
 } // namespace
 
-// Reduces n boxes 32:1 level by level into `levels` (device arrays owned by the caller's vectors); returns the table.
-static int build_box_levels(const float4 *lo0, const float4 *hi0, unsigned n, std::vector<float4 *> &own, BoxLevels &T, hipStream_t st) {
+static int build_nodes4(gvt_hip_mesh *M, BuildArena *A);
+
+// Reduces n boxes 32:1 level by level into `levels` (device arrays out of the build's arena); returns the table.
+static int build_box_levels(const float4 *lo0, const float4 *hi0, unsigned n, BuildArena &A, BoxLevels &T, hipStream_t st) {
   T.n_levels = 1;
   T.lo[0] = lo0; T.hi[0] = hi0;
   unsigned cnt = n;
   while (cnt > 32u && T.n_levels < GVT_BOX_LEVELS) {
     const unsigned n_out = (cnt + 31u) / 32u;
     float4 *l = nullptr, *h = nullptr;
-    int rc = dalloc(&l, n_out);
-    if (!rc) { own.push_back(l); rc = dalloc(&h, n_out); }
+    int rc = A.take(&l, n_out);
+    if (!rc) rc = A.take(&h, n_out);
     if (rc) return rc;
-    own.push_back(h);
     const unsigned threads = n_out * 32u;
     k_reduce32<<<(threads + 255u) / 256u, 256, 0, st>>>(T.lo[T.n_levels - 1], T.hi[T.n_levels - 1], cnt, l, h);
     T.lo[T.n_levels] = l; T.hi[T.n_levels] = h;
@@ -436,6 +457,14 @@ int build_lbvh(gvt_hip_mesh *M) {
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, st));
+  const bool trace = getenv("GVT_HIP_BUILD_TRACE") != nullptr;
+  const auto tr0 = std::chrono::steady_clock::now();
+  auto mark = [&](const char *what) {
+    if (!trace) return;
+    hipStreamSynchronize(st);
+    fprintf(stderr, "[build] %-28s %8.3f ms (hipMalloc so far %.3f ms)\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(), g_alloc_ms);
+  };
+  g_alloc_ms = 0.0;
 
   float4 *plo = nullptr, *phi = nullptr, *slo = nullptr, *shi = nullptr, *ilo = nullptr, *ihi = nullptr;
   unsigned long long *keys = nullptr, *keys2 = nullptr;
@@ -444,8 +473,9 @@ int build_lbvh(gvt_hip_mesh *M) {
   const bool want_q = C.quad != 0; // the quad-per-ray layouts (nodes4q + transposed leaf blocks)
   M->leaf_max = leaf_max;
   int *cl = nullptr, *cr = nullptr, *rf = nullptr, *rl = nullptr;
-  void *tmp = nullptr;
-  std::vector<float4 *> lvl_a, lvl_b; // device arrays of the two range-union tables
+  void *tmp = nullptr, *tmp2 = nullptr;
+  BuildArena A;
+  size_t tb_sort = 0, tb_scan = 0;
   int rc = 0;
   const unsigned B = 256, G = (n + B - 1) / B;
   const int n_inner = (int)n - 1;
@@ -454,11 +484,23 @@ int build_lbvh(gvt_hip_mesh *M) {
 #define OK(x) do { if ((rc = (x)) != 0) goto done; } while (0)
 #define HOK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(_e)); rc = GVT_HIP_ERR_DEVICE; goto done; } } while (0)
 
-  OK(dalloc(&plo, n)); OK(dalloc(&phi, n));
+  { // every temporary of the build, with 256-byte slack each (sizes of the library calls queried first)
+    if ((int)n > leaf_max) {
+      HOK(rocprim::radix_sort_pairs(nullptr, tb_sort, keys, keys2, vals, sorted, n, 0, 63, st));
+      HOK(rocprim::exclusive_scan(nullptr, tb_scan, live, newidx, 0u, (size_t)(n > 1 ? n - 1 : 1), rocprim::plus<unsigned>(), st));
+    }
+    const size_t per_tri = 6 * sizeof(float4) + 2 * sizeof(unsigned long long) + 9 * sizeof(unsigned) + 2 * sizeof(int);
+    const size_t levels = 4 * sizeof(float4) * ((size_t)n / 31 + 64 * GVT_BOX_LEVELS);
+    A.cap = per_tri * ((size_t)n + 1) + levels + tb_sort + tb_scan + 64 * 256 + 4096;
+    A.base = (char *)scratch_get(21, A.cap);
+    if (!A.base) { rc = GVT_HIP_ERR_DEVICE; goto done; }
+  }
+  mark("arena");
+  OK(A.take(&plo, n)); OK(A.take(&phi, n));
   k_tri_bounds<<<G, B, 0, st>>>(M->d_verts, M->d_tris, n, plo, phi);
   { // scene box: 32:1 reductions, the last <= 32 boxes on the host
     BoxLevels T;
-    OK(build_box_levels(plo, phi, n, lvl_a, T, st));
+    OK(build_box_levels(plo, phi, n, A, T, st));
     unsigned cnt = n;
     for (int l = 1; l < T.n_levels; l++) cnt = (cnt + 31u) / 32u;
     std::vector<float4> hl(cnt), hh(cnt);
@@ -474,15 +516,16 @@ int build_lbvh(gvt_hip_mesh *M) {
     for (int k = 0; k < 3; k++) { ext = fmaxf(ext, fabsf(M->lo[k])); ext = fmaxf(ext, fabsf(M->hi[k])); }
     pad = ext * 1e-5f; // keeps the slab test conservative w.r.t. the triangle test's rounding
   }
+  mark("scene box");
   OK(dalloc(&M->d_tri, (size_t)4 * n));
   OK(dalloc(&M->d_slot_of, n));
-  OK(dalloc(&leaf_of, n));
+  OK(A.take(&leaf_of, n));
   if (want_q) OK(dalloc(&M->d_triq, (size_t)4 * n));
 
   if ((int)n <= leaf_max) {
     OK(dalloc(&M->d_nodes, 1));
     M->nNodes = 1; M->nLeaves = 1;
-    OK(dalloc(&sorted, n));
+    OK(A.take(&sorted, n));
     {
       std::vector<unsigned> id(n);
       for (unsigned i = 0; i < n; i++) id[i] = i;
@@ -498,7 +541,7 @@ int build_lbvh(gvt_hip_mesh *M) {
       k_emit_trisq<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, leaf_of, n, M->d_triq);
     }
   } else {
-    OK(dalloc(&keys, n)); OK(dalloc(&keys2, n)); OK(dalloc(&vals, n)); OK(dalloc(&sorted, n));
+    OK(A.take(&keys, n)); OK(A.take(&keys2, n)); OK(A.take(&vals, n)); OK(A.take(&sorted, n));
     {
       float3 blo = make_float3(M->lo[0], M->lo[1], M->lo[2]);
       float ex = M->hi[0] - M->lo[0], ey = M->hi[1] - M->lo[1], ez = M->hi[2] - M->lo[2];
@@ -506,30 +549,27 @@ int build_lbvh(gvt_hip_mesh *M) {
       k_morton<<<G, B, 0, st>>>(plo, phi, n, blo, inv, keys, vals);
     }
     {
-      size_t tb = 0;
-      HOK(rocprim::radix_sort_pairs(nullptr, tb, keys, keys2, vals, sorted, n, 0, 63, st));
-      HOK(hipMalloc(&tmp, tb ? tb : 1));
-      HOK(rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, sorted, n, 0, 63, st));
+      OK(A.take((char **)&tmp, tb_sort));
+      HOK(rocprim::radix_sort_pairs(tmp, tb_sort, keys, keys2, vals, sorted, n, 0, 63, st));
     }
-    OK(dalloc(&cl, n)); OK(dalloc(&cr, n)); OK(dalloc(&rf, n)); OK(dalloc(&rl, n));
-    OK(dalloc(&slo, n)); OK(dalloc(&shi, n)); OK(dalloc(&ilo, n)); OK(dalloc(&ihi, n));
-    OK(dalloc(&live, n)); OK(dalloc(&newidx, n + 1)); OK(dalloc(&nleaves, 1));
+    mark("morton + sort");
+    OK(A.take(&cl, n)); OK(A.take(&cr, n)); OK(A.take(&rf, n)); OK(A.take(&rl, n));
+    OK(A.take(&slo, n)); OK(A.take(&shi, n)); OK(A.take(&ilo, n)); OK(A.take(&ihi, n));
+    OK(A.take(&live, n)); OK(A.take(&newidx, n + 1)); OK(A.take(&nleaves, 1));
     HOK(hipMemsetAsync(nleaves, 0, sizeof(unsigned), st));
     k_karras<<<(n_inner + B - 1) / B, B, 0, st>>>(keys2, (int)n, cl, cr, rf, rl);
     k_gather_boxes<<<G, B, 0, st>>>(sorted, plo, phi, n, slo, shi);
     {
       BoxLevels T;
-      OK(build_box_levels(slo, shi, n, lvl_b, T, st));
+      OK(build_box_levels(slo, shi, n, A, T, st));
       k_node_boxes<<<(n_inner + B - 1) / B, B, 0, st>>>(n_inner, rf, rl, T, ilo, ihi);
     }
     k_mark_live<<<(n_inner + B - 1) / B, B, 0, st>>>(n_inner, rf, rl, live, leaf_max);
     {
-      size_t tb = 0;
-      HOK(hipFree(tmp)); tmp = nullptr;
-      HOK(rocprim::exclusive_scan(nullptr, tb, live, newidx, 0u, (size_t)n_inner, rocprim::plus<unsigned>(), st));
-      HOK(hipMalloc(&tmp, tb ? tb : 1));
-      HOK(rocprim::exclusive_scan(tmp, tb, live, newidx, 0u, (size_t)n_inner, rocprim::plus<unsigned>(), st));
+      OK(A.take((char **)&tmp2, tb_scan));
+      HOK(rocprim::exclusive_scan(tmp2, tb_scan, live, newidx, 0u, (size_t)n_inner, rocprim::plus<unsigned>(), st));
     }
+    mark("karras + boxes + scan");
     unsigned last_idx = 0, last_live = 0;
     HOK(hipMemcpyAsync(&last_idx, newidx + (n_inner - 1), sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HOK(hipMemcpyAsync(&last_live, live + (n_inner - 1), sizeof(unsigned), hipMemcpyDeviceToHost, st));
@@ -539,22 +579,21 @@ int build_lbvh(gvt_hip_mesh *M) {
     k_emit_nodes<<<(n_inner + B - 1) / B, B, 0, st>>>(n_inner, live, newidx, slo, shi, ilo, ihi, cl, cr, rf, rl, pad, M->d_nodes, nleaves, leaf_max, leaf_of);
     k_emit_tris<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, n, M->d_tri, M->d_slot_of);
     if (want_q) k_emit_trisq<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, leaf_of, n, M->d_triq);
+    mark("emit nodes + slots");
     unsigned nl = 0;
     HOK(hipMemcpyAsync(&nl, nleaves, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HOK(hipStreamSynchronize(st));
     M->nLeaves = nl;
   }
-  if (gctx().wide4 || want_q) OK(build_nodes4(M)); // the traversal layout; counted in the build time
+  if (gctx().wide4 || want_q) OK(build_nodes4(M, &A)); // the traversal layout; counted in the build time
+  mark("4-wide collapse");
   HOK(hipEventRecord(e1, st));
   HOK(hipEventSynchronize(e1));
   HOK(hipEventElapsedTime(&M->build_ms, e0, e1));
   gctx().stats.ms_build += M->build_ms;
 done:
   hipStreamSynchronize(st);
-  hipFree(plo); hipFree(phi); hipFree(slo); hipFree(shi); hipFree(ilo); hipFree(ihi); hipFree(keys); hipFree(keys2); hipFree(vals);
-  hipFree(sorted); hipFree(live); hipFree(newidx); hipFree(nleaves); hipFree(leaf_of); hipFree(cl); hipFree(cr); hipFree(rf); hipFree(rl); hipFree(tmp);
-  for (float4 *p : lvl_a) hipFree(p);
-  for (float4 *p : lvl_b) hipFree(p);
+  if (A.cap > ((size_t)1 << 30)) scratch_release(21); // a large scene's temporaries are not kept
   hipEventDestroy(e0); hipEventDestroy(e1);
   return rc;
 #undef OK
@@ -573,7 +612,7 @@ int sort_pairs_u32(unsigned *keys_in, unsigned *keys_out, unsigned *vals_in, uns
 }
 
 // Compressed 4-wide collapse of the emitted binary tree (the traversal layout of k_trace's wide4 variant)
-int build_nodes4(gvt_hip_mesh *M) {
+static int build_nodes4(gvt_hip_mesh *M, BuildArena *A) {
   if (M->d_nodes4 || !M->nNodes) return 0;
   Ctx &C = gctx();
   hipStream_t st = C.stream;
@@ -581,9 +620,15 @@ int build_nodes4(gvt_hip_mesh *M) {
   unsigned *cnt = nullptr;
   int rc = dalloc(&M->d_nodes4, (size_t)GVT_NODE4_F4 * M->nNodes);
   if (!rc && M->d_triq) rc = dalloc(&M->d_nodes4q, (size_t)GVT_NODE4_F4 * M->nNodes);
-  if (!rc) rc = dalloc(&fa, M->nNodes);
-  if (!rc) rc = dalloc(&fb, M->nNodes);
-  if (!rc) rc = dalloc(&cnt, 1);
+  if (A) { // called from build_lbvh: the frontier arrays out of the build's arena
+    if (!rc) rc = A->take(&fa, M->nNodes);
+    if (!rc) rc = A->take(&fb, M->nNodes);
+    if (!rc) rc = A->take(&cnt, 1);
+  } else {
+    if (!rc) rc = dalloc(&fa, M->nNodes);
+    if (!rc) rc = dalloc(&fb, M->nNodes);
+    if (!rc) rc = dalloc(&cnt, 1);
+  }
   if (!rc) {
     const int root = 0;
     hipError_t e = hipMemcpyAsync(fa, &root, sizeof root, hipMemcpyHostToDevice, st);
@@ -602,10 +647,11 @@ int build_nodes4(gvt_hip_mesh *M) {
     M->nNodes4 = base;
     if (e != hipSuccess) { set_error("4-wide collapse: %s", hipGetErrorString(e)); rc = GVT_HIP_ERR_DEVICE; }
   }
-  hipFree(fa); hipFree(fb); hipFree(cnt);
+  if (!A) { hipFree(fa); hipFree(fb); hipFree(cnt); }
   if (rc) { hipFree(M->d_nodes4); M->d_nodes4 = nullptr; hipFree(M->d_nodes4q); M->d_nodes4q = nullptr; }
   return rc;
 }
+int build_nodes4(gvt_hip_mesh *M) { return build_nodes4(M, nullptr); }
 
 // diagnostic: marks[k] = 1 where binary node k is the root of a `width`-wide node (width 2..8); *n_wide = number of wide nodes
 int wide_root_marks(gvt_hip_mesh *M, int width, unsigned char *d_marks, size_t *n_wide) {
