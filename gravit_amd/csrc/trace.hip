@@ -116,7 +116,9 @@ __device__ __forceinline__ RaySlab make_slab(float ix, float iy, float iz, float
   return S;
 }
 __device__ __forceinline__ f2 splat2(float v) { return (f2){ v, v }; }
-__device__ __forceinline__ void node4_test(const uint4 *__restrict__ nd, const RaySlab &S, float lim, float tn[4], int rr[4]) {
+// hit[k] (optional): child k is entered -- the same predicate as tn[k] < GVT_FLT_MAX, for callers that need no distances (any hit: saves
+// the select and the second compare per child)
+__device__ __forceinline__ void node4_test(const uint4 *__restrict__ nd, const RaySlab &S, float lim, float tn[4], int rr[4], bool *hit = nullptr) {
   const uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3];
   const float sx = __uint_as_float(w0.w) * S.ix, sy = __uint_as_float(w3.z) * S.iy, sz = __uint_as_float(w3.w) * S.iz;
   const f2 bx = __builtin_elementwise_fma(splat2(__uint_as_float(w0.x)), splat2(S.ix), -S.ox); // (near offset, far offset)
@@ -137,8 +139,10 @@ __device__ __forceinline__ void node4_test(const uint4 *__restrict__ nd, const R
     const f2 fz_ = __builtin_elementwise_fma(GVT_Q2(qfz, SH), splat2(sz), splat2(bz.y));                              \
     const float na_ = fmaxf(fmaxf(nx_.x, ny_.x), fmaxf(nz_.x, 0.f)), nb_ = fmaxf(fmaxf(nx_.y, ny_.y), fmaxf(nz_.y, 0.f)); \
     const float fa_ = fminf(fminf(fx_.x, fy_.x), fz_.x) * 1.0000004f, fb_ = fminf(fminf(fx_.y, fy_.y), fz_.y) * 1.0000004f; \
-    tn[A] = (na_ <= fminf(fa_, lim)) ? na_ : GVT_FLT_MAX; /* a miss sorts last */                                    \
-    tn[B] = (nb_ <= fminf(fb_, lim)) ? nb_ : GVT_FLT_MAX;                                                            \
+    const bool ha_ = na_ <= fminf(fa_, lim), hb_ = nb_ <= fminf(fb_, lim);                                            \
+    tn[A] = ha_ ? na_ : GVT_FLT_MAX; /* a miss sorts last */                                                         \
+    tn[B] = hb_ ? nb_ : GVT_FLT_MAX;                                                                                 \
+    if (hit) { hit[A] = ha_; hit[B] = hb_; }                                                                         \
   }
   GVT_SLAB2(0, 0, 1) GVT_SLAB2(16, 2, 3)
 #undef GVT_SLAB2
@@ -448,7 +452,9 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
         if (at_inner) { // one 64-byte fetch decides four children (8-bit boxes on the node's own grid)
           float tn[4];
           int rr[4];
-          node4_test((MULTI ? nodes4_l : T.nodes4) + (size_t)GVT_NODE4_F4 * cur, S, ANY ? GVT_FLT_MAX : bt, tn, rr);
+          bool entered[4];
+          node4_test((MULTI ? nodes4_l : T.nodes4) + (size_t)GVT_NODE4_F4 * cur, S, ANY ? GVT_FLT_MAX : bt, tn, rr, ANY ? entered : nullptr);
+#define KT_ENTERED(K) (ANY ? entered[K] : (tn[K] < GVT_FLT_MAX)) // (closest hit: tn / rr are sorted below, the flags are not)
           if (!ANY) { // nearest first; for any-hit the order does not matter
 #define GVT_CE(A, B) { const bool sw_ = tn[B] < tn[A]; const float ta_ = sw_ ? tn[B] : tn[A], tb_ = sw_ ? tn[A] : tn[B]; \
                        const int ra_ = sw_ ? rr[B] : rr[A], rb_ = sw_ ? rr[A] : rr[B]; tn[A] = ta_; tn[B] = tb_; rr[A] = ra_; rr[B] = rb_; }
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
           if (sp + 3 <= TRAV_STACK) { // room for three entries in the LDS part: no bounds checks, no spill path
 #pragma unroll
             for (int c4 = 3; c4 >= 0; c4--) {
-              if (tn[c4] < GVT_FLT_MAX) {
+              if (KT_ENTERED(c4)) {
                 if (have) { lds[sp * TRAV_BLOCK] = nxt; sp++; }
                 nxt = rr[c4]; have = true;
               }
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
           } else {
 #pragma unroll
             for (int c4 = 3; c4 >= 0; c4--) {
-              if (tn[c4] < GVT_FLT_MAX) {
+              if (KT_ENTERED(c4)) {
                 if (have) KT_PUSH(nxt)
                 nxt = rr[c4]; have = true;
               }
@@ -477,6 +483,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
           }
           if (have) cur = nxt;
           else KT_POP()
+#undef KT_ENTERED
         }
       }
 #ifdef GVT_EXPERIMENTS
@@ -746,10 +753,11 @@ __device__ __forceinline__ bool wave_any_run(const uint4 *__restrict__ nodes4, c
       ns -= take;
       float tn[4];
       int rr[4];
-      if (mine) node4_test(nodes4 + (size_t)GVT_NODE4_F4 * ref, S, GVT_FLT_MAX, tn, rr);
+      bool entered[4] = { false, false, false, false };
+      if (mine) node4_test(nodes4 + (size_t)GVT_NODE4_F4 * ref, S, GVT_FLT_MAX, tn, rr, entered);
 #pragma unroll
       for (int c = 3; c >= 0; c--) {
-        const bool hit = mine && tn[c] < GVT_FLT_MAX;
+        const bool hit = mine && entered[c];
         const bool inner = hit && rr[c] >= 0, leaf = hit && rr[c] < 0;
         const unsigned long long mi = ballot64(inner), ml = ballot64(leaf);
         if (inner) s_ref[ns + (int)lanes_below(mi)] = rr[c];
