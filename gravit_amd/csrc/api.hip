@@ -41,7 +41,7 @@ static int ctx_setup(Ctx &C, int device) {
   HIPCHK(hipStreamCreateWithFlags(&C.own_stream, hipStreamNonBlocking));
   C.stream = C.own_stream;
   // traversal kernels: 24 KiB LDS per 256-thread block -> 6 blocks/CU; grid = resident blocks, waves pull work
-  C.trav_blocks = C.n_cu * 8 * (256 / trav_block_threads());
+  C.trav_blocks = std::max(C.n_cu, C.n_cu * 32 / (trav_block_threads() / 64)); // at most 8 waves per SIMD, whatever the block size
   const size_t spill_ints = (size_t)C.trav_blocks * trav_block_threads() * trav_spill_ints_per_thread();
   HIPCHK(hipMalloc((void **)&C.d_spill, spill_ints * sizeof(int)));
   HIPCHK(hipMalloc((void **)&C.d_counters, 64 * sizeof(unsigned)));

@@ -24,7 +24,7 @@
 #ifndef TRAV_BLOCK
 #define TRAV_BLOCK 256   // threads per traversal block (64: every wave is its own block and gives its registers / LDS back when IT ends)
 #endif
-#define TRAV_BLOCK_SCALE (256 / TRAV_BLOCK) // blocks-per-CU knobs count 256-thread blocks
+#define TRAV_WAVES_PER_BLOCK (TRAV_BLOCK / 64) // (the blocks-per-CU knobs count 256-thread blocks = waves per SIMD)
 #ifndef TRAV_STACK
 #define TRAV_STACK 24   // LDS entries per lane; deeper levels spill to a per-thread global area
 #endif
@@ -227,7 +227,7 @@ struct MultiSrc {
   unsigned long long *tot_any;  // any hit over a direct-mapped list: the rays actually traced are added here (one atomic per wave)
 };
 template <bool ANY, bool XFORM, int MODE, bool COOP, bool W4, bool MULTI = false>
-__global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSEST) * TRAV_BLOCK_SCALE) void k_trace(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, Trav T, float tnear,
+__global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSEST)) void k_trace(RayPlanes q, const unsigned *__restrict__ idx, unsigned n, Mat4 minv, Trav T, float tnear,
                                                        gvt_hip_hit *__restrict__ hits, int *__restrict__ flags, RayPlanes out, unsigned *out_count,
                                                        unsigned *counter, int *spill_base, int refill_min, int inner_min, const unsigned *__restrict__ n_dev, int share, unsigned share_min, TermSink sink, LongQ LQ,
                                                        MultiSrc MS = MultiSrc{}) {
@@ -1405,7 +1405,8 @@ static void long_limits(LongQ &LQ, size_t n) {
 // persistent-wave kernel: fewer, longer-lived waves so that every lane is refilled several times
 int trav_grid2(size_t n, bool closest = false) {
   Ctx &C = gctx();
-  size_t want = (size_t)C.n_cu * (size_t)((closest && C.blocks_per_cu_closest) ? C.blocks_per_cu_closest : C.blocks_per_cu) * TRAV_BLOCK_SCALE;
+  size_t want = (size_t)C.n_cu * (((size_t)((closest && C.blocks_per_cu_closest) ? C.blocks_per_cu_closest : C.blocks_per_cu) * 4) / TRAV_WAVES_PER_BLOCK);
+  if (!want) want = C.n_cu;
   size_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
   if (want > (size_t)C.trav_blocks) want = (size_t)C.trav_blocks;
   return (int)(need < want ? (need ? need : 1) : want);
