@@ -16,9 +16,19 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libgvt_hip.so")
 LIB_EXP = os.path.join(HERE, "libgvt_hip_exp.so")
 SOURCES = ["api.hip", "lbvh.hip", "trace.hip", "sched.hip", "domain.hip"]
-HEADERS = ["gvt_device.h", "gvt_internal.h", "diag_kernels.inc", os.path.join("..", "..", "include", "gvt_hip.h"),
-           os.path.join("..", "..", "include", "gvt_math.h")]
-EXP_HEADERS = [os.path.join("experiments", f) for f in ("fused_kernel.inc", "packet_kernel.inc", "quad_kernel.inc", "binary_node_arm.inc", "coop_leaf_arm.inc")]
+
+
+def _headers(experiments):
+    """Every header / include a translation unit may pull in: csrc/*.h, csrc/*.inc, include/*.h (+ csrc/experiments/* for the
+    experiments build) -- the same set source_hash() hashes, so a stale object can never carry a fresh hash."""
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))]
+    out += [os.path.join(inc, f) for f in sorted(os.listdir(inc)) if f.endswith(".h")]
+    if experiments:
+        exp = os.path.join(CSRC, "experiments")
+        out += [os.path.join(exp, f) for f in sorted(os.listdir(exp)) if f.endswith((".h", ".inc"))]
+    return out
+
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 
@@ -67,7 +77,7 @@ def build(force=False, verbose=False, experiments=False):
     if experiments:
         extra = extra + ["-DGVT_EXPERIMENTS"]
     cc = hipcc()
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS + (EXP_HEADERS if experiments else [])]
+    hdrs = _headers(experiments)
     objs = []
     procs = []
     for s in SOURCES:
