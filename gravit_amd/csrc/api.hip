@@ -44,8 +44,8 @@ static int ctx_setup(Ctx &C, int device) {
   C.trav_blocks = std::max(C.n_cu, C.n_cu * 32 / (trav_block_threads() / 64)); // at most 8 waves per SIMD, whatever the block size
   const size_t spill_ints = (size_t)C.trav_blocks * trav_block_threads() * trav_spill_ints_per_thread();
   HIPCHK(hipMalloc((void **)&C.d_spill, spill_ints * sizeof(int)));
-  HIPCHK(hipMalloc((void **)&C.d_counters, GVT_CTX_COUNTER_WORDS * sizeof(unsigned)));
-  HIPCHK(hipMemset(C.d_counters, 0, GVT_CTX_COUNTER_WORDS * sizeof(unsigned)));
+  HIPCHK(hipMalloc((void **)&C.d_counters, 64 * sizeof(unsigned)));
+  HIPCHK(hipMemset(C.d_counters, 0, 64 * sizeof(unsigned)));
   HIPCHK(hipHostMalloc((void **)&C.h_pinned, 64 * sizeof(unsigned), hipHostMallocDefault));
   std::memset(C.h_pinned, 0, 64 * sizeof(unsigned));
   C.ready = true;
@@ -87,22 +87,10 @@ extern "C" void gvt_hip_ctx_destroy(gvt_hip_ctx *c) {
     C->abi_lanes.clear();
     hipSetDevice(C->device);
     for (int k = 0; k < 24; k++) if (C->scratch[k]) hipFree(C->scratch[k]);
-    hipFree(C->d_spill); hipFree(C->d_spill_side); hipFree(C->d_counters); hipHostFree(C->h_pinned);
-    if (C->side_stream) { hipStreamSynchronize(C->side_stream); hipStreamDestroy(C->side_stream); hipEventDestroy(C->ev_fork); hipEventDestroy(C->ev_join); }
+    hipFree(C->d_spill); hipFree(C->d_counters); hipHostFree(C->h_pinned);
     hipStreamDestroy(C->own_stream);
   }
   delete C;
-}
-
-int ctx_side_stream() {
-  Ctx &C = g_ctx;
-  if (C.side_stream) return 0;
-  const size_t spill_ints = (size_t)C.trav_blocks * trav_block_threads() * trav_spill_ints_per_thread();
-  HIPCHK(hipMalloc((void **)&C.d_spill_side, spill_ints * sizeof(int)));
-  HIPCHK(hipEventCreateWithFlags(&C.ev_fork, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&C.ev_join, hipEventDisableTiming));
-  HIPCHK(hipStreamCreateWithFlags(&C.side_stream, hipStreamNonBlocking));
-  return 0;
 }
 
 int ensure_init() {
@@ -227,7 +215,7 @@ extern "C" int gvt_hip_set_option(const char *name, int value) {
   if (!std::strcmp(name, "round_room_mb")) { g_ctx.round_room_mb = value < 0 ? 0 : value; return 0; }
   if (!std::strcmp(name, "first_round_async")) { g_ctx.first_round_async = value; return 0; }
   if (!std::strcmp(name, "lean_frame")) { g_ctx.lean_frame = value; return 0; }
-  if (!std::strcmp(name, "frame_slices")) { if (value < 1 || value > GVT_MAX_SLICES) { set_error("frame_slices must be 1..%d", GVT_MAX_SLICES); return GVT_HIP_ERR_INVALID; } g_ctx.frame_slices = value; return 0; }
+  if (!std::strcmp(name, "skip_known")) { g_ctx.skip_known = value != 0; return 0; }
   if (!std::strcmp(name, "abi_lanes")) { if (value < 0 || value > 8) { set_error("abi_lanes must be 0..8"); return GVT_HIP_ERR_INVALID; } g_ctx.abi_lanes_n = value; return 0; }
   if (!std::strcmp(name, "abi_chunk")) { if (value < 16384) { set_error("abi_chunk must be >= 16384"); return GVT_HIP_ERR_INVALID; } g_ctx.abi_chunk = value; return 0; }
   if (!std::strcmp(name, "abi_pipe_min")) { g_ctx.abi_pipe_min = value < 0 ? 0 : value; return 0; }
@@ -359,6 +347,7 @@ int queue_reserve(gvt_hip_queue *q, size_t cap) {
     for (int k = 0; k < 4; k++)
       HIPCHK(hipMemcpyAsync(np + (size_t)k * ncap, q->d_planes + (size_t)k * q->cap, sizeof(float4) * q->size, hipMemcpyDeviceToDevice, C.stream));
     HIPCHK(hipMemcpyAsync(np + 4 * ncap, q->d_planes + 4 * q->cap, sizeof(uint32_t) * q->size, hipMemcpyDeviceToDevice, C.stream));
+    HIPCHK(hipMemcpyAsync((uint32_t *)(np + 4 * ncap) + ncap, (const uint32_t *)(q->d_planes + 4 * q->cap) + q->cap, 3 * sizeof(uint32_t) * q->size, hipMemcpyDeviceToDevice, C.stream));
   }
   HIPCHK(hipStreamSynchronize(C.stream));
   if (q->d_planes) HIPCHK(hipFree(q->d_planes));
@@ -611,7 +600,7 @@ static int stage_od(const float *org, const float *dir, size_t n, RayPlanes &pla
   float *d_dir = d_org + 3 * n;
   HIPCHK(hipMemcpyAsync(d_org, org, sizeof(float) * 3 * n, hipMemcpyHostToDevice, C.stream));
   HIPCHK(hipMemcpyAsync(d_dir, dir, sizeof(float) * 3 * n, hipMemcpyHostToDevice, C.stream));
-  planes.p0 = d_pl; planes.p1 = d_pl + n; planes.p2 = nullptr; planes.p3 = nullptr; planes.p4 = nullptr;
+  planes.p0 = d_pl; planes.p1 = d_pl + n; planes.p2 = nullptr; planes.p3 = nullptr; planes.p4 = nullptr; planes.p5 = nullptr;
   return convert_od_to_planes(d_org, d_dir, n, planes);
 }
 

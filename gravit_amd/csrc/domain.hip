@@ -25,7 +25,6 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
-#include <algorithm>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -38,8 +37,7 @@
 int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *from_arr, int from, gvt_hip_queue *const *queues, const uint8_t *keep_mask,
                   gvt_hip_fb *fb, unsigned *d_overflow, const void *d_qdesc);
 int shuffle_exact(gvt_hip_top *T, gvt_hip_queue *q_in, const int *from_arr, int from, gvt_hip_queue *const *queues, gvt_hip_fb *fb);
-int camera_one_instance_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *q, gvt_hip_fb *fb, unsigned *d_overflow, unsigned *d_moved_count,
-                              int n_slices, unsigned *slice_first);
+int camera_one_instance_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *q, gvt_hip_fb *fb, unsigned *d_overflow, unsigned *d_moved_count);
 int camera_filter_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *const *queues, const uint8_t *keep_mask, unsigned *d_overflow,
                         size_t first, size_t count);
 
@@ -383,14 +381,11 @@ __global__ void k_round_report(unsigned *const *__restrict__ count_ptr, const in
                                unsigned *sizes, int *__restrict__ ann /* [world][ANN_HEAD + n_inst] */, unsigned *counters,
                                const unsigned *__restrict__ overflow, unsigned *tail /* sizes + n_inst: tot[4], ovf trav, ovf queue, bbox[4] */,
                                const int *__restrict__ bbox, int chain_end = 0, const unsigned char *__restrict__ chain_mask = nullptr,
-                               unsigned *host_report = nullptr, unsigned host_seq = 0u, int err_code = 0, int tick = 0, int n_slices = 1) {
+                               unsigned *host_report = nullptr, unsigned host_seq = 0u, int err_code = 0, int tick = 0) {
   __shared__ unsigned long long sh_out, sh_local;
   if (threadIdx.x == 0) { sh_out = 0; sh_local = 0; }
   if (chain_end) { // the launch chain in front left its k_wave_end to this kernel: last pass's shadow rays into the frame total, traced queues cleared
-    if (threadIdx.x == 0) { // (a sliced frame: every slice's chain counted its last pass's shadow rays in its own counter block)
-      unsigned long long *tot = (unsigned long long *)(counters + 16);
-      for (int s = 0; s < n_slices; s++) { tot[1] += counters[GVT_SLICE_CTR_WORDS * s + 1]; if (s) counters[8] |= counters[GVT_SLICE_CTR_WORDS * s + 8]; }
-    }
+    if (threadIdx.x == 0) { unsigned long long *tot = (unsigned long long *)(counters + 16); tot[1] += counters[1]; }
     for (int i = threadIdx.x; i < n_inst; i += blockDim.x)
       if (chain_mask[i]) *count_ptr[i] = 0u;
   }
@@ -449,6 +444,7 @@ __global__ __launch_bounds__(256) void k_pack_wire(RayPlanes q, unsigned n, int 
   unsigned v = 0;
   if (w < 16) { const float4 *pl = w < 4 ? q.p0 : w < 8 ? q.p1 : w < 12 ? q.p2 : q.p3; v = ((const unsigned *)(pl + ray))[w & 3]; }
   else if (w == 16) v = q.p4[ray];
+  else v = q.p5[3 * (size_t)ray + (w - 17)]; // the known-miss list travels with the ray (bytes 68..79)
   dst[t] = v;
 }
 // the reverse, appended behind the queue's current rays (its count word is advanced by k_add_count afterwards)
@@ -463,6 +459,7 @@ __global__ __launch_bounds__(256) void k_unpack_wire(const unsigned *__restrict_
   const unsigned v = src[2 + t];
   if (w < 16) { float4 *pl = w < 4 ? q.p0 : w < 8 ? q.p1 : w < 12 ? q.p2 : q.p3; ((unsigned *)(pl + slot))[w & 3] = v; }
   else if (w == 16) q.p4[slot] = v;
+  else q.p5[3 * (size_t)slot + (w - 17)] = v;
 }
 // bounding rectangle (x0, y0, x1, y1 exclusive) of the pixels that hold a deposit (every deposit adds 1.0 to alpha, IceTComposite::localAdd)
 __global__ void k_bbox_init(int *bbox, int W, int H) { if (!blockIdx.x && !threadIdx.x) { bbox[0] = W; bbox[1] = H; bbox[2] = 0; bbox[3] = 0; } }
@@ -531,8 +528,6 @@ struct gvt_hip_tracer {
   bool chain_timed = false, payload_timed = false;
   uint64_t last_local_pending = 0;
   std::vector<size_t> present; // host-known queue sizes as of the last report
-  int n_slices = 1;            // sliced one-instance frame (Knobs::frame_slices): the cut the camera filter made this frame
-  unsigned slice_first[GVT_MAX_SLICES + 1] = { 0 };
 };
 
 extern "C" void gvt_hip_tracer_destroy(gvt_hip_tracer *R) {
@@ -743,12 +738,11 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
   if (n_seg == 1 && R->meshes[R->h_segs[0].inst] && C.wave_single) {
     const int i0 = R->h_segs[0].inst;
     one.planes = make_planes(R->h_segs[0].planes, R->h_segs[0].cap);
+    if (nI == 1) one.planes.p5 = nullptr; // no other instance a ray could have missed: the list is neither read nor written
     one.mesh = R->meshes[i0]; one.inst = i0;
     one.coherent = (fresh_from_camera && C.camera_tile == 8) ? 1 : 0;
     one.n_dev = count_on_device ? R->queues[i0]->d_count : nullptr; // present[i0] is then only the bound (the whole camera list)
     one.pass0_begun = pass0_begun ? 1 : 0;
-    one.n_slices = (count_on_device && pass0_begun) ? R->n_slices : 1;
-    std::memcpy(one.slice_first, R->slice_first, sizeof one.slice_first);
     std::memcpy(one.minv.m, R->minv.data() + 16 * (size_t)i0, 64);
     std::memcpy(one.normi.n, R->normi.data() + 9 * (size_t)i0, 36);
   }
@@ -764,7 +758,7 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
 }
 
 // (3)+(4)+(5): report kernel -> [announce exchange] -> ONE device-to-host copy -> ONE host synchronisation
-int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_end = false, int err_code = 0, int tick = 0, gvt_hip_frame_stats *S = nullptr, int n_slices = 1) {
+int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_end = false, int err_code = 0, int tick = 0, gvt_hip_frame_stats *S = nullptr) {
   Ctx &C = gctx();
   const size_t nI = R->n_inst, row = ANN_HEAD + nI;
   hipStream_t st = C.stream;
@@ -776,7 +770,7 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_e
     k_fb_bbox<<<(unsigned)(((size_t)R->fb->w * R->fb->h + 255) / 256), 256, 0, st>>>((const float4 *)R->fb->d_rgba, R->fb->w, R->fb->h, d_bbox);
   }
   k_round_report<<<1, 256, 0, st>>>(R->d_count_ptr, R->d_owner, (int)nI, R->rank, R->world, R->d_report, R->d_ann_out, C.d_counters, R->d_overflow,
-                                    R->d_report + nI, d_bbox, chain_end ? 1 : 0, R->d_mask, poll ? R->h_report : nullptr, poll ? ++R->report_seq : 0u, err_code, tick, n_slices);
+                                    R->d_report + nI, d_bbox, chain_end ? 1 : 0, R->d_mask, poll ? R->h_report : nullptr, poll ? ++R->report_seq : 0u, err_code, tick);
   HIPCHK(hipGetLastError());
   if (exchange && R->world > 1) {
     gvt_hip_comm *K = R->comm;
@@ -875,18 +869,12 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     const size_t n_cam = (size_t)R->cam.width * R->cam.height * R->cam.samples * R->cam.samples;
     const int passes0 = R->cam.depth > 1 ? R->cam.depth : 1;
     if ((rc = queue_reserve(R->queues[0], n_cam * (size_t)(1 + (int)R->lights.size() * passes0)))) return rc; // what local_chain will ask for: no move later
-    R->n_slices = 1;
-    if (lean) {
-      // the frame in slices on two streams (trace.hip wave_trace_chain) when the list is long enough for its launches to have a tail worth hiding
-      const int want = (C.frame_slices > 1 && n_cam >= ((size_t)1 << 19)) ? std::min(C.frame_slices, GVT_MAX_SLICES) : 1;
-      if ((rc = camera_one_instance_async(R->top, &R->cam, C.camera_tile, R->queues[0], R->fb, R->d_overflow, R->q_moved->d_count, want, R->slice_first))) return rc;
-      R->n_slices = want;
-    }
+    if (lean) { if ((rc = camera_one_instance_async(R->top, &R->cam, C.camera_tile, R->queues[0], R->fb, R->d_overflow, R->q_moved->d_count))) return rc; }
     else if ((rc = camera_filter_async(R->top, &R->cam, C.camera_tile, R->queues.data(), nullptr, R->d_overflow, 0, 0))) return rc;
     R->present[0] = n_cam;
     R->queues[0]->size = n_cam; // bound of what the device holds (a reallocation would copy at least that)
     if ((rc = local_chain(R, nullptr, &S.chains, true, true, lean, lean))) return rc;
-    if ((rc = round_report(R, false, &S.host_syncs, lean, 0, 0, nullptr, lean ? R->n_slices : 1))) return rc;
+    if ((rc = round_report(R, false, &S.host_syncs, lean))) return rc;
   } else if (image_split) {
     const size_t n_cam = (size_t)R->cam.width * R->cam.height * R->cam.samples * R->cam.samples;
     const size_t portion = n_cam / (size_t)R->world, first = (size_t)R->rank * portion;

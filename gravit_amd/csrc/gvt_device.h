@@ -71,16 +71,20 @@ __host__ __device__ inline V3 mat3_mul(const Mat3 &N, V3 v) {
 //            per TBB chunk (EmbreeMeshAdapter.cpp:446-447: schedule dependent); here the stream belongs to the ray and travels with
 //            it -- through queues, shuffles and the wire -- so a frame does not depend on list order, rank count or scheduling.
 //            p4 may be null (lists that never shade: object-space query rays, shadow-ray scratch): loads read 0, stores skip it.
+//   plane5 = three uint32 per ray: the ray's KNOWN MISSES = bytes 68..79 of the Ray image (same unused part of Ray::data): six 16-bit
+//            entries, instance + 1, of the instances the ray has crossed without a hit on its current straight segment (the schedulers'
+//            known-miss shortcut, below).  p5 may be null (one-instance scenes, scratch lists): loads read 0, stores skip it.
 // The traversal kernels touch planes 0 and 1 only (32 B/ray).
 // ---------------------------------------------------------------------------------------------
 struct RayPlanes {
   float4 *p0, *p1, *p2, *p3;
   uint32_t *p4;
+  uint32_t *p5;
 };
-#define GVT_QUEUE_BYTES_PER_RAY (4 * sizeof(float4) + sizeof(uint32_t))
+#define GVT_QUEUE_BYTES_PER_RAY (4 * sizeof(float4) + 4 * sizeof(uint32_t)) // = the 80 bytes of the Ray image
 __host__ __device__ inline RayPlanes make_planes(float4 *base, size_t cap) { // a queue allocation: GVT_QUEUE_BYTES_PER_RAY * cap
   RayPlanes r;
-  r.p0 = base; r.p1 = base + cap; r.p2 = base + 2 * cap; r.p3 = base + 3 * cap; r.p4 = (uint32_t *)(base + 4 * cap);
+  r.p0 = base; r.p1 = base + cap; r.p2 = base + 2 * cap; r.p3 = base + 3 * cap; r.p4 = (uint32_t *)(base + 4 * cap); r.p5 = r.p4 + cap;
   return r;
 }
 
@@ -90,6 +94,7 @@ struct RayRec { // unpacked ray in registers
   V3 c; float t;
   int id, depth; float w; int type;
   uint32_t rng; // stream word (plane 4)
+  uint32_t km[3]; // known misses (plane 5)
 };
 __device__ inline RayRec load_ray(const RayPlanes &q, size_t i) {
   float4 a = q.p0[i], b = q.p1[i], c = q.p2[i], d = q.p3[i];
@@ -99,6 +104,8 @@ __device__ inline RayRec load_ray(const RayPlanes &q, size_t i) {
   r.c = mk3(c.x, c.y, c.z); r.t = c.w;
   r.id = __float_as_int(d.x); r.depth = __float_as_int(d.y); r.w = d.z; r.type = __float_as_int(d.w);
   r.rng = q.p4 ? q.p4[i] : 0u;
+  if (q.p5) { r.km[0] = q.p5[3 * i]; r.km[1] = q.p5[3 * i + 1]; r.km[2] = q.p5[3 * i + 2]; }
+  else { r.km[0] = 0u; r.km[1] = 0u; r.km[2] = 0u; }
   return r;
 }
 __device__ inline void store_ray(const RayPlanes &q, size_t i, const RayRec &r) {
@@ -107,7 +114,9 @@ __device__ inline void store_ray(const RayPlanes &q, size_t i, const RayRec &r) 
   q.p2[i] = make_float4(r.c.x, r.c.y, r.c.z, r.t);
   q.p3[i] = make_float4(__int_as_float(r.id), __int_as_float(r.depth), r.w, __int_as_float(r.type));
   if (q.p4) q.p4[i] = r.rng;
+  if (q.p5) { q.p5[3 * i] = r.km[0]; q.p5[3 * i + 1] = r.km[1]; q.p5[3 * i + 2] = r.km[2]; }
 }
+__device__ inline void store_no_known(const RayPlanes &q, size_t i) { if (q.p5) { q.p5[3 * i] = 0u; q.p5[3 * i + 1] = 0u; q.p5[3 * i + 2] = 0u; } }
 
 // ---------------------------------------------------------------------------------------------
 // BVH node: 64 B, both children's boxes in the parent (one fetch decides both).
@@ -368,4 +377,51 @@ __device__ inline int top_nearest(const float4 a, const float4 b, const TopDev &
   for (int k = 0; k < T.n_inst; k++) GVT_TOP_LEAF(k)
 #undef GVT_TOP_LEAF
   return next;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Known misses: an image-identical shortcut of shuffleRays (NOT in the reference; restated in the checker, oracle/gvt_oracle.c).
+// shuffleRays (TracerBase.h:392-400) sends a ray that left instance A without a hit to the nearest other instance box ahead of it,
+// its origin advanced by 95 % of the distance (:393).  Where the boxes of A and B overlap, a ray that has crossed both without a hit
+// is handed back and forth -- A, B, A, B, ..., five or six hops until the remaining distance falls below the box test's 1e-6 -- and every
+// hop is a full traversal (and, between ranks, an exchange) that cannot find anything: it is the same half-line from an origin further
+// along, and the instance held nothing on the longer one.  With the shortcut on, a ray carries the instances it has crossed without a
+// hit on its current straight segment (plane 5); when shuffleRays' choice is one of them, the trace there is taken as the miss it must
+// be: the origin advance is replayed with the reference's arithmetic and the next choice is made as if the ray came from there.  A
+// bounce starts a new segment (list cleared), a shadow ray is born with an empty list.  The ray that finally reaches a queue or the
+// framebuffer is bit for bit the ray the reference's hops deliver; only the number of rays traced and sent drops.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline bool km_has(const uint32_t km[3], int inst) {
+  if (inst < 0 || inst >= 65535) return false;
+  const uint32_t v = (uint32_t)(inst + 1);
+  return (km[0] & 0xffffu) == v || (km[0] >> 16) == v || (km[1] & 0xffffu) == v || (km[1] >> 16) == v || (km[2] & 0xffffu) == v || (km[2] >> 16) == v;
+}
+__host__ __device__ inline void km_add(uint32_t km[3], int inst) { // first free entry; a full list forgets its oldest entry (forgetting only costs a trace)
+  if (inst < 0 || inst >= 65535 || km_has(km, inst)) return;
+  const uint32_t v = (uint32_t)(inst + 1);
+  for (int k = 0; k < 3; k++) {
+    if (!(km[k] & 0xffffu)) { km[k] |= v; return; }
+    if (!(km[k] >> 16)) { km[k] |= v << 16; return; }
+  }
+  km[0] = (km[0] >> 16) | (km[1] << 16);
+  km[1] = (km[1] >> 16) | (km[2] << 16);
+  km[2] = (km[2] >> 16) | (v << 16);
+}
+#define GVT_KM_MAX_HOPS 64
+// shuffleRays' decision for one ray (a = origin | t_min, b = direction | t_max) leaving instance `from`, with the shortcut: the instance it
+// goes on in -- its origin advanced, `walked` set when that advance has been applied to `a` here -- or -1.  `from` joins the list.
+__device__ inline int shuffle_walk(float4 &a, const float4 b, const TopDev &T, int from, uint32_t km[3], float &ret_t, bool &walked) {
+  km_add(km, from);
+  walked = false;
+  int next = top_nearest(a, b, T, from, ret_t);
+  if (next < 0 || !km_has(km, next)) return next; // the ordinary case: the caller advances the origin by ret_t (TracerBase.h:393)
+  walked = true;
+  for (int hop = 0;; hop++) {
+    const V3 o = add3(mk3(a.x, a.y, a.z), scl3(mk3(b.x, b.y, b.z), ret_t * 0.95f)); // :393, replayed
+    a.x = o.x; a.y = o.y; a.z = o.z;
+    if (!km_has(km, next) || hop >= GVT_KM_MAX_HOPS) return next;
+    from = next; // crossed without a hit before: as if traced there again and forwarded as it is
+    next = top_nearest(a, b, T, from, ret_t);
+    if (next < 0) return -1;
+  }
 }

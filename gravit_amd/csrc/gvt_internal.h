@@ -51,8 +51,8 @@ struct Knobs {
   int abi_pipe_min = 131072; // ... lists shorter than this take the one-shot path
   int lean_frame = 1;    // one-instance scenes on one rank: framebuffer clear, counter resets and the chain's begin / end folded into the camera filter's
                          // two kernels and the round's report (8 launches per frame instead of 14)
-  int frame_slices = 2;  // one-instance frames (lean_frame): the camera's list is cut into this many slices whose launch chains run on two streams, so
-                         // that the drain of one slice's traversal launch is covered by the bulk of the next one's (1: one chain, one stream)
+  int skip_known = 1;    // shuffleRays' known-miss shortcut (gvt_device.h): a ray is not traced again in an instance it has already crossed without a hit
+                         // on the same straight segment (image-identical; 0: the reference's hop-by-hop behaviour, same ray counts as its schedulers)
   int inject_fail_tick = -1; // tests: this rank's local work "fails" at that exchange of a multi-rank frame (the announce carries the error to every rank)
   int report_poll = 1;   // one rank: a round's report is written into pinned host memory by the kernel and polled (no copy, no stream synchronisation)
   int first_round_async = 1; // one-instance scenes on one rank: no read-back after the camera filter (the chain reads its ray count on the device)
@@ -70,16 +70,6 @@ struct Knobs {
   int blocks_per_cu_quad = 8; // k_traceq grid: resident 256-thread blocks per CU
 };
 
-#define GVT_MAX_SLICES 8
-// A counter block: 64 words of counters (gvt_device.h / trace.hip list them) followed by k_trace's work counters -- GVT_STRIPES words,
-// GVT_STRIPE_WORDS apart (256 bytes: atomics on one word are served one after the other, ~90 per microsecond; on words in different
-// lines they are not).  Stripe s hands out the chunks s, s + GVT_STRIPES, s + 2 GVT_STRIPES, ... of a launch's ray range.
-#define GVT_STRIPES 32
-#define GVT_STRIPE_WORDS 64
-#define GVT_WORK_OFFSET 64
-#define GVT_SLICE_CTR_WORDS (GVT_WORK_OFFSET + GVT_STRIPES * GVT_STRIPE_WORDS)
-#define GVT_CTX_COUNTER_WORDS (GVT_SLICE_CTR_WORDS * GVT_MAX_SLICES)
-#define GVT_SLICE_COUNT_WORD 10 // word of a slice's counter block that holds its ray count (written by k_cam1_scatter)
 struct Ctx : Knobs {
   bool ready = false;
   int device = -1;
@@ -93,10 +83,7 @@ struct Ctx : Knobs {
   int n_cu = 256;
   int trav_blocks = 0;
   int *d_spill = nullptr;
-  int *d_spill_side = nullptr;    // ... for launches on the side stream (they run beside launches on `stream`), allocated on first use
-  hipStream_t side_stream = nullptr; // second stream of a sliced frame (frame_slices), with the events that fork it from / join it to `stream`
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  unsigned *d_counters = nullptr; // GVT_CTX_COUNTER_WORDS device counters: blocks of GVT_SLICE_CTR_WORDS words, block 0 = the context's, blocks 1.. = further slices of a sliced frame
+  unsigned *d_counters = nullptr; // small array of device counters (work fetch, temps)
   // pinned host scratch for small read-backs
   unsigned *h_pinned = nullptr;
   // grow-only device scratch arenas (never freed inside hot calls)
@@ -284,12 +271,7 @@ struct WaveSingle { // the launch has ONE segment: its queue planes and instance
   int coherent; // the queue holds camera rays in tile order, straight from the filter: packet traversal (k_packet)
   const unsigned *n_dev; // the first pass's ray count lives in device memory (the queue's count word; n_total is only its bound)
   int pass0_begun;       // the producer of the queue (k_cam1_scatter) has already done k_wave_pass_begin's pass-0 resets
-  // sliced frame (Knobs::frame_slices): slice s holds the rays of the camera's list positions [slice_first[s], slice_first[s + 1]), compacted
-  // at queue slots slice_first[s].. ; its count lives in word GVT_SLICE_COUNT_WORD of counter block s.  n_slices <= 1: one list from slot 0
-  int n_slices;
-  unsigned slice_first[GVT_MAX_SLICES + 1];
 };
-int ctx_side_stream(); // creates the context's side stream, its events and spill area on first use
 // defer_end: the caller's next kernel (k_round_report) does k_wave_end's work
 int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
                      const gvt_hip_light *lights_host, const WaveSingle *single, unsigned *const *d_count_ptr, const unsigned char *d_mask, int n_inst,

@@ -5,8 +5,6 @@
 //   k_top_scatter   AbstractTrace::shuffleRays, mesh branch  (algorithm/TracerBase.h:392-400) and
 //                   Tracer<DomainScheduler>::shuffleDropRays (algorithm/DomainTracer.h:148-183)
 //   framebuffer     IceTComposite::localAdd / reset / write  (composite/IceTComposite.cpp:79-157)
-#include <algorithm>
-
 #include "gvt_internal.h"
 
 namespace {
@@ -57,6 +55,7 @@ __device__ inline RayRec camera_ray(const CamArgs &A, unsigned long long ridx) {
   r.c = mk3(0.f, 0.f, 0.f); r.t = GVT_FLT_MAX;
   r.id = (int)pix; r.depth = A.depth; r.w = A.contri; r.type = 0;
   r.rng = camera_stream_word((unsigned long long)pix * samples2 + sub);
+  r.km[0] = 0u; r.km[1] = 0u; r.km[2] = 0u;
   return r;
 }
 
@@ -88,7 +87,7 @@ struct RaySrc {
 __global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RaySrc S, unsigned n, TopDev top,
                                                             int n_inst, int from, int *__restrict__ next_out, float *__restrict__ t_out,
                                                             unsigned *__restrict__ hist, int use_lds, unsigned *__restrict__ blk_cnt,
-                                                            const unsigned *__restrict__ n_dev = nullptr, const int *__restrict__ from_arr = nullptr) {
+                                                            const unsigned *__restrict__ n_dev = nullptr, const int *__restrict__ from_arr = nullptr, int skip_known = 0) {
   extern __shared__ unsigned sh_cnt[];
   if (n_dev) n = min(n, *n_dev);
   if (use_lds) {
@@ -102,7 +101,18 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RaySrc S, unsigned n
     float4 a, b;
     if (S.from_cam) { const RayRec r = camera_ray(S.cam, (unsigned long long)S.cam.first + i); a = make_float4(r.o.x, r.o.y, r.o.z, r.t_min); b = make_float4(r.d.x, r.d.y, r.d.z, r.t_max); }
     else { a = S.q.p0[i]; b = S.q.p1[i]; }
-    next = top_nearest(a, b, top, from_arr ? from_arr[i] : from, ret_t);
+    const int fr = from_arr ? from_arr[i] : from;
+    if (skip_known && !S.from_cam && S.q.p5 && fr >= 0) {
+      // the known-miss shortcut (gvt_device.h): `fr` joins the ray's list; a choice that is on the list is walked through here, the
+      // advanced origin left in the source list (consumed by the scatter that follows) and t_out = -1 says "already advanced"
+      uint32_t km[3] = { S.q.p5[3 * (size_t)i], S.q.p5[3 * (size_t)i + 1], S.q.p5[3 * (size_t)i + 2] };
+      bool walked;
+      next = shuffle_walk(a, b, top, fr, km, ret_t, walked);
+      if (walked) { S.q.p0[i] = a; ret_t = -1.f; }
+      S.q.p5[3 * (size_t)i] = km[0]; S.q.p5[3 * (size_t)i + 1] = km[1]; S.q.p5[3 * (size_t)i + 2] = km[2];
+    } else {
+      next = top_nearest(a, b, top, fr, ret_t);
+    }
     next_out[i] = next;
     t_out[i] = ret_t;
   }
@@ -180,7 +190,8 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_scatter(RaySrc S, unsigned n,
     next = next_in[i];
     r = S.from_cam ? camera_ray(S.cam, (unsigned long long)S.cam.first + i) : load_ray(S.q, i);
     if (next >= 0) {
-      r.o = add3(r.o, scl3(r.d, t_in[i] * 0.95f)); // TracerBase.h:393
+      const float t_adv = t_in[i];
+      if (t_adv >= 0.f) r.o = add3(r.o, scl3(r.d, t_adv * 0.95f)); // TracerBase.h:393 (< 0: k_top_classify has walked the ray through known misses)
     } else if (fb && r.type == 1 && len3(r.c) > 0.f) { // TracerBase.h:396-400 -> localAdd
       if ((unsigned)r.id < n_pix) {
         const V3 c = scl3(r.c, r.w);
@@ -254,21 +265,11 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_cam1_count(CamArgs A, unsigned n,
   if (blockIdx.x == 0 && threadIdx.x < 4) c[16 + threadIdx.x] = 0u; // the frame's ray totals (k_zero_totals)
   if (blockIdx.x == 0 && threadIdx.x == 4) { *ovf = 0u; c[9] = 0u; }
 }
-// Slices (CamSlices): the list may be cut at block boundaries into up to GVT_MAX_SLICES slices, each compacted on its own from the slot of
-// its first camera position (host-known) and counted in its own counter block -- the launch chains of the slices then run side by side
-// on two streams (trace.hip wave_trace_chain).  One slice = the whole list from slot 0, count also in the queue's count word.
-struct CamSlices {
-  int n;
-  unsigned first_blk[GVT_MAX_SLICES + 1]; // slice s = blocks [first_blk[s], first_blk[s + 1])
-};
 __global__ __launch_bounds__(TOP_BLOCK) void k_cam1_scatter(CamArgs A, unsigned n, TopDev top, const unsigned *__restrict__ blk_cnt, QueueDesc Q,
-                                                            unsigned *__restrict__ overflow, unsigned *__restrict__ c, unsigned *__restrict__ moved_count, CamSlices SL) {
+                                                            unsigned *__restrict__ overflow, unsigned *__restrict__ c, unsigned *__restrict__ moved_count) {
   __shared__ unsigned sh_w[TOP_BLOCK / 64], sh_p[TOP_BLOCK / 64];
-  int sl = 0;
-  while (sl + 1 < SL.n && blockIdx.x >= SL.first_blk[sl + 1]) sl++;
-  const unsigned b_first = SL.first_blk[sl], b_last = SL.first_blk[sl + 1] - 1u;
   unsigned part = 0;
-  for (unsigned b = b_first + threadIdx.x; b < blockIdx.x; b += TOP_BLOCK) part += blk_cnt[b];
+  for (unsigned b = threadIdx.x; b < blockIdx.x; b += TOP_BLOCK) part += blk_cnt[b];
   for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
   const unsigned i = blockIdx.x * TOP_BLOCK + threadIdx.x;
   bool hit = false;
@@ -285,21 +286,19 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_cam1_scatter(CamArgs A, unsigned 
   unsigned base = 0, mine = 0;
   for (int w = 0; w < TOP_BLOCK / 64; w++) { base += sh_p[w]; if (w < (int)(threadIdx.x >> 6)) mine += sh_w[w]; }
   if (hit) {
-    const unsigned slot = b_first * TOP_BLOCK + base + mine + lanes_below(m);
-    if (slot < Q.cap) store_ray(make_planes(Q.planes, Q.cap), slot, r);
+    const unsigned slot = base + mine + lanes_below(m);
+    RayPlanes qp = make_planes(Q.planes, Q.cap);
+    qp.p5 = nullptr; // a one-instance scene: no other instance a ray could have missed
+    if (slot < Q.cap) store_ray(qp, slot, r);
     else atomicOr(overflow, 1u);
   }
-  if (blockIdx.x == b_last && threadIdx.x < GVT_STRIPES) c[GVT_SLICE_CTR_WORDS * sl + GVT_WORK_OFFSET + threadIdx.x * GVT_STRIPE_WORDS] = 0u; // the closest-hit launch's work counters
-  if (blockIdx.x == b_last && threadIdx.x == 0) { // the slice's list is complete behind this block
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { // the list is complete behind this block
     unsigned total = base;
     for (int w = 0; w < TOP_BLOCK / 64; w++) total += sh_w[w];
-    unsigned *cs = c + GVT_SLICE_CTR_WORDS * sl;
-    cs[GVT_SLICE_COUNT_WORD] = total;
-    if (SL.n == 1) *Q.count = total;
-    atomicAdd((unsigned long long *)(c + 16), (unsigned long long)total); // k_wave_pass_begin, pass 0 (trace.hip): the frame's closest-hit rays
-    if (sl == 0) *moved_count = 0u;
-    cs[2] = 0u; cs[5] = 0u;
-    cs[0] = 0u; cs[1] = 0u; cs[3] = 0u; cs[4] = 0u; cs[6] = 0u;
+    *Q.count = total;
+    unsigned long long *tot = (unsigned long long *)(c + 16); // k_wave_pass_begin, pass 0 (trace.hip)
+    *moved_count = 0u; c[2] = 0u; c[5] = 0u; tot[0] += total;
+    c[0] = 0u; c[1] = 0u; c[3] = 0u; c[4] = 0u; c[6] = 0u;
   }
 }
 
@@ -526,7 +525,7 @@ static int shuffle_impl(gvt_hip_top *T, const RaySrc &in, size_t n, int from, gv
   {
     ProfScope ps(KC_SHUFFLE);
     k_top_classify<<<n_blk, TOP_BLOCK, use_lds ? sizeof(unsigned) * nI : 0, st>>>(in, (unsigned)n, T->dev(), (int)nI, from, d_next, d_t,
-                                                                                scan_totals ? nullptr : T->d_hist, use_lds, d_blk, nullptr, from_arr);
+                                                                                scan_totals ? nullptr : T->d_hist, use_lds, d_blk, nullptr, from_arr, C.skip_known);
   }
   HIPCHK(hipGetLastError());
   if (!roomy) {
@@ -589,9 +588,7 @@ int camera_filter_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt
 }
 // clearBuffer + generateRays + FilterRaysLocally for a ONE-instance scene on one rank, with the launch chain's pass-0 resets folded
 // in (k_cam1_count / k_cam1_scatter).  q must have room for all W*H*samples^2 rays; its count lives on the device only.
-// n_slices > 1: the list is cut into slices of whole blocks (slice_first[s] = first camera position of slice s, slice_first[n_slices] = n)
-int camera_one_instance_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *q, gvt_hip_fb *fb, unsigned *d_overflow, unsigned *d_moved_count,
-                              int n_slices, unsigned *slice_first) {
+int camera_one_instance_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *q, gvt_hip_fb *fb, unsigned *d_overflow, unsigned *d_moved_count) {
   Ctx &C = gctx();
   const size_t n = (size_t)cam->width * cam->height * cam->samples * cam->samples;
   if (!n || n > 0xffffffffull || T->n != 1) { set_error("camera_one_instance: bad arguments"); return GVT_HIP_ERR_INVALID; }
@@ -600,17 +597,10 @@ int camera_one_instance_async(gvt_hip_top *T, const gvt_hip_camera *cam, int til
   unsigned *d_blk = (unsigned *)scratch_get(14, sizeof(unsigned) * n_blk);
   if (!d_blk) return GVT_HIP_ERR_DEVICE;
   QueueDesc Q{ q->d_planes, q->cap, q->d_count, 1u };
-  CamSlices SL{};
-  SL.n = std::max(1, std::min(std::min(n_slices, GVT_MAX_SLICES), (int)n_blk));
-  for (int k = 0; k <= SL.n; k++) SL.first_blk[k] = (unsigned)(((size_t)n_blk * (size_t)k) / (size_t)SL.n);
-  if (slice_first) {
-    for (int k = 0; k <= SL.n; k++) slice_first[k] = (unsigned)std::min<size_t>((size_t)SL.first_blk[k] * TOP_BLOCK, n);
-    for (int k = SL.n + 1; k <= GVT_MAX_SLICES; k++) slice_first[k] = (unsigned)n;
-  }
   {
     ProfScope ps(KC_SHUFFLE);
     k_cam1_count<<<n_blk, TOP_BLOCK, 0, C.stream>>>(A, (unsigned)n, T->dev(), d_blk, fb ? (float4 *)fb->d_rgba : nullptr, fb ? (unsigned)(fb->w * fb->h) : 0u, C.d_counters, d_overflow);
-    k_cam1_scatter<<<n_blk, TOP_BLOCK, 0, C.stream>>>(A, (unsigned)n, T->dev(), d_blk, Q, d_overflow, C.d_counters, d_moved_count, SL);
+    k_cam1_scatter<<<n_blk, TOP_BLOCK, 0, C.stream>>>(A, (unsigned)n, T->dev(), d_blk, Q, d_overflow, C.d_counters, d_moved_count);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -649,7 +639,7 @@ static int shuffle_async_src(gvt_hip_top *T, const RaySrc &S, size_t n_ub, const
   {
     ProfScope ps(KC_SHUFFLE);
     k_top_classify<<<n_blk, TOP_BLOCK, use_lds ? sizeof(unsigned) * nI : 0, st>>>(S, (unsigned)n_ub, T->dev(), (int)nI, from, d_next, d_t, nullptr, use_lds, d_blk,
-                                                                                n_dev, from_arr);
+                                                                                n_dev, from_arr, C.skip_known);
     if (d_blk) k_top_scan<<<(unsigned)nI, TOP_BLOCK, 0, st>>>(d_blk, n_blk, qd, nullptr);
     const size_t lds = d_blk ? sizeof(unsigned) * nI * (TOP_BLOCK / 64) : (use_lds ? 2 * sizeof(unsigned) * nI : 0);
     k_top_scatter<<<n_blk, TOP_BLOCK, lds, st>>>(S, (unsigned)n_ub, d_next, d_t, qd, (int)nI, fb ? fb->d_rgba : nullptr,

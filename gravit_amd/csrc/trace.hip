@@ -172,6 +172,7 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
       const unsigned src = pend[k];
       out.p0[base + k] = q.p0[src]; out.p1[base + k] = q.p1[src]; out.p2[base + k] = q.p2[src]; out.p3[base + k] = q.p3[src];
       if (out.p4) out.p4[base + k] = 0u; // shadow rays never draw: their stream word is 0
+      store_no_known(out, base + k);     // ... and have crossed nothing yet
       if (out_from) out_from[base + k] = ray_inst[src];
     }
     return;
@@ -207,7 +208,7 @@ __device__ inline void flush_pending(volatile unsigned *pend, int n_pend, const 
       unsigned base = 0;
       if (lane_id() == 0) base = atomicAdd(out_count, (unsigned)__popcll(m));
       base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-      if (go_on) { const unsigned slot = base + lanes_below(m); out.p0[slot] = a; out.p1[slot] = b; out.p2[slot] = c; out.p3[slot] = d; if (out.p4) out.p4[slot] = 0u; if (out_from) out_from[slot] = from; }
+      if (go_on) { const unsigned slot = base + lanes_below(m); out.p0[slot] = a; out.p1[slot] = b; out.p2[slot] = c; out.p3[slot] = d; if (out.p4) out.p4[slot] = 0u; store_no_known(out, slot); if (out_from) out_from[slot] = from; }
     }
   }
 }
@@ -231,20 +232,15 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
                                                        gvt_hip_hit *__restrict__ hits, int *__restrict__ flags, RayPlanes out, unsigned *out_count,
                                                        unsigned *counter, int *spill_base, int refill_min, int inner_min, const unsigned *__restrict__ n_dev, int share, unsigned share_min, TermSink sink, LongQ LQ,
                                                        MultiSrc MS = MultiSrc{}) {
-  // Work distribution: fully dynamic.  The launch's range is cut into chunks of `dyn` rays (1/16 of a wave's fair share, at least 64);
-  // stripe s of the counter block (GVT_STRIPES words in lines of their own behind `counter`) hands out the chunks s, s + GVT_STRIPES, ...
-  // and a wave asks its home stripe (wave number mod GVT_STRIPES) first, then the following ones: 160 waves per word instead of 5120
-  // -- one word serves ~90 atomics per microsecond, which is why the first chunk of every wave used to be assigned statically -- and all
-  // stripes advance together, so the chip still sweeps the list as one front.  Nothing is tied to a wave that has not started yet: a
-  // launch that shares the chip with another one (the slices of a frame on two streams, several contexts) loses nothing when its
-  // later blocks only become resident as the other launch drains -- they take what is left or leave at once.
+  // Work distribution: wave w first takes the static range [w*chunk, (w+1)*chunk) -- no atomic, see the refill below -- and after that
+  // dynamic ranges of `dyn` rays from the counter.  chunk is a fraction of a wave's fair share (3/8 for closest-hit launches, whose
+  // per-ray cost varies most, 5/8 for any-hit; measured at 1 M rays: 96/128/160 rays -> 0.542/0.549/0.579 ms closest, 0.400/0.400/0.384
+  // any), never less than one wave's width; dyn is 1/16 of the share, at least 64 (32: the counter word saturates).
   const unsigned n_waves_total = gridDim.x * (unsigned)(TRAV_BLOCK / 64);
   if (n_dev) n = *n_dev; // ray count produced by the previous kernel on this stream (no host round trip)
   const unsigned share_w = n / n_waves_total;
+  const unsigned chunk = max(64u, ((share_w * (ANY ? 5u : 3u) / 8u) + 16u) & ~31u);
   const unsigned dyn = max(64u, (share_w / 16u) & ~63u);
-  const unsigned n_chunks = (n + dyn - 1u) / dyn;
-  unsigned *const work = counter + GVT_WORK_OFFSET;
-  unsigned stripe = (blockIdx.x * (unsigned)(TRAV_BLOCK / 64) + (threadIdx.x >> 6)) % GVT_STRIPES; // wave-uniform
   __shared__ int stack[TRAV_STACK * TRAV_BLOCK];
   int *lds = &stack[threadIdx.x];
   int *spill = spill_base + (size_t)(blockIdx.x * TRAV_BLOCK + threadIdx.x) * TRAV_SPILL;
@@ -276,6 +272,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
   int n_pend = 0;                 // wave-uniform
   unsigned c_next = 0, c_end = 0; // wave-uniform
   bool exhausted = false;         // wave-uniform
+  bool first_chunk = true;        // wave-uniform
   bool active = false;
   unsigned j = 0;
   V3 O = mk3(0, 0, 0), D = mk3(0, 0, 1);
@@ -307,19 +304,19 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
     if (!exhausted && (nidle >= refill_min || nidle == 64)) {
       while (nidle > 0) {
         if (c_next == c_end) {
-          unsigned base = 0xffffffffu;
-          for (int tries = 0; tries < GVT_STRIPES; tries++) {
-            const unsigned mine = stripe < n_chunks ? (n_chunks - stripe + GVT_STRIPES - 1u) / GVT_STRIPES : 0u; // chunks this stripe hands out
-            unsigned m = 0xffffffffu;
-            if (mine && lane_id() == 0) { // (a used-up stripe is seen with a load; only live ones are asked with an atomic)
-              unsigned *w = work + stripe * GVT_STRIPE_WORDS;
-              if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < mine) m = atomicAdd(w, 1u);
-            }
-            m = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
-            if (m < mine) { base = (m * GVT_STRIPES + stripe) * dyn; break; }
-            stripe = (stripe + 1u) % GVT_STRIPES;
+          // the first chunk of every wave is assigned statically (chunk number = wave number): 4096 waves hitting one counter word at
+          // launch would queue for ~45 us (a single word sustains ~90 atomics/us); the dynamic chunks start behind those
+          unsigned base = 0;
+          unsigned this_chunk = chunk;
+          if (first_chunk) {
+            first_chunk = false;
+            base = (blockIdx.x * (unsigned)(TRAV_BLOCK / 64) + (threadIdx.x >> 6)) * chunk;
+          } else {
+            if (lane_id() == 0) base = atomicAdd(counter, dyn);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + n_waves_total * chunk;
+            this_chunk = dyn;
           }
-          if (base == 0xffffffffu) {
+          if (base >= n) {
             exhausted = true;
 #if GVT_STAMP
             if (!t_exh) { t_exh = __builtin_amdgcn_s_memtime(); it_exh = n_inner_it; out_exh = n_outer_it; act_exh = 64 - nidle; }
@@ -327,7 +324,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
             break;
           }
           c_next = base;
-          c_end = min(base + dyn, n);
+          c_end = min(base + this_chunk, n);
         }
         const unsigned take = min(c_end - c_next, (unsigned)nidle);
         const unsigned rank = lanes_below(idle);
@@ -933,6 +930,7 @@ __global__ __launch_bounds__(256) void k_wave_any(RayPlanes q, const unsigned *_
         const unsigned slot = atomicAdd(out_count, 1u);
         out.p0[slot] = a; out.p1[slot] = b; out.p2[slot] = c; out.p3[slot] = d;
         if (out.p4) out.p4[slot] = 0u;
+        store_no_known(out, slot);
         if (MULTI && MS.out_from) MS.out_from[slot] = inst;
       }
     }
@@ -1119,7 +1117,7 @@ struct ShadeArgs {
   Mat3 normi;
   int normal_mode, n_lights;
   uint32_t seed;
-  unsigned *zero_word;     // base of the counter block whose work counters (word 0 and the stripes) are reset for the launch that follows (any hit)
+  unsigned *zero_word;     // reset for the launch that follows (the any-hit kernel's work counter)
   TermSink sink;           // terminal rule of the shuffle for rays that leave this instance without a hit (fb == nullptr: off)
   int update_in_place;     // 1: every shaded ray is written back (gvt_hip_trace: the caller reads rayList); 0: only rays that bounce
   const unsigned *n_dev;   // ray count of this pass in device memory (a pass launched without a host round trip); null: n
@@ -1140,7 +1138,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void k_shade(ShadeArgs A, MeshView 
   __syncthreads();
   const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j == 0 && A.zero_word) *A.zero_word = 0u;
-  if (j < GVT_STRIPES && A.zero_word) A.zero_word[GVT_WORK_OFFSET + j * GVT_STRIPE_WORDS] = 0u; // (zero_word = the base of a counter block)
   const unsigned n = A.n_dev ? *A.n_dev : A.n;
   const bool in_range = j < n;
   unsigned i = in_range ? (A.idx ? A.idx[j] : j) : 0u; // index in rayList (MULTI: virtual index, then index in the ray's queue)
@@ -1244,6 +1241,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void k_shade(ShadeArgs A, MeshView 
         s.c = c; s.t = r.t;
         s.id = r.id; s.depth = r.depth; s.w = r.w; s.type = 1;
         s.rng = 0u;
+        s.km[0] = 0u; s.km[1] = 0u; s.km[2] = 0u;
       }
     }
     if (A.shadow_stride) {
@@ -1269,6 +1267,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void k_shade(ShadeArgs A, MeshView 
       r.d = nd;
       r.w = r.w * dot3(nd, N);
       r.depth = ndepth;
+      r.km[0] = 0u; r.km[1] = 0u; r.km[2] = 0u; // a new straight segment: nothing is known about it
       bounce = true;
     }
     if (bounce || A.update_in_place) { // rayList is updated in place; a list the caller discards anyway (device queues) only needs it for the next pass
@@ -1298,13 +1297,15 @@ __global__ __launch_bounds__(256) void k_aos_to_planes(const float4 *__restrict_
   const float4 *s = src + (size_t)5 * i;
   dst.p0[off + i] = s[0]; dst.p1[off + i] = s[1]; dst.p2[off + i] = s[2]; dst.p3[off + i] = s[3];
   if (dst.p4) dst.p4[off + i] = __float_as_uint(s[4].x); // bytes 64..67: the stream word
+  if (dst.p5) { dst.p5[3 * (off + i)] = __float_as_uint(s[4].y); dst.p5[3 * (off + i) + 1] = __float_as_uint(s[4].z); dst.p5[3 * (off + i) + 2] = __float_as_uint(s[4].w); } // 68..79: known misses
 }
 __global__ __launch_bounds__(256) void k_planes_to_aos(RayPlanes src, unsigned long long off, unsigned n, float4 *__restrict__ dst) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 *d = dst + (size_t)5 * i;
   d[0] = src.p0[off + i]; d[1] = src.p1[off + i]; d[2] = src.p2[off + i]; d[3] = src.p3[off + i];
-  d[4] = make_float4(__uint_as_float(src.p4 ? src.p4[off + i] : 0u), 0.f, 0.f, 0.f);
+  d[4] = make_float4(__uint_as_float(src.p4 ? src.p4[off + i] : 0u), __uint_as_float(src.p5 ? src.p5[3 * (off + i)] : 0u), __uint_as_float(src.p5 ? src.p5[3 * (off + i) + 1] : 0u),
+                     __uint_as_float(src.p5 ? src.p5[3 * (off + i) + 2] : 0u));
 }
 __global__ __launch_bounds__(256) void k_od_to_planes(const float *__restrict__ org, const float *__restrict__ dir, unsigned n, RayPlanes dst) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1362,7 +1363,6 @@ __global__ void k_set_u32(unsigned *p, unsigned v) { if (threadIdx.x == 0 && blo
 // start of a trace call: moved_rays count := its current size, work counter / shadow count / next count := 0 (one launch, not three memsets)
 __global__ void k_trace_begin(unsigned *out_count, unsigned out_size, unsigned *counters) {
   if (blockIdx.x == 0 && threadIdx.x < 5) counters[threadIdx.x] = 0u; // work counter, shadow count, next count, parked rays, their work counter
-  if (blockIdx.x == 0 && threadIdx.x < GVT_STRIPES) counters[GVT_WORK_OFFSET + threadIdx.x * GVT_STRIPE_WORDS] = 0u; // k_trace's work counters
   if (blockIdx.x == 0 && threadIdx.x == 5) *out_count = out_size;
 }
 
@@ -1491,10 +1491,7 @@ int launch_closest(gvt_hip_mesh *M, RayPlanes q, const unsigned *idx, size_t n, 
   const bool have_nodes4 = M->d_nodes4 != nullptr;
   Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
   unsigned *counter = C.d_counters + 0;
-  if (!counter_is_zero) {
-    HIPCHK(hipMemsetAsync(C.d_counters, 0, 5 * sizeof(unsigned), C.stream));
-    HIPCHK(hipMemsetAsync(C.d_counters + GVT_WORK_OFFSET, 0, GVT_STRIPES * GVT_STRIPE_WORDS * sizeof(unsigned), C.stream)); // k_trace's work counters
-  }
+  if (!counter_is_zero) HIPCHK(hipMemsetAsync(C.d_counters, 0, 5 * sizeof(unsigned), C.stream));
   LongQ LQ{};
   if (C.trav_kernel == 1 && C.wide4 && have_nodes4 && C.long_steps > 0 && n >= (size_t)C.long_min_rays) { // long rays are parked and traversed a wave per ray
     LQ.recs = (LongRec *)scratch_get(15, long_scratch_bytes(n));
@@ -1567,7 +1564,6 @@ int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const M
   Trav T{ M->d_nodes, M->d_tri, M->d_nodes4 };
   unsigned *counter = C.d_counters + 0;
   HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned), C.stream));
-  HIPCHK(hipMemsetAsync(counter + GVT_WORK_OFFSET, 0, GVT_STRIPES * GVT_STRIPE_WORDS * sizeof(unsigned), C.stream));
   RayPlanes none{};
   {
     ProfScope ps(KC_ANY);
@@ -1621,7 +1617,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
     }
   }
   RayPlanes shadow = make_planes(d_shadow, shadow_cap);
-  shadow.p4 = nullptr; // shadow rays carry no stream
+  shadow.p4 = nullptr; shadow.p5 = nullptr; // shadow rays carry no stream and no list
   RayPlanes outp = make_planes(out->d_planes, out->cap);
   unsigned *c_shadow = C.d_counters + 1, *c_next = C.d_counters + 2;
   k_trace_begin<<<1, 64, 0, st>>>(out->d_count, (unsigned)out->size, C.d_counters); // c_shadow, c_next, work counter
@@ -1769,20 +1765,19 @@ extern "C" int gvt_hip_math_probe(int kind, const float *in, size_t n, float *ou
 // (closest, any) accumulated over the frame and read back with the queue sizes.
 // ------------------------------------------------------------------------------------------------
 namespace {
-__global__ void k_wave_pass_begin(unsigned *c, int pass, unsigned n_host, unsigned *out_count, const unsigned *n_dev0 = nullptr, unsigned long long *tot = nullptr) {
-  if (!blockIdx.x && threadIdx.x < GVT_STRIPES) c[GVT_WORK_OFFSET + threadIdx.x * GVT_STRIPE_WORDS] = 0u; // k_trace's work counters
+__global__ void k_wave_pass_begin(unsigned *c, int pass, unsigned n_host, unsigned *out_count, const unsigned *n_dev0 = nullptr) {
   if (blockIdx.x || threadIdx.x) return;
-  if (!tot) tot = (unsigned long long *)(c + 16); // (a slice of a sliced frame: the context's totals, several chains add to them)
+  unsigned long long *tot = (unsigned long long *)(c + 16);
   const int cur = (pass & 1) ? 5 : 2, prev = (pass & 1) ? 2 : 5;
-  if (pass == 0) { if (out_count) *out_count = 0u; c[2] = 0u; c[5] = 0u; atomicAdd(&tot[0], (unsigned long long)(n_dev0 ? *n_dev0 : n_host)); }
-  else { atomicAdd(&tot[1], (unsigned long long)c[1]); atomicAdd(&tot[0], (unsigned long long)c[prev]); c[cur] = 0u; }
+  if (pass == 0) { *out_count = 0u; c[2] = 0u; c[5] = 0u; tot[0] += n_dev0 ? *n_dev0 : n_host; }
+  else { tot[1] += c[1]; tot[0] += c[prev]; c[cur] = 0u; }
   c[0] = 0u; c[1] = 0u; c[3] = 0u; c[4] = 0u; c[6] = 0u;
 }
 // end of a round's chain: the last pass's shadow rays into the frame total; and the traced queues' clear() (count words of the
 // queues whose mask byte is set) in the same launch
-__global__ void k_wave_end(unsigned *c, unsigned *const *__restrict__ count_ptr, const unsigned char *__restrict__ mask, int n_inst, int n_slices) {
+__global__ void k_wave_end(unsigned *c, unsigned *const *__restrict__ count_ptr, const unsigned char *__restrict__ mask, int n_inst) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) { unsigned long long *tot = (unsigned long long *)(c + 16); for (int s = 0; s < n_slices; s++) tot[1] += c[GVT_SLICE_CTR_WORDS * s + 1]; }
+  if (i == 0) { unsigned long long *tot = (unsigned long long *)(c + 16); tot[1] += c[1]; }
   if (count_ptr && i < n_inst && mask[i]) *count_ptr[i] = 0u;
 }
 } // namespace
@@ -1802,8 +1797,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
   unsigned *d_idx_b = (unsigned *)scratch_get(4, sizeof(unsigned) * n);
   gvt_hip_light *d_lights = (gvt_hip_light *)scratch_get(5, sizeof(gvt_hip_light) * (nL > 0 ? nL : 1));
   int *d_shadow_inst = (int *)scratch_get(16, sizeof(int) * shadow_cap);
-  const int n_slices_alloc = (single && single->n_slices > 1) ? single->n_slices : 1;
-  LongRec *d_long = (LongRec *)scratch_get(15, sizeof(LongRec) * n + sizeof(int) * LONG_SAVE * (size_t)LONG_STK_CAP * (size_t)n_slices_alloc);
+  LongRec *d_long = (LongRec *)scratch_get(15, long_scratch_bytes(n));
   if (!d_hits || !d_shadow || !d_idx_a || !d_idx_b || !d_lights || !d_shadow_inst || !d_long) return GVT_HIP_ERR_DEVICE;
   {
     std::vector<unsigned char> &cached = C.lights_cached;
@@ -1817,7 +1811,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     }
   }
   RayPlanes shadow = make_planes(d_shadow, shadow_cap);
-  shadow.p4 = nullptr;
+  shadow.p4 = nullptr; shadow.p5 = nullptr;
   RayPlanes outp = make_planes(out->d_planes, out->cap);
   RayPlanes none{};
   unsigned *c = C.d_counters;
@@ -1826,59 +1820,25 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
   const bool use_long = C.long_steps > 0 && n >= (size_t)C.long_min_rays;
   const bool small = n <= (size_t)C.small_rays; // a wave per ray (see k_long_seed)
   const int small_grid = (int)std::min<size_t>((n + 3) / 4, (size_t)C.n_cu * 3);
-  // ---- ONE segment (a single non-empty local queue, e.g. the one-domain benchmark): the single-mesh kernels -- no segment lookup and no
-  // per-ray table loads at a refill -- with the same device-side counts.  Sliced frame (WaveSingle::n_slices > 1): the list is the
-  // concatenation of slices, each compacted from its own first slot and counted in its own counter block; slice s runs its launches
-  // (closest, long, shade, any; every pass) on stream s % 2, so that the drain of one slice's traversal launch -- a third of a launch
-  // at 1080p -- is covered by the bulk of the other stream's next launch.  Every per-slice array is the whole-list array offset by the
-  // slice's first slot (host-known); results cannot depend on the cut (a camera ray carries its RNG stream).
-  const int n_slices = (single && single->n_slices > 1) ? single->n_slices : 1;
-  int rc_single = 0;
-  if (n_slices > 1) {
-    if ((rc_single = ctx_side_stream())) return rc_single;
-    HIPCHK(hipEventRecord(C.ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(C.side_stream, C.ev_fork, 0));
-  }
-  int *d_stk_all = (int *)(d_long + n); // parked rays' saved stacks: one region per slice behind the records
-  auto single_pass = [&](int pass) -> int {
-    gvt_hip_mesh *M = single->mesh;
-    const bool have4 = M->d_nodes4 != nullptr;
-    Trav TS{ M->d_nodes, M->d_tri, M->d_nodes4 };
-    MeshView mv;
-    mv.slots = M->d_tri; mv.slot_of = M->d_slot_of; mv.verts = M->d_verts; mv.tris = M->d_tris; mv.normals = M->d_normals; mv.vcolors = M->d_vcolors;
-    mv.materials = M->d_materials; mv.n_mat = (unsigned)M->nMat; mv.face_mat = M->d_face_mat; mv.mat = M->mesh_mat;
-    for (int sl = 0; sl < n_slices; sl++) {
-      const size_t j0 = n_slices > 1 ? single->slice_first[sl] : 0, ns = n_slices > 1 ? (size_t)single->slice_first[sl + 1] - j0 : n; // ns: the slice's bound
-      if (!ns) continue;
-      const bool side = (sl & 1) != 0;
-      hipStream_t ss = side ? C.side_stream : st;
-      C.stream = ss; // (ProfScope records its events on the context's current stream)
-      struct Back { Ctx &C; hipStream_t st; ~Back() { C.stream = st; } } back{ C, st };
-      unsigned *cs = c + GVT_SLICE_CTR_WORDS * sl;
-      int *spill = side ? C.d_spill_side : C.d_spill;
-      const unsigned *n_dev0 = n_slices > 1 ? cs + GVT_SLICE_COUNT_WORD : ((single->n_dev) ? single->n_dev : nullptr);
-      const unsigned *n_dev = pass ? cs + ((pass & 1) ? 2 : 5) : n_dev0; // count written by the previous pass's k_shade
-      const unsigned *idx = pass ? ((pass & 1) ? d_idx_a : d_idx_b) + j0 : nullptr;
-      unsigned *next = ((pass & 1) ? d_idx_b : d_idx_a) + j0;
-      unsigned *c_next = cs + ((pass & 1) ? 5 : 2);
-      RayPlanes pl = single->planes;
-      pl.p0 += j0; pl.p1 += j0; pl.p2 += j0; pl.p3 += j0; if (pl.p4) pl.p4 += j0;
-      gvt_hip_hit *hits = d_hits + j0;
-      const size_t sh_off = j0 * (size_t)(nL > 0 ? nL : 1), sh_cap = ns * (size_t)(nL > 0 ? nL : 1);
-      RayPlanes shadow_s = shadow;
-      shadow_s.p0 += sh_off; shadow_s.p1 += sh_off; shadow_s.p2 += sh_off; shadow_s.p3 += sh_off;
-      if (!(pass == 0 && single->pass0_begun))
-        k_wave_pass_begin<<<1, 64, 0, ss>>>(cs, pass, (unsigned)ns, sl == 0 ? out->d_count : nullptr, n_dev0, (unsigned long long *)(c + 16));
+  for (int pass = 0; pass < passes; pass++) {
+    const unsigned *n_dev = pass ? c + ((pass & 1) ? 2 : 5) : ((single && single->n_dev) ? single->n_dev : nullptr); // count written by the previous pass's k_shade
+    const unsigned *idx = pass ? ((pass & 1) ? d_idx_a : d_idx_b) : nullptr;    // its bounce list
+    unsigned *next = (pass & 1) ? d_idx_b : d_idx_a;
+    unsigned *c_next = c + ((pass & 1) ? 5 : 2);
+    if (!(pass == 0 && single && single->pass0_begun))
+      k_wave_pass_begin<<<1, 64, 0, st>>>(c, pass, (unsigned)n, out->d_count, (single && single->n_dev) ? single->n_dev : nullptr);
+    if (single) {
+      // one segment (a single non-empty local queue, e.g. the one-domain benchmark): the single-mesh kernels -- no segment lookup and
+      // no per-ray table loads at a refill -- with the same device-side counts
+      gvt_hip_mesh *M = single->mesh;
+      const bool have4 = M->d_nodes4 != nullptr;
+      Trav TS{ M->d_nodes, M->d_tri, M->d_nodes4 };
       LongQ LQ{};
-      if (use_long && have4) {
-        LQ.recs = d_long + j0; LQ.count = cs + 3; long_limits(LQ, n);
-        if (LQ.stk) LQ.stk = d_stk_all + (size_t)sl * LONG_SAVE * (size_t)LONG_STK_CAP;
-      }
-      const bool small1 = ns <= (size_t)C.small_rays && have4;
-      const int small_grid1 = (int)std::min<size_t>((ns + 3) / 4, (size_t)C.n_cu * 3);
+      if (use_long && have4) { LQ.recs = d_long; LQ.count = c + 3; long_limits(LQ, n); }
+      const bool small1 = small && have4;
 #ifdef GVT_EXPERIMENTS
       // a coherent list (camera rays in 8x8 tiles, straight from the filter): a wave walks the tree for 64 rays at once (k_packet)
-      const bool pkt = C.packet && single->coherent && pass == 0 && have4 && !small1 && n_slices == 1;
+      const bool pkt = C.packet && single->coherent && pass == 0 && have4 && !small1;
       if (pkt) {
         ProfScope ps(KC_CLOSEST);
         LongQ LP{ d_long, c + 3, nullptr, 0u, 0, 0 };
@@ -1891,11 +1851,11 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
 #endif
       if (small1) {
         ProfScope ps(KC_CLOSEST);
-        k_long_seed<<<blocks_for(ns), 256, 0, ss>>>(d_long + j0, cs + 3, idx, (unsigned)ns, n_dev);
-        k_long_closest<true><<<small_grid1, 256, 0, ss>>>(pl, d_long + j0, cs + 3, single->minv, TS, GVT_RAY_EPSILON, hits, cs + 4);
+        k_long_seed<<<blocks_for(n), 256, 0, st>>>(d_long, c + 3, idx, (unsigned)n, n_dev);
+        k_long_closest<true><<<small_grid, 256, 0, st>>>(single->planes, d_long, c + 3, single->minv, TS, GVT_RAY_EPSILON, d_hits, c + 4);
       }
 #ifdef GVT_EXPERIMENTS
-      else if (quad_usable(M) && n_slices == 1) {
+      else if (quad_usable(M)) {
         ProfScope ps(KC_CLOSEST);
         k_traceq<false, true, 0><<<quad_grid(n), 256, 0, st>>>(single->planes, idx, (unsigned)n, single->minv, TravQ{ M->d_nodes4q, M->d_triq }, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
                                                              c + 0, C.d_spill, C.quad_refill_min, C.quad_inner_min, n_dev, TermSink{}, LQ);
@@ -1903,24 +1863,27 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
 #endif
       else {
         ProfScope ps(KC_CLOSEST);
-        launch_trace<false, true, 0>(have4, trav_grid2(ns, true), ss, pl, idx, (unsigned)ns, single->minv, TS, GVT_RAY_EPSILON, hits, nullptr, none, nullptr,
-                                     cs + 0, spill, C.refill_min, C.inner_min, n_dev, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
+        launch_trace<false, true, 0>(have4, trav_grid2(n, true), st, single->planes, idx, (unsigned)n, single->minv, TS, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
+                                     c + 0, C.d_spill, C.refill_min, C.inner_min, n_dev, C.share, (unsigned)C.share_min_rays, TermSink{}, LQ);
       }
       if (LQ.steps && !small1 && !pkt) {
         ProfScope ps(KC_LONG);
-        k_long_closest<true><<<C.n_cu * 3, 256, 0, ss>>>(pl, LQ.recs, cs + 3, single->minv, TS, GVT_RAY_EPSILON, hits, cs + 4, WaveSet{}, LQ.stk);
+        k_long_closest<true><<<C.n_cu * 3, 256, 0, st>>>(single->planes, d_long, c + 3, single->minv, TS, GVT_RAY_EPSILON, d_hits, c + 4, WaveSet{}, LQ.stk);
       }
       ShadeArgs A;
-      A.in = pl; A.idx = idx; A.n = (unsigned)ns; A.index_base = j0; A.hits = hits;
-      A.first_pass = (pass == 0); A.carried_rng = 1; A.out = outp; A.out_count = out->d_count; A.shadow = shadow_s; A.shadow_count = cs + 1;
+      A.in = single->planes; A.idx = idx; A.n = (unsigned)n; A.index_base = 0; A.hits = d_hits;
+      A.first_pass = (pass == 0); A.carried_rng = 1; A.out = outp; A.out_count = out->d_count; A.shadow = shadow; A.shadow_count = c + 1;
       A.next_idx = next; A.next_count = c_next; A.lights = d_lights; A.normi = single->normi; A.normal_mode = P.normal_mode;
-      A.n_lights = nL; A.seed = P.seed; A.zero_word = cs + 0;
+      A.n_lights = nL; A.seed = P.seed; A.zero_word = c + 0;
       A.sink = P.sink; A.sink.from = single->inst; A.update_in_place = 0;
       A.n_dev = n_dev; A.W = WaveSet{}; A.out_from = nullptr; A.shadow_inst = nullptr; A.shadow_stride = 0;
       if (pkt) { A.shadow_inst = d_shadow_inst; A.shadow_stride = (unsigned)n; } // shadow rays in the primaries' order: packets again
+      MeshView mv;
+      mv.slots = M->d_tri; mv.slot_of = M->d_slot_of; mv.verts = M->d_verts; mv.tris = M->d_tris; mv.normals = M->d_normals; mv.vcolors = M->d_vcolors;
+      mv.materials = M->d_materials; mv.n_mat = (unsigned)M->nMat; mv.face_mat = M->d_face_mat; mv.mat = M->mesh_mat;
       {
         ProfScope ps(KC_SHADE);
-        k_shade<false><<<blocks_for(ns, SHADE_BLOCK), SHADE_BLOCK, 0, ss>>>(A, mv);
+        k_shade<false><<<blocks_for(n, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, mv);
       }
       if (nL) {
         ProfScope ps(KC_ANY);
@@ -1935,28 +1898,20 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
           // rays of packets that bailed out: one lane per ray (an empty list costs a few microseconds)
           launch_trace<true, true, 1>(have4, trav_grid2(4096), st, shadow, d_retry, 0u, single->minv, TS, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
                                       c + 0, C.d_spill, C.refill_min, C.inner_min, c + 6, C.share, (unsigned)C.share_min_rays, sk, LongQ{});
-        } else if (quad_usable(M) && !small1 && n_slices == 1)
+        } else if (quad_usable(M) && !small1)
           k_traceq<true, true, 1><<<quad_grid(shadow_cap), 256, 0, st>>>(shadow, nullptr, 0u, single->minv, TravQ{ M->d_nodes4q, M->d_triq }, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
                                                                        c + 0, C.d_spill, C.quad_refill_min, C.quad_inner_min, c + 1, sk, LongQ{});
         else
 #endif
-        if (small1) k_wave_any<false><<<(int)std::min<size_t>((sh_cap + 3) / 4, (size_t)C.n_cu * 3), 256, 0, ss>>>(shadow_s, cs + 1, single->minv, TS, GVT_RAY_EPSILON, outp, out->d_count, cs + 0, sk, MultiSrc{});
-        else launch_trace<true, true, 1>(have4, trav_grid2(sh_cap), ss, shadow_s, nullptr, 0u, single->minv, TS, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
-                                         cs + 0, spill, C.refill_min, C.inner_min, cs + 1, C.share, (unsigned)C.share_min_rays, sk, LongQ{});
+        if (small1) k_wave_any<false><<<(int)std::min<size_t>((shadow_cap + 3) / 4, (size_t)C.n_cu * 3), 256, 0, st>>>(shadow, c + 1, single->minv, TS, GVT_RAY_EPSILON, outp, out->d_count, c + 0, sk, MultiSrc{});
+        else launch_trace<true, true, 1>(have4, trav_grid2(shadow_cap), st, shadow, nullptr, 0u, single->minv, TS, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
+                                         c + 0, C.d_spill, C.refill_min, C.inner_min, c + 1, C.share, (unsigned)C.share_min_rays, sk, LongQ{});
       }
       HIPCHK(hipGetLastError());
       C.stats.launches_closest++;
       C.stats.launches_any++;
+      continue;
     }
-    return 0;
-  };
-  for (int pass = 0; pass < passes; pass++) {
-    const unsigned *n_dev = pass ? c + ((pass & 1) ? 2 : 5) : ((single && single->n_dev) ? single->n_dev : nullptr); // count written by the previous pass's k_shade
-    const unsigned *idx = pass ? ((pass & 1) ? d_idx_a : d_idx_b) : nullptr;    // its bounce list
-    unsigned *next = (pass & 1) ? d_idx_b : d_idx_a;
-    unsigned *c_next = c + ((pass & 1) ? 5 : 2);
-    if (single) { rc_single = single_pass(pass); if (rc_single) return rc_single; continue; }
-    k_wave_pass_begin<<<1, 64, 0, st>>>(c, pass, (unsigned)n, out->d_count, nullptr);
 #ifdef GVT_EXPERIMENTS
     if (C.fused && P.sink.fb) {
       // one launch: closest hit, shade, the first light's shadow rays, terminal rule (k_fused); lights 1.. through the list
@@ -1971,7 +1926,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
         k_fused<<<trav_grid2(n), TRAV_BLOCK, 0, st>>>(F);
       }
       if (nL > 1) {
-        HIPCHK(hipMemsetAsync(c + GVT_WORK_OFFSET, 0, GVT_STRIPES * GVT_STRIPE_WORDS * sizeof(unsigned), st)); // the work counters of the launch that follows
+        k_set_u32<<<1, 64, 0, st>>>(c + 0, 0u); // the work counter of the launch that follows
         ProfScope ps(KC_ANY);
         MultiSrc MA{ W, d_shadow_inst, d_out_from, nullptr };
         k_trace<true, true, 1, false, true, true><<<trav_grid2(n * (size_t)(nL - 1)), TRAV_BLOCK, 0, st>>>(shadow, nullptr, 0u, id, T, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
@@ -2040,11 +1995,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     C.stats.launches_closest++;
     C.stats.launches_any++;
   }
-  if (n_slices > 1) { // the side stream's chains end before anything behind this chain on the context's stream
-    HIPCHK(hipEventRecord(C.ev_join, C.side_stream));
-    HIPCHK(hipStreamWaitEvent(st, C.ev_join, 0));
-  }
-  if (!defer_end) k_wave_end<<<(unsigned)((std::max(n_inst, 1) + 255) / 256), 256, 0, st>>>(c, d_count_ptr, d_mask, n_inst, n_slices); // + queue[instTarget].clear()
+  if (!defer_end) k_wave_end<<<(unsigned)((std::max(n_inst, 1) + 255) / 256), 256, 0, st>>>(c, d_count_ptr, d_mask, n_inst); // + queue[instTarget].clear()
   HIPCHK(hipGetLastError());
   C.stats.trace_calls++;
   return 0;
@@ -2078,7 +2029,7 @@ int finish_round(const WaveSet &W, size_t n_total, const TraceParams &P, const g
   A.queues = (const QueueDesc *)d_qdesc; A.owner = d_owner; A.rank = rank;
   A.counter = C.d_counters + 0; A.tot = (unsigned long long *)(C.d_counters + 16);
   A.queue_overflow = d_queue_overflow; A.trav_overflow = C.d_counters + TRAV_OVF_WORD;
-  A.seed = P.seed; A.index_base = 0ull;
+  A.seed = P.seed; A.index_base = 0ull; A.skip_known = C.skip_known;
   HIPCHK(hipMemsetAsync(C.d_counters, 0, sizeof(unsigned), st));
   {
     ProfScope ps(KC_CLOSEST);

@@ -17,9 +17,11 @@ FLT_MAX = np.float32(np.finfo(np.float32).max)
 
 RAY_DTYPE = np.dtype(
     {
-        "names": ["origin", "t_min", "direction", "t_max", "color", "t", "id", "depth", "w", "type", "rng"],
-        "formats": [("<f4", 3), "<f4", ("<f4", 3), "<f4", ("<f4", 3), "<f4", "<i4", "<i4", "<f4", "<i4", "<u4"],
-        "offsets": [0, 12, 16, 28, 32, 44, 48, 52, 56, 60, 64],  # rng: the per-ray RNG stream word in Ray::data[64..67] (unused by the reference)
+        "names": ["origin", "t_min", "direction", "t_max", "color", "t", "id", "depth", "w", "type", "rng", "known"],
+        "formats": [("<f4", 3), "<f4", ("<f4", 3), "<f4", ("<f4", 3), "<f4", "<i4", "<i4", "<f4", "<i4", "<u4", ("<u2", 6)],
+        # rng: the per-ray RNG stream word in Ray::data[64..67]; known: the instances (+1) the ray has crossed without a hit on its current
+        # segment, Ray::data[68..79] (the schedulers' known-miss shortcut) -- both unused by the reference
+        "offsets": [0, 12, 16, 28, 32, 44, 48, 52, 56, 60, 64, 68],
         "itemsize": 80,
     }
 )

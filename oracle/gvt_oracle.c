@@ -104,6 +104,37 @@ static inline uint32_t camera_stream_word(uint64_t ridx) { /* ridx = position in
 static inline uint32_t ray_word(const orc_ray *r) { uint32_t w; memcpy(&w, &r->pad[0], 4); return w; }
 static inline void set_ray_word(orc_ray *r, uint32_t w) { memcpy(&r->pad[0], &w, 4); }
 
+/* ---- known misses (NOT in the reference; an image-identical shortcut of the build's schedulers, restated here so that the checker
+ * can follow it ray for ray).  shuffleRays (TracerBase.h:392-400) sends a ray that left instance A without a hit to the nearest other
+ * instance box ahead of it, origin advanced by 95 % of the distance (:393).  Where the boxes of A and B overlap, a ray that has
+ * crossed A and B without a hit is handed back and forth -- A, B, A, B, ... five or six times, each hop a full traversal that CANNOT
+ * find anything: the ray is the same half-line from an origin further along, and the instance held nothing on the longer one.
+ * With the shortcut on, a ray carries the instances it has already crossed without a hit on its current straight segment (six 16-bit
+ * entries, instance + 1, in bytes 68..79 of the 80-byte Ray image: inside Ray::data, copied by every copy / pack of the reference and
+ * never read by it, actor/Ray.h:95,128-151); when shuffleRays' choice is such an instance, the trace there is taken as the miss it
+ * must be: the origin advance is replayed with the reference's arithmetic and the next choice is made as if the ray came from there.
+ * A bounce starts a new segment (list cleared); a shadow ray is born with an empty list.  The ray that finally reaches a queue, or the
+ * framebuffer, is bit for bit the ray the reference's hops would have delivered; only the rays_closest / adapter-call / rays_sent
+ * counts drop.  Off (the default here): the reference's behaviour, hop by hop. */
+static int g_skip_known = 0;
+void orc_set_skip_known_misses(int on) { g_skip_known = on ? 1 : 0; }
+int orc_get_skip_known_misses(void) { return g_skip_known; }
+static inline void km_get(const orc_ray *r, uint16_t e[6]) { memcpy(e, &r->pad[1], 12); }
+static inline void km_put(orc_ray *r, const uint16_t e[6]) { memcpy(&r->pad[1], e, 12); }
+static inline void km_clear(orc_ray *r) { memset(&r->pad[1], 0, 12); }
+static inline int km_has(const uint16_t e[6], int inst) {
+  if (inst < 0 || inst >= 65535) return 0;
+  const uint16_t v = (uint16_t)(inst + 1);
+  return e[0] == v || e[1] == v || e[2] == v || e[3] == v || e[4] == v || e[5] == v;
+}
+static inline void km_add(uint16_t e[6], int inst) { /* first free entry; a full list forgets its oldest entry (forgetting only costs a trace) */
+  if (inst < 0 || inst >= 65535 || km_has(e, inst)) return;
+  const uint16_t v = (uint16_t)(inst + 1);
+  for (int k = 0; k < 6; k++) if (!e[k]) { e[k] = v; return; }
+  for (int k = 0; k < 5; k++) e[k] = e[k + 1];
+  e[5] = v;
+}
+
 /* ------------------------------------------------------------------------- */
 /* Lights (data/scene/Light.cpp:58-133)                                       */
 /* ------------------------------------------------------------------------- */
@@ -694,6 +725,7 @@ static void trace_range(trace_job *J) {
         st3(r->direction, nd);
         r->w = r->w * dot3(nd, N);
         r->depth = ndepth;
+        km_clear(r); /* a new straight segment: nothing is known about it */
       } else {
         alive = 0;
       }
@@ -1002,14 +1034,38 @@ void orc_fb_to_ppm_bytes(const float *fb, int W, int H, unsigned char *out) { /*
 /* ------------------------------------------------------------------------- */
 /* Schedulers                                                                 */
 /* ------------------------------------------------------------------------- */
+/* shuffleRays' decision for ONE ray leaving instance `from` (TracerBase.h:392-400): the instance it goes on in (its origin advanced,
+ * :393) or -1.  With the known-miss shortcut: `from` joins the ray's list, and choices that are on the list are walked through. */
+#define KM_MAX_HOPS 64
+static int shuffle_one(const float *lo, const float *hi, const int32_t *order, size_t nInst, orc_ray *r, int from) {
+  float t;
+  int next = top_one(r, lo, hi, order, nInst, from, &t);
+  if (!g_skip_known) {
+    if (next != -1) st3(r->origin, add3(ld3(r->origin), scl3(ld3(r->direction), t * 0.95f)));
+    return next;
+  }
+  uint16_t e[6];
+  km_get(r, e);
+  km_add(e, from);
+  for (int hop = 0; next != -1; hop++) {
+    st3(r->origin, add3(ld3(r->origin), scl3(ld3(r->direction), t * 0.95f)));
+    if (!km_has(e, next) || hop >= KM_MAX_HOPS) break;
+    from = next; /* crossed without a hit before: as if traced there again and forwarded */
+    next = top_one(r, lo, hi, order, nInst, from, &t);
+  }
+  km_put(r, e);
+  return next;
+}
+/* the same for n rays (in place), for the checker backend of the Python scheduler harness */
+void orc_shuffle_step(const float *lo, const float *hi, const int32_t *order, size_t nInst, orc_ray *rays, size_t n, int from, int32_t *next_out) {
+  for (size_t i = 0; i < n; i++) next_out[i] = shuffle_one(lo, hi, order, nInst, &rays[i], from);
+}
 /* shuffleRays non-volume branch (TracerBase.h:325-343, 392-414) */
 static void shuffle_rays(const orc_scene *S, const int32_t *order, rayvec *rays, int domID, rayvec *queues, float *fb) {
   for (size_t i = 0; i < rays->n; i++) {
     orc_ray *r = &rays->v[i];
-    float t;
-    int next = top_one(r, S->inst_lo, S->inst_hi, order, S->nInst, domID, &t);
+    int next = shuffle_one(S->inst_lo, S->inst_hi, order, S->nInst, r, domID);
     if (next != -1) {
-      st3(r->origin, add3(ld3(r->origin), scl3(ld3(r->direction), t * 0.95f)));
       rv_push(&queues[next], r);
     } else if (r->type == 1 && len3(ld3(r->color)) > 0) {
       fb_local_add(fb, (size_t)r->id, scl3(ld3(r->color), r->w), 1.f);

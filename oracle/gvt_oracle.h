@@ -152,6 +152,13 @@ void orc_render_image(const orc_scene *, orc_ray *camera_rays /* consumed */, si
                       float *fb, orc_frame_stats *stats);
 /* Domain scheduler simulated over P virtual ranks (instance i lives on rank owner[i]); the per-rank
  * framebuffers are summed and clamped (the build's composite) into fb. */
+/* The build's image-identical shortcut of shuffleRays (gvt_oracle.c "known misses"; NOT reference behaviour, off by default): */
+void orc_set_skip_known_misses(int on);
+int orc_get_skip_known_misses(void);
+/* shuffleRays' decision for n rays leaving instance `from` (in place: origins advanced, known-miss lists updated); next_out[i] = the
+ * instance ray i goes on in, or -1 */
+void orc_shuffle_step(const float *inst_lo, const float *inst_hi, const int32_t *order, size_t nInst, orc_ray *rays, size_t n, int from,
+                      int32_t *next_out);
 void orc_render_domain(const orc_scene *, const int32_t *owner, int P, const orc_ray *camera_rays, size_t nRays,
                        int width, int height, float *fb, orc_frame_stats *stats);
 

@@ -15,9 +15,11 @@ REF_PATH = os.path.join(HERE, "_ref", "libgvtref.so")
 
 RAY_DTYPE = np.dtype(
     {
-        "names": ["origin", "t_min", "direction", "t_max", "color", "t", "id", "depth", "w", "type", "rng"],
-        "formats": [("<f4", 3), "<f4", ("<f4", 3), "<f4", ("<f4", 3), "<f4", "<i4", "<i4", "<f4", "<i4", "<u4"],
-        "offsets": [0, 12, 16, 28, 32, 44, 48, 52, 56, 60, 64],  # rng: the per-ray RNG stream word in Ray::data[64..67] (unused by the reference)
+        "names": ["origin", "t_min", "direction", "t_max", "color", "t", "id", "depth", "w", "type", "rng", "known"],
+        "formats": [("<f4", 3), "<f4", ("<f4", 3), "<f4", ("<f4", 3), "<f4", "<i4", "<i4", "<f4", "<i4", "<u4", ("<u2", 6)],
+        # rng: the per-ray RNG stream word in Ray::data[64..67]; known: the instances (+1) the ray has crossed without a hit on its current
+        # segment, Ray::data[68..79] (the schedulers' known-miss shortcut) -- both unused by the reference
+        "offsets": [0, 12, 16, 28, 32, 44, 48, 52, 56, 60, 64, 68],
         "itemsize": 80,
     }
 )
@@ -228,6 +230,24 @@ def toplevel_intersect(inst_lo, inst_hi, order, rays, frm=-1):
     lib().orc_toplevel_intersect(_p(lo), _p(hi), _p(order), C.c_size_t(len(lo)), _p(rays), C.c_size_t(len(rays)),
                                  C.c_int(frm), _p(nxt), _p(t))
     return nxt, t
+
+
+def set_skip_known_misses(on):
+    """The build's image-identical shortcut of shuffleRays (gvt_oracle.c "known misses"); off = the reference's hop-by-hop behaviour."""
+    lib().orc_set_skip_known_misses(C.c_int(1 if on else 0))
+
+
+def get_skip_known_misses():
+    return bool(lib().orc_get_skip_known_misses())
+
+
+def shuffle_step(inst_lo, inst_hi, order, rays, frm=-1):
+    """shuffleRays' decision per ray, in place (origins advanced, known-miss lists updated): the next instance or -1."""
+    lo, hi = _f32(inst_lo, (-1, 3)), _f32(inst_hi, (-1, 3))
+    order = np.ascontiguousarray(order, np.int32)
+    nxt = np.zeros(len(rays), np.int32)
+    lib().orc_shuffle_step(_p(lo), _p(hi), _p(order), C.c_size_t(len(lo)), _p(rays), C.c_size_t(len(rays)), C.c_int(frm), _p(nxt))
+    return nxt
 
 
 class _Scene(C.Structure):

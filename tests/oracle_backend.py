@@ -45,10 +45,10 @@ class OracleBackend:
     def _shuffle(self, rays, frm, keep_mask=None):
         if len(rays) == 0:
             return
-        nxt, t = orc.toplevel_intersect(self.scene.inst_lo, self.scene.inst_hi, self.order, rays, frm)
+        rays = np.ascontiguousarray(rays).copy()
+        nxt = orc.shuffle_step(self.scene.inst_lo, self.scene.inst_hi, self.order, rays, frm)  # origins advanced in place (TracerBase.h:393)
         hit = nxt >= 0
-        moved = rays[hit].copy()
-        moved["origin"] = moved["origin"] + moved["direction"] * (t[hit] * np.float32(0.95))[:, None]
+        moved = rays[hit]
         for q in np.unique(nxt[hit]):
             if keep_mask is None or keep_mask[q]:
                 self.queues[q] = cat_rays([self.queues[q], moved[nxt[hit] == q]])

@@ -53,7 +53,7 @@ def test_rounds_equal_the_reference_order_loop(hip, name, mode, exact):
     tr.close()
 
 
-def run_native_ranks(scene, owner, world, mode, bsp, full_reduce=False, image=False):
+def run_native_ranks(scene, owner, world, mode, bsp, full_reduce=False, image=False, opts=()):
     hub = capi.load().gvt_hip_hub_create(world)
     out, errs = {}, []
 
@@ -61,6 +61,8 @@ def run_native_ranks(scene, owner, world, mode, bsp, full_reduce=False, image=Fa
         ctx = None
         try:
             ctx = Context(0)
+            for k, v in opts:  # (knobs belong to the rank's context)
+                capi.set_option(k, v)
             comm = Comm.local(hub, rank)
             tr = NativeTracer(scene, mode, owner, comm, replicate=image)
             B = tr(bsp=bsp, full_reduce=full_reduce, image=image)
@@ -133,6 +135,48 @@ def test_soup_domains_with_cross_traffic_native(hip):
         ref, st = oracle_render_domain(sc, owner, 2, 0)
         assert np.array_equal(res[0][0][..., :3], ref[..., :3])
         assert sum(r[1]["rays_sent"] for r in res.values()) == st.rays_sent and st.rays_sent > 1000
+
+
+@pytest.mark.parametrize("case", ["soup2", "soup4", "soup8", "config4", "config5"])
+def test_known_miss_shortcut_is_image_identical(hip, case):
+    """shuffleRays' known-miss shortcut (gvt_device.h; default on): a ray is not traced again, nor sent again, in an instance it has
+    already crossed without a hit on the same straight segment.  Against the reference's hop-by-hop behaviour (skip_known = 0, the
+    checker in its default mode): the composited float framebuffer is the same bit for bit (config 5: several deposits per pixel
+    meet in another order, 1e-5, equal deposit counts), fewer rays are traced and sent, fewer exchanges are needed -- and in both
+    modes the ray counts are the checker's."""
+    from oracle import orc
+
+    sc, mode, world, exact = {
+        "soup2": lambda: (scenes.soup_domains_scene(400_000, 2, 480, 270), NORMALS_FLAT, 2, True),
+        "soup4": lambda: (scenes.soup_domains_scene(400_000, 4, 480, 270), NORMALS_FLAT, 4, True),
+        "soup8": lambda: (scenes.soup_domains_scene(400_000, 8, 480, 270), NORMALS_FLAT, 8, True),
+        "config4": lambda: (scenes.bunny_grid_scene(width=475, height=270), NORMALS_SMOOTH, 8, True),
+        "config5": lambda: (config5(256, 4), NORMALS_FLAT, 4, False)}[case]()
+    owner = [i % world for i in range(sc.n_inst)]
+    got = {}
+    for skip in (0, 1):
+        orc.set_skip_known_misses(bool(skip))
+        ref, st = oracle_render_domain(sc, owner, world, mode)
+        for bsp in (True, False):
+            res = run_native_ranks(sc, owner, world, mode, bsp, opts=(("skip_known", skip),))
+            fb = res[0][0]
+            if exact:
+                assert np.array_equal(fb[..., :3], ref[..., :3])
+            else:
+                assert np.abs(fb[..., :3] - ref[..., :3]).max() <= 1e-5
+            assert np.array_equal(fb[..., 3], ref[..., 3])
+            assert sum(r[1]["rays_sent"] for r in res.values()) == st.rays_sent
+            assert sum(r[1]["rays_closest"] for r in res.values()) == st.rays_closest and sum(r[1]["rays_any"] for r in res.values()) == st.rays_any
+            if bsp:
+                assert all(r[1]["rounds"] == st.rounds for r in res.values())
+            got[(skip, bsp)] = (fb, max(r[1]["rounds"] for r in res.values()), st.rays_sent, st.rays_closest)
+    for bsp in (True, False):
+        a, b = got[(0, bsp)], got[(1, bsp)]
+        assert np.array_equal(a[0][..., 3], b[0][..., 3])
+        assert np.array_equal(a[0], b[0]) if exact else np.abs(a[0] - b[0]).max() <= 1e-5
+        assert b[1] <= a[1] and b[2] <= a[2] and b[3] <= a[3]
+    if case.startswith("soup"):  # the tiles' boxes overlap: the hand-back hops are there to be skipped
+        assert got[(1, True)][1] < got[(0, True)][1] and got[(1, True)][2] < got[(0, True)][2]
 
 
 def test_composite_rectangles_equal_the_full_reduce(hip):
