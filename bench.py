@@ -180,6 +180,28 @@ def abi_path(scene, tracer, capi, np):
     return out
 
 
+def sustained(frame, rays_per_frame, seconds=2.5, min_frames=2000):
+    """The same frame rendered back to back for at least `seconds` and `min_frames` frames (the headline is a window of K = 20 frames
+    behind the warm-up): does the rate survive seconds of load (clocks, thermals)?  Never `value`."""
+    import numpy as np
+
+    ts = []
+    t0 = time.perf_counter()
+    while len(ts) < min_frames or time.perf_counter() - t0 < seconds:
+        f0 = time.perf_counter()
+        frame()
+        ts.append(time.perf_counter() - f0)
+        if len(ts) >= 200_000:
+            break
+    el = time.perf_counter() - t0
+    a = np.array(ts) * 1e3
+    k = max(1, len(a) // 10)
+    return {"frames": len(ts), "seconds": el, "mean_ms": float(a.mean()), "p50_ms": float(np.percentile(a, 50)), "p99_ms": float(np.percentile(a, 99)),
+            "max_ms": float(a.max()), "first_tenth_mean_ms": float(a[:k].mean()), "last_tenth_mean_ms": float(a[-k:].mean()),
+            "Mrays/s": rays_per_frame * len(ts) / el / 1e6,
+            "note": "frames rendered back to back, one in flight, each ending with its host synchronisation; wall clock over the whole run; never `value`"}
+
+
 def two_frames_in_flight(scene, steps, rays_per_frame):
     """Throughput of a STREAM of frames: two tracers, each with its own library context (stream, scratch, counters, queues,
     framebuffer), render alternate frames from two host threads; one frame's launch tails overlap the other's bulk.  Reported
@@ -269,17 +291,110 @@ def measure_variant(run_frame, frame_stats, steps, warmup, barrier, reduce_sum, 
     return res, sums, mx[0], tot
 
 
+def weak_film(n, width, height):
+    """weak_soup: the film grows with the rank count (area x N, 16:9 kept, multiples of 8), so that every rank keeps about the one-GPU
+    benchmark's number of rays as well as its number of triangles."""
+    s = math.sqrt(n)
+    return max(8, int(round(width * s / 8.0)) * 8), max(8, int(round(height * s / 8.0)) * 8)
+
+
+def rank_roofline(st, rays_closest, rays_any, n_tris_local):
+    """This rank's dominant traversal kernel against the HBM roofline (algorithmic bytes) from the library's per-kernel HIP events."""
+    dom = "closest" if st["ms_closest"] >= st["ms_any"] else "any"
+    ms, nl = st["ms_%s" % dom], max(1, st["launches_%s" % dom])
+    rays = rays_closest if dom == "closest" else rays_any
+    b_ray = algorithmic_bytes_per_ray(n_tris_local)
+    ach = (rays * b_ray / nl) / (ms / nl / 1e3) / 1e9 if ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_ray": b_ray, "rays_per_launch": rays / nl, "avg_launch_ms": ms / nl, "launches": nl}
+
+
+CONFIG4_NOTE = ("BASELINE configs[3]: 8 bunny instances on a 4x2 grid (pitch 0.3, data/bunny.conf:27-29) at the film of data/bunny.conf:8, smooth normals, "
+                "Domain scheduler, domain d on rank d mod N (DomainTracer.h:115-144); never `value`")
+WEAK_NOTE = ("weak scaling of config 3: N tiles of %d triangles EACH (every rank generates and holds only its own tile; triangle size ~ N^(-1/3): config 3's "
+             "extent-to-spacing ratio), film %dx%d (area x N), Domain scheduler asynchronous; ideal = N x the one-GPU value; never `value`")
+
+
+def run_inproc(scene, owner, N, mode, call, replicate, args, roofline=False):
+    """One scheduler variant on N in-process ranks (threads of this process, one context each, the library's in-process transport)."""
+    import threading
+
+    from gravit_amd import capi
+    from gravit_amd.scheduler import Comm, Context, NativeTracer
+
+    hub = capi.load().gvt_hip_hub_create(N)
+    bar = threading.Barrier(N)
+    per_rank, errs = {}, []
+
+    def rank_main(r):
+        ctx = None
+        try:
+            ctx = Context(0)
+            for o in args.opt:
+                k, v = o.split("=")
+                capi.set_option(k, int(v))
+            comm = Comm.local(hub, r)
+            tr = NativeTracer(scene, mode, owner, comm, replicate=replicate)
+            for _ in range(args.warmup):
+                tr(**call)
+            capi.synchronize(); bar.wait()
+            if roofline:
+                capi.stats_reset(); capi.profile(2)
+            sums = {}
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                tr(**call)
+                for k, v in tr.stats.items():
+                    sums[k] = sums.get(k, 0) + v
+            capi.synchronize(); bar.wait()
+            el = time.perf_counter() - t0
+            roof = None
+            if roofline:
+                st = capi.stats(); capi.profile(False)
+                mine = [scene.meshes[scene.inst_mesh[i]] for i in range(scene.n_inst) if owner[i] == r and scene.meshes[scene.inst_mesh[i]] is not None]
+                roof = rank_roofline(st, sums.get("rays_closest", 0), sums.get("rays_any", 0), max([len(m.tris) for m in mine] or [8]))
+            per_rank[r] = (sums, el, roof)
+            tr.close(); comm.close()
+            tr = None
+        except Exception:  # noqa: BLE001
+            import traceback
+            errs.append(traceback.format_exc())
+            capi.load().gvt_hip_hub_abort(hub)
+            bar.abort()
+        finally:
+            import gc
+            gc.collect()
+            if ctx is not None:
+                ctx.close()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(N)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    capi.load().gvt_hip_hub_destroy(hub)
+    if errs:
+        print(errs[0], file=sys.stderr)
+        sys.exit(1)
+    el = max(v[1] for v in per_rank.values())
+    tot = lambda k: float(sum(v[0].get(k, 0) for v in per_rank.values()))  # noqa: E731
+    mx = lambda k: float(max(v[0].get(k, 0) for v in per_rank.values()))  # noqa: E731
+    ticks = mx("rounds") / args.steps
+    res = {"value": (tot("rays_closest") + tot("rays_any")) / el / 1e6, "unit": "Mrays/s", "ms_per_step": el / args.steps * 1e3,
+           "ticks_per_step": ticks, "ms_per_tick": el / args.steps * 1e3 / ticks if ticks else None,
+           "launch_chains_per_step": mx("chains") / args.steps, "host_syncs_per_step": mx("host_syncs") / args.steps,
+           "rays_per_step": (tot("rays_closest") + tot("rays_any")) / args.steps,
+           "rays_sent_per_step": tot("rays_sent") / args.steps, "bytes_sent_per_step": tot("bytes_sent") / args.steps,
+           "phase_ms_per_step_max_over_ranks": {k[3:]: mx(k) / args.steps for k in PHASES}}
+    if roofline:
+        res["roofline_per_rank"] = [per_rank[r][2] for r in range(N)]
+    return res
+
+
 def inproc_ranks(args):
     """--inproc-ranks N: the native multi-rank frame loop (announces, wire packing, payload, vote, composite) with the N ranks as
     threads of THIS process on ONE GPU, joined by the library's in-process transport: the same control flow and the same keys as a
     --gpus N run, for looking at tick counts and per-tick cost where only one GPU is at hand.  Not a scaling number."""
-    import threading
-
-    import numpy as np
-
     from gravit_amd import capi, scenes
-    from gravit_amd.layouts import NORMALS_FLAT
-    from gravit_amd.scheduler import Comm, Context, NativeTracer
+    from gravit_amd.layouts import NORMALS_FLAT, NORMALS_SMOOTH
 
     N = args.inproc_ranks
     capi.init(0)
@@ -292,59 +407,19 @@ def inproc_ranks(args):
     for name, kind, call in variants:
         scene = scene_dom if kind == "domain" else scene_img
         owner = [i % N for i in range(scene.n_inst)] if kind == "domain" else [0] * scene.n_inst
-        hub = capi.load().gvt_hip_hub_create(N)
-        bar = threading.Barrier(N)
-        per_rank, errs = {}, []
-
-        def rank_main(r):
-            ctx = None
-            try:
-                ctx = Context(0)
-                for o in args.opt:
-                    k, v = o.split("=")
-                    capi.set_option(k, int(v))
-                comm = Comm.local(hub, r)
-                tr = NativeTracer(scene, NORMALS_FLAT, owner, comm, replicate=(kind == "image"))
-                for _ in range(args.warmup):
-                    tr(**call)
-                capi.synchronize(); bar.wait()
-                sums = {}
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    tr(**call)
-                    for k, v in tr.stats.items():
-                        sums[k] = sums.get(k, 0) + v
-                capi.synchronize(); bar.wait()
-                per_rank[r] = (sums, time.perf_counter() - t0)
-                tr.close(); comm.close()
-                tr = None
-            except Exception:  # noqa: BLE001
-                import traceback
-                errs.append(traceback.format_exc())
-                capi.load().gvt_hip_hub_abort(hub)
-                bar.abort()
-            finally:
-                import gc
-                gc.collect()
-                if ctx is not None:
-                    ctx.close()
-
-        th = [threading.Thread(target=rank_main, args=(r,)) for r in range(N)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-        capi.load().gvt_hip_hub_destroy(hub)
-        if errs:
-            print(errs[0], file=sys.stderr)
-            sys.exit(1)
-        el = max(v[1] for v in per_rank.values())
-        tot = lambda k: float(sum(v[0].get(k, 0) for v in per_rank.values()))  # noqa: E731
-        mx = lambda k: float(max(v[0].get(k, 0) for v in per_rank.values()))  # noqa: E731
-        ticks = mx("rounds") / args.steps
-        out["variants"][name] = {"value": (tot("rays_closest") + tot("rays_any")) / el / 1e6, "unit": "Mrays/s", "ms_per_step": el / args.steps * 1e3,
-                                 "ticks_per_step": ticks, "ms_per_tick": el / args.steps * 1e3 / ticks if ticks else None,
-                                 "launch_chains_per_step": mx("chains") / args.steps, "host_syncs_per_step": mx("host_syncs") / args.steps,
-                                 "rays_sent_per_step": tot("rays_sent") / args.steps, "bytes_sent_per_step": tot("bytes_sent") / args.steps,
-                                 "phase_ms_per_step_max_over_ranks": {k[3:]: mx(k) / args.steps for k in PHASES}}
+        out["variants"][name] = run_inproc(scene, owner, N, NORMALS_FLAT, call, kind == "image", args)
+    scene_dom = scene_img = None
+    if not args.no_extra_legs:
+        sc4 = scenes.bunny_grid_scene(width=args.config4_width, height=args.config4_height)
+        own4 = [i % N for i in range(sc4.n_inst)]
+        out["config4_bunny_grid"] = {"workload": CONFIG4_NOTE, "film": [args.config4_width, args.config4_height],
+                                     "domain_async": run_inproc(sc4, own4, N, NORMALS_SMOOTH, dict(bsp=False), False, args),
+                                     "domain_bsp": run_inproc(sc4, own4, N, NORMALS_SMOOTH, dict(bsp=True), False, args)}
+        ww, wh = weak_film(N, args.width, args.height)
+        scw = scenes.soup_weak_scene(args.weak_tris, N, ww, wh)
+        r = run_inproc(scw, list(range(N)), N, NORMALS_FLAT, dict(bsp=False), False, args, roofline=True)
+        r.update({"workload": WEAK_NOTE % (args.weak_tris, ww, wh), "scaling": "weak", "tiles": N, "tris_per_tile": args.weak_tris, "film": [ww, wh]})
+        out["weak_soup"] = r
     out["value"] = out["variants"]["domain_async"]["value"]
     out["unit"] = "Mrays/s"
     print(json.dumps(out))
@@ -369,6 +444,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (gvt_hip_set_option), for experiments")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-abi-path", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the `sustained` key (>= 2000 frames / 2.5 s of the same frame back to back)")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal only: every rank uses device 0 (needs an RCCL that tolerates it)")
     ap.add_argument("--single-variant", action="store_true", help="N>1: only the variant --scheduler / --bsp select (default: Domain asynchronous = `value`, "
@@ -376,6 +452,11 @@ def main():
     ap.add_argument("--inproc-ranks", type=int, default=0, help="N=1 only: run the native multi-rank frame loop with this many in-process ranks on ONE GPU "
                                                                  "(hub transport) and print the per-variant tick / byte / phase table; a diagnostic, not a scaling run")
     ap.add_argument("--exchange-timeout-ms", type=int, default=0, help="N>1: deadline of every blocking point of the ray exchange (default: the library's 20 s)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="N>1 / --inproc-ranks: skip the extra keys config4_bunny_grid (BASELINE configs[3]: the 8-bunny grid at "
+                                                                  "1900x1080, domain d on rank d mod N) and weak_soup (N tiles of --weak-tris triangles each, film scaled with N)")
+    ap.add_argument("--weak-tris", type=int, default=10_000_000, help="weak_soup: triangles per tile (= per rank)")
+    ap.add_argument("--config4-width", type=int, default=1900)
+    ap.add_argument("--config4-height", type=int, default=1080)
     args = ap.parse_args()
     if args.inproc_ranks > 1:
         if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
@@ -517,18 +598,18 @@ def main():
 
     # N > 1: the scheduler variants in ONE invocation -- Domain asynchronous, Domain BSP and (native harness) the replicated Image
     # scheduler -- as extra keys of the line; `value` stays the primary variant measured above
+    def reduce_sum(v):
+        t = torch.tensor(v, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(x) for x in t]
+
+    def reduce_max(v):
+        t = torch.tensor(v, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t]
+
     variants = None
     if world > 1 and not args.single_variant:
-        def reduce_sum(v):
-            t = torch.tensor(v, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            return [float(x) for x in t]
-
-        def reduce_max(v):
-            t = torch.tensor(v, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return [float(x) for x in t]
-
         variants = {}
         primary = "image_replicated" if image_split else ("domain_bsp" if args.bsp else "domain_async")
         todo = [("domain_async", "domain", False), ("domain_bsp", "domain", True)] + ([("image_replicated", "image", False)] if args.harness == "native" else [])
@@ -561,6 +642,82 @@ def main():
             variants[name] = res_v
             if made is not None and hasattr(made, "close"):
                 made.close()
+
+    # N > 1, two more keys of the same line (never `value`): BASELINE configs[3] -- the 8-bunny grid under the Domain scheduler, the
+    # configuration BASELINE.json names for the scaling curve -- and the weak-scaling soup (N tiles of 10 M triangles each)
+    extra = {}
+    if world > 1 and not args.no_extra_legs and not args.single_variant:
+        from gravit_amd.layouts import NORMALS_SMOOTH
+
+        def tracer_for(sc, mode, own, bsp_v):
+            """(run_frame, frame_stats, close) of one Domain-scheduler variant on scene sc"""
+            if args.harness == "native":
+                t = NativeTracer(sc, mode, own, comm)
+                return (lambda: t(bsp=bsp_v)), (lambda: t.stats), t.close
+            be = None if on_gpu else OracleBackend(sc, mode, [o == rank for o in own])
+            t = DomainTracer(sc, own, dist, torch, dev, mode, backend=be, overlap=not bsp_v)
+            last = {"c": 0, "a": 0}
+
+            def run():
+                t()
+                t.composite(download=False)
+
+            def stats():
+                c, a = getattr(t.backend, "rays_closest", 0), getattr(t.backend, "rays_any", 0)
+                if on_gpu:
+                    g = capi.stats()
+                    c, a = g["rays_closest"], g["rays_any"]
+                d = {"rays_closest": c - last["c"], "rays_any": a - last["a"], "rays_sent": getattr(t, "rays_sent", 0), "rounds": getattr(t, "rounds", 0)}
+                last["c"], last["a"] = c, a
+                return d
+            return run, stats, (lambda: None)
+
+        sc4 = scenes.bunny_grid_scene(width=args.config4_width, height=args.config4_height)
+        own4 = [i % world for i in range(sc4.n_inst)]
+        leg = {"workload": CONFIG4_NOTE, "film": [args.config4_width, args.config4_height]}
+        for name, bsp_v in (("domain_async", False), ("domain_bsp", True)):
+            run_v, stats_v, close_v = tracer_for(sc4, NORMALS_SMOOTH, own4, bsp_v)
+            leg[name], _, _, tot4 = measure_variant(run_v, stats_v, args.steps, args.warmup, barrier, reduce_sum, reduce_max, rank, world, "config4_bunny_grid " + name)
+            leg[name]["rays_per_step"] = (tot4[0] + tot4[1]) / args.steps
+            close_v()
+        extra["config4_bunny_grid"] = leg
+        sc4 = None
+        # weak_soup: every rank generates its own tile only; the tiles' boxes are exchanged through the rendezvous group (a Domain-scheduler
+        # rank knows every instance's box, DomainTracer.h:115-144)
+        ww, wh = weak_film(world, args.width, args.height)
+        mine = scenes.soup_weak_scene(args.weak_tris, world, ww, wh, own=[rank], boxes=[(np.zeros(3), np.zeros(3))] * world)
+        boxes = [None] * world
+        dist.all_gather_object(boxes, (mine.inst_lo[rank].tolist(), mine.inst_hi[rank].tolist()))
+        mine.inst_lo[:] = np.array([b[0] for b in boxes], np.float32)
+        mine.inst_hi[:] = np.array([b[1] for b in boxes], np.float32)
+        run_v, stats_v, close_v = tracer_for(mine, NORMALS_FLAT, list(range(world)), False)
+        if on_gpu:
+            capi.stats_reset()
+
+        for _ in range(args.warmup):
+            run_v()
+        if on_gpu:
+            capi.stats_reset(); capi.profile(2)
+        wsum = {}
+
+        def stats_w():
+            d = stats_v()
+            for k in ("rays_closest", "rays_any"):
+                wsum[k] = wsum.get(k, 0) + d.get(k, 0)
+            return d
+
+        weak, _, _, totw = measure_variant(run_v, stats_w, args.steps, 0, barrier, reduce_sum, reduce_max, rank, world, "weak_soup")
+        roof = None
+        if on_gpu:
+            stw = capi.stats(); capi.profile(False)
+            roof = rank_roofline(stw, wsum.get("rays_closest", 0), wsum.get("rays_any", 0), args.weak_tris)
+        roofs = [None] * world
+        dist.all_gather_object(roofs, roof)
+        weak.update({"workload": WEAK_NOTE % (args.weak_tris, ww, wh), "scaling": "weak", "tiles": world, "tris_per_tile": args.weak_tris, "film": [ww, wh],
+                     "rays_per_step": (totw[0] + totw[1]) / args.steps, "roofline_per_rank": roofs})
+        extra["weak_soup"] = weak
+        close_v()
+        mine = None
 
     if rank == 0:
         gpu_fb = tracer.backend.framebuffer(False) if (on_gpu and world == 1 and n_dom == 1) else None  # before the extra legs reuse the backend
@@ -606,6 +763,7 @@ def main():
             out["config"]["bytes_sent_per_step"] = ([v for v in variants.values() if v["is_value"]] or [{}])[0].get("bytes_sent_per_step")
         if variants is not None:
             out["variants"] = variants  # Domain asynchronous / Domain BSP / replicated Image, each: ticks, ms per tick, rays and bytes sent, per-phase ms
+        out.update(extra)  # config4_bunny_grid, weak_soup
         if on_gpu:
             dom = "closest" if st["ms_closest"] >= st["ms_any"] else "any"
             ms_dom = st["ms_%s" % dom]
@@ -647,6 +805,11 @@ def main():
                                                                   "triangle_tests": vs["tri_tests_per_ray"], "sample_rays": int(len(rr))}
                 except Exception as e:
                     out["roofline"]["visits_per_primary_ray"] = "failed: %r" % (e,)
+        if on_gpu and world == 1 and n_dom == 1 and args.harness == "native" and not args.no_sustained:
+            try:
+                out["sustained"] = sustained(frame, rays_total / args.steps)
+            except Exception as e:
+                out["sustained"] = {"failed": repr(e)}
         if on_gpu and world == 1 and n_dom == 1 and args.harness == "native" and not args.no_abi_path:
             try:
                 out["two_frames_in_flight"] = two_frames_in_flight(scene, args.steps, rays_total / args.steps)

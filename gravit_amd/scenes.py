@@ -340,6 +340,41 @@ def soup_domains_scene(n_tris=10_000_000, n_domains=8, width=1920, height=1080, 
     return _assemble(meshes, list(range(len(meshes))), mats, point_light((0.5, 0.5, 3.0)), cam, "soup-%d-dom%d" % (n_tris, n_domains))
 
 
+def soup_weak_tile(d, n_tiles, n_per_tile, seed=12345, half_extent=None):
+    """Tile d of the WEAK-scaling soup: n_per_tile triangles of its own (Philox(seed + 7919 (d + 1))) with centres uniform in cell d of
+    domain_grid(n_tiles) -- every rank generates only what it owns.  The triangle size shrinks with the density (half_extent =
+    0.005 n_tiles^(-1/3) unless given), so that the scene keeps config 3's extent-to-spacing ratio."""
+    gx, gy, gz = domain_grid(n_tiles)
+    he = F(0.005 * n_tiles ** (-1.0 / 3.0)) if half_extent is None else F(half_extent)
+    rng = np.random.Generator(np.random.Philox(seed + 7919 * (d + 1)))
+    ix, iy, iz = d % gx, (d // gx) % gy, d // (gx * gy)
+    c = rng.random((n_per_tile, 1, 3), dtype=F) * np.array([1.0 / gx, 1.0 / gy, 1.0 / gz], F) + np.array([ix / gx, iy / gy, iz / gz], F)
+    o = (rng.random((n_per_tile, 3, 3), dtype=F) * F(2.0) - F(1.0)) * he
+    verts = (c + o).reshape(-1, 3).astype(F)
+    return verts, np.arange(n_per_tile * 3, dtype=np.int32).reshape(-1, 3)
+
+
+def soup_weak_scene(n_per_tile, n_tiles, width, height, own=None, boxes=None, seed=12345, half_extent=None):
+    """Weak scaling of config 3: n_tiles domains of n_per_tile triangles EACH (camera and light of config 3, film as given).  own: the
+    tiles whose geometry this process generates (None: all); boxes[d] = (lo, hi) of every tile it does not (a Domain-scheduler rank
+    knows every instance's box but holds only its own meshes, DomainTracer.h:115-144) -- meshes[d] is None there."""
+    own = list(range(n_tiles)) if own is None else list(own)
+    meshes, lo, hi, mats = [None] * n_tiles, [None] * n_tiles, [None] * n_tiles, []
+    for d in range(n_tiles):
+        if d in own:
+            v, t = soup_weak_tile(d, n_tiles, n_per_tile, seed, half_extent)
+            meshes[d] = MeshData(v, t, default_material())
+            lo[d], hi[d] = meshes[d].bbox()
+        else:
+            lo[d], hi[d] = np.asarray(boxes[d][0], F), np.asarray(boxes[d][1], F)
+        mats.append(mat_translate_scale((0, 0, 0), (1, 1, 1)))
+    minv, normi = zip(*[instance_matrices(m) for m in mats])
+    cam = Camera((0.5, 0.5, 3.0), (0.5, 0.5, 0.5), (0.0, 1.0, 0.0), float(F(30.0 * np.pi / 180.0)), width, height, 1, 1, 0.0)
+    return Scene(meshes, list(range(n_tiles)), np.array(mats, F).reshape(-1, 16), np.array(minv, F).reshape(-1, 16), np.array(normi, F).reshape(-1, 9),
+                 np.array(lo, F).reshape(-1, 3), np.array(hi, F).reshape(-1, 3), np.ascontiguousarray(point_light((0.5, 0.5, 3.0)), LIGHT_DTYPE), cam,
+                 "soup-weak-%dx%d" % (n_tiles, n_per_tile))
+
+
 # ------------------------------------------------------------------ legacy .conf scenes (data/bunny.conf, data/README.conf)
 def load_conf(path, geom_dirs=None, width=None, height=None):
     """Scene from one of the reference's legacy .conf files, as src/apps/render/ConfigFileLoader.cpp:70-285 reads them

@@ -118,7 +118,7 @@ def test_bench_script_multi_rank_branch_under_gloo(tmp_path):
     for r in range(2):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--harness", "checker", "--tris", "20000",
-                                       "--width", "96", "--height", "54", "--steps", "2", "--warmup", "1"],
+                                       "--width", "96", "--height", "54", "--steps", "2", "--warmup", "1", "--weak-tris", "8000", "--config4-width", "95", "--config4-height", "54"],
                                       env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs[0][1][-2000:] + outs[1][1][-2000:]
@@ -132,3 +132,9 @@ def test_bench_script_multi_rank_branch_under_gloo(tmp_path):
     assert set(v) == {"domain_async", "domain_bsp"} and v["domain_async"]["is_value"] and not v["domain_bsp"]["is_value"]
     for r in v.values():
         assert r["value"] > 0 and r["ms_per_step"] > 0 and set(r["phase_ms_per_step_max_over_ranks"]) == {"chain", "announce", "payload", "composite", "host_wait"}
+    # the two extra legs: BASELINE configs[3] (the 8-bunny grid, domain d on rank d mod N) and the weak-scaling soup (a tile per rank)
+    c4, wk = j["config4_bunny_grid"], j["weak_soup"]
+    for r in (c4["domain_async"], c4["domain_bsp"], wk):
+        assert r["value"] > 0 and r["rays_per_step"] > 100 and r["ticks_per_step"] >= 1
+    assert c4["film"] == [95, 54] and c4["domain_async"]["rays_sent_per_step"] == c4["domain_bsp"]["rays_sent_per_step"] > 0
+    assert wk["scaling"] == "weak" and wk["tiles"] == 2 and wk["tris_per_tile"] == 8000 and wk["film"] == [136, 80] and len(wk["roofline_per_rank"]) == 2

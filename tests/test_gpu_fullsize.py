@@ -141,3 +141,26 @@ def test_config1_bunny_conf_at_its_full_film(hip):
     it = ImageTracer(sc, NORMALS_SMOOTH)
     fb = it().framebuffer(True)
     assert np.array_equal(fb[..., :3].view(np.uint32), ref[..., :3].view(np.uint32)) and it.adapter_calls == st.adapter_calls
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_config4_bunny_grid_at_its_full_film_under_the_native_domain_scheduler(hip, world):
+    """BASELINE config 4 at the film of data/bunny.conf:8 (1900 x 1080): the 8-bunny grid, domain d on rank d mod N
+    (DomainTracer.h:115-144), through the native Domain scheduler on `world` in-process ranks -- asynchronous ticks and BSP rounds --
+    against the oracle's restated DomainTracer and its one-rank image: whole float framebuffer bit for bit, equal ray counts."""
+    from gravit_amd.layouts import NORMALS_SMOOTH
+    from tests.helpers import oracle_render_domain
+    from tests.test_gpu_native import run_native_ranks
+
+    sc = scenes.bunny_grid_scene()
+    assert (sc.camera.width, sc.camera.height) == (1900, 1080) and sc.n_inst == 8
+    owner = [i % world for i in range(sc.n_inst)]
+    ref, st = oracle_render_domain(sc, owner, world, NORMALS_SMOOTH, nthreads=16)
+    one, _ = oracle_render(sc, NORMALS_SMOOTH, nthreads=16)
+    assert (ref[..., 3] > 0).sum() > 100_000 and np.array_equal(ref[..., :3].view(np.uint32), one[..., :3].view(np.uint32))
+    for bsp in (False, True):
+        res = run_native_ranks(sc, owner, world, NORMALS_SMOOTH, bsp)
+        fb = res[0][0]
+        assert np.array_equal(fb[..., :3].view(np.uint32), ref[..., :3].view(np.uint32)) and np.array_equal(fb[..., 3], ref[..., 3])
+        assert sum(r[1]["rays_sent"] for r in res.values()) == st.rays_sent and st.rays_sent > 1000
+        assert sum(r[1]["rays_closest"] for r in res.values()) == st.rays_closest and sum(r[1]["rays_any"] for r in res.values()) == st.rays_any

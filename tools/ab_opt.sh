@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/ab
 for o in "$@"; do
   args=""; for kv in ${o//,/ }; do args="$args --opt $kv"; done
-  python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-abi-path $args > gpurun_out/ab/ab.log 2>&1
+  python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-abi-path --no-sustained $args > gpurun_out/ab/ab.log 2>&1
   python - <<PY
 import json
 l=[x for x in open("gpurun_out/ab/ab.log") if x.startswith("{")][-1]; j=json.loads(l); k=j["roofline"]["kernel_ms"]; s=j["steps"]
