@@ -1,13 +1,19 @@
 // api.hip -- C ABI glue of include/gvt_hip.h: context, meshes, device ray queues, Adapter::trace.
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <new>
 #include <thread>
 
 #include "gvt_internal.h"
 
 size_t trav_spill_ints_per_thread();
 int trav_block_threads();
+void abi_pool_destroy(void *);
 
 static thread_local std::string g_err;
 static Ctx g_default_ctx;
@@ -83,6 +89,7 @@ extern "C" void gvt_hip_ctx_destroy(gvt_hip_ctx *c) {
     for (auto e : C->event_pool) hipEventDestroy(e);
     if (C->abi_qin) gvt_hip_queue_destroy(C->abi_qin);
     if (C->abi_qout) gvt_hip_queue_destroy(C->abi_qout);
+    abi_pool_destroy(C->abi_pool); C->abi_pool = nullptr; // (joins the lane threads)
     for (Ctx *L : C->abi_lanes) gvt_hip_ctx_destroy((gvt_hip_ctx *)L);
     C->abi_lanes.clear();
     hipSetDevice(C->device);
@@ -489,21 +496,74 @@ extern "C" int gvt_hip_trace(gvt_hip_mesh *M, gvt_hip_ray *rays, size_t n_rays, 
 // directions of the link and the kernels overlap.  Results do not depend on the cut: a ray's RNG stream is keyed on its index in
 // rayList (trace_core's index_base).  Used when rays_out has room for the worst case n * (1 + n_lights), so that a capacity error
 // cannot arise after the rayList has begun to change; smaller buffers take the one-shot path below.
-static int trace_pipelined(Ctx &C, gvt_hip_mesh *M, gvt_hip_ray *rays, size_t begin, size_t n, gvt_hip_ray *rays_out, size_t *n_out, const TraceParams &P,
-                           const gvt_hip_light *lights, size_t n_lights, bool write_back) {
+// The lanes are PERSISTENT threads of the calling context (created at the first pipelined call, parked on a condition variable between
+// calls, joined when the context is destroyed; the default context's are never joined -- the process ends with them parked).
+struct AbiPool {
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  std::vector<std::thread> threads;
+  std::function<void(int)> job; // the current call's work, by lane number
+  uint64_t generation = 0;      // bumped per call
+  int wanted = 0, running = 0;  // lanes that take part in the current call / have not finished it yet
+  bool stop = false;
+  void worker(int li) {
+    uint64_t seen = 0;
+    for (;;) {
+      std::function<void(int)> j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_go.wait(lk, [&] { return stop || (generation != seen && li < wanted); });
+        if (stop) return;
+        seen = generation;
+        j = job;
+      }
+      j(li);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--running == 0) cv_done.notify_all();
+      }
+    }
+  }
+  // runs job(0..n-1) on n lanes and waits for them; false: the threads could not be created (the caller falls back to the one-shot path)
+  bool run(int n, std::function<void(int)> f) {
+    try {
+      while ((int)threads.size() < n) { const int li = (int)threads.size(); threads.emplace_back([this, li] { worker(li); }); }
+    } catch (...) { return false; }
+    std::unique_lock<std::mutex> lk(mu);
+    job = std::move(f); wanted = n; running = n; generation++;
+    cv_go.notify_all();
+    cv_done.wait(lk, [&] { return running == 0; });
+    job = nullptr;
+    return true;
+  }
+  void shutdown() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv_go.notify_all();
+    for (auto &t : threads) if (t.joinable()) t.join();
+    threads.clear();
+  }
+};
+void abi_pool_destroy(void *p) { AbiPool *P = (AbiPool *)p; if (P) { P->shutdown(); delete P; } }
+
+static int trace_pipelined(Ctx &C, gvt_hip_mesh *M, gvt_hip_ray *rays, size_t begin, size_t n, gvt_hip_ray *rays_out, size_t cap, size_t *n_out, const TraceParams &P,
+                           const gvt_hip_light *lights, size_t n_lights, bool write_back, bool *fell_back) {
   const int L = C.abi_lanes_n < 1 ? 1 : (C.abi_lanes_n > 8 ? 8 : C.abi_lanes_n);
   while ((int)C.abi_lanes.size() < L) {
     Ctx *LC = (Ctx *)gvt_hip_ctx_create(C.device);
     if (!LC) return GVT_HIP_ERR_DEVICE;
     C.abi_lanes.push_back(LC);
   }
+  if (!C.abi_pool) C.abi_pool = new (std::nothrow) AbiPool();
+  if (!C.abi_pool) { *fell_back = true; return 0; }
   const size_t chunk = (size_t)(C.abi_chunk < 16384 ? 16384 : C.abi_chunk);
   const size_t n_chunks = (n + chunk - 1) / chunk;
-  std::atomic<size_t> next{ 0 }, out_pos{ 0 };
+  std::atomic<size_t> next{ 0 }, out_pos{ 0 }, traced{ 0 };
   std::atomic<int> err{ 0 };
-  std::mutex mu;
-  std::string err_msg;
+  std::mutex mu; // (one upload / one download at a time -- a mutex per direction, 128 K-ray chunks -- was measured: 6.1 ms against 5.0-5.6 with the lanes'
+  std::string err_msg; // copies left to share the link: each chunk's conversion kernel and synchronisation then sit on the link's critical path)
   Ctx *caller_ctx = &C;
+  static const bool trace_chunks = getenv("GVT_HIP_ABI_TRACE") != nullptr;
+  const auto t_call = std::chrono::steady_clock::now();
   auto work = [&](int li) {
     Ctx *LC = C.abi_lanes[(size_t)li];
     gvt_hip_ctx_make_current((gvt_hip_ctx *)LC);
@@ -519,13 +579,28 @@ static int trace_pipelined(Ctx &C, gvt_hip_mesh *M, gvt_hip_ray *rays, size_t be
       if (k >= n_chunks) break;
       const size_t off = k * chunk, cn = std::min(chunk, n - off);
       size_t got = 0;
+      const auto tc0 = std::chrono::steady_clock::now();
       if ((rc = gvt_hip_queue_clear(qin)) || (rc = gvt_hip_queue_clear(qout))) break;
       if ((rc = gvt_hip_queue_append(qin, rays + begin + off, cn, 0))) break;
+      const auto tc1 = std::chrono::steady_clock::now();
       if ((rc = queue_reserve(qout, cn * (1 + n_lights)))) break;
       if ((rc = trace_core(M, make_planes(qin->d_planes, qin->cap), cn, begin + off, qout, P, lights))) break;
+      traced.fetch_add(1);
       const size_t moved = qout->size, pos = out_pos.fetch_add(moved);
+      if (pos + moved > cap) { // only rays that bounce (depth > 1) can emit more than the n * (1 + lights) the caller was asked to provide
+        set_error("trace: more than %zu outgoing rays (rays that bounce emit shadow rays in every pass); rayList and rays_out are partly written", cap);
+        rc = GVT_HIP_ERR_CAPACITY;
+        break;
+      }
+      const auto tc2 = std::chrono::steady_clock::now();
       if (write_back && (rc = gvt_hip_queue_export(qin, rays + begin + off, cn, &got, 0))) break; // rayList is updated in place (r.mice.t, bounce state)
+      const auto tc3 = std::chrono::steady_clock::now();
       if (moved && (rc = gvt_hip_queue_export(qout, rays_out + pos, moved, &got, 0))) break;
+      if (trace_chunks) { // GVT_HIP_ABI_TRACE=1: where a chunk's time goes (ms since the call began)
+        const auto ms = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(t - t_call).count(); };
+        std::fprintf(stderr, "abi chunk %2zu lane %d: upload %.3f-%.3f trace -%.3f rayList back -%.3f moved (%zu) back -%.3f\n", k, li, ms(tc0), ms(tc1), ms(tc2), ms(tc3), moved,
+                     ms(std::chrono::steady_clock::now()));
+      }
     }
     if (rc) {
       std::lock_guard<std::mutex> lk(mu);
@@ -541,11 +616,12 @@ static int trace_pipelined(Ctx &C, gvt_hip_mesh *M, gvt_hip_ray *rays, size_t be
     }
     gvt_hip_ctx_make_current(nullptr);
   };
-  std::vector<std::thread> th;
   const int n_thr = (int)std::min<size_t>((size_t)L, n_chunks);
-  for (int li = 0; li < n_thr; li++) th.emplace_back(work, li);
-  for (auto &t : th) t.join();
-  C.stats.trace_calls -= (uint64_t)(n_chunks ? n_chunks - 1 : 0); // ONE Adapter::trace call
+  if (!((AbiPool *)C.abi_pool)->run(n_thr, work)) { *fell_back = true; return 0; } // no threads to be had: nothing has been touched yet
+  const uint64_t done = traced.load();
+  if (done > 1) C.stats.trace_calls -= done - 1; // ONE Adapter::trace call, however many chunks were traced
+  // A device error in the middle of a call leaves rayList partly updated and rays_out partly filled (only capacity errors are excluded
+  // up front, by the worst-case room the pipelined path requires): the error is returned and *n_out stays 0
   if (err.load()) { set_error("%s", err_msg.c_str()); return err.load(); }
   *n_out = out_pos.load();
   return 0;
@@ -569,7 +645,9 @@ extern "C" int gvt_hip_trace_ex(gvt_hip_mesh *M, gvt_hip_ray *rays, size_t n_ray
   if (!n) return 0;
   if (C.abi_lanes_n > 0 && n >= (size_t)C.abi_pipe_min && rays_out && cap >= n * (1 + n_lights)) {
     P.update_in_place = write_back ? 1 : 0;
-    return trace_pipelined(C, M, rays, begin, n, rays_out, n_out, P, lights, n_lights, write_back);
+    bool fell_back = false;
+    rc = trace_pipelined(C, M, rays, begin, n, rays_out, cap, n_out, P, lights, n_lights, write_back, &fell_back);
+    if (!fell_back) return rc;
   }
   if (!C.abi_qin) { C.abi_qin = gvt_hip_queue_create(0); C.abi_qout = gvt_hip_queue_create(0); }
   gvt_hip_queue *qin = C.abi_qin, *qout = C.abi_qout;

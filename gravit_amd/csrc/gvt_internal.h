@@ -95,6 +95,7 @@ struct Ctx : Knobs {
   // staging queues of gvt_hip_trace (host RayVector in / out)
   gvt_hip_queue *abi_qin = nullptr, *abi_qout = nullptr;
   std::vector<Ctx *> abi_lanes; // contexts of the pipelined host path's lanes (api.hip trace_pipelined), created on first use
+  void *abi_pool = nullptr;     // ... and their persistent threads (api.hip AbiPool)
 };
 // The context API calls run on: the calling thread's current context (gvt_hip_ctx_make_current), else the process default one
 // (gvt_hip_init).  A context owns a stream, scratch arenas, counters, statistics and knobs; meshes / queues / framebuffers are plain

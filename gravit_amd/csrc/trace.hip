@@ -1589,7 +1589,7 @@ int launch_any_flags(gvt_hip_mesh *M, RayPlanes q, size_t n, bool xform, const M
 }
 
 // Adapter::trace on device planes.  `in` holds n rays at [0,n); `out` must have been reserved for
-// out->size + n*(1+n_lights).  On return out->size is exact (one small read-back).
+// out->size + n*(1+n_lights) -- what the first pass can emit; further passes (bounces) grow it themselves.  On return out->size is exact (one small read-back).
 int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt_hip_queue *out, const TraceParams &P,
                const gvt_hip_light *lights_host) {
   Ctx &C = gctx();
@@ -1628,6 +1628,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
   mv.mat = M->mesh_mat;
 
   size_t n_active = n;
+  const size_t out_size0 = out->size;
   const unsigned *idx = nullptr;
   unsigned *next = d_idx_a;
   int pass = 0;
@@ -1736,8 +1737,13 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
     idx = next;
     next = (next == d_idx_a) ? d_idx_b : d_idx_a;
     pass++;
+    if (n_active) { // a further pass (bounces): room for everything IT can emit -- a forward or nL shadow rays per ray -- behind what is there
+      out->size = C.h_pinned[2];
+      if ((rc = queue_reserve(out, out->size + n_active * (size_t)(1 + nL)))) return rc;
+      outp = make_planes(out->d_planes, out->cap);
+    }
   }
-  C.stats.rays_forwarded += C.h_pinned[2] - out->size; // read back with the last pass
+  C.stats.rays_forwarded += C.h_pinned[2] - out_size0; // read back with the last pass
   out->size = C.h_pinned[2];
   return 0;
 }

@@ -103,6 +103,10 @@ void HipMeshAdapter::trace(gvt::render::actor::RayVector &rayList, gvt::render::
   std::unique_lock<std::mutex> moved(_outqueue);
   const size_t old = moved_rays.size();
   moved_rays.resize(old + cap);
+  // (Both schedulers hand the adapter a moved_rays vector reserved afresh for every call -- ImageTracer.h:240, DomainTracer.h:308 -- whose
+  // pages have never been touched: the device-to-host copies fault them in, ~0.4 us per 4 KiB page, 15 ms for the 166 MB a 1080p call
+  // returns.  Populating them from a helper thread while the upload runs (MADV_POPULATE_WRITE) was measured and made the call SLOWER,
+  // 19.8 -> 23 ms: the runtime's registration of the upload's host pages waits behind the populate's hold on the address space.)
   int rc = gvt_hip_trace_ex(mesh_, reinterpret_cast<gvt_hip_ray *>(rayList.data()), rayList.size(), begin, end,
                             reinterpret_cast<gvt_hip_ray *>(moved_rays.data() + old), cap, &n_out, &(*m)[0][0], &(*minv)[0][0], &(*normi)[0][0],
                             pods.empty() ? nullptr : pods.data(), pods.size(), normal_mode_, trace_calls_++,

@@ -52,8 +52,8 @@ int main(int argc, char **argv) {
   // optional 5th argument: timed repetitions of the same call on copies of the list (the drop-in path's rate: host RayVector in,
   // host RayVector out, through the virtual interface)
   const int reps = argc > 5 ? std::atoi(argv[5]) : 0;
-  double best_ms = -1.0;
-  for (int r = 0; r < reps; r++) {
+  double best_ms = -1.0, best_reused_ms = -1.0;
+  for (int r = 0; r < reps; r++) { // (a) the schedulers' own pattern: moved_rays reserved afresh for every call (ImageTracer.h:240) -- its pages untouched
     RayVector in2 = rays, mv2;
     mv2.reserve(in2.size() * 10);
     const auto t0 = std::chrono::steady_clock::now();
@@ -61,10 +61,23 @@ int main(int argc, char **argv) {
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (best_ms < 0 || ms < best_ms) best_ms = ms;
   }
+  if (reps) {
+    RayVector mv3; // (b) a moved_rays vector whose capacity is kept between the calls (pages already touched): the call's transfers and kernels alone
+    mv3.reserve(rays.size() * 10);
+    for (int r = 0; r < reps + 1; r++) {
+      RayVector in2 = rays;
+      mv3.clear();
+      const auto t0 = std::chrono::steady_clock::now();
+      adapter->trace(in2, mv3, &m, &minv, &normi, lights);
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (r > 0 && (best_reused_ms < 0 || ms < best_reused_ms)) best_reused_ms = ms;
+    }
+  }
   RayVector moved;
   moved.reserve(rays.size() * 10); // ImageTracer.h:240
   adapter->trace(rays, moved, &m, &minv, &normi, lights);
-  if (reps) std::printf("dropin_demo: trace_ms %.3f (best of %d) for %zu rays in, %zu moved\n", best_ms, reps, rays.size(), moved.size());
+  if (reps) std::printf("dropin_demo: trace_ms %.3f (best of %d) for %zu rays in, %zu moved; reused_ms %.3f with moved_rays' capacity kept between calls\n", best_ms, reps,
+                        rays.size(), moved.size(), best_reused_ms);
 
   std::ofstream out(argv[4], std::ios::binary);
   const unsigned long long n = moved.size();

@@ -49,18 +49,22 @@ def test_dropin_path_at_1080p_with_its_rate(tmp_path, hip):
     sc = scenes.bunny_scene(W, H)
     rays = oracle_camera_rays(sc)
     rays.tofile(rin)
-    r = subprocess.run([DEMO, os.path.join(GOLDEN, "bunny.obj"), str(rin), "0", str(out), "3"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([DEMO, os.path.join(GOLDEN, "bunny.obj"), str(rin), "0", str(out), "3"], capture_output=True, text=True, timeout=600)  # 3 + 4 timed calls go before
     assert r.returncode == 0, r.stdout + r.stderr
     line = [ln for ln in r.stdout.splitlines() if "trace_ms" in ln][-1]
     ms = float(line.split("trace_ms")[1].split()[0])
+    reused_ms = float(line.split("reused_ms")[1].split()[0])
     print(line)
     raw = np.fromfile(out, np.uint8)
     n = int(raw[:8].view(np.uint64)[0])
     moved = raw[8:8 + 80 * n].view(orc.RAY_DTYPE)
     ray_list = raw[8 + 80 * n:].view(orc.RAY_DTYPE)
     om = orc.Mesh(sc.meshes[0].verts, sc.meshes[0].tris, mesh_mat=sc.meshes[0].material)
-    exp = om.trace(rays, sc.m[0], sc.minv[0], sc.normi[0], sc.lights, 0, 3, 8)  # seed 3: the binding passes its call counter, 3 timed calls went before
+    exp = om.trace(rays, sc.m[0], sc.minv[0], sc.normi[0], sc.lights, 0, 7, 8)  # seed 7: the binding passes its call counter, 3 + 4 timed calls went before
     assert n == len(exp) and n > 1_000_000
     assert rays_equal_bits(sort_rays(moved.copy()), sort_rays(exp))
     assert rays_equal_bits(ray_list.copy(), rays)
-    assert 0.5 < ms < 500.0  # sanity: a measured, finite call time (2 M rays in, ~2 M out over PCIe)
+    # 498 MB cross the link per call (2 M rays in, the updated rayList and ~2 M moved rays out): 8.7 ms at its 57 GB/s.  With moved_rays'
+    # capacity kept between calls the call runs at 9.3-9.7 ms; with a vector reserved afresh per call -- the schedulers' own pattern,
+    # ImageTracer.h:240 -- the copies also fault in and zero 166 MB of untouched pages (25 ms; any adapter that fills that vector pays it)
+    assert 0.5 < reused_ms <= 12.0 and reused_ms <= ms < 80.0
