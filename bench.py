@@ -330,6 +330,7 @@ def run_inproc(scene, owner, N, mode, call, replicate, args, roofline=False):
         ctx = None
         try:
             ctx = Context(0)
+            capi.set_option("frame_timing", 1)  # the per-phase breakdown (five more event calls per exchange: ms_per_step here includes them)
             for o in args.opt:
                 k, v = o.split("=")
                 capi.set_option(k, int(v))
@@ -609,6 +610,8 @@ def main():
         return [float(x) for x in t]
 
     variants = None
+    if world > 1 and on_gpu and args.harness == "native":
+        capi.set_option("frame_timing", 1)  # the variants and the extra legs carry the per-phase breakdown (five more event calls per exchange); `value` above ran without
     if world > 1 and not args.single_variant:
         variants = {}
         primary = "image_replicated" if image_split else ("domain_bsp" if args.bsp else "domain_async")

@@ -223,6 +223,7 @@ extern "C" int gvt_hip_set_option(const char *name, int value) {
   if (!std::strcmp(name, "first_round_async")) { g_ctx.first_round_async = value; return 0; }
   if (!std::strcmp(name, "lean_frame")) { g_ctx.lean_frame = value; return 0; }
   if (!std::strcmp(name, "skip_known")) { g_ctx.skip_known = value != 0; return 0; }
+  if (!std::strcmp(name, "frame_timing")) { g_ctx.frame_timing = value != 0; return 0; }
   if (!std::strcmp(name, "abi_lanes")) { if (value < 0 || value > 8) { set_error("abi_lanes must be 0..8"); return GVT_HIP_ERR_INVALID; } g_ctx.abi_lanes_n = value; return 0; }
   if (!std::strcmp(name, "abi_chunk")) { if (value < 16384) { set_error("abi_chunk must be >= 16384"); return GVT_HIP_ERR_INVALID; } g_ctx.abi_chunk = value; return 0; }
   if (!std::strcmp(name, "abi_pipe_min")) { g_ctx.abi_pipe_min = value < 0 ? 0 : value; return 0; }

@@ -25,6 +25,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -107,18 +108,31 @@ __global__ __launch_bounds__(256) void k_add_f32(float *__restrict__ dst, const 
 // ------------------------------------------------------------------------------------------------
 struct gvt_hip_hub {
   int world = 0;
-  std::mutex mu;
-  std::condition_variable cv;
   struct Slot {
     const void *ptr = nullptr;
     size_t bytes = 0;
     hipEvent_t ready = nullptr;  // recorded by the sender: the buffer is complete
     hipEvent_t copied = nullptr; // recorded by the receiver: the buffer has been read
-    int state = 0;               // 0 empty, 1 posted, 2 consumed
+    std::atomic<int> state{ 0 }; // 0 empty, 1 posted (ptr / bytes / ready valid), 2 consumed (copied valid)
   };
-  std::vector<Slot> slots; // [dst * world + src]
-  bool aborted = false;
+  std::unique_ptr<Slot[]> slots; // [dst * world + src]; a slot has ONE writer per state: the sender for 0 -> 1 and 2 -> 0, the receiver for 1 -> 2
+  std::atomic<bool> aborted{ false };
 };
+namespace {
+// The ranks are threads with a core each: a slot's state is awaited with loads (a condition variable costs a futex wake-up and the
+// scheduler's latency, 10-50 us, several times per exchange), yielding once the wait gets long; false: deadline passed or hub aborted.
+bool hub_await(gvt_hip_hub *H, std::atomic<int> &state, int want, int deadline_ms) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; spins++) {
+    if (state.load(std::memory_order_acquire) == want) return true;
+    if (H->aborted.load(std::memory_order_relaxed)) return false;
+    if ((spins & 1023u) == 1023u) {
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(deadline_ms)) return false;
+      if (spins > (1u << 16)) std::this_thread::yield();
+    }
+  }
+}
+} // namespace
 
 struct gvt_hip_comm {
   int rank = 0, world = 1;
@@ -138,17 +152,15 @@ extern "C" gvt_hip_hub *gvt_hip_hub_create(int world) {
   if (world < 1) { set_error("hub_create: world < 1"); return nullptr; }
   gvt_hip_hub *H = new gvt_hip_hub();
   H->world = world;
-  H->slots.resize((size_t)world * world);
+  H->slots.reset(new gvt_hip_hub::Slot[(size_t)world * world]);
   return H;
 }
-extern "C" void gvt_hip_hub_abort(gvt_hip_hub *H) { // wakes every rank blocked in an exchange (a rank failed)
-  if (!H) return;
-  { std::lock_guard<std::mutex> lk(H->mu); H->aborted = true; }
-  H->cv.notify_all();
+extern "C" void gvt_hip_hub_abort(gvt_hip_hub *H) { // every rank waiting in an exchange sees it (a rank failed)
+  if (H) H->aborted.store(true);
 }
 extern "C" void gvt_hip_hub_destroy(gvt_hip_hub *H) {
   if (!H) return;
-  for (auto &s : H->slots) { if (s.ready) hipEventDestroy(s.ready); if (s.copied) hipEventDestroy(s.copied); }
+  for (size_t k = 0; k < (size_t)H->world * H->world; k++) { auto &s = H->slots[k]; if (s.ready) hipEventDestroy(s.ready); if (s.copied) hipEventDestroy(s.copied); }
   delete H;
 }
 
@@ -236,7 +248,7 @@ int bounded_event_wait(gvt_hip_comm *K, hipEvent_t ev, const char *what, const c
     if (e == hipSuccess) break;
     if (e != hipErrorNotReady) { set_error("hipEventQuery while waiting for %s: %s", what, hipGetErrorString(e)); rc = GVT_HIP_ERR_DEVICE; break; }
     if ((spins & 63u) == 63u) {
-      if (K->hub && K->hub->aborted) { set_error("hub: aborted while waiting for %s", what); K->dead = true; rc = GVT_HIP_ERR_TIMEOUT; break; }
+      if (K->hub && K->hub->aborted.load()) { set_error("hub: aborted while waiting for %s", what); K->dead = true; rc = GVT_HIP_ERR_TIMEOUT; break; }
       if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(K->deadline_ms)) { rc = comm_timed_out(K, what, diag); break; }
       if (spins > 4096u) std::this_thread::yield();
     }
@@ -255,48 +267,41 @@ void comm_recv(gvt_hip_comm *K, void *p, size_t bytes, int peer, int accumulate 
 int hub_group_end(gvt_hip_comm *K) {
   gvt_hip_hub *H = K->hub;
   const int W = H->world, me = K->rank;
+  auto gone = [&](const char *what) -> int {
+    if (H->aborted.load()) { set_error("hub: aborted"); K->dead = true; return GVT_HIP_ERR_TIMEOUT; }
+    return comm_timed_out(K, what, nullptr);
+  };
   // 1. post every send (the slot is free: the previous group waited for its consumption)
   for (auto &o : K->ops) {
     if (!o.send) continue;
-    std::unique_lock<std::mutex> lk(H->mu);
     gvt_hip_hub::Slot &s = H->slots[(size_t)o.peer * W + me];
-    if (!H->cv.wait_for(lk, std::chrono::milliseconds(K->deadline_ms), [&] { return s.state == 0 || H->aborted; })) { lk.unlock(); return comm_timed_out(K, "a free send slot (in-process transport)", nullptr); }
-    if (H->aborted) { set_error("hub: aborted"); K->dead = true; return GVT_HIP_ERR_TIMEOUT; }
+    if (!hub_await(H, s.state, 0, K->deadline_ms)) return gone("a free send slot (in-process transport)");
     if (!s.ready) { hipEventCreateWithFlags(&s.ready, hipEventDisableTiming); hipEventCreateWithFlags(&s.copied, hipEventDisableTiming); }
     HIPCHK(hipEventRecord(s.ready, K->stream));
-    s.ptr = o.ptr; s.bytes = o.bytes; s.state = 1;
-    lk.unlock();
-    H->cv.notify_all();
+    s.ptr = o.ptr; s.bytes = o.bytes;
+    s.state.store(1, std::memory_order_release);
   }
   // 2. every receive: wait for the matching send, copy behind its event
   for (auto &o : K->ops) {
     if (o.send) continue;
-    std::unique_lock<std::mutex> lk(H->mu);
     gvt_hip_hub::Slot &s = H->slots[(size_t)me * W + o.peer];
-    if (!H->cv.wait_for(lk, std::chrono::milliseconds(K->deadline_ms), [&] { return s.state == 1 || H->aborted; })) { lk.unlock(); return comm_timed_out(K, "a peer's matching send (in-process transport)", nullptr); }
-    if (H->aborted) { set_error("hub: aborted"); K->dead = true; return GVT_HIP_ERR_TIMEOUT; }
-    if (s.bytes != o.bytes) { set_error("hub: rank %d expects %zu bytes from %d, which sends %zu", me, o.bytes, o.peer, s.bytes); H->aborted = true; H->cv.notify_all(); return GVT_HIP_ERR_INVALID; }
+    if (!hub_await(H, s.state, 1, K->deadline_ms)) return gone("a peer's matching send (in-process transport)");
+    if (s.bytes != o.bytes) { set_error("hub: rank %d expects %zu bytes from %d, which sends %zu", me, o.bytes, o.peer, s.bytes); H->aborted.store(true); return GVT_HIP_ERR_INVALID; }
     HIPCHK(hipStreamWaitEvent(K->stream, s.ready, 0));
     if (o.bytes) {
       if (o.accumulate) k_add_f32<<<(unsigned)((o.bytes / 16 + 255) / 256), 256, 0, K->stream>>>((float *)o.ptr, (const float *)s.ptr, o.bytes / 16);
       else HIPCHK(hipMemcpyAsync(o.ptr, s.ptr, o.bytes, hipMemcpyDeviceToDevice, K->stream));
     }
     HIPCHK(hipEventRecord(s.copied, K->stream));
-    s.state = 2;
-    lk.unlock();
-    H->cv.notify_all();
+    s.state.store(2, std::memory_order_release);
   }
   // 3. own sends consumed: later work on this stream must not overwrite a buffer that is still being read
   for (auto &o : K->ops) {
     if (!o.send) continue;
-    std::unique_lock<std::mutex> lk(H->mu);
     gvt_hip_hub::Slot &s = H->slots[(size_t)o.peer * W + me];
-    if (!H->cv.wait_for(lk, std::chrono::milliseconds(K->deadline_ms), [&] { return s.state == 2 || H->aborted; })) { lk.unlock(); return comm_timed_out(K, "a peer to take a send (in-process transport)", nullptr); }
-    if (H->aborted) { set_error("hub: aborted"); K->dead = true; return GVT_HIP_ERR_TIMEOUT; }
+    if (!hub_await(H, s.state, 2, K->deadline_ms)) return gone("a peer to take a send (in-process transport)");
     HIPCHK(hipStreamWaitEvent(K->stream, s.copied, 0));
-    s.state = 0;
-    lk.unlock();
-    H->cv.notify_all();
+    s.state.store(0, std::memory_order_release);
   }
   K->ops.clear();
   return 0;
@@ -377,12 +382,38 @@ namespace {
 
 // sizes[i] = *count_ptr[i]; the announce row for every peer; totals (2 x u64) and flags copied next to them so that ONE device-to-host
 // copy carries everything the host needs from a round
-__global__ void k_round_report(unsigned *const *__restrict__ count_ptr, const int *__restrict__ owner, int n_inst, int rank, int world,
+// scan_fb (exchanging ranks): the launch has many blocks; every block first folds its share of the framebuffer into the rectangle of the
+// pixels that hold a deposit (every deposit adds 1.0 to alpha, IceTComposite::localAdd; deposits only ever add pixels within a frame,
+// so the rectangle accumulates from k_zero_totals on), takes a ticket, and the LAST block to arrive writes the report -- one launch where
+// there were three (k_bbox_init, k_fb_bbox, k_round_report).
+__global__ __launch_bounds__(256) void k_round_report(unsigned *const *__restrict__ count_ptr, const int *__restrict__ owner, int n_inst, int rank, int world,
                                unsigned *sizes, int *__restrict__ ann /* [world][ANN_HEAD + n_inst] */, unsigned *counters,
-                               const unsigned *__restrict__ overflow, unsigned *tail /* sizes + n_inst: tot[4], ovf trav, ovf queue, bbox[4] */,
-                               const int *__restrict__ bbox, int chain_end = 0, const unsigned char *__restrict__ chain_mask = nullptr,
-                               unsigned *host_report = nullptr, unsigned host_seq = 0u, int err_code = 0, int tick = 0) {
+                               unsigned *overflow /* [0] flags, [4..7] rectangle, [10] this kernel's ticket */, unsigned *tail /* sizes + n_inst: tot[4], ovf trav, ovf queue, bbox[4] */,
+                               int *bbox, int chain_end = 0, const unsigned char *__restrict__ chain_mask = nullptr,
+                               unsigned *host_report = nullptr, unsigned host_seq = 0u, int err_code = 0, int tick = 0, const float4 *__restrict__ scan_fb = nullptr,
+                               int fb_w = 0, int fb_h = 0) {
   __shared__ unsigned long long sh_out, sh_local;
+  if (scan_fb) {
+    __shared__ int sh_bb[4];
+    __shared__ unsigned sh_ticket;
+    if (threadIdx.x == 0) { sh_bb[0] = fb_w; sh_bb[1] = fb_h; sh_bb[2] = 0; sh_bb[3] = 0; }
+    __syncthreads();
+    const unsigned n_pix = (unsigned)(fb_w * fb_h);
+    int x0 = fb_w, y0 = fb_h, x1 = 0, y1 = 0;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += gridDim.x * blockDim.x)
+      if (scan_fb[i].w > 0.f) { const int x = (int)(i % (unsigned)fb_w), y = (int)(i / (unsigned)fb_w); x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x + 1); y1 = max(y1, y + 1); }
+    if (x1 > x0) { atomicMin(&sh_bb[0], x0); atomicMin(&sh_bb[1], y0); atomicMax(&sh_bb[2], x1); atomicMax(&sh_bb[3], y1); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (sh_bb[2] > sh_bb[0]) { atomicMin(&bbox[0], sh_bb[0]); atomicMin(&bbox[1], sh_bb[1]); atomicMax(&bbox[2], sh_bb[2]); atomicMax(&bbox[3], sh_bb[3]); }
+      __threadfence();
+      sh_ticket = atomicAdd(&overflow[10], 1u);
+    }
+    __syncthreads();
+    if (sh_ticket != gridDim.x - 1) return; // not the last block
+    __threadfence();
+    if (threadIdx.x == 0) overflow[10] = 0u; // for the next report
+  }
   if (threadIdx.x == 0) { sh_out = 0; sh_local = 0; }
   if (chain_end) { // the launch chain in front left its k_wave_end to this kernel: last pass's shadow rays into the frame total, traced queues cleared
     if (threadIdx.x == 0) { unsigned long long *tot = (unsigned long long *)(counters + 16); tot[1] += counters[1]; }
@@ -397,6 +428,8 @@ __global__ void k_round_report(unsigned *const *__restrict__ count_ptr, const in
   }
   __syncthreads();
   const int row = ANN_HEAD + n_inst;
+  int bb[4];
+  for (int k = 0; k < 4; k++) bb[k] = __hip_atomic_load(&bbox[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int p = threadIdx.x; p < world; p += blockDim.x) {
     unsigned rays = 0, queues = 0;
     for (int i = 0; i < n_inst; i++) {
@@ -408,15 +441,16 @@ __global__ void k_round_report(unsigned *const *__restrict__ count_ptr, const in
     ann[p * row + 1] = (int)(rays * 80u + queues * 8u); // SendRays: packed rays + {queue number, ray count} per queue (:397-407)
     ann[p * row + 2] = (int)sh_out;
     ann[p * row + 3] = (int)sh_local;
-    for (int k = 0; k < 4; k++) ann[p * row + 4 + k] = bbox[k];
+    for (int k = 0; k < 4; k++) ann[p * row + 4 + k] = bb[k];
     ann[p * row + 8] = err_code;
     ann[p * row + 9] = tick;
   }
   if (threadIdx.x == 0) {
     tail[0] = counters[16]; tail[1] = counters[17]; tail[2] = counters[18]; tail[3] = counters[19];
-    tail[4] = counters[8]; tail[5] = *overflow;
-    for (int k = 0; k < 4; k++) tail[6 + k] = (unsigned)bbox[k];
+    tail[4] = counters[8]; tail[5] = overflow[0];
+    for (int k = 0; k < 4; k++) tail[6 + k] = (unsigned)bb[k];
     tail[10] = counters[9]; // packets handed over by k_packet
+    counters[0] = 0u;       // the work counter of the next small chain (k_finish starts from 0 without a memset in front)
   }
   if (host_report) { // one rank: the report goes straight into the host's pinned copy, the sequence word last -- the host polls it
     __syncthreads(); // instead of a device-to-host copy + a stream synchronisation (an interrupt and a wake-up per round)
@@ -433,47 +467,75 @@ __global__ void k_zero_counts(unsigned *const *__restrict__ count_ptr, const uns
   if (i < n_inst && (!mask || mask[i])) *count_ptr[i] = 0u;
 }
 
-// wire image of one queue: [int32 queueId][int32 nRays][nRays x 80-byte Ray] (DomainTracer.h:441-455); one thread per dword
-__global__ __launch_bounds__(256) void k_pack_wire(RayPlanes q, unsigned n, int qid, unsigned *__restrict__ dst) {
-  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned long long total = 2ull + 20ull * n;
-  if (t >= total) return;
-  if (t < 2) { dst[t] = t == 0 ? (unsigned)qid : n; return; }
-  const unsigned long long d = t - 2;
-  const unsigned ray = (unsigned)(d / 20), w = (unsigned)(d % 20);
-  unsigned v = 0;
+// wire image of one queue: [int32 queueId][int32 nRays][nRays x 80-byte Ray] (DomainTracer.h:441-455); one thread per dword.  ALL queues
+// of a tick -- every peer, every queue -- go through ONE launch: the items travel by value in the kernel's arguments (<= WIRE_MAX per
+// launch), a thread finds its item by its dword number.
+#define WIRE_MAX 48
+struct WireItem {
+  float4 *planes;            // the queue
+  unsigned long long cap;
+  unsigned *count;
+  unsigned *buf;             // the item's wire image (header first)
+  unsigned n;                // rays
+  int qid;
+  unsigned dword0;           // number of this item's first dword in the launch
+  unsigned prior;            // unpack: rays of earlier items of this launch that go to the same queue
+};
+struct WireBatch {
+  int n_items;
+  unsigned total;            // dwords of the launch
+  WireItem it[WIRE_MAX];
+};
+__device__ inline int wire_item_of(const WireBatch &B, unsigned t) {
+  int lo = 0, hi = B.n_items - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (B.it[mid].dword0 <= t) lo = mid; else hi = mid - 1; }
+  return lo;
+}
+// pack: also the sender's q.second.clear() (:455) -- the queue's count word is reset by the item's first thread (nothing reads it here: n comes from the host)
+__global__ __launch_bounds__(256) void k_pack_all(const WireBatch B) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B.total) return;
+  const WireItem &I = B.it[wire_item_of(B, t)];
+  const unsigned l = t - I.dword0;
+  if (l == 0) *I.count = 0u;
+  if (l < 2) { I.buf[l] = l == 0 ? (unsigned)I.qid : I.n; return; }
+  const unsigned d = l - 2, ray = d / 20u, w = d % 20u;
+  const RayPlanes q = make_planes(I.planes, I.cap);
+  unsigned v;
   if (w < 16) { const float4 *pl = w < 4 ? q.p0 : w < 8 ? q.p1 : w < 12 ? q.p2 : q.p3; v = ((const unsigned *)(pl + ray))[w & 3]; }
   else if (w == 16) v = q.p4[ray];
   else v = q.p5[3 * (size_t)ray + (w - 17)]; // the known-miss list travels with the ray (bytes 68..79)
-  dst[t] = v;
+  I.buf[l] = v;
 }
-// the reverse, appended behind the queue's current rays (its count word is advanced by k_add_count afterwards)
-__global__ __launch_bounds__(256) void k_unpack_wire(const unsigned *__restrict__ src, unsigned n, int qid, RayPlanes q, unsigned long long cap,
-                                                      const unsigned *__restrict__ count, unsigned *__restrict__ err) {
-  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0 && (src[0] != (unsigned)qid || src[1] != n)) atomicOr(err, 2u); // in-band header disagrees with the announce
-  if (t >= 20ull * n) return;
-  const unsigned ray = (unsigned)(t / 20), w = (unsigned)(t % 20);
-  const unsigned long long slot = (unsigned long long)*count + ray;
-  if (slot >= cap) { atomicOr(err, 1u); return; }
-  const unsigned v = src[2 + t];
-  if (w < 16) { float4 *pl = w < 4 ? q.p0 : w < 8 ? q.p1 : w < 12 ? q.p2 : q.p3; ((unsigned *)(pl + slot))[w & 3] = v; }
-  else if (w == 16) q.p4[slot] = v;
-  else q.p5[3 * (size_t)slot + (w - 17)] = v;
-}
-// bounding rectangle (x0, y0, x1, y1 exclusive) of the pixels that hold a deposit (every deposit adds 1.0 to alpha, IceTComposite::localAdd)
-__global__ void k_bbox_init(int *bbox, int W, int H) { if (!blockIdx.x && !threadIdx.x) { bbox[0] = W; bbox[1] = H; bbox[2] = 0; bbox[3] = 0; } }
-__global__ __launch_bounds__(256) void k_fb_bbox(const float4 *__restrict__ fb, int W, int H, int *__restrict__ bbox) {
-  __shared__ int sh[4];
-  if (threadIdx.x == 0) { sh[0] = W; sh[1] = H; sh[2] = 0; sh[3] = 0; }
-  __syncthreads();
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (unsigned)(W * H) && fb[i].w > 0.f) {
-    const int x = (int)(i % (unsigned)W), y = (int)(i / (unsigned)W);
-    atomicMin(&sh[0], x); atomicMin(&sh[1], y); atomicMax(&sh[2], x + 1); atomicMax(&sh[3], y + 1);
+// unpack: appended behind the queue's current rays.  Every thread reads the queue's count word as its base; the LAST block of the
+// launch to finish (ticket) -- every other block has read its bases by then -- advances the count words.
+__global__ __launch_bounds__(256) void k_unpack_all(const WireBatch B, unsigned *__restrict__ err, unsigned *ticket) {
+  __shared__ unsigned sh_ticket;
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < B.total) {
+    const WireItem &I = B.it[wire_item_of(B, t)];
+    const unsigned l = t - I.dword0;
+    if (l < 2) { if (I.buf[l] != (l == 0 ? (unsigned)I.qid : I.n)) atomicOr(err, 2u); } // in-band header disagrees with the announce
+    else {
+      const unsigned d = l - 2, ray = d / 20u, w = d % 20u;
+      const unsigned long long slot = (unsigned long long)__hip_atomic_load(I.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + I.prior + ray;
+      if (slot >= I.cap) atomicOr(err, 1u);
+      else {
+        const RayPlanes q = make_planes(I.planes, I.cap);
+        const unsigned v = I.buf[l];
+        if (w < 16) { float4 *pl = w < 4 ? q.p0 : w < 8 ? q.p1 : w < 12 ? q.p2 : q.p3; ((unsigned *)(pl + slot))[w & 3] = v; }
+        else if (w == 16) q.p4[slot] = v;
+        else q.p5[3 * (size_t)slot + (w - 17)] = v;
+      }
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0 && sh[2] > sh[0]) { atomicMin(&bbox[0], sh[0]); atomicMin(&bbox[1], sh[1]); atomicMax(&bbox[2], sh[2]); atomicMax(&bbox[3], sh[3]); }
+  if (threadIdx.x == 0) { __threadfence(); sh_ticket = atomicAdd(ticket, 1u); }
+  __syncthreads();
+  if (sh_ticket != gridDim.x - 1) return;
+  __threadfence();
+  for (int k = threadIdx.x; k < B.n_items; k += blockDim.x) atomicAdd(B.it[k].count, B.it[k].n);
+  if (threadIdx.x == 0) *ticket = 0u;
 }
 // rectangle of the framebuffer <-> contiguous buffer (float4 pixels); ADD: buffer added into the framebuffer
 template <bool ADD> __global__ __launch_bounds__(256) void k_rect(float4 *__restrict__ fb, int W, int x0, int y0, int w, int h, float4 *__restrict__ buf) {
@@ -483,8 +545,13 @@ template <bool ADD> __global__ __launch_bounds__(256) void k_rect(float4 *__rest
   if (ADD) { float4 a = fb[px]; const float4 b = buf[i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; fb[px] = a; }
   else buf[i] = fb[px];
 }
-__global__ void k_add_count(unsigned *count, unsigned n) { if (!blockIdx.x && !threadIdx.x) *count += n; }
-__global__ void k_zero_totals(unsigned *c, unsigned *ovf) { if (!blockIdx.x && threadIdx.x < 4) c[16 + threadIdx.x] = 0u; if (!blockIdx.x && threadIdx.x == 4) { *ovf = 0u; c[9] = 0u; } }
+// start of a frame: ray totals, flags, the work counter of the first small chain, the deposit rectangle (empty) and the kernels' tickets
+__global__ void k_zero_totals(unsigned *c, unsigned *ovf, int fb_w, int fb_h) {
+  if (blockIdx.x) return;
+  if (threadIdx.x < 4) c[16 + threadIdx.x] = 0u;
+  if (threadIdx.x == 4) { *ovf = 0u; c[9] = 0u; c[0] = 0u; ovf[10] = 0u; ovf[11] = 0u; }
+  if (threadIdx.x == 5) { int *bb = (int *)(ovf + 4); bb[0] = fb_w; bb[1] = fb_h; bb[2] = 0; bb[3] = 0; }
+}
 } // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -537,7 +604,7 @@ extern "C" void gvt_hip_tracer_destroy(gvt_hip_tracer *R) {
   for (auto q : R->queues) gvt_hip_queue_destroy(q);
   gvt_hip_queue_destroy(R->q_moved);
   hipFree(R->d_insts); hipFree(R->d_round); hipHostFree(R->h_round); hipFree(R->d_count_ptr); hipFree(R->d_owner);
-  hipFree(R->d_report); hipHostFree(R->h_report); hipFree(R->d_ann_out); hipFree(R->d_ann_in); hipHostFree(R->h_ann_in);
+  hipFree(R->d_ann_out); hipFree(R->d_ann_in); hipHostFree(R->h_ann_in); // (d_report / h_report live behind the announces)
   hipFree(R->d_overflow);
   for (void *p : R->send_buf) hipFree(p);
   for (void *p : R->recv_buf) hipFree(p);
@@ -550,16 +617,20 @@ static int tracer_alloc_tables(gvt_hip_tracer *R) {
   const size_t row = ANN_HEAD + R->n_inst;
   hipFree(R->d_ann_out); hipFree(R->d_ann_in); hipHostFree(R->h_ann_in);
   R->d_ann_out = R->d_ann_in = R->h_ann_in = nullptr;
+  // the peers' announces as received and, right behind them, this rank's report: one device block, one pinned mirror, one copy per tick
+  const size_t view = sizeof(int) * W * row + sizeof(unsigned) * (n + REPORT_TAIL);
   HIPCHK(hipMalloc((void **)&R->d_ann_out, sizeof(int) * W * row));
-  HIPCHK(hipMalloc((void **)&R->d_ann_in, sizeof(int) * W * row));
-  HIPCHK(hipHostMalloc((void **)&R->h_ann_in, sizeof(int) * W * row, hipHostMallocDefault));
-  HIPCHK(hipMemset(R->d_ann_in, 0, sizeof(int) * W * row));
-  std::memset(R->h_ann_in, 0, sizeof(int) * W * row);
+  HIPCHK(hipMalloc((void **)&R->d_ann_in, view));
+  HIPCHK(hipHostMalloc((void **)&R->h_ann_in, view, hipHostMallocDefault));
+  HIPCHK(hipMemset(R->d_ann_in, 0, view));
+  std::memset(R->h_ann_in, 0, view);
+  R->d_report = (unsigned *)(R->d_ann_in + W * row);
+  R->h_report = (unsigned *)(R->h_ann_in + W * row);
+  R->report_seq = 0;
   for (void *p : R->send_buf) hipFree(p);
   for (void *p : R->recv_buf) hipFree(p);
   R->send_buf.assign(W, nullptr); R->recv_buf.assign(W, nullptr);
   R->send_cap.assign(W, 0); R->recv_cap.assign(W, 0);
-  (void)n;
   return 0;
 }
 
@@ -603,8 +674,6 @@ extern "C" gvt_hip_tracer *gvt_hip_tracer_create(gvt_hip_top *T, gvt_hip_mesh *c
   ok = ok && hipMalloc((void **)&R->d_insts, sizeof(WaveInst) * n1) == hipSuccess && hipMalloc(&R->d_round, R->round_bytes) == hipSuccess &&
        hipHostMalloc(&R->h_round, R->round_bytes, hipHostMallocDefault) == hipSuccess &&
        hipMalloc((void **)&R->d_count_ptr, sizeof(unsigned *) * n1) == hipSuccess && hipMalloc((void **)&R->d_owner, sizeof(int) * n1) == hipSuccess &&
-       hipMalloc((void **)&R->d_report, sizeof(unsigned) * (n1 + REPORT_TAIL)) == hipSuccess &&
-       hipHostMalloc((void **)&R->h_report, sizeof(unsigned) * (n1 + REPORT_TAIL), hipHostMallocDefault) == hipSuccess && std::memset(R->h_report, 0, sizeof(unsigned) * (n1 + REPORT_TAIL)) &&
        hipMalloc((void **)&R->d_overflow, 64) == hipSuccess;
   if (ok) {
     R->h_segs = (WaveSeg *)R->h_round; R->d_segs = (WaveSeg *)R->d_round;
@@ -728,9 +797,7 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
   WaveSet W{ R->d_segs, R->d_insts, n_seg, R->all_quad ? 1 : 0, (int)nI };
   if (C.finish_rays > 0 && N <= (size_t)C.finish_rays && P.sink.fb && !count_on_device && !exact) {
     // a small round: ONE launch follows every ray to its end on this rank (finish_kernel.inc); what remains are rays in other ranks' queues
-    if ((rc = finish_round(W, N, P, R->lights.data(), R->d_qdesc, R->d_owner, R->world > 1 ? R->rank : -1, R->d_overflow))) return rc;
-    k_zero_counts<<<(unsigned)((nI + 255) / 256), 256, 0, st>>>(R->d_count_ptr, R->d_mask, (int)nI); // the traced queues' clear()
-    HIPCHK(hipGetLastError());
+    if ((rc = finish_round(W, N, P, R->lights.data(), R->d_qdesc, R->d_owner, R->world > 1 ? R->rank : -1, R->d_overflow, R->d_count_ptr, R->d_mask))) return rc; // (+ the traced queues' clear())
     if (chains) (*chains)++;
     return 0;
   }
@@ -764,19 +831,21 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_e
   hipStream_t st = C.stream;
   int *d_bbox = (int *)(R->d_overflow + 4);
   const bool poll = !(exchange && R->world > 1) && C.report_poll;
+  const bool timing = C.frame_timing != 0; // the per-phase breakdown of gvt_hip_frame_stats costs five event calls per tick: on request only
   int rc_wait = 0;
-  if (exchange && R->world > 1) { // the rectangle this rank's deposits lie in, for the composite: carried by the announce
-    k_bbox_init<<<1, 64, 0, st>>>(d_bbox, R->fb->w, R->fb->h);
-    k_fb_bbox<<<(unsigned)(((size_t)R->fb->w * R->fb->h + 255) / 256), 256, 0, st>>>((const float4 *)R->fb->d_rgba, R->fb->w, R->fb->h, d_bbox);
-  }
-  k_round_report<<<1, 256, 0, st>>>(R->d_count_ptr, R->d_owner, (int)nI, R->rank, R->world, R->d_report, R->d_ann_out, C.d_counters, R->d_overflow,
-                                    R->d_report + nI, d_bbox, chain_end ? 1 : 0, R->d_mask, poll ? R->h_report : nullptr, poll ? ++R->report_seq : 0u, err_code, tick);
+  // exchanging ranks: the rectangle this rank's deposits lie in (for the composite, carried by the announce) is folded into the same
+  // launch -- many blocks scan the framebuffer, the last one to finish writes the report
+  const bool scan = exchange && R->world > 1;
+  const unsigned n_blk = scan ? (unsigned)std::min<size_t>(1024, ((size_t)R->fb->w * R->fb->h + 1023) / 1024) : 1u;
+  k_round_report<<<n_blk, 256, 0, st>>>(R->d_count_ptr, R->d_owner, (int)nI, R->rank, R->world, R->d_report, R->d_ann_out, C.d_counters, R->d_overflow,
+                                        R->d_report + nI, d_bbox, chain_end ? 1 : 0, R->d_mask, poll ? R->h_report : nullptr, poll ? ++R->report_seq : 0u, err_code, tick,
+                                        scan ? (const float4 *)R->fb->d_rgba : nullptr, R->fb->w, R->fb->h);
   HIPCHK(hipGetLastError());
   if (exchange && R->world > 1) {
     gvt_hip_comm *K = R->comm;
     HIPCHK(hipEventRecord(R->ev_compute, st)); // (timing event: the end of this tick's local chain)
     HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0));
-    HIPCHK(hipEventRecord(R->ev_ann0, K->stream));
+    if (timing) HIPCHK(hipEventRecord(R->ev_ann0, K->stream));
     comm_group_begin(K);
     for (int p = 0; p < R->world; p++) {
       if (p == R->rank) continue;
@@ -785,8 +854,9 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_e
     }
     int rc = comm_group_end(K);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(R->h_ann_in, R->d_ann_in, sizeof(int) * R->world * row, hipMemcpyDeviceToHost, K->stream));
-    HIPCHK(hipMemcpyAsync(R->h_report, R->d_report, sizeof(unsigned) * (nI + REPORT_TAIL - 1), hipMemcpyDeviceToHost, K->stream)); // (the last word is the polled reports' sequence number)
+    // ONE copy brings the peers' announces and this rank's report (adjacent on both sides, tracer_alloc_tables; the report's last word is
+    // the polled reports' sequence number and stays the host's)
+    HIPCHK(hipMemcpyAsync(R->h_ann_in, R->d_ann_in, sizeof(int) * R->world * row + sizeof(unsigned) * (nI + REPORT_TAIL - 1), hipMemcpyDeviceToHost, K->stream));
     HIPCHK(hipEventRecord(R->ev_report, K->stream));
     { // bounded: a peer that never joins the exchange must not hang this rank
       char diag[256];
@@ -794,7 +864,7 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_e
                     (size_t)R->last_local_pending, err_code, nI ? R->h_report[0] : 0u);
       if ((rc_wait = bounded_event_wait(K, R->ev_report, "the announce exchange", diag))) return rc_wait;
     }
-    if (S) { // phase times of this tick (all three events are complete now)
+    if (S && timing) { // phase times of this tick (all three events are complete now)
       float ms = 0.f;
       if (R->chain_timed && hipEventElapsedTime(&ms, R->ev_chain0, R->ev_compute) == hipSuccess) S->ms_chain += ms;
       if (hipEventElapsedTime(&ms, R->ev_ann0, R->ev_report) == hipSuccess) S->ms_announce += ms;
@@ -863,7 +933,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   if (!lean) {
     if ((rc = gvt_hip_fb_clear(R->fb))) return rc;
     if (nI) k_zero_counts<<<(unsigned)((nI + 255) / 256), 256, 0, st>>>(R->d_count_ptr, nullptr, (int)nI); // every queue.clear() in one launch
-    k_zero_totals<<<1, 64, 0, st>>>(C.d_counters, R->d_overflow);
+    k_zero_totals<<<1, 64, 0, st>>>(C.d_counters, R->d_overflow, R->fb->w, R->fb->h);
   }
   if (one_shot) {
     const size_t n_cam = (size_t)R->cam.width * R->cam.height * R->cam.samples * R->cam.samples;
@@ -893,9 +963,29 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   bool payload_pending = false;
   std::vector<int> pending_ann; // the announces the payload in flight was posted from
 
+  // ALL queues of a tick's payload through ONE pack / unpack launch (the items by value in the kernel arguments, <= WIRE_MAX per launch)
+  auto wire_flush = [&](WireBatch &B, bool unpack) -> int {
+    if (!B.n_items) return 0;
+    if (unpack) k_unpack_all<<<(B.total + 255) / 256, 256, 0, st>>>(B, R->d_overflow, R->d_overflow + 11);
+    else k_pack_all<<<(B.total + 255) / 256, 256, 0, st>>>(B);
+    HIPCHK(hipGetLastError());
+    B.n_items = 0; B.total = 0;
+    return 0;
+  };
+  auto wire_add = [&](WireBatch &B, bool unpack, gvt_hip_queue *q, void *buf, unsigned n, int qid) -> int {
+    if (B.n_items == WIRE_MAX || (unsigned long long)B.total + 2ull + 20ull * n > 0xf0000000ull) { int rc_ = wire_flush(B, unpack); if (rc_) return rc_; }
+    WireItem &I = B.it[B.n_items];
+    I.planes = q->d_planes; I.cap = q->cap; I.count = q->d_count; I.buf = (unsigned *)buf; I.n = n; I.qid = qid; I.dword0 = B.total; I.prior = 0u;
+    if (unpack) for (int k = 0; k < B.n_items; k++) if (B.it[k].qid == qid) I.prior += B.it[k].n;
+    B.n_items++; B.total += 2u + 20u * n;
+    return 0;
+  };
   auto unpack_pending = [&]() -> int { // (2): append what the last exchange delivered, behind its event
     if (!payload_pending) return 0;
     HIPCHK(hipStreamWaitEvent(st, R->ev_recv, 0));
+    WireBatch B;
+    B.n_items = 0; B.total = 0;
+    int rc_;
     for (int p = 0; p < R->world; p++) {
       if (p == R->rank) continue;
       const int *a = pending_ann.data() + (size_t)p * row;
@@ -903,15 +993,11 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
       for (size_t i = 0; i < nI; i++) {
         const unsigned n = (unsigned)a[ANN_HEAD + i];
         if (!n) continue;
-        gvt_hip_queue *q = R->queues[i];
-        const unsigned long long dwords = 20ull * n;
-        k_unpack_wire<<<(unsigned)((dwords + 255) / 256), 256, 0, st>>>((const unsigned *)((const char *)R->recv_buf[p] + off), n, (int)i,
-                                                                        make_planes(q->d_planes, q->cap), q->cap, q->d_count, R->d_overflow);
-        k_add_count<<<1, 64, 0, st>>>(q->d_count, n);
+        if ((rc_ = wire_add(B, true, R->queues[i], (char *)R->recv_buf[p] + off, n, (int)i))) return rc_;
         off += 8 + 80ull * n;
       }
     }
-    HIPCHK(hipGetLastError());
+    if ((rc_ = wire_flush(B, true))) return rc_;
     payload_pending = false;
     for (size_t i = 0; i < nI; i++) { R->present[i] += incoming[i]; R->queues[i]->size = R->present[i]; incoming[i] = 0; } // exact: announced per queue
     return 0;
@@ -942,7 +1028,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   int tick = 0;
   for (;; tick++) {
     // (1) local work: one merged chain (asynchronous ticks), or chains until the local queues are dry (BSP rounds / one rank)
-    if (multi && R->world > 1) { HIPCHK(hipEventRecord(R->ev_chain0, st)); R->chain_timed = true; }
+    if (multi && R->world > 1 && C.frame_timing) { HIPCHK(hipEventRecord(R->ev_chain0, st)); R->chain_timed = true; }
     if (C.inject_fail_tick == tick && multi) { set_error("injected failure at exchange %d (test knob inject_fail_tick)", tick); failed(GVT_HIP_ERR_CAPACITY); }
     if (R->world == 1 || bsp) {
       if (!local_err && failed(unpack_pending()) && !multi) return local_err;
@@ -982,6 +1068,8 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     gvt_hip_comm *K = R->comm;
     bool any_traffic = false;
     std::vector<size_t> bytes_out(R->world, 0), bytes_in(R->world, 0);
+    WireBatch PB;
+    PB.n_items = 0; PB.total = 0;
     for (int p = 0; p < R->world; p++) {
       if (p == R->rank) continue;
       for (size_t i = 0; i < nI; i++) if (R->owner[i] == p && R->present[i]) bytes_out[p] += 8 + 80 * R->present[i];
@@ -996,16 +1084,14 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
         if (R->owner[i] != p || !R->present[i]) continue;
         gvt_hip_queue *q = R->queues[i];
         const unsigned n = (unsigned)R->present[i];
-        const unsigned long long dwords = 2ull + 20ull * n;
-        k_pack_wire<<<(unsigned)((dwords + 255) / 256), 256, 0, st>>>(make_planes(q->d_planes, q->cap), n, (int)i, (unsigned *)((char *)R->send_buf[p] + off));
+        if ((rc = wire_add(PB, false, q, (char *)R->send_buf[p] + off, n, (int)i))) return rc;
         off += 8 + 80ull * n;
         S.rays_sent += n;
-        R->present[i] = 0; q->size = 0; // the sender's q.second.clear() (:455)
-        HIPCHK(hipMemsetAsync(q->d_count, 0, sizeof(unsigned), st));
+        R->present[i] = 0; q->size = 0; // the sender's q.second.clear() (:455): the count word is reset by k_pack_all
       }
       any_traffic = any_traffic || bytes_out[p] || bytes_in[p];
     }
-    HIPCHK(hipGetLastError());
+    if ((rc = wire_flush(PB, false))) return rc;
     pending_ann.assign(R->h_ann_in, R->h_ann_in + (size_t)R->world * row);
     for (int p = 0; p < R->world; p++)
       if (p != R->rank)
@@ -1016,7 +1102,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
         if (incoming[i] && (rc = queue_reserve(R->queues[i], R->present[i] + incoming[i]))) return rc;
       HIPCHK(hipEventRecord(R->ev_pack, st));
       HIPCHK(hipStreamWaitEvent(K->stream, R->ev_pack, 0));
-      HIPCHK(hipEventRecord(R->ev_pay0, K->stream)); R->payload_timed = true;
+      if (C.frame_timing) { HIPCHK(hipEventRecord(R->ev_pay0, K->stream)); R->payload_timed = true; }
       comm_group_begin(K); // sizes are known on both sides from the announces: no size handshake on the wire
       for (int p = 0; p < R->world; p++) {
         if (p == R->rank) continue;
@@ -1036,7 +1122,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   if (R->world > 1 && !(flags & GVT_HIP_FRAME_NO_COMPOSITE)) {
     gvt_hip_comm *K = R->comm;
     const int W = R->fb->w;
-    HIPCHK(hipEventRecord(R->ev_comp0, st));
+    if (C.frame_timing) HIPCHK(hipEventRecord(R->ev_comp0, st));
     if (flags & GVT_HIP_FRAME_FULL_REDUCE) {
       HIPCHK(hipEventRecord(R->ev_compute, st));
       HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0));
@@ -1080,7 +1166,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     HIPCHK(hipStreamWaitEvent(st, R->ev_comm, 0));
     if ((rc = bounded_event_wait(K, R->ev_comm, "the framebuffer composite"))) return rc;
     S.host_syncs++;
-    { float ms = 0.f; if (hipEventElapsedTime(&ms, R->ev_comp0, R->ev_comm) == hipSuccess) S.ms_composite += ms; }
+    if (C.frame_timing) { float ms = 0.f; if (hipEventElapsedTime(&ms, R->ev_comp0, R->ev_comm) == hipSuccess) S.ms_composite += ms; }
   }
   if (R->comm) S.ms_host_wait = R->comm->ms_host_wait;
   const unsigned *tail = R->h_report + nI;

@@ -53,6 +53,7 @@ struct Knobs {
                          // two kernels and the round's report (8 launches per frame instead of 14)
   int skip_known = 1;    // shuffleRays' known-miss shortcut (gvt_device.h): a ray is not traced again in an instance it has already crossed without a hit
                          // on the same straight segment (image-identical; 0: the reference's hop-by-hop behaviour, same ray counts as its schedulers)
+  int frame_timing = 0;  // multi-rank frames: fill gvt_hip_frame_stats' ms_chain / ms_announce / ms_payload / ms_composite (five more event calls per exchange)
   int inject_fail_tick = -1; // tests: this rank's local work "fails" at that exchange of a multi-rank frame (the announce carries the error to every rank)
   int report_poll = 1;   // one rank: a round's report is written into pinned host memory by the kernel and polled (no copy, no stream synchronisation)
   int first_round_async = 1; // one-instance scenes on one rank: no read-back after the camera filter (the chain reads its ray count on the device)
@@ -278,7 +279,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
                      const gvt_hip_light *lights_host, const WaveSingle *single, unsigned *const *d_count_ptr, const unsigned char *d_mask, int n_inst,
                      bool defer_end = false);
 int finish_round(const WaveSet &W, size_t n_total, const TraceParams &P, const gvt_hip_light *lights_host, const void *d_qdesc, const int *d_owner, int rank,
-                 unsigned *d_queue_overflow);
+                 unsigned *d_queue_overflow, unsigned *const *d_count_ptr, const unsigned char *d_mask);
 int convert_aos_to_planes(const gvt_hip_ray *d_src, size_t n, RayPlanes dst, size_t dst_off);
 int convert_planes_to_aos(RayPlanes src, size_t src_off, size_t n, gvt_hip_ray *d_dst);
 int convert_od_to_planes(const float *d_org, const float *d_dir, size_t n, RayPlanes dst);

@@ -2011,7 +2011,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
 // everything that moves on is followed through this rank's instances; rays for other ranks' instances are appended to their queues
 // (which must have room: n_total * (1 + n_lights * depth) each), everything else ends in the framebuffer.  No shuffle follows.
 int finish_round(const WaveSet &W, size_t n_total, const TraceParams &P, const gvt_hip_light *lights_host, const void *d_qdesc, const int *d_owner, int rank,
-                 unsigned *d_queue_overflow) {
+                 unsigned *d_queue_overflow, unsigned *const *d_count_ptr, const unsigned char *d_mask) {
   Ctx &C = gctx();
   if (!n_total) return 0;
   hipStream_t st = C.stream;
@@ -2036,7 +2036,8 @@ int finish_round(const WaveSet &W, size_t n_total, const TraceParams &P, const g
   A.counter = C.d_counters + 0; A.tot = (unsigned long long *)(C.d_counters + 16);
   A.queue_overflow = d_queue_overflow; A.trav_overflow = C.d_counters + TRAV_OVF_WORD;
   A.seed = P.seed; A.index_base = 0ull; A.skip_known = C.skip_known;
-  HIPCHK(hipMemsetAsync(C.d_counters, 0, sizeof(unsigned), st));
+  A.count_ptr = d_count_ptr; A.clear_mask = d_mask; A.n_inst = W.n_inst;
+  // (the work counter is 0: the frame's start and every round's report leave it so -- k_zero_totals, k_round_report)
   {
     ProfScope ps(KC_CLOSEST);
     k_finish<<<(int)std::min<size_t>((n_total + 3) / 4, (size_t)C.n_cu * 3), 256, 0, st>>>(A); // 48 KiB of LDS per block

@@ -267,7 +267,8 @@ typedef struct gvt_hip_frame_stats {
   uint64_t rays_any;     /* ... through the any-hit kernel */
   uint64_t packets_bailed; /* 64-ray packets the packet traversal handed to the one-lane-per-ray kernels (stack / step budget) */
   uint64_t bytes_sent;   /* payload bytes this rank sent to other ranks (wire format, DomainTracer.h:441-455), composite excluded */
-  /* where a multi-rank frame's time goes (HIP events on the compute / communication streams, host clock for the waits); 0 on one rank */
+  /* where a multi-rank frame's time goes (HIP events on the compute / communication streams, host clock for the waits); 0 on one rank, and 0
+   * unless gvt_hip_set_option("frame_timing", 1): the breakdown costs five more event calls per exchange */
   double ms_chain;       /* local launch chains (incl. unpacking what arrived) */
   double ms_announce;    /* announce exchanges: group of sends / receives + the report's device-to-host copy */
   double ms_payload;     /* payload exchanges, posting to arrival (overlaps the next chain) */
