@@ -193,60 +193,57 @@ extern "C" int gvt_hip_stats_reset(void) {
   return 0;
 }
 
+// ---- tuning knobs: one table.  `shipped`: the knob is part of the product's surface -- a switch of behaviour (the reference's hop-by-hop
+// shuffle rule, the sink, the list order), a budget (memory, chunk sizes, round sizes) or a test hook.  The others have ONE measured-best
+// value (DESIGN.md / EXPERIMENTS.md); they can be moved only in the experiments build of the library (libgvt_hip_exp.so), where the knob
+// sweeps run; the shipped library answers GVT_HIP_ERR_INVALID when one of them is switched away from its default.
+namespace {
+struct KnobDef { const char *name; int Knobs::*field; int lo, hi; bool shipped; };
+const KnobDef g_knobs[] = {
+  // shipped (15)
+  { "skip_known", &Knobs::skip_known, 0, 1, true },           { "frame_timing", &Knobs::frame_timing, 0, 1, true },
+  { "term_sink", &Knobs::term_sink, 0, 1, true },             { "camera_tile", &Knobs::camera_tile, 0, 8, true },
+  { "sort_rays", &Knobs::sort_rays, 0, 1, true },             { "leaf_max", &Knobs::leaf_max, 1, 4, true },
+  { "long_steps", &Knobs::long_steps, 0, 1 << 20, true },     { "small_rays", &Knobs::small_rays, 0, 1 << 30, true },
+  { "finish_rays", &Knobs::finish_rays, 0, 1 << 30, true },   { "round_room_mb", &Knobs::round_room_mb, 0, 1 << 30, true },
+  { "abi_lanes", &Knobs::abi_lanes_n, 0, 8, true },           { "abi_chunk", &Knobs::abi_chunk, 16384, 1 << 30, true },
+  { "abi_pipe_min", &Knobs::abi_pipe_min, 0, 1 << 30, true }, { "inject_fail_tick", &Knobs::inject_fail_tick, -1, 1 << 30, true },
+  { "long_min_rays", &Knobs::long_min_rays, 0, 1 << 30, true },
+  // experiments build only: the alternative was measured and lost, or the value is a tuned constant
+  { "trav_kernel", &Knobs::trav_kernel, 0, 1, false },        { "wide4", &Knobs::wide4, 0, 1, false },
+  { "coop_fetch", &Knobs::coop_fetch, 0, 1, false },          { "fused", &Knobs::fused, 0, 1, false },
+  { "packet", &Knobs::packet, 0, 1, false },                  { "quad", &Knobs::quad, 0, 1, false },
+  { "quad_inner_min", &Knobs::quad_inner_min, 1, 16, false }, { "quad_refill_min", &Knobs::quad_refill_min, 1, 16, false },
+  { "blocks_per_cu_quad", &Knobs::blocks_per_cu_quad, 1, 8, false },
+  { "blocks_per_cu", &Knobs::blocks_per_cu, 1, 8, false },    { "blocks_per_cu_closest", &Knobs::blocks_per_cu_closest, 0, 8, false },
+  { "refill_min", &Knobs::refill_min, 1, 64, false },         { "inner_min", &Knobs::inner_min, 1, 64, false },
+  { "share", &Knobs::share, 0, 3, false },                    { "share_min_rays", &Knobs::share_min_rays, 0, 1 << 30, false },
+  { "sort_gather", &Knobs::sort_gather, 0, 1, false },        { "sort_bits", &Knobs::sort_bits, 8, 32, false },
+  { "long_steps_drain", &Knobs::long_steps_drain, 0, 1 << 20, false }, { "long_save", &Knobs::long_save, 0, 1, false },
+  { "lean_frame", &Knobs::lean_frame, 0, 1, false },          { "report_poll", &Knobs::report_poll, 0, 1, false },
+  { "first_round_async", &Knobs::first_round_async, 0, 1, false }, { "wave_single", &Knobs::wave_single, 0, 1, false },
+  { "shadow_direct", &Knobs::shadow_direct, 0, 1, false },    { "top_ordered", &Knobs::top_ordered, 0, 1, false },
+  { "top_lds", &Knobs::top_lds, 0, 1, false },
+};
+} // namespace
+
 extern "C" int gvt_hip_set_option(const char *name, int value) {
   if (!name) { set_error("set_option: null name"); return GVT_HIP_ERR_INVALID; }
-#ifndef GVT_EXPERIMENTS
-  { // the variants behind these knobs live in the experiments build only (libgvt_hip_exp.so, -DGVT_EXPERIMENTS)
-    static const struct { const char *name; int shipped; } exp_only[] = { { "trav_kernel", 1 }, { "wide4", 1 }, { "coop_fetch", 0 }, { "fused", 0 }, { "packet", 0 }, { "quad", 0 } };
-    for (const auto &e : exp_only)
-      if (!std::strcmp(name, e.name) && value != e.shipped) {
-        set_error("set_option: %s=%d needs the experiments build of the library (libgvt_hip_exp.so)", name, value);
-        return GVT_HIP_ERR_INVALID;
-      }
-  }
-#endif
-  if (!std::strcmp(name, "sort_rays")) { g_ctx.sort_rays = value; return 0; }
-  if (!std::strcmp(name, "sort_gather")) { g_ctx.sort_gather = value; return 0; }
-  if (!std::strcmp(name, "sort_bits")) { if (value < 8 || value > 32) { set_error("sort_bits must be 8..32"); return GVT_HIP_ERR_INVALID; } g_ctx.sort_bits = value; return 0; }
-  if (!std::strcmp(name, "share")) { g_ctx.share = value; return 0; }
-  if (!std::strcmp(name, "share_min_rays")) { g_ctx.share_min_rays = value < 0 ? 0 : value; return 0; }
   if (!std::strcmp(name, "defaults")) { static_cast<Knobs &>(g_ctx) = Knobs{}; return 0; }
-  if (!std::strcmp(name, "long_steps")) { g_ctx.long_steps = value < 0 ? 0 : value; return 0; }
-  if (!std::strcmp(name, "long_save")) { g_ctx.long_save = value != 0; return 0; }
-  if (!std::strcmp(name, "long_steps_drain")) { g_ctx.long_steps_drain = value < 0 ? 0 : value; return 0; }
-  if (!std::strcmp(name, "long_min_rays")) { g_ctx.long_min_rays = value < 0 ? 0 : value; return 0; }
-  if (!std::strcmp(name, "fused")) { g_ctx.fused = value; return 0; }
-  if (!std::strcmp(name, "packet")) { g_ctx.packet = value; return 0; }
-  if (!std::strcmp(name, "small_rays")) { g_ctx.small_rays = value < 0 ? 0 : value; return 0; }
-  if (!std::strcmp(name, "finish_rays")) { g_ctx.finish_rays = value < 0 ? 0 : value; return 0; }
-  if (!std::strcmp(name, "round_room_mb")) { g_ctx.round_room_mb = value < 0 ? 0 : value; return 0; }
-  if (!std::strcmp(name, "first_round_async")) { g_ctx.first_round_async = value; return 0; }
-  if (!std::strcmp(name, "lean_frame")) { g_ctx.lean_frame = value; return 0; }
-  if (!std::strcmp(name, "skip_known")) { g_ctx.skip_known = value != 0; return 0; }
-  if (!std::strcmp(name, "frame_timing")) { g_ctx.frame_timing = value != 0; return 0; }
-  if (!std::strcmp(name, "abi_lanes")) { if (value < 0 || value > 8) { set_error("abi_lanes must be 0..8"); return GVT_HIP_ERR_INVALID; } g_ctx.abi_lanes_n = value; return 0; }
-  if (!std::strcmp(name, "abi_chunk")) { if (value < 16384) { set_error("abi_chunk must be >= 16384"); return GVT_HIP_ERR_INVALID; } g_ctx.abi_chunk = value; return 0; }
-  if (!std::strcmp(name, "abi_pipe_min")) { g_ctx.abi_pipe_min = value < 0 ? 0 : value; return 0; }
-  if (!std::strcmp(name, "report_poll")) { g_ctx.report_poll = value; return 0; }
-  if (!std::strcmp(name, "inject_fail_tick")) { g_ctx.inject_fail_tick = value; return 0; }
-  if (!std::strcmp(name, "wave_single")) { g_ctx.wave_single = value; return 0; }
-  if (!std::strcmp(name, "shadow_direct")) { g_ctx.shadow_direct = value; return 0; }
-  if (!std::strcmp(name, "term_sink")) { g_ctx.term_sink = value; return 0; }
-  if (!std::strcmp(name, "camera_tile")) { if (value != 0 && value != 8) { set_error("camera_tile: 0 or 8"); return GVT_HIP_ERR_INVALID; } g_ctx.camera_tile = value; return 0; }
-  if (!std::strcmp(name, "top_ordered")) { g_ctx.top_ordered = value; return 0; }
-  if (!std::strcmp(name, "wide4")) { g_ctx.wide4 = value; return 0; }
-  if (!std::strcmp(name, "coop_fetch")) { g_ctx.coop_fetch = value; return 0; }
-  if (!std::strcmp(name, "top_lds")) { g_ctx.top_lds = value; return 0; }
-  if (!std::strcmp(name, "quad")) { g_ctx.quad = value; return 0; }
-  if (!std::strcmp(name, "leaf_max")) { if (value < 1 || value > 4) { set_error("leaf_max must be 1..4"); return GVT_HIP_ERR_INVALID; } g_ctx.leaf_max = value; return 0; }
-  if (!std::strcmp(name, "quad_inner_min")) { if (value < 1 || value > 16) { set_error("quad_inner_min must be 1..16"); return GVT_HIP_ERR_INVALID; } g_ctx.quad_inner_min = value; return 0; }
-  if (!std::strcmp(name, "quad_refill_min")) { if (value < 1 || value > 16) { set_error("quad_refill_min must be 1..16"); return GVT_HIP_ERR_INVALID; } g_ctx.quad_refill_min = value; return 0; }
-  if (!std::strcmp(name, "blocks_per_cu_quad")) { if (value < 1 || value > 8) { set_error("blocks_per_cu_quad must be 1..8"); return GVT_HIP_ERR_INVALID; } g_ctx.blocks_per_cu_quad = value; return 0; }
-  if (!std::strcmp(name, "trav_kernel")) { g_ctx.trav_kernel = value; return 0; }
-  if (!std::strcmp(name, "blocks_per_cu_closest")) { if (value < 0 || value > 8) { set_error("blocks_per_cu_closest must be 0..8"); return GVT_HIP_ERR_INVALID; } g_ctx.blocks_per_cu_closest = value; return 0; }
-  if (!std::strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 8) { set_error("blocks_per_cu must be 1..8"); return GVT_HIP_ERR_INVALID; } g_ctx.blocks_per_cu = value; return 0; }
-  if (!std::strcmp(name, "inner_min")) { if (value < 1 || value > 64) { set_error("inner_min must be 1..64"); return GVT_HIP_ERR_INVALID; } g_ctx.inner_min = value; return 0; }
-  if (!std::strcmp(name, "refill_min")) { if (value < 1 || value > 64) { set_error("refill_min must be 1..64"); return GVT_HIP_ERR_INVALID; } g_ctx.refill_min = value; return 0; }
+  for (const KnobDef &k : g_knobs) {
+    if (std::strcmp(name, k.name)) continue;
+    if (value < k.lo || value > k.hi) { set_error("set_option: %s must be %d..%d", name, k.lo, k.hi); return GVT_HIP_ERR_INVALID; }
+    if (!std::strcmp(name, "camera_tile") && value != 0 && value != 8) { set_error("camera_tile: 0 or 8"); return GVT_HIP_ERR_INVALID; }
+#ifndef GVT_EXPERIMENTS
+    if (!k.shipped && value != Knobs{}.*(k.field)) {
+      set_error("set_option: %s=%d needs the experiments build of the library (libgvt_hip_exp.so); the shipped library carries its measured-best value %d", name, value,
+                Knobs{}.*(k.field));
+      return GVT_HIP_ERR_INVALID;
+    }
+#endif
+    static_cast<Knobs &>(g_ctx).*(k.field) = value;
+    return 0;
+  }
   set_error("set_option: unknown option '%s'", name);
   return GVT_HIP_ERR_INVALID;
 }

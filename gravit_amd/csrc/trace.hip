@@ -236,6 +236,11 @@ __global__ __launch_bounds__(TRAV_BLOCK, (ANY ? KT_BLOCKS_ANY : KT_BLOCKS_CLOSES
   // dynamic ranges of `dyn` rays from the counter.  chunk is a fraction of a wave's fair share (3/8 for closest-hit launches, whose
   // per-ray cost varies most, 5/8 for any-hit; measured at 1 M rays: 96/128/160 rays -> 0.542/0.549/0.579 ms closest, 0.400/0.400/0.384
   // any), never less than one wave's width; dyn is 1/16 of the share, at least 64 (32: the counter word saturates).
+#ifdef GVT_EXPERIMENTS
+  if (!ANY && (share & 2)) LQ.steps = 0; // closest-hit drain sharing (a rejected variant) and parking both go after a launch's last rays: one at a time
+#endif
+  // (refill_min / inner_min / share stay kernel arguments in the shipped library too, although only the experiments build can move them: as
+  // compile-time constants they cost 1.5 % of the any-hit launch -- 0.3555 against 0.3500 ms, the register allocation changes)
   const unsigned n_waves_total = gridDim.x * (unsigned)(TRAV_BLOCK / 64);
   if (n_dev) n = *n_dev; // ray count produced by the previous kernel on this stream (no host round trip)
   const unsigned share_w = n / n_waves_total;

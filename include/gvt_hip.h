@@ -312,12 +312,24 @@ int gvt_hip_wide_visit_stats(gvt_hip_mesh *, const float *org, const float *dir,
  * 1 gvt_cosf(x), 2 (float)gvt_acos(sqrt(1.0 - x)) -- so that a test can compare the device's bits with the host's for the
  * functions the bounce path (EmbreeMeshAdapter.cpp:289-318) is built on. */
 int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
-/* adapter-internal tuning knobs (results never depend on them; gvt_internal.h `struct Knobs` lists them with their defaults):
- * "blocks_per_cu", "blocks_per_cu_closest", "refill_min", "inner_min", "share", "share_min_rays", "long_steps", "long_steps_drain", "long_save", "long_min_rays",
- * "sort_rays", "sort_bits", "top_ordered", "top_lds", "small_rays", "first_round_async", "wave_single", "shadow_direct", "term_sink", "camera_tile", "leaf_max";
- * ("defaults", 0) restores all of them.  The variants that were measured and lost -- "trav_kernel" = 0, "wide4" = 0, "coop_fetch", "fused", "packet", "quad"
- * -- are compiled only into the experiments build of the library (libgvt_hip_exp.so, -DGVT_EXPERIMENTS); the shipped library answers
- * GVT_HIP_ERR_INVALID when one of them is switched away from its default. */
+/* Knobs of the library (gvt_internal.h `struct Knobs` lists them with their defaults; ("defaults", 0) restores all of them).  Results never
+ * depend on them -- except "skip_known", which switches between two shuffle rules with the same image (below).  The shipped surface, 15 knobs:
+ *   behaviour    "skip_known"   1: shuffleRays' known-miss shortcut (a ray is not traced / sent again into an instance it has already crossed
+ *                               without a hit on the same straight segment; image-identical) -- 0: the reference's hop-by-hop rule, ray for ray
+ *                "term_sink"    1: gvt_hip_trace_queue_sink applies shuffleRays' terminal rule inside the kernels -- 0: every moved ray goes through the shuffle
+ *                "camera_tile"  8: camera rays listed in 8x8-pixel tiles -- 0: generateRays' pixel-major order
+ *                "sort_rays"    1: Morton-sort a list before traversal (pays on incoherent lists; off)
+ *                "frame_timing" 1: fill gvt_hip_frame_stats' per-phase milliseconds (five more event calls per exchange)
+ *   build time   "leaf_max"     triangles per leaf of meshes created afterwards (1..4, default 2)
+ *   budgets      "long_steps" / "long_min_rays"  closest hit: node steps after which a ray is parked for a whole wave (0: never), launches it applies to
+ *                "small_rays" / "finish_rays"    rounds of at most so many rays: a wave per ray / the whole round in one launch (k_finish)
+ *                "round_room_mb"                 memory a round's worst-case reservation may add before it falls back to exact growth
+ *                "abi_lanes" / "abi_chunk" / "abi_pipe_min"   gvt_hip_trace on a host RayVector: pipeline lanes (0: one shot), rays per chunk, shortest pipelined list
+ *   test hook    "inject_fail_tick"
+ * Everything else -- the tuned constants of the kernels (refill / phase thresholds, grid sizes, drain sharing ...) and the variants that were
+ * measured and lost ("trav_kernel" = 0, "wide4" = 0, "coop_fetch", "fused", "packet", "quad", merged kernels for one queue, compacted shadow
+ * slots, non-lean frames ...: EXPERIMENTS.md) -- can be moved only in the experiments build of the library (libgvt_hip_exp.so,
+ * -DGVT_EXPERIMENTS), where the knob sweeps run; the shipped library answers GVT_HIP_ERR_INVALID when one of them is switched away from its default. */
 int gvt_hip_set_option(const char *name, int value);
 /* 1 in the experiments build (every variant behind its knob), 0 in the shipped library */
 int gvt_hip_is_experiments_build(void);

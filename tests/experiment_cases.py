@@ -1,4 +1,4 @@
-"""The variants that were measured and lost still have to return the oracle's bits: this module runs against the
+"""The variants that were measured and lost (EXPERIMENTS.md) and the tuned constants of the shipped kernels still have to return the oracle's bits whatever their setting: this module runs against the
 EXPERIMENTS build of the library (libgvt_hip_exp.so, -DGVT_EXPERIMENTS), where they sit behind their knobs -- the first-version
 kernels (trav_kernel=0), the binary-node and quad-cooperative-fetch arms of k_trace (wide4=0, coop_fetch=1), k_fused, k_packet and
 k_traceq (four lanes per ray, quad=1, with its own node / leaf-block layouts).  It is not collected by `pytest tests` (the shipped
@@ -23,7 +23,11 @@ def test_this_is_the_experiments_build(hip):
     assert capi.load().gvt_hip_is_experiments_build() == 1
 
 
-@pytest.mark.parametrize("opts", [dict(trav_kernel=0), dict(wide4=0, coop_fetch=0), dict(wide4=0, coop_fetch=1, refill_min=3, inner_min=5), dict(wide4=0, sort_rays=1),
+@pytest.mark.parametrize("opts", [dict(refill_min=1, inner_min=1), dict(refill_min=64, inner_min=64), dict(blocks_per_cu=1, refill_min=8, inner_min=16), dict(sort_rays=0, top_lds=0),
+                                  dict(sort_rays=1, sort_bits=32), dict(refill_min=2, inner_min=60), dict(share=0), dict(share=3, blocks_per_cu=6, refill_min=64, share_min_rays=0),
+                                  dict(share=3, share_min_rays=0), dict(share=3, share_min_rays=0, long_steps=3, long_min_rays=0), dict(share=1, share_min_rays=0, blocks_per_cu=1),
+                                  dict(top_ordered=0), dict(leaf_max=3, share=3, share_min_rays=0), dict(sort_rays=1, sort_gather=1),
+                                  dict(trav_kernel=0), dict(wide4=0, coop_fetch=0), dict(wide4=0, coop_fetch=1, refill_min=3, inner_min=5), dict(wide4=0, sort_rays=1),
                                   dict(wide4=0, share=3, share_min_rays=0, long_steps=3, long_min_rays=0),
                                   dict(quad=1), dict(quad=1, leaf_max=4), dict(quad=1, leaf_max=1, quad_inner_min=1, quad_refill_min=1),
                                   dict(quad=1, leaf_max=3, quad_inner_min=16, quad_refill_min=16, blocks_per_cu_quad=1),
@@ -75,7 +79,9 @@ def test_quad_kernel_on_surface_meshes_and_deep_stacks(hip, name):
         hip.set_option("defaults", 0)
 
 
-@pytest.mark.parametrize("opts", [dict(packet=1), dict(packet=1, camera_tile=0), dict(first_round_async=1, packet=1), dict(fused=1), dict(quad=1, leaf_max=4),
+@pytest.mark.parametrize("opts", [dict(first_round_async=0), dict(wave_single=0), dict(shadow_direct=0), dict(small_rays=1 << 30, wave_single=0), dict(blocks_per_cu_closest=0, term_sink=0),
+                                  dict(lean_frame=0), dict(report_poll=0), dict(lean_frame=0, report_poll=0, first_round_async=0),
+                                  dict(packet=1), dict(packet=1, camera_tile=0), dict(first_round_async=1, packet=1), dict(fused=1), dict(quad=1, leaf_max=4),
                                   dict(quad=1, leaf_max=2, small_rays=0), dict(quad=1, leaf_max=4, wave_single=0, shadow_direct=0)])
 def test_round_results_do_not_depend_on_experimental_variants(hip, opts):
     for sc, mode, tol in ((config5(192, 4), NORMALS_FLAT, 1e-5), (scenes.bunny_grid_scene(width=380, height=216), NORMALS_SMOOTH, 0.0),
@@ -109,3 +115,11 @@ def test_binary_tree_and_quad_kernel_agree_with_the_default_at_one_million_trian
     assert a.tobytes() == b.tobytes(), "4-wide compressed layout and binary tree disagree"
     assert a.tobytes() == c.tobytes(), "one lane per ray and four lanes per ray disagree"
     assert (a["prim"] >= 0).sum() > 50_000
+
+
+def test_long_ray_path_variants(hip):
+    """tests/test_gpu_parity.py::test_long_ray_path_is_bit_exact with the knobs only this build can move: no saved stack (long_save = 0),
+    a lower parking threshold for draining waves (long_steps_drain)."""
+    from tests.test_gpu_parity import test_long_ray_path_is_bit_exact
+
+    test_long_ray_path_is_bit_exact(hip)

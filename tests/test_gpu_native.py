@@ -390,14 +390,18 @@ def test_top_level_bvh_with_1056_instances(hip):
     assert np.array_equal(it().framebuffer(True)[..., :3], ref[..., :3]) and it.adapter_calls == st.adapter_calls
 
 
-@pytest.mark.parametrize("opts", [dict(first_round_async=0), dict(small_rays=0), dict(small_rays=1 << 30), dict(wave_single=0), dict(shadow_direct=0),
-                                  dict(small_rays=1 << 30, wave_single=0), dict(blocks_per_cu_closest=0, term_sink=0), dict(leaf_max=4, small_rays=0), dict(lean_frame=0), dict(report_poll=0), dict(finish_rays=0), dict(round_room_mb=0), dict(round_room_mb=0, finish_rays=0, small_rays=0), dict(finish_rays=1 << 30), dict(finish_rays=1 << 30, leaf_max=4), dict(lean_frame=0, report_poll=0, first_round_async=0)])
+@pytest.mark.parametrize("opts", [dict(small_rays=0), dict(small_rays=1 << 30), dict(term_sink=0), dict(leaf_max=4, small_rays=0), dict(finish_rays=0), dict(round_room_mb=0),
+                                  dict(round_room_mb=0, finish_rays=0, small_rays=0), dict(finish_rays=1 << 30), dict(finish_rays=1 << 30, leaf_max=4), dict(skip_known=0, finish_rays=0),
+                                  dict(sort_rays=1, camera_tile=0)])
 def test_round_results_do_not_depend_on_knobs(hip, opts):
-    """The round chain's variants -- a wave per ray for small rounds, single-mesh kernels for one-queue rounds, direct-mapped shadow
-    slots, no terminal sink -- return the oracle's image on a multi-domain depth-2 frame and on config 4 (k_fused / k_packet /
-    k_traceq: tests/experiment_cases.py, against the experiments build)."""
+    """The round chain under every knob of the shipped library -- a wave per ray for small rounds or never, k_finish or rounds, exact
+    growth, no terminal sink, the reference's hop-by-hop shuffle -- returns the oracle's image on a multi-domain depth-2 frame, on config 4
+    and on a soup (the variants that lost -- merged kernels for one queue, compacted shadow slots, non-lean frames, k_fused / k_packet /
+    k_traceq -- tests/experiment_cases.py, against the experiments build)."""
     for sc, mode, tol in ((config5(192, 4), NORMALS_FLAT, 1e-5), (scenes.bunny_grid_scene(width=380, height=216), NORMALS_SMOOTH, 0.0),
                           (scenes.soup_scene(100_000, 160, 90), NORMALS_FLAT, 0.0)):
+        from oracle import orc
+        orc.set_skip_known_misses(bool(opts.get("skip_known", 1)))
         ref, st = oracle_render(sc, mode, nthreads=8)
         try:
             for k, v in opts.items():
@@ -409,6 +413,7 @@ def test_round_results_do_not_depend_on_knobs(hip, opts):
             tr.close()
         finally:
             hip.set_option("defaults", 0)
+            orc.set_skip_known_misses(True)
 
 
 def test_degenerate_scenes_through_the_native_tracer(hip):

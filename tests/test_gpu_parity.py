@@ -64,15 +64,12 @@ def test_closest_and_any_hit_match_oracle(hip, name):
     assert info["n_tris"] == len(mesh.tris) and np.allclose(info["bbox_lo"], lo) and np.allclose(info["bbox_hi"], hi)
 
 
-@pytest.mark.parametrize("opts", [dict(refill_min=1, inner_min=1), dict(refill_min=64, inner_min=64),
-                                  dict(blocks_per_cu=1, refill_min=8, inner_min=16), dict(sort_rays=0, top_lds=0), dict(sort_rays=1, sort_bits=32),
-                                  dict(refill_min=2, inner_min=60), dict(share=0), dict(share=3, blocks_per_cu=6, refill_min=64, share_min_rays=0), dict(share=3, share_min_rays=0),
-                                  dict(share=3, share_min_rays=0, long_steps=3, long_min_rays=0), dict(share=1, share_min_rays=0, blocks_per_cu=1),
-                                  dict(long_steps=2, long_min_rays=0), dict(long_steps=0), dict(top_ordered=0), dict(term_sink=0, camera_tile=0),
-                                  dict(leaf_max=1), dict(leaf_max=4, long_steps=4, long_min_rays=0), dict(leaf_max=3, share=3, share_min_rays=0)])
+@pytest.mark.parametrize("opts", [dict(sort_rays=1), dict(long_steps=2, long_min_rays=0), dict(long_steps=0), dict(term_sink=0, camera_tile=0),
+                                  dict(leaf_max=1), dict(leaf_max=4, long_steps=4, long_min_rays=0), dict(leaf_max=3)])
 def test_results_do_not_depend_on_tuning_knobs(hip, opts):
-    """Every refill / phase / grid / sorting / leaf-size setting of the shipped kernels returns the same bits (the variants that live
-    in the experiments build only: tests/experiment_cases.py)."""
+    """Every knob of the shipped library that touches the adapter call -- sorting, parking threshold, sink, list order, leaf size -- returns
+    the same bits (the tuned constants -- refill / phase thresholds, grid sizes, drain sharing -- and the variants that lost can be moved
+    in the experiments build only: tests/experiment_cases.py sweeps them there)."""
     sc = scenes.soup_scene(150_000, 160, 90)
     mesh = sc.meshes[0]
     om = orc.Mesh(mesh.verts, mesh.tris, mesh_mat=mesh.material)
@@ -471,8 +468,8 @@ def test_shuffle_keeps_list_order_and_fused_camera_filter(hip):
 
 def test_long_ray_path_is_bit_exact(hip):
     """Rays that exceed `long_steps` node steps are parked by k_trace and finished by k_long_closest, a wave per ray.  Forced onto
-    (nearly) every ray here -- threshold 1..24 steps, no minimum launch size, with and without the saved stack -- hits and whole
-    frames must not change by a bit."""
+    (nearly) every ray here -- threshold 1..24 steps, no minimum launch size; in the experiments build also without the saved stack and
+    with a lower threshold for draining waves -- hits and whole frames must not change by a bit."""
     from gravit_amd import capi
 
     v, t = scenes.load_mesh_file(os.path.join(GOLDEN, "bun_zipper.npz"))
@@ -494,10 +491,12 @@ def test_long_ray_path_is_bit_exact(hip):
         capi.set_option("long_min_rays", 0)
         # long_save: the record carries the ray's pending stack (k_long_closest goes on from it) or not (it starts again at the root);
         # long_steps_drain: the lower threshold of waves whose work counter has run dry
-        for steps, save, drain in ((1, 1, 0), (3, 1, 0), (8, 1, 0), (3, 0, 0), (8, 0, 0), (24, 1, 4), (24, 0, 2)):
+        exp = capi.load().gvt_hip_is_experiments_build() == 1  # (tests/experiment_cases.py runs this test against the experiments build too)
+        for steps, save, drain in ((1, 1, 0), (3, 1, 0), (8, 1, 0), (24, 1, 0)) + (((3, 0, 0), (8, 0, 0), (24, 1, 4), (24, 0, 2)) if exp else ()):
             capi.set_option("long_steps", steps)
-            capi.set_option("long_save", save)
-            capi.set_option("long_steps_drain", drain)
+            if exp:
+                capi.set_option("long_save", save)
+                capi.set_option("long_steps_drain", drain)
             h = ad.intersect(org, d.astype(np.float32))
             assert h.tobytes() == ref_hits.tobytes(), "hits differ with long_steps=%d long_save=%d long_steps_drain=%d" % (steps, save, drain)
             fb = ImageTracer(sc, NORMALS_SMOOTH)().framebuffer(False)

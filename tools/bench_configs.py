@@ -8,6 +8,11 @@ from gravit_amd.layouts import NORMALS_SMOOTH, NORMALS_FLAT
 from gravit_amd.scheduler import ImageTracer, NativeTracer
 
 capi.init(0)
+ONLY = None
+for a in sys.argv[1:]:  # opt=value: library options; only=1,2,4: a subset of the configurations
+    k, v = a.split("=")
+    if k == "only": ONLY = set(v.split(","))
+    else: capi.set_option(k, int(v))
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
@@ -25,6 +30,8 @@ cfgs = [
     ("config 5 stand-in cut into 8 domains (one rank)", lambda: config5(1024, 8), NORMALS_FLAT),
 ]
 for name, mk, mode in cfgs:
+    if ONLY is not None and name.split(":")[0].replace("config ", "").split(" ")[0] not in ONLY:
+        continue
     sc = mk()
     tris = sum(len(m.tris) for m in sc.meshes)
     for label, tr in (("rounds", NativeTracer(sc, mode)), ("reference order", ImageTracer(sc, mode))):
