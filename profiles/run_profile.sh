@@ -3,12 +3,12 @@
 # separate PMC passes (FETCH_SIZE and WRITE_SIZE do not fit in one pass; never combined with sys/hip traces).
 # usage (from the repo root, via gpurun):  bash profiles/run_profile.sh <tag> [bench args...]
 # Outputs land in gpurun_out/prof_<tag>/ ; profiles/summarize.py condenses them into profiles/<tag>_*.{csv,json}.
-TAG=${1:-r02}; shift
+TAG=${1:-r04}; shift
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-abi-path $@"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-abi-path --no-sustained $@"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $REPO/bench.py $ARGS > $OUT/bench_trace.log 2>&1
 # (TA_* counters abort rocprofv3 on this pool -- signal 6, the pass then runs into its timeout: gpurun_out/pmc_q0_ta, round 3 -- so the
 # vector-memory path is read through the TCP counters: tag look-ups, requests to L2, latencies, stall cycles)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the measured text files under profiles/ on the GPU box (outputs in gpurun_out/refresh_<tag>/; copy them over afterwards):
 #   bash tools/refresh_profiles.sh <tag>
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/refresh_$TAG
 mkdir -p $OUT
@@ -11,5 +11,7 @@ python3 tools/tail_probe.py any > $OUT/tail_fit.txt 2>&1
 python3 tools/bench_configs.py > $OUT/configs.txt 2>&1
 python3 bench.py --domains 8 --steps 20 --warmup 3 > $OUT/domains8.log 2>&1
 for n in 2 4 8; do python3 bench.py --inproc-ranks $n --steps 10 --warmup 2 > $OUT/inproc_$n.log 2>&1; done
+python3 tools/tick_probe.py > $OUT/tick_probe.txt 2>&1; python3 tools/tick_probe.py frame_timing=1 >> $OUT/tick_probe.txt 2>&1
+bash tools/dropin_probe.sh > $OUT/dropin.txt 2>&1
 bash tools/timeline.sh $TAG > $OUT/timeline.txt 2>&1
 tail -3 $OUT/tail_fit.txt; grep rounds $OUT/configs.txt
