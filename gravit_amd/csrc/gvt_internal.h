@@ -159,6 +159,7 @@ struct gvt_hip_queue {
 struct gvt_hip_top {
   size_t n = 0;
   std::vector<int> order;   // DFS leaf order of the reference's top-level BVH
+  std::vector<float> h_lo, h_hi; // the instance boxes as given (host copies: the projection of a rank's instances onto the film)
   float4 *d_lo = nullptr;   // in `order` order: (lo.xyz, inst id)
   float4 *d_hi = nullptr;
   float4 *d_nlo = nullptr, *d_nhi = nullptr; // the BVH's nodes (gvt_device.h TopDev), root = 0

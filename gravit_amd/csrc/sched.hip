@@ -5,6 +5,9 @@
 //   k_top_scatter   AbstractTrace::shuffleRays, mesh branch  (algorithm/TracerBase.h:392-400) and
 //                   Tracer<DomainScheduler>::shuffleDropRays (algorithm/DomainTracer.h:148-183)
 //   framebuffer     IceTComposite::localAdd / reset / write  (composite/IceTComposite.cpp:79-157)
+#include <algorithm>
+#include <cmath>
+
 #include "gvt_internal.h"
 
 namespace {
@@ -15,6 +18,10 @@ struct CamArgs {
   int W, H, samples, depth;
   int tile; // 0: rays in the reference's order (pixel-major); 8: pixels enumerated in 8x8 tiles (one wave of rays = one tile)
   unsigned first; // the kernels' ray i is ray `first + i` of the generated list (a rank's portion, ImageTracer.h:112-120)
+  // Domain scheduler, shuffleDropRays: a rank keeps only the camera rays whose first domain is one of ITS instances, and those can only
+  // come from the pixels its instances' boxes project onto.  rect_on: the list is enumerated over that rectangle only -- 8x8 tiles,
+  // row-major over the rectangle's tiles (positions of tiles that reach beyond x1 / y1 hold no ray) -- instead of the whole film.
+  int rect_on, rx0, ry0, rx1, ry1, rtpr; // rectangle in pixels (x0, y0 multiples of 8), tiles per row
 };
 
 // position in the generated list -> pixel.  tile == 8: the W8 x H8 part of the image that whole 8x8 tiles cover comes first, tile
@@ -33,9 +40,19 @@ __device__ inline unsigned camera_slot_pixel(unsigned slot, int W, int H, int ti
   return (H8 + r / (unsigned)W) * (unsigned)W + r % (unsigned)W;
 }
 
+// rect_on: pixel of list position `slot`, or 0xffffffff where the rectangle's last tile column / row reaches beyond it
+__device__ inline unsigned camera_rect_pixel(const CamArgs &A, unsigned slot) {
+  const unsigned t = slot >> 6, k = slot & 63u;
+  const unsigned px = (unsigned)A.rx0 + (t % (unsigned)A.rtpr) * 8u + (k & 7u), py = (unsigned)A.ry0 + (t / (unsigned)A.rtpr) * 8u + (k >> 3);
+  return (px < (unsigned)A.rx1 && py < (unsigned)A.ry1) ? py * (unsigned)A.W + px : 0xffffffffu;
+}
+__device__ inline bool camera_slot_valid(const CamArgs &A, unsigned long long ridx) {
+  return !A.rect_on || camera_rect_pixel(A, (unsigned)(ridx / (unsigned)(A.samples * A.samples))) != 0xffffffffu;
+}
 __device__ inline RayRec camera_ray(const CamArgs &A, unsigned long long ridx) {
   const unsigned samples2 = (unsigned)(A.samples * A.samples);
-  const unsigned pix = camera_slot_pixel((unsigned)(ridx / samples2), A.W, A.H, A.tile);
+  unsigned pix = A.rect_on ? camera_rect_pixel(A, (unsigned)(ridx / samples2)) : camera_slot_pixel((unsigned)(ridx / samples2), A.W, A.H, A.tile);
+  if (pix == 0xffffffffu) pix = 0u; // (a position without a ray: the callers skip it, camera_slot_valid)
   const unsigned sub = (unsigned)(ridx % samples2);
   const int k = (int)(sub / (unsigned)A.samples), ww = (int)(sub % (unsigned)A.samples);
   const int i = (int)(pix % (unsigned)A.W), j = (int)(pix / (unsigned)A.W);
@@ -102,7 +119,8 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_top_classify(RaySrc S, unsigned n
     if (S.from_cam) { const RayRec r = camera_ray(S.cam, (unsigned long long)S.cam.first + i); a = make_float4(r.o.x, r.o.y, r.o.z, r.t_min); b = make_float4(r.d.x, r.d.y, r.d.z, r.t_max); }
     else { a = S.q.p0[i]; b = S.q.p1[i]; }
     const int fr = from_arr ? from_arr[i] : from;
-    if (skip_known && !S.from_cam && S.q.p5 && fr >= 0) {
+    if (S.from_cam && !camera_slot_valid(S.cam, (unsigned long long)S.cam.first + i)) { next = -1; ret_t = GVT_FLT_MAX; }
+    else if (skip_known && !S.from_cam && S.q.p5 && fr >= 0) {
       // the known-miss shortcut (gvt_device.h): `fr` joins the ray's list; a choice that is on the list is walked through here, the
       // advanced origin left in the source list (consumed by the scatter that follows) and t_out = -1 says "already advanced"
       uint32_t km[3] = { S.q.p5[3 * (size_t)i], S.q.p5[3 * (size_t)i + 1], S.q.p5[3 * (size_t)i + 2] };
@@ -346,6 +364,7 @@ static CamArgs make_cam_args(const float eye[3], const float focus[3], const flo
   A.half_sample = samples * 0.5f;
   A.contri = 1.f / (samples * samples);
   A.W = W; A.H = H; A.samples = samples; A.depth = depth; A.tile = tile; A.first = 0u;
+  A.rect_on = 0; A.rx0 = 0; A.ry0 = 0; A.rx1 = W; A.ry1 = H; A.rtpr = 1;
   return A;
 }
 
@@ -446,6 +465,7 @@ extern "C" gvt_hip_top *gvt_hip_top_create(const float *inst_lo, const float *in
   for (size_t i = 0; i < n; i++) B.set[i] = (int)i;
   if (n) B.build(0, (int)n);
   T->order = B.sorted;
+  T->h_lo.assign(inst_lo, inst_lo + 3 * n); T->h_hi.assign(inst_hi, inst_hi + 3 * n);
   std::vector<float4> lo(n ? n : 1), hi(n ? n : 1);
   for (size_t k = 0; k < n; k++) {
     int q = T->order[k];
@@ -681,6 +701,40 @@ int shuffle_exact(gvt_hip_top *T, gvt_hip_queue *q_in, const int *from_arr, int 
   return shuffle_impl(T, S, n, from, queues, nullptr, fb, from_arr);
 }
 
+// The pixels the kept instances' boxes project onto, as a tile-aligned rectangle of the film (two pixels of margin): a camera ray of any
+// other pixel cannot enter one of those boxes at all, so it cannot have one of them as its first domain (shuffleDropRays keeps nothing of
+// it).  False -- the whole film -- when a box reaches behind the eye plane, when sub-samples are spread by a jitter window, or when the
+// rectangle is nearly the whole film anyway.  An empty rectangle (no kept instance in view) sets rx1 <= rx0.
+static bool camera_keep_rect(const gvt_hip_top *T, CamArgs &A, const uint8_t *keep_mask) {
+  if (A.offset != 0.f || T->h_lo.size() != 3 * T->n) return false;
+  double x0 = 1e30, y0 = 1e30, x1 = -1e30, y1 = -1e30;
+  bool any = false;
+  for (size_t i = 0; i < T->n; i++) {
+    if (!keep_mask[i]) continue;
+    any = true;
+    for (int c = 0; c < 8; c++) {
+      const double p[3] = { (c & 1) ? T->h_hi[3 * i] : T->h_lo[3 * i], (c & 2) ? T->h_hi[3 * i + 1] : T->h_lo[3 * i + 1], (c & 4) ? T->h_hi[3 * i + 2] : T->h_lo[3 * i + 2] };
+      const double q[3] = { p[0] - A.eye.x, p[1] - A.eye.y, p[2] - A.eye.z };
+      const double depth = q[0] * A.w.x + q[1] * A.w.y + q[2] * A.w.z;
+      if (!(depth > 1e-4)) return false; // at or behind the eye plane: no bounded projection
+      const double x = (q[0] * A.u.x + q[1] * A.u.y + q[2] * A.u.z) / depth, y = (q[0] * A.v.x + q[1] * A.v.y + q[2] * A.v.z) / depth;
+      const double px = (x / A.horz + 1.0) / A.wmult, py = (y / A.vert + 1.0) / A.hmult; // the inverse of camera_ray's x0 / y0
+      x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
+    }
+  }
+  int ix0 = 0, iy0 = 0, ix1 = 0, iy1 = 0;
+  if (any) {
+    ix0 = (int)std::max(0.0, std::floor(x0) - 2.0); iy0 = (int)std::max(0.0, std::floor(y0) - 2.0);
+    ix1 = (int)std::min((double)A.W, std::ceil(x1) + 3.0); iy1 = (int)std::min((double)A.H, std::ceil(y1) + 3.0);
+    if (ix1 < ix0) ix1 = ix0;
+    if (iy1 < iy0) iy1 = iy0;
+  }
+  ix0 &= ~7; iy0 &= ~7;
+  if ((double)(ix1 - ix0) * (double)(iy1 - iy0) > 0.9 * (double)A.W * (double)A.H) return false;
+  A.rect_on = 1; A.rx0 = ix0; A.ry0 = iy0; A.rx1 = ix1; A.ry1 = iy1; A.rtpr = std::max(1, (ix1 - ix0 + 7) / 8);
+  return true;
+}
+
 // generateRays + FilterRaysLocally in one step: the camera's rays go straight to the queues of the instances they enter first
 extern "C" int gvt_hip_camera_filter(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *const *queues, const uint8_t *keep_mask) {
   if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
@@ -693,7 +747,11 @@ extern "C" int gvt_hip_camera_filter(gvt_hip_top *T, const gvt_hip_camera *cam, 
   RaySrc S{};
   S.cam = make_cam_args(cam->eye, cam->focus, cam->up, cam->fov, cam->width, cam->height, cam->samples, cam->depth, cam->jitter_window_size, tile);
   S.from_cam = 1;
-  return shuffle_impl(T, S, n, -1, queues, keep_mask, nullptr);
+  size_t n_list = n;
+  if (keep_mask && tile == 8 && camera_keep_rect(T, S.cam, keep_mask)) // shuffleDropRays: only the pixels this rank's instances project onto
+    n_list = (size_t)S.cam.rtpr * (size_t)((S.cam.ry1 - S.cam.ry0 + 7) / 8) * 64u * (size_t)(cam->samples * cam->samples);
+  if (!n_list) return 0;
+  return shuffle_impl(T, S, n_list, -1, queues, keep_mask, nullptr);
 }
 
 // ---- framebuffer ----
