@@ -90,12 +90,18 @@ def main():
     cf = os.path.join(ROOT, "profiles", ".profiled_commit")  # written by the caller before the tree travels to the GPU box (no .git there)
     if os.path.exists(cf):
         commit = open(cf).read().strip() or None
-    try:
-        sys.path.insert(0, ROOT)
-        from gravit_amd import _build
-        src_hash = _build.source_hash()
-    except Exception:
-        src_hash = None
+    src_hash = None
+    for f in find(os.path.join(base, "bench_trace.log")) + find(os.path.join(base, "bench_pmc_FETCH_SIZE.log")):  # the hash the PROFILED tree printed in its own bench line
+        for line in open(f, errors="replace"):
+            if line.startswith("{"):
+                src_hash = src_hash or json.loads(line).get("roofline", {}).get("source_hash")
+    if src_hash is None:
+        try:
+            sys.path.insert(0, ROOT)
+            from gravit_amd import _build
+            src_hash = _build.source_hash()
+        except Exception:
+            src_hash = None
     traffic = {"tag": tag, "commit": commit, "source_hash": src_hash,
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE over `bench.py --steps 5 --warmup 2`, tag %s" % tag,
                "note": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch; x2 on reads: gfx950 tallies 128-byte fabric requests "
