@@ -200,7 +200,7 @@ extern "C" int gvt_hip_stats_reset(void) {
 namespace {
 struct KnobDef { const char *name; int Knobs::*field; int lo, hi; bool shipped; };
 const KnobDef g_knobs[] = {
-  // shipped (15)
+  // shipped (16)
   { "skip_known", &Knobs::skip_known, 0, 1, true },           { "frame_timing", &Knobs::frame_timing, 0, 1, true },
   { "term_sink", &Knobs::term_sink, 0, 1, true },             { "camera_tile", &Knobs::camera_tile, 0, 8, true },
   { "sort_rays", &Knobs::sort_rays, 0, 1, true },             { "leaf_max", &Knobs::leaf_max, 1, 4, true },
@@ -208,7 +208,7 @@ const KnobDef g_knobs[] = {
   { "finish_rays", &Knobs::finish_rays, 0, 1 << 30, true },   { "round_room_mb", &Knobs::round_room_mb, 0, 1 << 30, true },
   { "abi_lanes", &Knobs::abi_lanes_n, 0, 8, true },           { "abi_chunk", &Knobs::abi_chunk, 16384, 1 << 30, true },
   { "abi_pipe_min", &Knobs::abi_pipe_min, 0, 1 << 30, true }, { "inject_fail_tick", &Knobs::inject_fail_tick, -1, 1 << 30, true },
-  { "long_min_rays", &Knobs::long_min_rays, 0, 1 << 30, true },
+  { "long_min_rays", &Knobs::long_min_rays, 0, 1 << 30, true }, { "long_auto", &Knobs::long_auto, 0, 1, true },
   // experiments build only: the alternative was measured and lost, or the value is a tuned constant
   { "trav_kernel", &Knobs::trav_kernel, 0, 1, false },        { "wide4", &Knobs::wide4, 0, 1, false },
   { "coop_fetch", &Knobs::coop_fetch, 0, 1, false },          { "fused", &Knobs::fused, 0, 1, false },

@@ -378,7 +378,7 @@ namespace {
                     // pixels my framebuffer holds deposits in (x0, y0, x1, y1; for the composite), my error code (0: none -- a rank whose
                     // local work failed still takes part in the exchange, so that EVERY rank leaves the frame, with the same error),
                     // my exchange number (ranks out of step are a protocol error, not a hang), rays per queue [n_inst]}
-#define REPORT_TAIL 12 // words behind the queue sizes in the round's report
+#define REPORT_TAIL 13 // words behind the queue sizes in the round's report (the last one: the sequence number of a polled report)
 
 // sizes[i] = *count_ptr[i]; the announce row for every peer; totals (2 x u64) and flags copied next to them so that ONE device-to-host
 // copy carries everything the host needs from a round
@@ -450,6 +450,7 @@ __global__ __launch_bounds__(256) void k_round_report(unsigned *const *__restric
     tail[4] = counters[8]; tail[5] = overflow[0];
     for (int k = 0; k < 4; k++) tail[6 + k] = (unsigned)bb[k];
     tail[10] = counters[9]; // packets handed over by k_packet
+    tail[11] = counters[20] + counters[3]; // closest-hit rays parked for k_long_closest so far this frame (earlier launches + the last one)
     counters[0] = 0u;       // the work counter of the next small chain (k_finish starts from 0 without a memset in front)
   }
   if (host_report) { // one rank: the report goes straight into the host's pinned copy, the sequence word last -- the host polls it
@@ -549,7 +550,7 @@ template <bool ADD> __global__ __launch_bounds__(256) void k_rect(float4 *__rest
 __global__ void k_zero_totals(unsigned *c, unsigned *ovf, int fb_w, int fb_h) {
   if (blockIdx.x) return;
   if (threadIdx.x < 4) c[16 + threadIdx.x] = 0u;
-  if (threadIdx.x == 4) { *ovf = 0u; c[9] = 0u; c[0] = 0u; ovf[10] = 0u; ovf[11] = 0u; }
+  if (threadIdx.x == 4) { *ovf = 0u; c[9] = 0u; c[0] = 0u; ovf[10] = 0u; ovf[11] = 0u; c[3] = 0u; c[20] = 0u; }
   if (threadIdx.x == 5) { int *bb = (int *)(ovf + 4); bb[0] = fb_w; bb[1] = fb_h; bb[2] = 0; bb[3] = 0; }
 }
 } // namespace
@@ -595,6 +596,7 @@ struct gvt_hip_tracer {
   bool chain_timed = false, payload_timed = false;
   uint64_t last_local_pending = 0;
   std::vector<size_t> present; // host-known queue sizes as of the last report
+  int long_cur = 0;            // the parking threshold this tracer's frames run with (0: Knobs::long_steps), adapted frame by frame (long_auto)
 };
 
 extern "C" void gvt_hip_tracer_destroy(gvt_hip_tracer *R) {
@@ -921,6 +923,12 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   } restore{ R, world_saved, &owned_saved };
   gvt_hip_frame_stats S{};
   int rc;
+  // closest hit: the node-step count after which a ray is parked for a whole wave (Knobs::long_steps) suits the benchmark's density; a
+  // sparser scene has more rays beyond it (1 M-triangle soup: 4 % of the rays, k_long_closest 0.25 ms of a 1.27 ms frame).  long_auto:
+  // the tracer raises the threshold from frame to frame while more than 0.3 % of a frame's closest-hit rays were parked, and lets it
+  // fall back towards the knob when fewer than 0.05 % were.  Results never depend on it.
+  struct LongOverride { Ctx &C; ~LongOverride() { C.long_steps_override = 0; } } long_override{ C };
+  C.long_steps_override = (C.long_auto && C.long_steps > 0 && R->long_cur > C.long_steps) ? R->long_cur : 0;
   // clearBuffer + generateRays + FilterRaysLocally / shuffleDropRays (ImageTracer.h:137-146, DomainTracer.h:148-183, 204-211)
   // One instance, one rank, terminal rule inside the kernels: the first (and only) launch chain takes its ray count from the queue's
   // count word on the device -- the camera filter needs no read-back and the frame has ONE host synchronisation.
@@ -1173,6 +1181,14 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   S.rays_closest = (uint64_t)tail[0] | ((uint64_t)tail[1] << 32);
   S.rays_any = (uint64_t)tail[2] | ((uint64_t)tail[3] << 32);
   S.packets_bailed = tail[10];
+  if (C.long_auto && C.long_steps > 0 && S.rays_closest >= 65536) {
+    const double frac = (double)tail[11] / (double)S.rays_closest;
+    int cur = std::max(R->long_cur, C.long_steps);
+    if (frac > 0.01) cur = std::min(1024, cur + cur / 2);
+    else if (frac > 0.003) cur = std::min(1024, cur + cur / 4);
+    else if (frac < 0.0005) cur = std::max(C.long_steps, cur - cur / 5);
+    R->long_cur = cur;
+  }
   C.stats.rays_closest += S.rays_closest;
   C.stats.rays_any += S.rays_any;
   if (out) *out = S;

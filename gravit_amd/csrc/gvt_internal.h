@@ -53,6 +53,7 @@ struct Knobs {
                          // two kernels and the round's report (8 launches per frame instead of 14)
   int skip_known = 1;    // shuffleRays' known-miss shortcut (gvt_device.h): a ray is not traced again in an instance it has already crossed without a hit
                          // on the same straight segment (image-identical; 0: the reference's hop-by-hop behaviour, same ray counts as its schedulers)
+  int long_auto = 1;     // native tracer: raise the parking threshold from frame to frame while more than 0.3 % of a frame's closest-hit rays get parked (sparser scenes than the benchmark)
   int frame_timing = 0;  // multi-rank frames: fill gvt_hip_frame_stats' ms_chain / ms_announce / ms_payload / ms_composite (five more event calls per exchange)
   int inject_fail_tick = -1; // tests: this rank's local work "fails" at that exchange of a multi-rank frame (the announce carries the error to every rank)
   int report_poll = 1;   // one rank: a round's report is written into pinned host memory by the kernel and polled (no copy, no stream synchronisation)
@@ -77,6 +78,7 @@ struct Ctx : Knobs {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   int profile = 0; // 0 off, 1 every kernel class, 2 the traversal kernels only (closest, long, any)
+  int long_steps_override = 0; // > 0: the parking threshold of the frame in progress (gvt_hip_tracer_frame's long_auto), instead of Knobs::long_steps
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;
   gvt_hip_stats stats{};

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_cam1_count(CamArgs A, unsigned n,
     for (int w = 0; w < TOP_BLOCK / 64; w++) tot += sh_w[w];
     blk_cnt[blockIdx.x] = tot;
   }
-  if (blockIdx.x == 0 && threadIdx.x < 4) c[16 + threadIdx.x] = 0u; // the frame's ray totals (k_zero_totals)
+  if (blockIdx.x == 0 && threadIdx.x < 5) c[16 + threadIdx.x] = 0u; // the frame's ray totals and parked-ray total (k_zero_totals)
   if (blockIdx.x == 0 && threadIdx.x == 4) { *ovf = 0u; c[9] = 0u; }
 }
 __global__ __launch_bounds__(TOP_BLOCK) void k_cam1_scatter(CamArgs A, unsigned n, TopDev top, const unsigned *__restrict__ blk_cnt, QueueDesc Q,

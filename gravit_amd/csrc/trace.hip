@@ -97,8 +97,8 @@ template <bool ANY, bool XFORM, int MODE, typename... Args> void launch_trace(bo
 static size_t long_scratch_bytes(size_t n) { return sizeof(LongRec) * n + sizeof(int) * LONG_SAVE * (size_t)LONG_STK_CAP; }
 static void long_limits(LongQ &LQ, size_t n) {
   Ctx &C = gctx();
-  LQ.steps = C.long_steps;
-  LQ.steps_drain = C.long_steps_drain > 0 && C.long_steps_drain < C.long_steps ? C.long_steps_drain : C.long_steps;
+  LQ.steps = C.long_steps_override > 0 ? C.long_steps_override : C.long_steps;
+  LQ.steps_drain = C.long_steps_drain > 0 && C.long_steps_drain < LQ.steps ? C.long_steps_drain : LQ.steps;
   LQ.stk = C.long_save ? (int *)(LQ.recs + n) : nullptr;
   LQ.stk_cap = LONG_STK_CAP;
 }
@@ -472,6 +472,7 @@ __global__ void k_wave_pass_begin(unsigned *c, int pass, unsigned n_host, unsign
   const int cur = (pass & 1) ? 5 : 2, prev = (pass & 1) ? 2 : 5;
   if (pass == 0) { *out_count = 0u; c[2] = 0u; c[5] = 0u; tot[0] += n_dev0 ? *n_dev0 : n_host; }
   else { tot[1] += c[1]; tot[0] += c[prev]; c[cur] = 0u; }
+  c[20] += c[3]; // rays parked by the launch before (the frame's total: the tracer adapts its parking threshold to it)
   c[0] = 0u; c[1] = 0u; c[3] = 0u; c[4] = 0u; c[6] = 0u;
 }
 // end of a round's chain: the last pass's shadow rays into the frame total; and the traced queues' clear() (count words of the

@@ -501,3 +501,25 @@ def test_tracer_contexts_and_queues_release_their_memory(hip):
         cycle()
     free1 = free_bytes()
     assert free0 - free1 < 64 << 20, "leaked %.1f MiB over 6 create/destroy cycles" % ((free0 - free1) / 2 ** 20)
+
+
+def test_parking_threshold_adapts_to_a_sparser_scene(hip):
+    """long_auto (default on): on a scene that parks more than 0.3 % of its closest-hit rays at the benchmark's threshold -- a 1 M-triangle
+    soup is sparser than the 10 M one, its rays take more node steps -- the native tracer raises the threshold from frame to frame; the
+    frames stay the same bit for bit (parking never changes a result) and far fewer rays end up in k_long_closest."""
+    sc = scenes.soup_scene(1_000_000, 960, 540)
+    tr = NativeTracer(sc, NORMALS_FLAT)
+    fb0 = tr().framebuffer(False).copy()
+    parked0, rays = int(hip.counters_peek()[3]), tr.stats["rays_closest"]
+    for _ in range(8):
+        fb = tr().framebuffer(False)
+        assert np.array_equal(fb, fb0)
+    parked = int(hip.counters_peek()[3])
+    assert rays > 200_000 and parked0 > 0.003 * rays, (parked0, rays)  # the premise: this scene does park a lot at 96 steps
+    assert parked < 0.004 * rays and parked < parked0 // 3, (parked0, parked, rays)
+    tr.close()
+    hip.set_option("long_auto", 0)
+    tr = NativeTracer(sc, NORMALS_FLAT)
+    fb = tr().framebuffer(False)
+    assert np.array_equal(fb, fb0) and int(hip.counters_peek()[3]) == parked0  # off: the knob's threshold, frame after frame
+    tr.close()
