@@ -1,44 +1,58 @@
 """Copies what tools/refresh_profiles.sh measured on the GPU box (gpurun_out/refresh_<tag>/) into the tracked profiles/<tag>_* files.
    usage: python tools/collect_profiles.py <tag>"""
-import json, os, subprocess, sys
+import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "refresh_" + tag)
 dst = os.path.join(ROOT, "profiles")
 commit = open(os.path.join(dst, ".profiled_commit")).read().strip()
 
 
-def keys(d, path, default=None):
-    for k in path:
-        if not isinstance(d, dict) or k not in d: return default
-        d = d[k]
-    return d
+def last_json(path):
+    return json.loads([l for l in open(path) if l.startswith("{")][-1])
 
 
 bench = json.load(open(os.path.join(src, "bench.json")))
+h = bench["roofline"]["source_hash"]
 json.dump(bench, open(os.path.join(dst, tag + "_bench.json"), "w"), indent=1, sort_keys=True)
-open(os.path.join(dst, tag + "_tail_fit.txt"), "w").write("# tools/tail_probe.py at %s (source hash %s): the two traversal launches of the benchmark scene for 0.25 M .. 4.2 M camera rays\n" % (commit, bench["roofline"]["source_hash"]) + open(os.path.join(src, "tail_fit.txt")).read())
+open(os.path.join(dst, tag + "_tail_fit.txt"), "w").write("# tools/tail_probe.py at %s (source hash %s): the two traversal launches of the benchmark scene for 0.25 M .. 4.2 M camera rays\n" % (commit, h) + open(os.path.join(src, "tail_fit.txt")).read())
 open(os.path.join(dst, tag + "_configs.txt"), "w").write("# tools/bench_configs.py at %s: BASELINE.json's configurations on one MI355X, 10 frames each\n" % commit + open(os.path.join(src, "configs.txt")).read())
 tl = [l for l in open(os.path.join(src, "timeline.txt")).read().splitlines() if l.strip()]
-old = open(os.path.join(dst, tag + "_frame_timeline.txt")).read().split("\n## ")
-head = "# tools/timeline.sh (rocprofv3 --kernel-trace of one benchmark frame, native tracer, 10 M soup, 1080p), round 3 at %s\n## lean frame (default): 7 kernels\n" % commit
-rest = ["## " + s for s in old[2:]]  # the sections measured once (round 2's launch sequence, --domains 8) stay as they were taken
-open(os.path.join(dst, tag + "_frame_timeline.txt"), "w").write(head + "\n".join(tl) + "\n\n" + "\n".join(rest))
-rows = []
+open(os.path.join(dst, tag + "_frame_timeline.txt"), "w").write(
+    "# tools/timeline.sh (rocprofv3 --kernel-trace of one benchmark frame, native tracer, 10 M soup, 1080p) at %s: start, gap to the previous kernel's end, duration\n" % commit + "\n".join(tl) +
+    "\n# (two slices of this frame on two streams, and four: profiles/%s_frame_slices.txt -- measured slower, removed)\n" % tag)
+rows, legs = [], []
 for n in (2, 4, 8):
-    line = [l for l in open(os.path.join(src, "inproc_%d.log" % n)) if l.startswith("{")][-1]
-    j = json.loads(line)
+    j = last_json(os.path.join(src, "inproc_%d.log" % n))
     for name, v in j["variants"].items():
         ph = v["phase_ms_per_step_max_over_ranks"]
         rows.append("%d %-18s %8.3f %6.1f %7.1f %6.1f %10d %11d | %5.2f %8.2f %7.2f %9.2f %9.2f" % (
             n, name, v["ms_per_step"], v.get("ticks_per_step", 0), v.get("launch_chains_per_step", 0), v.get("host_syncs_per_step", 0),
             v.get("rays_sent_per_step", 0), v.get("bytes_sent_per_step", 0), ph["chain"], ph["announce"], ph["payload"], ph["composite"], ph["host_wait"]))
-d8 = json.loads([l for l in open(os.path.join(src, "domains8.log")) if l.startswith("{")][-1])
+    c4, wk = j.get("config4_bunny_grid"), j.get("weak_soup")
+    if c4:
+        for name in ("domain_async", "domain_bsp"):
+            v = c4[name]
+            legs.append("%d config4_bunny_grid %-13s %8.3f ms/frame %8.1f Mrays/s  ticks %.1f  rays sent %d  rays %d" % (n, name, v["ms_per_step"], v["value"], v["ticks_per_step"], v["rays_sent_per_step"], v["rays_per_step"]))
+    if wk:
+        legs.append("%d weak_soup (%d tiles x %d triangles, film %dx%d)  %8.3f ms/frame %8.1f Mrays/s  ticks %.1f  rays sent %d  rays %d; per-rank roofline frac of the dominant kernel: %s" % (
+            n, wk["tiles"], wk["tris_per_tile"], wk["film"][0], wk["film"][1], wk["ms_per_step"], wk["value"], wk["ticks_per_step"], wk["rays_sent_per_step"], wk["rays_per_step"],
+            " ".join("%.3f" % r["frac"] for r in wk["roofline_per_rank"])))
+d8 = last_json(os.path.join(src, "domains8.log"))
 open(os.path.join(dst, tag + "_domain_ticks.txt"), "w").write(
-    "# bench.py --inproc-ranks N --steps 10 --warmup 2 (round 3, %s): the native multi-rank frame loop with N in-process ranks sharing ONE MI355X (hub transport).\n"
-    "# Tick counts, rays / bytes sent and the per-phase times (max over ranks, ms per frame) of the config-3 soup cut into N x-y tiles; NOT a scaling number:\n"
-    "# the ranks' launch chains serialise on one device and the rank threads share one interpreter.\n"
-    "# N variant            ms/frame  ticks  chains  syncs  rays_sent  bytes_sent | chain announce payload composite host_wait\n" % commit + "\n".join(rows) +
-    "\n# bench.py --domains 8 (one rank owns all 8 tiles): %.3f ms per frame, %s launch chains, %s host synchronisations (round 2: 2.4-2.9 ms, 8 chains; k_finish runs every round after the first in one launch)\n"
-    % (d8["ms_per_step"], keys(d8, ["config", "launch_chains_per_step"], "2"), keys(d8, ["config", "host_syncs_per_step"], "3")))
-print("profiles/%s_* refreshed from %s" % (tag, src))
+    "# bench.py --inproc-ranks N --steps 10 --warmup 2 at %s (source hash %s): the native multi-rank frame loop with N in-process ranks sharing ONE MI355X (hub transport).\n"
+    "# Tick counts, rays / bytes sent and the per-phase times (max over ranks, ms per frame; frame_timing on: five more event calls per tick) of the config-3 soup cut into N x-y tiles;\n"
+    "# NOT a scaling number: the ranks' launch chains serialise on one device.  Known-miss shortcut ON (the default); with skip_known = 0 -- the reference's hop-by-hop rule -- the\n"
+    "# same scenes took 6 / 8 / 8 ticks and sent 5,578 / 9,412 / 25,626 rays (round 3's table, re-measured this round at 93933e1: 4.26 / 8.18 / 12.9 ms per frame).\n"
+    "# N variant            ms/frame  ticks  chains  syncs  rays_sent  bytes_sent | chain announce payload composite host_wait\n" % (commit, h) + "\n".join(rows) +
+    "\n# the extra legs of the same invocation (BASELINE configs[3] at its 1900x1080 film; the weak-scaling soup):\n" + "\n".join(legs) +
+    "\n# bench.py --domains 8 (one rank owns all 8 tiles): %.3f ms per frame, %s launch chains, %s host synchronisations\n"
+    % (d8["ms_per_step"], d8["config"].get("launch_chains_per_step"), d8["config"].get("host_syncs_per_step")))
+dp = [l for l in open(os.path.join(src, "dropin.txt")) if l.startswith("dropin_demo: trace_ms")]
+open(os.path.join(dst, tag + "_dropin.txt"), "w").write(
+    "# tools/dropin_probe.sh at %s: oracle/_ref/dropin_demo = gravit_amd/host/HipMeshAdapter.cpp compiled against the reference's own headers; 2,073,600 gvt::render::actor::Ray\n"
+    "# (1920x1080 camera rays of the bunny scene) through gvt::render::Adapter::trace -- 166 MB in, 166 MB of updated rayList and 166 MB of moved rays out = 498 MB over a 57 GB/s link (8.7 ms).\n"
+    "# trace_ms: moved_rays reserved afresh per call (ImageTracer.h:240), its pages untouched: the copies fault them in and zero them; reused_ms: its capacity kept between calls.\n" % commit + "".join(dp) +
+    "# bench.py abi_path (gvt_hip_trace on the benchmark frame's 1,040,400 rays, 250 MB): %.2f ms with write-back (%.1f GB/s), %.2f ms without (%.1f GB/s)\n" % (
+        bench["abi_path"]["ms"], bench["abi_path"]["pcie_GB/s"], bench["abi_path"]["no_write_back"]["ms"], bench["abi_path"]["no_write_back"]["pcie_GB/s"]))
+print("profiles/%s_* refreshed from %s (commit %s, source hash %s)" % (tag, src, commit, h))
