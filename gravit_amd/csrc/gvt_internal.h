@@ -38,9 +38,9 @@ struct Knobs {
   int long_save = 1;     // parked rays carry their pending stack and go on from it (0: they start again at the root with their best hit as the bound)
   int long_min_rays = 65536; // ... only in launches of at least this many rays (small launches have no tail to speak of)
   int fused = 0;         // scheduler rounds: closest hit + shade + first-light shadow rays in one kernel (k_fused) instead of three launches.
-                         // Measured 2.4x SLOWER than the three launches: shading inside the persistent kernel is latency-exposed
+                         // Measured 2.4x SLOWER than the three launches (EXPERIMENTS.md): shading inside the persistent kernel is latency-exposed
   int packet = 0;        // scheduler rounds: camera rays in tile order (and their direct-mapped shadow rays) traversed a packet of 64 per wave (k_packet).
-                         // Off: 8 % faster on a surface mesh (bun_zipper), 2.5x-20x SLOWER on the random soups
+                         // Off: 8 % faster on a surface mesh (bun_zipper), 2.5x-20x SLOWER on the random soups (EXPERIMENTS.md)
   int round_room_mb = 16384; // scheduler rounds: memory the worst-case reservation of the destination queues may add (MiB); beyond it the round shuffles with exact growth
   int finish_rays = 32768; // scheduler rounds holding at most this many rays are run by ONE kernel that follows every ray to its end on this rank (k_finish):
                          // no per-hop rounds for the few rays that move between the rank's own domains (0: off)
@@ -65,7 +65,7 @@ struct Knobs {
   int top_ordered = 1;   // shuffle: order-preserving, deterministic slots (<= 64 destinations) instead of arrival-order atomics
   int top_lds = 1;       // shuffle kernels: aggregate destination counters in LDS per 1024-thread block
   int quad = 0;          // experiments build: four lanes per ray (k_traceq, experiments/quad_kernel.inc) instead of one (k_trace); meshes created while it
-                         // is set carry the quad layouts.  Measured 1.5x slower on the 10 M soup (VALU bound: 16 rays per wave), DESIGN.md 4.1
+                         // is set carry the quad layouts.  Measured 1.5x slower on the 10 M soup (VALU bound: 16 rays per wave), EXPERIMENTS.md
   int leaf_max = 2;      // triangles per leaf at mesh build (1..4): closest hit on the 10 M soup 0.51 ms (2) vs 0.57 ms (4)
   int quad_inner_min = 8; // k_traceq: the node loop is left once fewer quads than this still descend
   int quad_refill_min = 4; // k_traceq: idle quads needed before a refill

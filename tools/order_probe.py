@@ -1,5 +1,5 @@
 """Does the ORDER in which a launch takes its 64-ray tiles shorten its drain?  A persistent-wave launch ends with the dependent chain of
-the last rays started (closest T = 0.18 ms + 0.31 ms per M rays); if the tiles that hold the longest rays are started
+the last rays started (EXPERIMENTS.md: closest T = 0.18 ms + 0.31 ms per M rays); if the tiles that hold the longest rays are started
 first, the rays left for the end are short ones.  This probe permutes the benchmark frame's ray lists tile by tile -- by the tile's
 maximum node-visit count (from the diagnostic kernel: a perfect predictor, the upper bound of what a previous frame or the primary
 ray's own count can give) -- and times the two traversal launches for each order.

@@ -1,5 +1,5 @@
 """Steps per ray of W-wide collapses of the benchmark's tree (W = 2, 4, 6, 8), primary rays and their shadow rays: what an 8-wide
-layout would buy in dependent steps, priced against what a node of that width costs to fetch and test.
+layout would buy in dependent steps, priced against what a node of that width costs to fetch and test (EXPERIMENTS.md).
    python tools/wide_steps.py [leaf_max=2]   (GPU box)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
