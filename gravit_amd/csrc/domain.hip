@@ -845,8 +845,8 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_e
   HIPCHK(hipGetLastError());
   if (exchange && R->world > 1) {
     gvt_hip_comm *K = R->comm;
-    HIPCHK(hipEventRecord(R->ev_compute, st)); // (timing event: the end of this tick's local chain)
-    HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0));
+    if (K->stream != st || timing) HIPCHK(hipEventRecord(R->ev_compute, st)); // (also the timing event at the end of this tick's local chain)
+    if (K->stream != st) HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0));
     if (timing) HIPCHK(hipEventRecord(R->ev_ann0, K->stream));
     comm_group_begin(K);
     for (int p = 0; p < R->world; p++) {
@@ -990,7 +990,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   };
   auto unpack_pending = [&]() -> int { // (2): append what the last exchange delivered, behind its event
     if (!payload_pending) return 0;
-    HIPCHK(hipStreamWaitEvent(st, R->ev_recv, 0));
+    if (R->comm->stream != st) HIPCHK(hipStreamWaitEvent(st, R->ev_recv, 0));
     WireBatch B;
     B.n_items = 0; B.total = 0;
     int rc_;
@@ -1033,6 +1033,14 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   auto failed = [&](int rc_) { if (rc_ && !local_err) { local_err = rc_; local_msg = gvt_hip_last_error(); } return rc_ != 0; };
   const bool multi = world_saved > 1;
   if (R->comm) R->comm->ms_host_wait = 0.0;
+  // The exchanges of a frame are issued on the COMPUTE stream itself (the communicator's own stream is bound to it for the frame): a tick is
+  // a short dependent sequence -- chain, report, announce, copy, pack, payload, unpack -- and every hop between two streams costs an event
+  // record, a wait and the queues' hand-over latency on the device (toy two-rank frame 914 -> 670 us, profiles/r04_tick_floor.txt).  What is
+  // given up is the overlap of a payload with the next chain: kilobytes to a few megabytes per tick against chains that are small after
+  // the frame's first one.  GVT_HIP_COMM_STREAM=1: the communicator's own stream, as in round 3.
+  struct StreamBind { gvt_hip_comm *K; hipStream_t saved; ~StreamBind() { if (K) K->stream = saved; } } stream_bind{ nullptr, nullptr };
+  static const bool own_comm_stream = getenv("GVT_HIP_COMM_STREAM") != nullptr;
+  if (R->comm && !own_comm_stream) { stream_bind.K = R->comm; stream_bind.saved = R->comm->stream; R->comm->stream = st; }
   int tick = 0;
   for (;; tick++) {
     // (1) local work: one merged chain (asynchronous ticks), or chains until the local queues are dry (BSP rounds / one rank)
@@ -1108,8 +1116,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
       // room for what arrives, reserved now (the unpack kernels are launched later, behind the next local chain)
       for (size_t i = 0; i < nI; i++)
         if (incoming[i] && (rc = queue_reserve(R->queues[i], R->present[i] + incoming[i]))) return rc;
-      HIPCHK(hipEventRecord(R->ev_pack, st));
-      HIPCHK(hipStreamWaitEvent(K->stream, R->ev_pack, 0));
+      if (K->stream != st) { HIPCHK(hipEventRecord(R->ev_pack, st)); HIPCHK(hipStreamWaitEvent(K->stream, R->ev_pack, 0)); }
       if (C.frame_timing) { HIPCHK(hipEventRecord(R->ev_pay0, K->stream)); R->payload_timed = true; }
       comm_group_begin(K); // sizes are known on both sides from the announces: no size handshake on the wire
       for (int p = 0; p < R->world; p++) {
@@ -1118,7 +1125,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
         if (bytes_in[p]) comm_recv(K, R->recv_buf[p], bytes_in[p], p);
       }
       if ((rc = comm_group_end(K))) return rc;
-      HIPCHK(hipEventRecord(R->ev_recv, K->stream));
+      if (K->stream != st || C.frame_timing) HIPCHK(hipEventRecord(R->ev_recv, K->stream));
       payload_pending = true;
     }
   }
@@ -1132,8 +1139,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     const int W = R->fb->w;
     if (C.frame_timing) HIPCHK(hipEventRecord(R->ev_comp0, st));
     if (flags & GVT_HIP_FRAME_FULL_REDUCE) {
-      HIPCHK(hipEventRecord(R->ev_compute, st));
-      HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0));
+      if (K->stream != st) { HIPCHK(hipEventRecord(R->ev_compute, st)); HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0)); }
       if ((rc = comm_reduce_sum(K, R->fb->d_rgba, (size_t)R->fb->w * R->fb->h * 4, 0))) return rc;
     } else if (R->rank != 0) {
       const int *bb = (const int *)(R->h_report + nI + 6);
@@ -1143,15 +1149,13 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
         if ((rc = grow(&R->send_buf[0], &R->send_cap[0], bytes))) return rc;
         k_rect<false><<<(unsigned)(((size_t)w * h + 255) / 256), 256, 0, st>>>((float4 *)R->fb->d_rgba, W, bb[0], bb[1], w, h, (float4 *)R->send_buf[0]);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(R->ev_compute, st));
-        HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0));
+        if (K->stream != st) { HIPCHK(hipEventRecord(R->ev_compute, st)); HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0)); }
         comm_group_begin(K);
         comm_send(K, R->send_buf[0], bytes, 0);
         if ((rc = comm_group_end(K))) return rc;
       }
     } else {
-      HIPCHK(hipEventRecord(R->ev_compute, st));
-      HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0));
+      if (K->stream != st) { HIPCHK(hipEventRecord(R->ev_compute, st)); HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0)); }
       comm_group_begin(K);
       for (int p = 1; p < R->world; p++) {
         const int *bb = R->h_ann_in + (size_t)p * row + 4;
@@ -1171,7 +1175,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
       HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(R->ev_comm, K->stream));
-    HIPCHK(hipStreamWaitEvent(st, R->ev_comm, 0));
+    if (K->stream != st) HIPCHK(hipStreamWaitEvent(st, R->ev_comm, 0));
     if ((rc = bounded_event_wait(K, R->ev_comm, "the framebuffer composite"))) return rc;
     S.host_syncs++;
     if (C.frame_timing) { float ms = 0.f; if (hipEventElapsedTime(&ms, R->ev_comp0, R->ev_comm) == hipSuccess) S.ms_composite += ms; }
