@@ -200,15 +200,16 @@ extern "C" int gvt_hip_stats_reset(void) {
 namespace {
 struct KnobDef { const char *name; int Knobs::*field; int lo, hi; bool shipped; };
 const KnobDef g_knobs[] = {
-  // shipped (16)
+  // shipped (15)
   { "skip_known", &Knobs::skip_known, 0, 1, true },           { "frame_timing", &Knobs::frame_timing, 0, 1, true },
-  { "term_sink", &Knobs::term_sink, 0, 1, true },             { "camera_tile", &Knobs::camera_tile, 0, 8, true },
+  { "term_sink", &Knobs::term_sink, 0, 1, true },
   { "sort_rays", &Knobs::sort_rays, 0, 1, true },             { "leaf_max", &Knobs::leaf_max, 1, 4, true },
   { "long_steps", &Knobs::long_steps, 0, 1 << 20, true },     { "small_rays", &Knobs::small_rays, 0, 1 << 30, true },
   { "finish_rays", &Knobs::finish_rays, 0, 1 << 30, true },   { "round_room_mb", &Knobs::round_room_mb, 0, 1 << 30, true },
   { "abi_lanes", &Knobs::abi_lanes_n, 0, 8, true },           { "abi_chunk", &Knobs::abi_chunk, 16384, 1 << 30, true },
-  { "abi_pipe_min", &Knobs::abi_pipe_min, 0, 1 << 30, true }, { "inject_fail_tick", &Knobs::inject_fail_tick, -1, 1 << 30, true },
+  { "inject_fail_tick", &Knobs::inject_fail_tick, -1, 1 << 30, true },
   { "long_min_rays", &Knobs::long_min_rays, 0, 1 << 30, true }, { "long_auto", &Knobs::long_auto, 0, 1, true },
+  { "payload_overlap_kb", &Knobs::payload_overlap_kb, 0, 1 << 30, true },
   // experiments build only: the alternative was measured and lost, or the value is a tuned constant
   { "trav_kernel", &Knobs::trav_kernel, 0, 1, false },        { "wide4", &Knobs::wide4, 0, 1, false },
   { "coop_fetch", &Knobs::coop_fetch, 0, 1, false },          { "fused", &Knobs::fused, 0, 1, false },
@@ -223,7 +224,8 @@ const KnobDef g_knobs[] = {
   { "lean_frame", &Knobs::lean_frame, 0, 1, false },          { "report_poll", &Knobs::report_poll, 0, 1, false },
   { "first_round_async", &Knobs::first_round_async, 0, 1, false }, { "wave_single", &Knobs::wave_single, 0, 1, false },
   { "shadow_direct", &Knobs::shadow_direct, 0, 1, false },    { "top_ordered", &Knobs::top_ordered, 0, 1, false },
-  { "top_lds", &Knobs::top_lds, 0, 1, false },
+  { "top_lds", &Knobs::top_lds, 0, 1, false },                { "camera_tile", &Knobs::camera_tile, 0, 8, false },
+  { "abi_pipe_min", &Knobs::abi_pipe_min, 0, 1 << 30, false },
 };
 } // namespace
 

@@ -968,7 +968,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     for (size_t i = 0; i < nI; i++) R->present[i] = R->queues[i]->size;
   }
   std::vector<size_t> incoming(nI, 0);
-  bool payload_pending = false;
+  bool payload_pending = false, payload_cross = false; // ... and whether it moves on another stream than the compute stream
   std::vector<int> pending_ann; // the announces the payload in flight was posted from
 
   // ALL queues of a tick's payload through ONE pack / unpack launch (the items by value in the kernel arguments, <= WIRE_MAX per launch)
@@ -990,7 +990,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   };
   auto unpack_pending = [&]() -> int { // (2): append what the last exchange delivered, behind its event
     if (!payload_pending) return 0;
-    if (R->comm->stream != st) HIPCHK(hipStreamWaitEvent(st, R->ev_recv, 0));
+    if (payload_cross) HIPCHK(hipStreamWaitEvent(st, R->ev_recv, 0)); // (the payload moved on the communicator's own stream)
     WireBatch B;
     B.n_items = 0; B.total = 0;
     int rc_;
@@ -1036,10 +1036,11 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   // The exchanges of a frame are issued on the COMPUTE stream itself (the communicator's own stream is bound to it for the frame): a tick is
   // a short dependent sequence -- chain, report, announce, copy, pack, payload, unpack -- and every hop between two streams costs an event
   // record, a wait and the queues' hand-over latency on the device (toy two-rank frame 914 -> 670 us, profiles/r04_tick_floor.txt).  What is
-  // given up is the overlap of a payload with the next chain: kilobytes to a few megabytes per tick against chains that are small after
-  // the frame's first one.  GVT_HIP_COMM_STREAM=1: the communicator's own stream, as in round 3.
+  // given up is the overlap of a SMALL payload with the next chain; a payload of a megabyte or more (knob payload_overlap_kb, sent +
+  // received) still moves on the communicator's own stream while the next chain runs.  GVT_HIP_COMM_STREAM=1: everything on that stream, as in round 3.
   struct StreamBind { gvt_hip_comm *K; hipStream_t saved; ~StreamBind() { if (K) K->stream = saved; } } stream_bind{ nullptr, nullptr };
   static const bool own_comm_stream = getenv("GVT_HIP_COMM_STREAM") != nullptr;
+  const size_t payload_overlap_min = (size_t)C.payload_overlap_kb << 10;
   if (R->comm && !own_comm_stream) { stream_bind.K = R->comm; stream_bind.saved = R->comm->stream; R->comm->stream = st; }
   int tick = 0;
   for (;; tick++) {
@@ -1116,6 +1117,13 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
       // room for what arrives, reserved now (the unpack kernels are launched later, behind the next local chain)
       for (size_t i = 0; i < nI; i++)
         if (incoming[i] && (rc = queue_reserve(R->queues[i], R->present[i] + incoming[i]))) return rc;
+      // A payload of a megabyte or more moves on the communicator's OWN stream, while the next tick's local chain runs on the compute
+      // stream (ordered by two events); smaller ones -- every late tick of a frame -- stay on the compute stream (StreamBind above).
+      size_t bytes_total = 0;
+      for (int p = 0; p < R->world; p++) bytes_total += bytes_out[p] + bytes_in[p];
+      const bool overlap = stream_bind.K && stream_bind.saved && bytes_total >= payload_overlap_min;
+      if (overlap) K->stream = stream_bind.saved;
+      struct Rebind { gvt_hip_comm *K; hipStream_t s; ~Rebind() { if (K) K->stream = s; } } rebind{ overlap ? K : nullptr, st };
       if (K->stream != st) { HIPCHK(hipEventRecord(R->ev_pack, st)); HIPCHK(hipStreamWaitEvent(K->stream, R->ev_pack, 0)); }
       if (C.frame_timing) { HIPCHK(hipEventRecord(R->ev_pay0, K->stream)); R->payload_timed = true; }
       comm_group_begin(K); // sizes are known on both sides from the announces: no size handshake on the wire
@@ -1125,7 +1133,8 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
         if (bytes_in[p]) comm_recv(K, R->recv_buf[p], bytes_in[p], p);
       }
       if ((rc = comm_group_end(K))) return rc;
-      if (K->stream != st || C.frame_timing) HIPCHK(hipEventRecord(R->ev_recv, K->stream));
+      payload_cross = K->stream != st;
+      if (payload_cross || C.frame_timing) HIPCHK(hipEventRecord(R->ev_recv, K->stream));
       payload_pending = true;
     }
   }

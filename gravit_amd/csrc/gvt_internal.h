@@ -54,6 +54,8 @@ struct Knobs {
   int skip_known = 1;    // shuffleRays' known-miss shortcut (gvt_device.h): a ray is not traced again in an instance it has already crossed without a hit
                          // on the same straight segment (image-identical; 0: the reference's hop-by-hop behaviour, same ray counts as its schedulers)
   int long_auto = 1;     // native tracer: raise the parking threshold from frame to frame while more than 0.3 % of a frame's closest-hit rays get parked (sparser scenes than the benchmark)
+  int payload_overlap_kb = 1024; // Domain scheduler: a tick's payload of at least this many KiB (sent + received) moves on the communicator's own stream while the next
+                         // chain runs; smaller ones stay on the compute stream (no cross-stream event pairs).  0: every payload on its own stream
   int frame_timing = 0;  // multi-rank frames: fill gvt_hip_frame_stats' ms_chain / ms_announce / ms_payload / ms_composite (five more event calls per exchange)
   int inject_fail_tick = -1; // tests: this rank's local work "fails" at that exchange of a multi-rank frame (the announce carries the error to every rank)
   int report_poll = 1;   // one rank: a round's report is written into pinned host memory by the kernel and polled (no copy, no stream synchronisation)

@@ -313,11 +313,10 @@ int gvt_hip_wide_visit_stats(gvt_hip_mesh *, const float *org, const float *dir,
  * functions the bounce path (EmbreeMeshAdapter.cpp:289-318) is built on. */
 int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
 /* Knobs of the library (gvt_internal.h `struct Knobs` lists them with their defaults; ("defaults", 0) restores all of them).  Results never
- * depend on them -- except "skip_known", which switches between two shuffle rules with the same image (below).  The shipped surface, 16 knobs:
+ * depend on them -- except "skip_known", which switches between two shuffle rules with the same image (below).  The shipped surface, 15 knobs:
  *   behaviour    "skip_known"   1: shuffleRays' known-miss shortcut (a ray is not traced / sent again into an instance it has already crossed
  *                               without a hit on the same straight segment; image-identical) -- 0: the reference's hop-by-hop rule, ray for ray
  *                "term_sink"    1: gvt_hip_trace_queue_sink applies shuffleRays' terminal rule inside the kernels -- 0: every moved ray goes through the shuffle
- *                "camera_tile"  8: camera rays listed in 8x8-pixel tiles -- 0: generateRays' pixel-major order
  *                "sort_rays"    1: Morton-sort a list before traversal (pays on incoherent lists; off)
  *                "frame_timing" 1: fill gvt_hip_frame_stats' per-phase milliseconds (five more event calls per exchange)
  *   build time   "leaf_max"     triangles per leaf of meshes created afterwards (1..4, default 2)
@@ -325,11 +324,12 @@ int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
  *                               applies to, and whether gvt_hip_tracer_frame raises it from frame to frame on scenes that park more than 0.3 % of their rays
  *                "small_rays" / "finish_rays"    rounds of at most so many rays: a wave per ray / the whole round in one launch (k_finish)
  *                "round_room_mb"                 memory a round's worst-case reservation may add before it falls back to exact growth
- *                "abi_lanes" / "abi_chunk" / "abi_pipe_min"   gvt_hip_trace on a host RayVector: pipeline lanes (0: one shot), rays per chunk, shortest pipelined list
+ *                "payload_overlap_kb"            Domain scheduler: payloads of at least this size move on the communicator's own stream beside the next chain
+ *                "abi_lanes" / "abi_chunk"     gvt_hip_trace on a host RayVector: pipeline lanes (0: one shot), rays per chunk
  *   test hook    "inject_fail_tick"
  * Everything else -- the tuned constants of the kernels (refill / phase thresholds, grid sizes, drain sharing ...) and the variants that were
  * measured and lost ("trav_kernel" = 0, "wide4" = 0, "coop_fetch", "fused", "packet", "quad", merged kernels for one queue, compacted shadow
- * slots, non-lean frames ...: EXPERIMENTS.md) -- can be moved only in the experiments build of the library (libgvt_hip_exp.so,
+ * slots, non-lean frames, camera rays in generateRays' pixel-major order ("camera_tile" = 0) ...: EXPERIMENTS.md) -- can be moved only in the experiments build of the library (libgvt_hip_exp.so,
  * -DGVT_EXPERIMENTS), where the knob sweeps run; the shipped library answers GVT_HIP_ERR_INVALID when one of them is switched away from its default. */
 int gvt_hip_set_option(const char *name, int value);
 /* 1 in the experiments build (every variant behind its knob), 0 in the shipped library */

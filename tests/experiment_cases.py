@@ -26,7 +26,7 @@ def test_this_is_the_experiments_build(hip):
 @pytest.mark.parametrize("opts", [dict(refill_min=1, inner_min=1), dict(refill_min=64, inner_min=64), dict(blocks_per_cu=1, refill_min=8, inner_min=16), dict(sort_rays=0, top_lds=0),
                                   dict(sort_rays=1, sort_bits=32), dict(refill_min=2, inner_min=60), dict(share=0), dict(share=3, blocks_per_cu=6, refill_min=64, share_min_rays=0),
                                   dict(share=3, share_min_rays=0), dict(share=3, share_min_rays=0, long_steps=3, long_min_rays=0), dict(share=1, share_min_rays=0, blocks_per_cu=1),
-                                  dict(top_ordered=0), dict(leaf_max=3, share=3, share_min_rays=0), dict(sort_rays=1, sort_gather=1),
+                                  dict(top_ordered=0), dict(leaf_max=3, share=3, share_min_rays=0), dict(sort_rays=1, sort_gather=1), dict(term_sink=0, camera_tile=0),
                                   dict(trav_kernel=0), dict(wide4=0, coop_fetch=0), dict(wide4=0, coop_fetch=1, refill_min=3, inner_min=5), dict(wide4=0, sort_rays=1),
                                   dict(wide4=0, share=3, share_min_rays=0, long_steps=3, long_min_rays=0),
                                   dict(quad=1), dict(quad=1, leaf_max=4), dict(quad=1, leaf_max=1, quad_inner_min=1, quad_refill_min=1),
@@ -80,7 +80,7 @@ def test_quad_kernel_on_surface_meshes_and_deep_stacks(hip, name):
 
 
 @pytest.mark.parametrize("opts", [dict(first_round_async=0), dict(wave_single=0), dict(shadow_direct=0), dict(small_rays=1 << 30, wave_single=0), dict(blocks_per_cu_closest=0, term_sink=0),
-                                  dict(lean_frame=0), dict(report_poll=0), dict(lean_frame=0, report_poll=0, first_round_async=0),
+                                  dict(lean_frame=0), dict(report_poll=0), dict(lean_frame=0, report_poll=0, first_round_async=0), dict(sort_rays=1, camera_tile=0),
                                   dict(packet=1), dict(packet=1, camera_tile=0), dict(first_round_async=1, packet=1), dict(fused=1), dict(quad=1, leaf_max=4),
                                   dict(quad=1, leaf_max=2, small_rays=0), dict(quad=1, leaf_max=4, wave_single=0, shadow_direct=0)])
 def test_round_results_do_not_depend_on_experimental_variants(hip, opts):

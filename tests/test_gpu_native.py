@@ -108,13 +108,14 @@ def test_native_domain_scheduler_config4(hip, world, bsp):
         assert all(r[1]["rounds"] == st.rounds for r in res.values())
 
 
-@pytest.mark.parametrize("size,n_dom,world,bsp", [(768, 4, 4, True), (384, 8, 8, False), (384, 4, 2, False), (256, 8, 3, True)])
-def test_native_domain_scheduler_config5(hip, size, n_dom, world, bsp):
+@pytest.mark.parametrize("size,n_dom,world,bsp,overlap_kb", [(768, 4, 4, True, 1024), (384, 8, 8, False, 1024), (384, 4, 2, False, 0), (256, 8, 3, True, 0)])
+def test_native_domain_scheduler_config5(hip, size, n_dom, world, bsp, overlap_kb):
     """BASELINE config 5 stand-in (4 rays per pixel, depth 2) under the native Domain scheduler: bounce and shadow rays cross slabs
-    and ranks in the reference's wire format with their RNG stream word."""
+    and ranks in the reference's wire format with their RNG stream word.  overlap_kb = 0: every payload moves on the communicator's
+    own stream beside the next chain (default: only payloads of a megabyte or more; the others stay on the compute stream)."""
     sc = config5(size, n_dom)
     owner = [i % world for i in range(sc.n_inst)]
-    res = run_native_ranks(sc, owner, world, NORMALS_FLAT, bsp)
+    res = run_native_ranks(sc, owner, world, NORMALS_FLAT, bsp, opts=(("payload_overlap_kb", overlap_kb),))
     fb = res[0][0]
     ref, st = oracle_render_domain(sc, owner, world, 0)
     assert (ref[..., :3].sum(axis=2) > 0).mean() > 0.2
@@ -392,7 +393,7 @@ def test_top_level_bvh_with_1056_instances(hip):
 
 @pytest.mark.parametrize("opts", [dict(small_rays=0), dict(small_rays=1 << 30), dict(term_sink=0), dict(leaf_max=4, small_rays=0), dict(finish_rays=0), dict(round_room_mb=0),
                                   dict(round_room_mb=0, finish_rays=0, small_rays=0), dict(finish_rays=1 << 30), dict(finish_rays=1 << 30, leaf_max=4), dict(skip_known=0, finish_rays=0),
-                                  dict(sort_rays=1, camera_tile=0)])
+                                  dict(sort_rays=1)])
 def test_round_results_do_not_depend_on_knobs(hip, opts):
     """The round chain under every knob of the shipped library -- a wave per ray for small rounds or never, k_finish or rounds, exact
     growth, no terminal sink, the reference's hop-by-hop shuffle -- returns the oracle's image on a multi-domain depth-2 frame, on config 4

@@ -64,7 +64,7 @@ def test_closest_and_any_hit_match_oracle(hip, name):
     assert info["n_tris"] == len(mesh.tris) and np.allclose(info["bbox_lo"], lo) and np.allclose(info["bbox_hi"], hi)
 
 
-@pytest.mark.parametrize("opts", [dict(sort_rays=1), dict(long_steps=2, long_min_rays=0), dict(long_steps=0), dict(term_sink=0, camera_tile=0),
+@pytest.mark.parametrize("opts", [dict(sort_rays=1), dict(long_steps=2, long_min_rays=0), dict(long_steps=0), dict(term_sink=0),
                                   dict(leaf_max=1), dict(leaf_max=4, long_steps=4, long_min_rays=0), dict(leaf_max=3)])
 def test_results_do_not_depend_on_tuning_knobs(hip, opts):
     """Every knob of the shipped library that touches the adapter call -- sorting, parking threshold, sink, list order, leaf size -- returns
