@@ -269,8 +269,8 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_cam1_count(CamArgs A, unsigned n,
   if (i < n) {
     const RayRec r = camera_ray(A, (unsigned long long)i);
     float ret_t;
-    hit = top_nearest(make_float4(r.o.x, r.o.y, r.o.z, r.t_min), make_float4(r.d.x, r.d.y, r.d.z, r.t_max), top, -1, ret_t) >= 0;
-    if (fb && i % (unsigned)(A.samples * A.samples) == 0u && (unsigned)r.id < n_pix) fb[(unsigned)r.id] = make_float4(0.f, 0.f, 0.f, 0.f); // clearBuffer
+    hit = camera_slot_valid(A, (unsigned long long)i) && top_nearest(make_float4(r.o.x, r.o.y, r.o.z, r.t_min), make_float4(r.d.x, r.d.y, r.d.z, r.t_max), top, -1, ret_t) >= 0;
+    if (fb && i % (unsigned)(A.samples * A.samples) == 0u && (unsigned)r.id < n_pix) fb[(unsigned)r.id] = make_float4(0.f, 0.f, 0.f, 0.f); // clearBuffer (whole-film enumeration only)
   }
   const unsigned long long m = ballot64(hit);
   if (lane_id() == 0) sh_w[threadIdx.x >> 6] = (unsigned)__popcll(m);
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_cam1_scatter(CamArgs A, unsigned 
   if (i < n) {
     r = camera_ray(A, (unsigned long long)i);
     float ret_t;
-    hit = top_nearest(make_float4(r.o.x, r.o.y, r.o.z, r.t_min), make_float4(r.d.x, r.d.y, r.d.z, r.t_max), top, -1, ret_t) >= 0;
+    hit = camera_slot_valid(A, (unsigned long long)i) && top_nearest(make_float4(r.o.x, r.o.y, r.o.z, r.t_min), make_float4(r.d.x, r.d.y, r.d.z, r.t_max), top, -1, ret_t) >= 0;
     if (hit) r.o = add3(r.o, scl3(r.d, ret_t * 0.95f)); // TracerBase.h:393
   }
   const unsigned long long m = ballot64(hit);
@@ -606,21 +606,33 @@ int camera_filter_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt
   S.from_cam = 1;
   return shuffle_async_src(T, S, count, nullptr, nullptr, -1, queues, keep_mask, nullptr, d_overflow, nullptr);
 }
+static bool camera_keep_rect(const gvt_hip_top *T, CamArgs &A, const uint8_t *keep_mask);
 // clearBuffer + generateRays + FilterRaysLocally for a ONE-instance scene on one rank, with the launch chain's pass-0 resets folded
 // in (k_cam1_count / k_cam1_scatter).  q must have room for all W*H*samples^2 rays; its count lives on the device only.
 int camera_one_instance_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *q, gvt_hip_fb *fb, unsigned *d_overflow, unsigned *d_moved_count) {
   Ctx &C = gctx();
   const size_t n = (size_t)cam->width * cam->height * cam->samples * cam->samples;
   if (!n || n > 0xffffffffull || T->n != 1) { set_error("camera_one_instance: bad arguments"); return GVT_HIP_ERR_INVALID; }
-  const CamArgs A = make_cam_args(cam->eye, cam->focus, cam->up, cam->fov, cam->width, cam->height, cam->samples, cam->depth, cam->jitter_window_size, tile);
-  const unsigned n_blk = blocks_for(n, TOP_BLOCK);
+  CamArgs A = make_cam_args(cam->eye, cam->focus, cam->up, cam->fov, cam->width, cam->height, cam->samples, cam->depth, cam->jitter_window_size, tile);
+  // only the film rectangle the instance's box projects onto is enumerated (no other camera ray can enter it); the kernels then no longer
+  // touch every pixel, so the framebuffer is cleared by a fill in front of them
+  size_t n_list = n;
+  if (tile == 8 && camera_keep_rect(T, A, nullptr)) {
+    n_list = (size_t)A.rtpr * (size_t)((A.ry1 - A.ry0 + 7) / 8) * 64u * (size_t)(cam->samples * cam->samples);
+    if (fb) HIPCHK(hipMemsetAsync(fb->d_rgba, 0, sizeof(float) * 4 * (size_t)fb->w * fb->h, C.stream));
+    fb = nullptr;
+  }
+  if (!n_list) n_list = 1; // (nothing in view: one empty position, so that the kernels still publish the counts and do the resets)
+  const size_t n_cam_all = n;
+  (void)n_cam_all;
+  const unsigned n_blk = blocks_for(n_list, TOP_BLOCK);
   unsigned *d_blk = (unsigned *)scratch_get(14, sizeof(unsigned) * n_blk);
   if (!d_blk) return GVT_HIP_ERR_DEVICE;
   QueueDesc Q{ q->d_planes, q->cap, q->d_count, 1u };
   {
     ProfScope ps(KC_SHUFFLE);
-    k_cam1_count<<<n_blk, TOP_BLOCK, 0, C.stream>>>(A, (unsigned)n, T->dev(), d_blk, fb ? (float4 *)fb->d_rgba : nullptr, fb ? (unsigned)(fb->w * fb->h) : 0u, C.d_counters, d_overflow);
-    k_cam1_scatter<<<n_blk, TOP_BLOCK, 0, C.stream>>>(A, (unsigned)n, T->dev(), d_blk, Q, d_overflow, C.d_counters, d_moved_count);
+    k_cam1_count<<<n_blk, TOP_BLOCK, 0, C.stream>>>(A, (unsigned)n_list, T->dev(), d_blk, fb ? (float4 *)fb->d_rgba : nullptr, fb ? (unsigned)(fb->w * fb->h) : 0u, C.d_counters, d_overflow);
+    k_cam1_scatter<<<n_blk, TOP_BLOCK, 0, C.stream>>>(A, (unsigned)n_list, T->dev(), d_blk, Q, d_overflow, C.d_counters, d_moved_count);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -701,7 +713,7 @@ int shuffle_exact(gvt_hip_top *T, gvt_hip_queue *q_in, const int *from_arr, int 
   return shuffle_impl(T, S, n, from, queues, nullptr, fb, from_arr);
 }
 
-// The pixels the kept instances' boxes project onto, as a tile-aligned rectangle of the film (two pixels of margin): a camera ray of any
+// The pixels the kept instances' boxes (keep_mask == NULL: all instances) project onto, as a tile-aligned rectangle of the film (two pixels of margin): a camera ray of any
 // other pixel cannot enter one of those boxes at all, so it cannot have one of them as its first domain (shuffleDropRays keeps nothing of
 // it).  False -- the whole film -- when a box reaches behind the eye plane, when sub-samples are spread by a jitter window, or when the
 // rectangle is nearly the whole film anyway.  An empty rectangle (no kept instance in view) sets rx1 <= rx0.
@@ -710,7 +722,7 @@ static bool camera_keep_rect(const gvt_hip_top *T, CamArgs &A, const uint8_t *ke
   double x0 = 1e30, y0 = 1e30, x1 = -1e30, y1 = -1e30;
   bool any = false;
   for (size_t i = 0; i < T->n; i++) {
-    if (!keep_mask[i]) continue;
+    if (keep_mask && !keep_mask[i]) continue;
     any = true;
     for (int c = 0; c < 8; c++) {
       const double p[3] = { (c & 1) ? T->h_hi[3 * i] : T->h_lo[3 * i], (c & 2) ? T->h_hi[3 * i + 1] : T->h_lo[3 * i + 1], (c & 4) ? T->h_hi[3 * i + 2] : T->h_lo[3 * i + 2] };
@@ -748,7 +760,7 @@ extern "C" int gvt_hip_camera_filter(gvt_hip_top *T, const gvt_hip_camera *cam, 
   S.cam = make_cam_args(cam->eye, cam->focus, cam->up, cam->fov, cam->width, cam->height, cam->samples, cam->depth, cam->jitter_window_size, tile);
   S.from_cam = 1;
   size_t n_list = n;
-  if (keep_mask && tile == 8 && camera_keep_rect(T, S.cam, keep_mask)) // shuffleDropRays: only the pixels this rank's instances project onto
+  if (tile == 8 && camera_keep_rect(T, S.cam, keep_mask)) // only the pixels the (kept) instances project onto: no other camera ray can enter one of them
     n_list = (size_t)S.cam.rtpr * (size_t)((S.cam.ry1 - S.cam.ry0 + 7) / 8) * 64u * (size_t)(cam->samples * cam->samples);
   if (!n_list) return 0;
   return shuffle_impl(T, S, n_list, -1, queues, keep_mask, nullptr);
