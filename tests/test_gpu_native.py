@@ -524,3 +524,32 @@ def test_parking_threshold_adapts_to_a_sparser_scene(hip):
     fb = tr().framebuffer(False)
     assert np.array_equal(fb, fb0) and int(hip.counters_peek()[3]) == parked0  # off: the knob's threshold, frame after frame
     tr.close()
+
+
+@pytest.mark.parametrize("case", ["partly_off_film", "box_behind_the_eye_plane", "nothing_in_view", "jitter_window"])
+def test_camera_rectangle_edge_cases(hip, case):
+    """The camera filter enumerates only the film rectangle the (kept) instances' boxes project onto (sched.hip camera_keep_rect).
+    Instances that leave the film on two sides, a box that reaches behind the eye plane (no bounded projection: the whole film is
+    enumerated), a camera that sees nothing, sub-samples spread by a jitter window (whole film): images and ray counts are the
+    oracle's, on one rank and on two."""
+    sc = scenes.bunny_grid_scene(width=333, height=190)
+    if case == "partly_off_film":
+        sc.camera.eye, sc.camera.focus = (0.45, 0.2, 1.1), (0.45, 0.2, 0.0)
+    elif case == "box_behind_the_eye_plane":
+        sc.camera.eye, sc.camera.focus = (0.0, 0.1, 0.12), (0.3, 0.1, 0.0)  # among the bunnies' boxes, looking sideways
+    elif case == "nothing_in_view":
+        sc.camera.eye, sc.camera.focus = (0.0, 0.1, 1.6), (0.0, 0.1, 3.0)
+    else:
+        sc.camera.samples, sc.camera.jitter = 2, 1.0
+    ref, st = oracle_render(sc, NORMALS_SMOOTH, nthreads=8)
+    tr = NativeTracer(sc, NORMALS_SMOOTH)
+    fb = tr().framebuffer(True)
+    assert np.abs(fb[..., :3] - ref[..., :3]).max() <= (1e-5 if case == "jitter_window" else 0.0) and np.array_equal(fb[..., 3], ref[..., 3])
+    assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any
+    assert (st.rays_closest == 0) == (case == "nothing_in_view")
+    tr.close()
+    owner = [i % 2 for i in range(sc.n_inst)]
+    res = run_native_ranks(sc, owner, 2, NORMALS_SMOOTH, False)
+    refd, std = oracle_render_domain(sc, owner, 2, NORMALS_SMOOTH)
+    assert np.abs(res[0][0][..., :3] - refd[..., :3]).max() <= (1e-5 if case == "jitter_window" else 0.0) and np.array_equal(res[0][0][..., 3], refd[..., 3])
+    assert sum(r[1]["rays_closest"] for r in res.values()) == std.rays_closest and sum(r[1]["rays_sent"] for r in res.values()) == std.rays_sent
