@@ -448,6 +448,8 @@ def main():
     ap.add_argument("--no-sustained", action="store_true", help="skip the `sustained` key (>= 2000 frames / 2.5 s of the same frame back to back)")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal only: every rank uses device 0 (needs an RCCL that tolerates it)")
+    ap.add_argument("--fake-comm", action="store_true", help="rehearsal only (one GPU, --same-gpu): no communicator -- every rank renders every scene alone, all domains local; "
+                                                              "exercises this script's N>1 native plumbing (variants, extra legs, reductions) where RCCL cannot run; the numbers mean nothing")
     ap.add_argument("--single-variant", action="store_true", help="N>1: only the variant --scheduler / --bsp select (default: Domain asynchronous = `value`, "
                                                                     "plus Domain BSP and the replicated Image scheduler as extra keys of the same line)")
     ap.add_argument("--inproc-ranks", type=int, default=0, help="N=1 only: run the native multi-rank frame loop with this many in-process ranks on ONE GPU "
@@ -510,10 +512,11 @@ def main():
     image_split = world > 1 and args.scheduler == "image" and args.harness == "native"
     n_dom = (world if not image_split else 1) if world > 1 else max(1, args.domains)
     scene = scenes.soup_scene(args.tris, args.width, args.height) if n_dom == 1 else scenes.soup_domains_scene(args.tris, n_dom, args.width, args.height)
-    owner = [i % world for i in range(scene.n_inst)]
+    own_map = (lambda n: [0] * n) if args.fake_comm else (lambda n: [i % world for i in range(n)])
+    owner = own_map(scene.n_inst)
     comm = None
     if args.harness == "native":
-        if world > 1:
+        if world > 1 and not args.fake_comm:
             uid = [Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             comm = Comm.rccl(uid[0], rank, world)  # fails unless ncclCommCount == world
@@ -551,7 +554,7 @@ def main():
     def frame():
         if args.harness == "native":
             try:
-                tracer(bsp=args.bsp, image=image_split)  # includes IceTComposite::composite (to rank 0); the PPM download is not part of the frame
+                tracer(bsp=args.bsp, image=image_split and not args.fake_comm)  # includes IceTComposite::composite (to rank 0); the PPM download is not part of the frame
             except capi.GvtHipError as e:
                 if world == 1:
                     raise
@@ -623,8 +626,8 @@ def main():
                     tr_v = tracer  # same scene and tracer as the primary variant
                 else:
                     sc_v = scenes.soup_scene(args.tris, args.width, args.height) if kind == "image" else scenes.soup_domains_scene(args.tris, world, args.width, args.height)
-                    tr_v = made = NativeTracer(sc_v, NORMALS_FLAT, [i % world for i in range(sc_v.n_inst)], comm, replicate=(kind == "image"))
-                run_v = (lambda t=tr_v, b=bsp_v, im=(kind == "image"): t(bsp=b, image=im))
+                    tr_v = made = NativeTracer(sc_v, NORMALS_FLAT, own_map(sc_v.n_inst), comm, replicate=(kind == "image"))
+                run_v = (lambda t=tr_v, b=bsp_v, im=(kind == "image" and not args.fake_comm): t(bsp=b, image=im))
                 stats_v = (lambda t=tr_v: t.stats)
             else:  # the Python scheduler loops (harness / CPU rehearsal): a tracer per variant, counters through the backend
                 be_v = None if on_gpu else OracleBackend(scene, NORMALS_FLAT, [o == rank for o in owner])
@@ -676,7 +679,7 @@ def main():
             return run, stats, (lambda: None)
 
         sc4 = scenes.bunny_grid_scene(width=args.config4_width, height=args.config4_height)
-        own4 = [i % world for i in range(sc4.n_inst)]
+        own4 = own_map(sc4.n_inst)
         leg = {"workload": CONFIG4_NOTE, "film": [args.config4_width, args.config4_height]}
         for name, bsp_v in (("domain_async", False), ("domain_bsp", True)):
             run_v, stats_v, close_v = tracer_for(sc4, NORMALS_SMOOTH, own4, bsp_v)
@@ -688,12 +691,12 @@ def main():
         # weak_soup: every rank generates its own tile only; the tiles' boxes are exchanged through the rendezvous group (a Domain-scheduler
         # rank knows every instance's box, DomainTracer.h:115-144)
         ww, wh = weak_film(world, args.width, args.height)
-        mine = scenes.soup_weak_scene(args.weak_tris, world, ww, wh, own=[rank], boxes=[(np.zeros(3), np.zeros(3))] * world)
+        mine = scenes.soup_weak_scene(args.weak_tris, world, ww, wh, own=None if args.fake_comm else [rank], boxes=[(np.zeros(3), np.zeros(3))] * world)
         boxes = [None] * world
         dist.all_gather_object(boxes, (mine.inst_lo[rank].tolist(), mine.inst_hi[rank].tolist()))
         mine.inst_lo[:] = np.array([b[0] for b in boxes], np.float32)
         mine.inst_hi[:] = np.array([b[1] for b in boxes], np.float32)
-        run_v, stats_v, close_v = tracer_for(mine, NORMALS_FLAT, list(range(world)), False)
+        run_v, stats_v, close_v = tracer_for(mine, NORMALS_FLAT, own_map(world) if args.fake_comm else list(range(world)), False)
         if on_gpu:
             capi.stats_reset()
 
@@ -761,7 +764,7 @@ def main():
             },
         }
         if world > 1 and args.harness == "native":
-            out["config"]["rccl_comm_count"] = comm.count  # == WORLD_SIZE (gvt_hip_comm_create refuses anything else)
+            out["config"]["rccl_comm_count"] = comm.count if comm is not None else None  # == WORLD_SIZE (gvt_hip_comm_create refuses anything else)
         if variants is not None:
             out["config"]["bytes_sent_per_step"] = ([v for v in variants.values() if v["is_value"]] or [{}])[0].get("bytes_sent_per_step")
         if variants is not None:
