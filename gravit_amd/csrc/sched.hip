@@ -623,8 +623,6 @@ int camera_one_instance_async(gvt_hip_top *T, const gvt_hip_camera *cam, int til
     fb = nullptr;
   }
   if (!n_list) n_list = 1; // (nothing in view: one empty position, so that the kernels still publish the counts and do the resets)
-  const size_t n_cam_all = n;
-  (void)n_cam_all;
   const unsigned n_blk = blocks_for(n_list, TOP_BLOCK);
   unsigned *d_blk = (unsigned *)scratch_get(14, sizeof(unsigned) * n_blk);
   if (!d_blk) return GVT_HIP_ERR_DEVICE;
