@@ -258,17 +258,27 @@ def die_on_exchange_error(rank, world, what, err, stats):
     os._exit(1)
 
 
+class LegFailed(Exception):
+    """A frame of a secondary measurement (a scheduler variant, an extra leg) failed in the ray exchange.  Such a failure is collective -- the
+    failing rank's error word travels in the announce, a silent peer runs everyone into the deadline -- so every rank gets here at the
+    same exchange: the leg is recorded as failed, the legs behind it (same communicator) are skipped, `value` (measured before) stands."""
+
+
 def measure_variant(run_frame, frame_stats, steps, warmup, barrier, reduce_sum, reduce_max, rank, world, name):
     """W untimed + K timed frames of one scheduler variant; rays and bytes summed over the ranks, wall time and the per-phase times
     as the maximum over the ranks.  run_frame() renders one frame, frame_stats() returns that frame's counters on this rank."""
     def frame():
         try:
+            if os.environ.get("GVT_BENCH_FAIL_LEG") == name:  # test hook (tests/test_domain_gloo.py): this leg fails on every rank, as an exchange failure does
+                raise type("GvtHipError", (Exception,), {})("injected failure (GVT_BENCH_FAIL_LEG)")
             run_frame()
         except Exception as e:  # noqa: BLE001 -- GvtHipError: a deadline passed or a peer reported an error
             if type(e).__name__ != "GvtHipError":
                 raise
-            die_on_exchange_error(rank, world, name, e, frame_stats())
+            print("bench.py: rank %d of %d: %s failed: %s\n  last frame stats of this rank: %s" % (rank, world, name, e, frame_stats()), file=sys.stderr, flush=True)
+            raise LegFailed("%s: %s" % (name, e)) from e
 
+    barrier()  # the ranks prepared their scenes at their own pace: start together, inside the exchange's deadline
     for _ in range(warmup):
         frame()
     barrier()
@@ -564,6 +574,7 @@ def main():
             if world > 1:
                 tracer.composite(download=False)
 
+    barrier()
     for _ in range(args.warmup):
         frame()
     barrier()
@@ -615,11 +626,14 @@ def main():
     variants = None
     if world > 1 and on_gpu and args.harness == "native":
         capi.set_option("frame_timing", 1)  # the variants and the extra legs carry the per-phase breakdown (five more event calls per exchange); `value` above ran without
+    legs_error = None  # the first secondary measurement that failed (LegFailed): what is behind it is skipped, the line is still printed
     if world > 1 and not args.single_variant:
         variants = {}
         primary = "image_replicated" if image_split else ("domain_bsp" if args.bsp else "domain_async")
         todo = [("domain_async", "domain", False), ("domain_bsp", "domain", True)] + ([("image_replicated", "image", False)] if args.harness == "native" else [])
         for name, kind, bsp_v in todo:
+            if legs_error is not None:
+                break
             made = None
             if args.harness == "native":
                 if (kind == "image") == image_split:
@@ -643,7 +657,12 @@ def main():
                     d = {"rays_closest": c - last["c"], "rays_any": a - last["a"], "rays_sent": getattr(t, "rays_sent", 0), "rounds": getattr(t, "rounds", 0)}
                     last["c"], last["a"] = c, a
                     return d
-            res_v, _, _, _ = measure_variant(run_v, stats_v, args.steps, args.warmup, barrier, reduce_sum, reduce_max, rank, world, name)
+            try:
+                res_v, _, _, _ = measure_variant(run_v, stats_v, args.steps, args.warmup, barrier, reduce_sum, reduce_max, rank, world, name)
+            except LegFailed as e:
+                legs_error = str(e)
+                variants[name] = {"failed": legs_error, "is_value": name == primary}
+                continue
             res_v["is_value"] = name == primary
             variants[name] = res_v
             if made is not None and hasattr(made, "close"):
@@ -652,78 +671,90 @@ def main():
     # N > 1, two more keys of the same line (never `value`): BASELINE configs[3] -- the 8-bunny grid under the Domain scheduler, the
     # configuration BASELINE.json names for the scaling curve -- and the weak-scaling soup (N tiles of 10 M triangles each)
     extra = {}
-    if world > 1 and not args.no_extra_legs and not args.single_variant:
+    if world > 1 and not args.no_extra_legs and not args.single_variant and legs_error is None:
         from gravit_amd.layouts import NORMALS_SMOOTH
 
-        def tracer_for(sc, mode, own, bsp_v):
-            """(run_frame, frame_stats, close) of one Domain-scheduler variant on scene sc"""
-            if args.harness == "native":
-                t = NativeTracer(sc, mode, own, comm)
-                return (lambda: t(bsp=bsp_v)), (lambda: t.stats), t.close
-            be = None if on_gpu else OracleBackend(sc, mode, [o == rank for o in own])
-            t = DomainTracer(sc, own, dist, torch, dev, mode, backend=be, overlap=not bsp_v)
-            last = {"c": 0, "a": 0}
+        def extra_legs():
+            def tracer_for(sc, mode, own, bsp_v):
+                """(run_frame, frame_stats, close) of one Domain-scheduler variant on scene sc"""
+                if args.harness == "native":
+                    t = NativeTracer(sc, mode, own, comm)
+                    return (lambda: t(bsp=bsp_v)), (lambda: t.stats), t.close
+                be = None if on_gpu else OracleBackend(sc, mode, [o == rank for o in own])
+                t = DomainTracer(sc, own, dist, torch, dev, mode, backend=be, overlap=not bsp_v)
+                last = {"c": 0, "a": 0}
 
-            def run():
-                t()
-                t.composite(download=False)
+                def run():
+                    t()
+                    t.composite(download=False)
 
-            def stats():
-                c, a = getattr(t.backend, "rays_closest", 0), getattr(t.backend, "rays_any", 0)
-                if on_gpu:
-                    g = capi.stats()
-                    c, a = g["rays_closest"], g["rays_any"]
-                d = {"rays_closest": c - last["c"], "rays_any": a - last["a"], "rays_sent": getattr(t, "rays_sent", 0), "rounds": getattr(t, "rounds", 0)}
-                last["c"], last["a"] = c, a
+                def stats():
+                    c, a = getattr(t.backend, "rays_closest", 0), getattr(t.backend, "rays_any", 0)
+                    if on_gpu:
+                        g = capi.stats()
+                        c, a = g["rays_closest"], g["rays_any"]
+                    d = {"rays_closest": c - last["c"], "rays_any": a - last["a"], "rays_sent": getattr(t, "rays_sent", 0), "rounds": getattr(t, "rounds", 0)}
+                    last["c"], last["a"] = c, a
+                    return d
+                return run, stats, (lambda: None)
+
+            sc4 = scenes.bunny_grid_scene(width=args.config4_width, height=args.config4_height)
+            own4 = own_map(sc4.n_inst)
+            leg = {"workload": CONFIG4_NOTE, "film": [args.config4_width, args.config4_height]}
+            for name, bsp_v in (("domain_async", False), ("domain_bsp", True)):
+                run_v, stats_v, close_v = tracer_for(sc4, NORMALS_SMOOTH, own4, bsp_v)
+                leg[name], _, _, tot4 = measure_variant(run_v, stats_v, args.steps, args.warmup, barrier, reduce_sum, reduce_max, rank, world, "config4_bunny_grid " + name)
+                leg[name]["rays_per_step"] = (tot4[0] + tot4[1]) / args.steps
+                close_v()
+            extra["config4_bunny_grid"] = leg
+            sc4 = None
+            # weak_soup: every rank generates its own tile only; the tiles' boxes are exchanged through the rendezvous group (a Domain-scheduler
+            # rank knows every instance's box, DomainTracer.h:115-144)
+            ww, wh = weak_film(world, args.width, args.height)
+            mine = scenes.soup_weak_scene(args.weak_tris, world, ww, wh, own=None if args.fake_comm else [rank], boxes=[(np.zeros(3), np.zeros(3))] * world)
+            boxes = [None] * world
+            dist.all_gather_object(boxes, (mine.inst_lo[rank].tolist(), mine.inst_hi[rank].tolist()))
+            mine.inst_lo[:] = np.array([b[0] for b in boxes], np.float32)
+            mine.inst_hi[:] = np.array([b[1] for b in boxes], np.float32)
+            run_v, stats_v, close_v = tracer_for(mine, NORMALS_FLAT, own_map(world) if args.fake_comm else list(range(world)), False)
+            if on_gpu:
+                capi.stats_reset()
+
+            barrier()
+            for _ in range(args.warmup):
+                try:
+                    run_v()
+                except Exception as e:  # noqa: BLE001
+                    if type(e).__name__ != "GvtHipError":
+                        raise
+                    raise LegFailed("weak_soup (warm-up): %s" % e) from e
+            if on_gpu:
+                capi.stats_reset(); capi.profile(2)
+            wsum = {}
+
+            def stats_w():
+                d = stats_v()
+                for k in ("rays_closest", "rays_any"):
+                    wsum[k] = wsum.get(k, 0) + d.get(k, 0)
                 return d
-            return run, stats, (lambda: None)
 
-        sc4 = scenes.bunny_grid_scene(width=args.config4_width, height=args.config4_height)
-        own4 = own_map(sc4.n_inst)
-        leg = {"workload": CONFIG4_NOTE, "film": [args.config4_width, args.config4_height]}
-        for name, bsp_v in (("domain_async", False), ("domain_bsp", True)):
-            run_v, stats_v, close_v = tracer_for(sc4, NORMALS_SMOOTH, own4, bsp_v)
-            leg[name], _, _, tot4 = measure_variant(run_v, stats_v, args.steps, args.warmup, barrier, reduce_sum, reduce_max, rank, world, "config4_bunny_grid " + name)
-            leg[name]["rays_per_step"] = (tot4[0] + tot4[1]) / args.steps
+            weak, _, _, totw = measure_variant(run_v, stats_w, args.steps, 0, barrier, reduce_sum, reduce_max, rank, world, "weak_soup")
+            roof = None
+            if on_gpu:
+                stw = capi.stats(); capi.profile(False)
+                roof = rank_roofline(stw, wsum.get("rays_closest", 0), wsum.get("rays_any", 0), args.weak_tris)
+            roofs = [None] * world
+            dist.all_gather_object(roofs, roof)
+            weak.update({"workload": WEAK_NOTE % (args.weak_tris, ww, wh), "scaling": "weak", "tiles": world, "tris_per_tile": args.weak_tris, "film": [ww, wh],
+                         "rays_per_step": (totw[0] + totw[1]) / args.steps, "roofline_per_rank": roofs})
+            extra["weak_soup"] = weak
             close_v()
-        extra["config4_bunny_grid"] = leg
-        sc4 = None
-        # weak_soup: every rank generates its own tile only; the tiles' boxes are exchanged through the rendezvous group (a Domain-scheduler
-        # rank knows every instance's box, DomainTracer.h:115-144)
-        ww, wh = weak_film(world, args.width, args.height)
-        mine = scenes.soup_weak_scene(args.weak_tris, world, ww, wh, own=None if args.fake_comm else [rank], boxes=[(np.zeros(3), np.zeros(3))] * world)
-        boxes = [None] * world
-        dist.all_gather_object(boxes, (mine.inst_lo[rank].tolist(), mine.inst_hi[rank].tolist()))
-        mine.inst_lo[:] = np.array([b[0] for b in boxes], np.float32)
-        mine.inst_hi[:] = np.array([b[1] for b in boxes], np.float32)
-        run_v, stats_v, close_v = tracer_for(mine, NORMALS_FLAT, own_map(world) if args.fake_comm else list(range(world)), False)
-        if on_gpu:
-            capi.stats_reset()
+            mine = None
 
-        for _ in range(args.warmup):
-            run_v()
-        if on_gpu:
-            capi.stats_reset(); capi.profile(2)
-        wsum = {}
-
-        def stats_w():
-            d = stats_v()
-            for k in ("rays_closest", "rays_any"):
-                wsum[k] = wsum.get(k, 0) + d.get(k, 0)
-            return d
-
-        weak, _, _, totw = measure_variant(run_v, stats_w, args.steps, 0, barrier, reduce_sum, reduce_max, rank, world, "weak_soup")
-        roof = None
-        if on_gpu:
-            stw = capi.stats(); capi.profile(False)
-            roof = rank_roofline(stw, wsum.get("rays_closest", 0), wsum.get("rays_any", 0), args.weak_tris)
-        roofs = [None] * world
-        dist.all_gather_object(roofs, roof)
-        weak.update({"workload": WEAK_NOTE % (args.weak_tris, ww, wh), "scaling": "weak", "tiles": world, "tris_per_tile": args.weak_tris, "film": [ww, wh],
-                     "rays_per_step": (totw[0] + totw[1]) / args.steps, "roofline_per_rank": roofs})
-        extra["weak_soup"] = weak
-        close_v()
-        mine = None
+        try:
+            extra_legs()
+        except LegFailed as e:
+            legs_error = str(e)
 
     if rank == 0:
         gpu_fb = tracer.backend.framebuffer(False) if (on_gpu and world == 1 and n_dom == 1) else None  # before the extra legs reuse the backend
@@ -770,6 +801,8 @@ def main():
         if variants is not None:
             out["variants"] = variants  # Domain asynchronous / Domain BSP / replicated Image, each: ticks, ms per tick, rays and bytes sent, per-phase ms
         out.update(extra)  # config4_bunny_grid, weak_soup
+        if legs_error is not None:
+            out["legs_error"] = legs_error  # a secondary measurement failed in the ray exchange; it and what was behind it are missing, `value` was measured before
         if on_gpu:
             dom = "closest" if st["ms_closest"] >= st["ms_any"] else "any"
             ms_dom = st["ms_%s" % dom]
@@ -783,7 +816,7 @@ def main():
             if os.path.exists(tf):
                 try:
                     tj = json.load(open(tf))
-                    traffic = tj.get("k_%s_bytes_per_launch" % dom)
+                    traffic = tj.get("k_%s_bytes_per_launch" % dom) if (world == 1 and n_dom == 1) else None  # counted on the one-GPU launch only
                     traffic_src = {"file": "profiles/traffic.json", "tag": tj.get("tag"), "profiled_commit": tj.get("commit"),
                                    "profiled_source_hash": tj.get("source_hash"), "kernel": tj.get("k_%s_kernel" % dom)}
                 except Exception:
@@ -831,8 +864,11 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(scene, args.cpu_row_stride, host_cores(), gpu_fb=gpu_fb, parity_out=out)
             except Exception as e:  # the checker is optional for the measurement itself
                 out["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        if legs_error is not None:  # the communicator was aborted: no tear-down through it, no barrier a missing peer would hang
+            sys.stderr.flush()
+            os._exit(0)  # (every rank: a non-zero worker would make the launcher stop rank 0 before its line is out)
         dist.barrier()
         dist.destroy_process_group()
 

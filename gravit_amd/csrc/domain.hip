@@ -144,6 +144,10 @@ struct gvt_hip_comm {
   int count = 1;          // ranks the transport itself reports (ncclCommCount / the hub's world)
   int deadline_ms = 20000; // every blocking point of an exchange gives up after this long (GVT_HIP_ERR_TIMEOUT)
   bool dead = false;      // a deadline passed: the communicator was aborted
+  // RCCL connects two ranks at their first send / receive (all pairs in a frame's first announce): that exchange alone may take as long
+  // as connect_ms (GVT_HIP_CONNECT_TIMEOUT_MS), whatever the deadline of the steady state
+  bool connected = false;
+  int connect_ms = 180000;
   hipEvent_t ev_wait = nullptr;
   double ms_host_wait = 0.0; // host time spent in bounded waits since the frame began
 };
@@ -183,6 +187,7 @@ static gvt_hip_comm *comm_new(int rank, int world) {
   if (hipStreamCreateWithFlags(&K->stream, hipStreamNonBlocking) != hipSuccess) { set_error("comm_create: stream"); delete K; return nullptr; }
   if (hipEventCreateWithFlags(&K->ev_wait, hipEventDisableTiming) != hipSuccess) { set_error("comm_create: event"); hipStreamDestroy(K->stream); delete K; return nullptr; }
   if (const char *e = getenv("GVT_HIP_EXCHANGE_TIMEOUT_MS")) { const int v = atoi(e); if (v > 0) K->deadline_ms = v; }
+  if (const char *e = getenv("GVT_HIP_CONNECT_TIMEOUT_MS")) { const int v = atoi(e); if (v > 0) K->connect_ms = v; }
   K->count = world;
   return K;
 }
@@ -231,25 +236,26 @@ namespace {
 // A deadline passed: nothing this rank still has in flight on the communicator can be trusted to complete.  The RCCL communicator is
 // aborted (its kernels leave the stream), the in-process hub wakes every rank; the caller returns GVT_HIP_ERR_TIMEOUT and the process
 // is expected to report and exit non-zero -- never to re-exec itself.
-int comm_timed_out(gvt_hip_comm *K, const char *what, const char *diag) {
+int comm_timed_out(gvt_hip_comm *K, const char *what, const char *diag, int waited_ms = 0) {
   K->dead = true;
   if (K->hub) gvt_hip_hub_abort(K->hub);
   else if (K->nccl && g_rccl.CommAbort) { g_rccl.CommAbort(K->nccl); K->nccl = nullptr; }
   set_error("ray exchange: rank %d of %d waited more than %d ms for %s%s%s -- a peer has stopped taking part; the communicator is aborted", K->rank, K->world,
-            K->deadline_ms, what, diag && *diag ? "; " : "", diag ? diag : "");
+            waited_ms ? waited_ms : K->deadline_ms, what, diag && *diag ? "; " : "", diag ? diag : "");
   return GVT_HIP_ERR_TIMEOUT;
 }
 // host wait for an event with the communicator's deadline (hipEventSynchronize would wait for ever on an exchange a peer never joins)
 int bounded_event_wait(gvt_hip_comm *K, hipEvent_t ev, const char *what, const char *diag = nullptr) {
   const auto t0 = std::chrono::steady_clock::now();
+  const int limit_ms = (K->nccl && !K->connected) ? std::max(K->deadline_ms, K->connect_ms) : K->deadline_ms;
   int rc = 0;
   for (unsigned spins = 0;; spins++) {
     const hipError_t e = hipEventQuery(ev);
-    if (e == hipSuccess) break;
+    if (e == hipSuccess) { K->connected = true; break; }
     if (e != hipErrorNotReady) { set_error("hipEventQuery while waiting for %s: %s", what, hipGetErrorString(e)); rc = GVT_HIP_ERR_DEVICE; break; }
     if ((spins & 63u) == 63u) {
       if (K->hub && K->hub->aborted.load()) { set_error("hub: aborted while waiting for %s", what); K->dead = true; rc = GVT_HIP_ERR_TIMEOUT; break; }
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(K->deadline_ms)) { rc = comm_timed_out(K, what, diag); break; }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(limit_ms)) { rc = comm_timed_out(K, what, diag, limit_ms); break; }
       if (spins > 4096u) std::this_thread::yield();
     }
   }

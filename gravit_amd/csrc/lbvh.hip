@@ -66,12 +66,27 @@ __global__ __launch_bounds__(256) void k_reduce32(const float4 *__restrict__ in_
   if (lane == 0) { out_lo[grp] = l; out_hi[grp] = h; }
 }
 
-__global__ __launch_bounds__(256) void k_gather_boxes(const unsigned *__restrict__ sorted, const float4 *__restrict__ plo, const float4 *__restrict__ phi,
-                                                      unsigned n, float4 *__restrict__ slo, float4 *__restrict__ shi) {
-  const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
-  const unsigned p = sorted[s];
-  slo[s] = plo[p]; shi[s] = phi[p];
+// The scene box's first reduction level straight from the vertices: out[k] = union of the boxes of triangles 32k .. 32k+31 (the
+// per-triangle boxes themselves are never stored: the Morton codes and the sorted boxes are computed from the vertices again)
+__device__ inline void tri_box(const float *__restrict__ verts, const int *__restrict__ tris, unsigned i, float lo[3], float hi[3]) {
+  const int a = tris[3 * i], b = tris[3 * i + 1], c = tris[3 * i + 2];
+  for (int k = 0; k < 3; k++) {
+    const float x = verts[3 * a + k], y = verts[3 * b + k], z = verts[3 * c + k];
+    lo[k] = fminf(x, fminf(y, z));
+    hi[k] = fmaxf(x, fmaxf(y, z));
+  }
+}
+__global__ __launch_bounds__(256) void k_tri_bounds32(const float *__restrict__ verts, const int *__restrict__ tris, unsigned n,
+                                                      float4 *__restrict__ out_lo, float4 *__restrict__ out_hi) {
+  const unsigned lane = threadIdx.x & 31u;
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned grp = i >> 5;
+  if (grp >= (n + 31u) / 32u) return; // (whole 32-lane groups leave together)
+  float lo[3] = { GVT_FLT_MAX, GVT_FLT_MAX, GVT_FLT_MAX }, hi[3] = { -GVT_FLT_MAX, -GVT_FLT_MAX, -GVT_FLT_MAX };
+  if (i < n) tri_box(verts, tris, i, lo, hi);
+  for (int off = 16; off > 0; off >>= 1)
+    for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off)); }
+  if (lane == 0) { out_lo[grp] = make_float4(lo[0], lo[1], lo[2], 0.f); out_hi[grp] = make_float4(hi[0], hi[1], hi[2], 0.f); }
 }
 
 __device__ inline unsigned long long expand21(unsigned v) { // 21 bits -> every third bit
@@ -84,14 +99,15 @@ __device__ inline unsigned long long expand21(unsigned v) { // 21 bits -> every 
   return x;
 }
 
-__global__ __launch_bounds__(256) void k_morton(const float4 *__restrict__ plo, const float4 *__restrict__ phi, unsigned n, float3 blo,
+__global__ __launch_bounds__(256) void k_morton(const float *__restrict__ verts, const int *__restrict__ tris, unsigned n, float3 blo,
                                                 float3 inv_ext, unsigned long long *__restrict__ keys, unsigned *__restrict__ vals) {
   unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float4 l = plo[i], h = phi[i];
-  float cx = (0.5f * (l.x + h.x) - blo.x) * inv_ext.x;
-  float cy = (0.5f * (l.y + h.y) - blo.y) * inv_ext.y;
-  float cz = (0.5f * (l.z + h.z) - blo.z) * inv_ext.z;
+  float lo[3], hi[3];
+  tri_box(verts, tris, i, lo, hi);
+  float cx = (0.5f * (lo[0] + hi[0]) - blo.x) * inv_ext.x;
+  float cy = (0.5f * (lo[1] + hi[1]) - blo.y) * inv_ext.y;
+  float cz = (0.5f * (lo[2] + hi[2]) - blo.z) * inv_ext.z;
   unsigned qx = (unsigned)fminf(fmaxf(cx * 2097152.f, 0.f), 2097151.f);
   unsigned qy = (unsigned)fminf(fmaxf(cy * 2097152.f, 0.f), 2097151.f);
   unsigned qz = (unsigned)fminf(fmaxf(cz * 2097152.f, 0.f), 2097151.f);
@@ -194,7 +210,7 @@ __global__ __launch_bounds__(256) void k_emit_nodes(int n_inner, const unsigned 
                                                     const float4 *__restrict__ slo, const float4 *__restrict__ shi,
                                                     const float4 *__restrict__ ilo, const float4 *__restrict__ ihi,
                                                     const int *__restrict__ child_l, const int *__restrict__ child_r, const int *__restrict__ rfirst,
-                                                    const int *__restrict__ rlast, float pad, BvhNode *__restrict__ nodes, unsigned *n_leaves, int leaf_max,
+                                                    const int *__restrict__ rlast, float pad, BvhNode *__restrict__ nodes, int leaf_max,
                                                     unsigned *__restrict__ leaf_of) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_inner || !live[i]) return;
@@ -209,20 +225,26 @@ __global__ __launch_bounds__(256) void k_emit_nodes(int n_inner, const unsigned 
   int r0 = final_ref(cl, rfirst, rlast, newidx, leaf_max), r1 = final_ref(cr, rfirst, rlast, newidx, leaf_max);
   nd.n3 = make_float4(__int_as_float(r0), __int_as_float(r1), 0.f, 0.f);
   nodes[newidx[i]] = nd;
-  unsigned nl = (r0 < 0) + (r1 < 0);
-  if (nl) atomicAdd(n_leaves, nl);
+  // (no leaf counter: the emitted nodes form a binary tree, so it has one leaf more than nodes -- counting them here took one atomic per
+  // wave on a single word, half of this kernel's 1.8 ms at 10 M triangles)
+  if (!leaf_of) return;
   // every sorted triangle learns its leaf (first slot, count): the transposed leaf blocks of k_emit_trisq are laid out per leaf
   if (r0 < 0) { const unsigned code = (unsigned)~r0; for (unsigned k = 0; k < (code & 7u); k++) leaf_of[(code >> 3) + k] = code; }
   if (r1 < 0) { const unsigned code = (unsigned)~r1; for (unsigned k = 0; k < (code & 7u); k++) leaf_of[(code >> 3) + k] = code; }
 }
 
 __global__ __launch_bounds__(256) void k_emit_tris(const float *__restrict__ verts, const int *__restrict__ tris, const unsigned *__restrict__ sorted,
-                                                   unsigned n, float4 *__restrict__ out, unsigned *__restrict__ slot_of) {
+                                                   unsigned n, float4 *__restrict__ out, unsigned *__restrict__ slot_of, float4 *__restrict__ slo,
+                                                   float4 *__restrict__ shi) {
   unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   unsigned p = sorted[s];
   int a = tris[3 * p], b = tris[3 * p + 1], c = tris[3 * p + 2];
   V3 v0 = ld3(verts + 3 * a), v1 = ld3(verts + 3 * b), v2 = ld3(verts + 3 * c);
+  if (slo) { // the triangle's box at its sorted position (what the range-union table of k_node_boxes is built over)
+    slo[s] = make_float4(fminf(v0.x, fminf(v1.x, v2.x)), fminf(v0.y, fminf(v1.y, v2.y)), fminf(v0.z, fminf(v1.z, v2.z)), 0.f);
+    shi[s] = make_float4(fmaxf(v0.x, fmaxf(v1.x, v2.x)), fmaxf(v0.y, fmaxf(v1.y, v2.y)), fmaxf(v0.z, fmaxf(v1.z, v2.z)), 0.f);
+  }
   V3 e1 = sub3(v0, v1), e2 = sub3(v2, v0); // same float ops as evaluating them per test (no contraction): bit-identical
   // the traversal reads (v0 | prim), e1, e2 (48 of the 64 bytes); the remaining six floats carry v1 and v2 as they are, so that the
   // shading kernel finds the whole triangle in the one line the traversal has just touched (EmbreeMeshAdapter.cpp:503-504 needs
@@ -286,9 +308,18 @@ __device__ inline float slot_area(const Slot4 &c) {
   const float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
   return dx * dy + dy * dz + dz * dx;
 }
-__global__ __launch_bounds__(256) void k_collapse4(const BvhNode *__restrict__ nodes, const int *__restrict__ fin, unsigned n_in, unsigned base_in,
-                                                   int *__restrict__ fout, unsigned *__restrict__ next_count, uint4 *__restrict__ nodes4,
-                                                   uint4 *__restrict__ nodes4q) {
+// Level `level` of the collapse: its frontier size is levels[level], written by the launch before; the host launches several levels back to
+// back with grids sized by a bound (4^level, at most every node) and reads the sizes once per batch -- a level used to cost a counter
+// reset, a launch, a copy and a host synchronisation (14 levels at 10 M triangles).
+#define GVT_COLLAPSE_BLOCK 512
+#define GVT_COLLAPSE_LEVELS 96
+__global__ __launch_bounds__(GVT_COLLAPSE_BLOCK) void k_collapse4(const BvhNode *__restrict__ nodes, const int *__restrict__ fin, unsigned *__restrict__ levels, int level,
+                                                                  int *__restrict__ fout, uint4 *__restrict__ nodes4, uint4 *__restrict__ nodes4q) {
+  const unsigned n_in = levels[level];
+  if (blockIdx.x * blockDim.x >= n_in) return; // (block-uniform)
+  unsigned base_in = 0;
+  for (int l = 0; l < level; l++) base_in += levels[l];
+  unsigned *next_count = levels + level + 1;
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n_in;
   Slot4 c[4];
@@ -298,36 +329,60 @@ __global__ __launch_bounds__(256) void k_collapse4(const BvhNode *__restrict__ n
     slot_from(nb, 0, c[0]); slot_from(nb, 1, c[1]);
     n = 2;
     if (c[1].ref == GVT_EMPTY_REF) n = 1; // single-leaf mesh (k_single_node)
-    for (int it = 0; it < 2 && n < 4; it++) {
+    // (slots addressed through unrolled compares, not a run-time index: the four of them stay in registers)
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      if (n >= 4) break;
       int k = -1;
       float best = -1.f;
-      for (int s = 0; s < n; s++)
-        if (c[s].ref >= 0) { const float a = slot_area(c[s]); if (a > best) { best = a; k = s; } }
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+        if (s < n && c[s].ref >= 0) { const float a = slot_area(c[s]); if (a > best) { best = a; k = s; } }
       if (k < 0) break;
-      const BvhNode nc = nodes[c[k].ref];
-      slot_from(nc, 0, c[k]); slot_from(nc, 1, c[n]);
+      int ref_k = 0;
+#pragma unroll
+      for (int s = 0; s < 4; s++) if (s == k) ref_k = c[s].ref;
+      const BvhNode nc = nodes[ref_k];
+      Slot4 a0, a1;
+      slot_from(nc, 0, a0); slot_from(nc, 1, a1);
+#pragma unroll
+      for (int s = 0; s < 4; s++) { if (s == k) c[s] = a0; if (s == n) c[s] = a1; }
       n++;
     }
   }
-  // next-level indices for the inner children: wave-aggregated
+  // next-level indices for the inner children: ONE atomic per block (a single word takes ~90 atomics per microsecond: one per wave was
+  // 47 K of them at 10 M triangles, half of the collapse's time)
   int want = 0;
-  for (int s = 0; s < n; s++) want += (c[s].ref >= 0) ? 1 : 0;
+#pragma unroll
+  for (int s = 0; s < 4; s++) want += (s < n && c[s].ref >= 0) ? 1 : 0;
   int incl = want;
   for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if ((int)lane_id() >= d) incl += v; }
-  const int total = __shfl(incl, 63);
-  unsigned base = 0;
-  if (lane_id() == 0 && total) base = atomicAdd(next_count, (unsigned)total);
-  base = (unsigned)__shfl((int)base, 0);
+  __shared__ unsigned s_wave[GVT_COLLAPSE_BLOCK / 64];
+  __shared__ unsigned s_base;
+  const unsigned wv = threadIdx.x >> 6;
+  if (lane_id() == 63) s_wave[wv] = (unsigned)incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned run = 0;
+    for (unsigned k = 0; k < GVT_COLLAPSE_BLOCK / 64; k++) { const unsigned t = s_wave[k]; s_wave[k] = run; run += t; }
+    s_base = run ? atomicAdd(next_count, run) : 0u;
+  }
+  __syncthreads();
   if (!live) return;
-  unsigned slot = base + (unsigned)(incl - want);
-  for (int s = 0; s < n; s++)
-    if (c[s].ref >= 0) { fout[slot] = c[s].ref; c[s].ref = (int)(base_in + n_in + slot); slot++; }
+  const unsigned base = s_base;
+  unsigned slot = base + s_wave[wv] + (unsigned)(incl - want);
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+    if (s < n && c[s].ref >= 0) { fout[slot] = c[s].ref; c[s].ref = (int)(base_in + n_in + slot); slot++; }
   // quantise (outwards, verified in double against the very expression the traversal decodes with)
   uint32_t w[16];
+#pragma unroll
   for (int k = 0; k < 16; k++) w[k] = 0u;
+#pragma unroll
   for (int a = 0; a < 3; a++) {
     float o = c[0].lo[a], h = c[0].hi[a];
-    for (int s = 1; s < n; s++) { o = fminf(o, c[s].lo[a]); h = fmaxf(h, c[s].hi[a]); }
+#pragma unroll
+    for (int s = 1; s < 4; s++) if (s < n) { o = fminf(o, c[s].lo[a]); h = fmaxf(h, c[s].hi[a]); }
     int k2 = 0;
     (void)frexpf((h - o) * (1.0f / 255.0f), &k2);
     int e = k2 + 127;
@@ -337,11 +392,13 @@ __global__ __launch_bounds__(256) void k_collapse4(const BvhNode *__restrict__ n
       const float scale = __int_as_float(e << 23);
       bool ok = true;
       ql = 0; qh = 0;
-      for (int s = 0; s < n && ok; s++) {
-        int l = (int)floorf((c[s].lo[a] - o) / scale);
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        if (s >= n || !ok) break;
+        int l = (int)floorf(ldexpf(c[s].lo[a] - o, 127 - e)); // (/ scale, a power of two: the same correctly rounded quotient in one instruction)
         l = l < 0 ? 0 : (l > 255 ? 255 : l);
         while (l > 0 && (double)o + (double)l * (double)scale > (double)c[s].lo[a]) l--;
-        int u = (int)ceilf((c[s].hi[a] - o) / scale);
+        int u = (int)ceilf(ldexpf(c[s].hi[a] - o, 127 - e));
         u = u < 0 ? 0 : u;
         while (u <= 255 && (double)o + (double)u * (double)scale < (double)c[s].hi[a]) u++;
         if (u > 255) { ok = false; break; }
@@ -350,11 +407,13 @@ __global__ __launch_bounds__(256) void k_collapse4(const BvhNode *__restrict__ n
       if (ok || e >= 254) break;
       e++;
     }
-    for (int s = n; s < 4; s++) ql |= 255u << (8 * s); // unused slots: an inverted box (lo plane 255, hi plane 0) that no ray enters
+#pragma unroll
+    for (int s = 0; s < 4; s++) if (s >= n) ql |= 255u << (8 * s); // unused slots: an inverted box (lo plane 255, hi plane 0) that no ray enters
     w[a] = __float_as_uint(o);
     w[a == 0 ? 3 : 13 + a] = (uint32_t)e << 23; // the grid step 2^(e-127) as a float: w0.w (x), w3.z (y), w3.w (z)
     w[4 + 2 * a] = ql; w[5 + 2 * a] = qh;
   }
+#pragma unroll
   for (int s = 0; s < 4; s++) w[10 + s] = (uint32_t)(s < n ? c[s].ref : GVT_EMPTY_REF);
   uint4 *dst = nodes4 + (size_t)GVT_NODE4_F4 * (base_in + i);
   dst[0] = make_uint4(w[0], w[1], w[2], w[3]); dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
@@ -401,8 +460,8 @@ __global__ __launch_bounds__(256) void k_collapse_mark(const BvhNode *__restrict
 }
 
 // The build's temporaries come out of ONE allocation (the context's scratch slot 21; given back when it is larger than 1 GiB) instead
-// of thirty hipMalloc / hipFree pairs.  (GVT_HIP_BUILD_TRACE=1 prints where a build's time goes -- tools/build_trace.py: 10 M triangles
-// take 7 ms, 1.4 Gtris/s; the first build of a process 15-17 ms, of which 8 are the first kernel launches: code objects, rocPRIM.)
+// of thirty hipMalloc / hipFree pairs.  (GVT_HIP_BUILD_TRACE=1 prints where a build's time goes -- tools/build_probe.py: 10 M triangles
+// take 4.1 ms, 2.4 Gtris/s; the first build of a process 13-18 ms, most of it the first kernel launches: code objects, rocPRIM.)
 struct BuildArena {
   char *base = nullptr;
   size_t off = 0, cap = 0;
@@ -468,7 +527,7 @@ int build_lbvh(gvt_hip_mesh *M) {
 
   float4 *plo = nullptr, *phi = nullptr, *slo = nullptr, *shi = nullptr, *ilo = nullptr, *ihi = nullptr;
   unsigned long long *keys = nullptr, *keys2 = nullptr;
-  unsigned *vals = nullptr, *sorted = nullptr, *live = nullptr, *newidx = nullptr, *nleaves = nullptr, *leaf_of = nullptr;
+  unsigned *vals = nullptr, *sorted = nullptr, *live = nullptr, *newidx = nullptr, *leaf_of = nullptr;
   const int leaf_max = C.leaf_max < 1 ? 1 : (C.leaf_max > 4 ? 4 : C.leaf_max);
   const bool want_q = C.quad != 0; // the quad-per-ray layouts (nodes4q + transposed leaf blocks)
   M->leaf_max = leaf_max;
@@ -479,6 +538,7 @@ int build_lbvh(gvt_hip_mesh *M) {
   int rc = 0;
   const unsigned B = 256, G = (n + B - 1) / B;
   const int n_inner = (int)n - 1;
+  const unsigned n32 = (n + 31u) / 32u;
   float pad = 0.f;
 
 #define OK(x) do { if ((rc = (x)) != 0) goto done; } while (0)
@@ -496,12 +556,12 @@ int build_lbvh(gvt_hip_mesh *M) {
     if (!A.base) { rc = GVT_HIP_ERR_DEVICE; goto done; }
   }
   mark("arena");
-  OK(A.take(&plo, n)); OK(A.take(&phi, n));
-  k_tri_bounds<<<G, B, 0, st>>>(M->d_verts, M->d_tris, n, plo, phi);
-  { // scene box: 32:1 reductions, the last <= 32 boxes on the host
+  OK(A.take(&plo, n32)); OK(A.take(&phi, n32));
+  k_tri_bounds32<<<G, B, 0, st>>>(M->d_verts, M->d_tris, n, plo, phi);
+  { // scene box: 32:1 reductions (the first one straight from the vertices), the last <= 32 boxes on the host
     BoxLevels T;
-    OK(build_box_levels(plo, phi, n, A, T, st));
-    unsigned cnt = n;
+    OK(build_box_levels(plo, phi, n32, A, T, st));
+    unsigned cnt = n32;
     for (int l = 1; l < T.n_levels; l++) cnt = (cnt + 31u) / 32u;
     std::vector<float4> hl(cnt), hh(cnt);
     HOK(hipMemcpyAsync(hl.data(), T.lo[T.n_levels - 1], sizeof(float4) * cnt, hipMemcpyDeviceToHost, st));
@@ -519,8 +579,7 @@ int build_lbvh(gvt_hip_mesh *M) {
   mark("scene box");
   OK(dalloc(&M->d_tri, (size_t)4 * n));
   OK(dalloc(&M->d_slot_of, n));
-  OK(A.take(&leaf_of, n));
-  if (want_q) OK(dalloc(&M->d_triq, (size_t)4 * n));
+  if (want_q) { OK(A.take(&leaf_of, n)); OK(dalloc(&M->d_triq, (size_t)4 * n)); }
 
   if ((int)n <= leaf_max) {
     OK(dalloc(&M->d_nodes, 1));
@@ -532,8 +591,11 @@ int build_lbvh(gvt_hip_mesh *M) {
       HOK(hipMemcpyAsync(sorted, id.data(), sizeof(unsigned) * n, hipMemcpyHostToDevice, st));
       HOK(hipStreamSynchronize(st));
     }
-    k_single_node<<<1, 64, 0, st>>>(plo, phi, n, pad, M->d_nodes);
-    k_emit_tris<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, n, M->d_tri, M->d_slot_of);
+    float4 *tlo = nullptr, *thi = nullptr; // n <= 4 triangle boxes
+    OK(A.take(&tlo, n)); OK(A.take(&thi, n));
+    k_tri_bounds<<<G, B, 0, st>>>(M->d_verts, M->d_tris, n, tlo, thi);
+    k_single_node<<<1, 64, 0, st>>>(tlo, thi, n, pad, M->d_nodes);
+    k_emit_tris<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, n, M->d_tri, M->d_slot_of, nullptr, nullptr);
     if (want_q) {
       std::vector<unsigned> lo_(n, (unsigned)~leaf_ref(0u, n));
       HOK(hipMemcpyAsync(leaf_of, lo_.data(), sizeof(unsigned) * n, hipMemcpyHostToDevice, st));
@@ -551,7 +613,7 @@ int build_lbvh(gvt_hip_mesh *M) {
       const float em = fmaxf(ex, fmaxf(ey, ez));
       const float iso = em > 0 ? 1.f / em : 0.f;
       float3 inv = make_float3(iso, iso, iso);
-      k_morton<<<G, B, 0, st>>>(plo, phi, n, blo, inv, keys, vals);
+      k_morton<<<G, B, 0, st>>>(M->d_verts, M->d_tris, n, blo, inv, keys, vals);
     }
     {
       OK(A.take((char **)&tmp, tb_sort));
@@ -560,10 +622,9 @@ int build_lbvh(gvt_hip_mesh *M) {
     mark("morton + sort");
     OK(A.take(&cl, n)); OK(A.take(&cr, n)); OK(A.take(&rf, n)); OK(A.take(&rl, n));
     OK(A.take(&slo, n)); OK(A.take(&shi, n)); OK(A.take(&ilo, n)); OK(A.take(&ihi, n));
-    OK(A.take(&live, n)); OK(A.take(&newidx, n + 1)); OK(A.take(&nleaves, 1));
-    HOK(hipMemsetAsync(nleaves, 0, sizeof(unsigned), st));
+    OK(A.take(&live, n)); OK(A.take(&newidx, n + 1));
     k_karras<<<(n_inner + B - 1) / B, B, 0, st>>>(keys2, (int)n, cl, cr, rf, rl);
-    k_gather_boxes<<<G, B, 0, st>>>(sorted, plo, phi, n, slo, shi);
+    k_emit_tris<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, n, M->d_tri, M->d_slot_of, slo, shi); // the slots, and the sorted boxes on the way
     {
       BoxLevels T;
       OK(build_box_levels(slo, shi, n, A, T, st));
@@ -581,14 +642,10 @@ int build_lbvh(gvt_hip_mesh *M) {
     HOK(hipStreamSynchronize(st));
     M->nNodes = (size_t)last_idx + last_live;
     OK(dalloc(&M->d_nodes, M->nNodes));
-    k_emit_nodes<<<(n_inner + B - 1) / B, B, 0, st>>>(n_inner, live, newidx, slo, shi, ilo, ihi, cl, cr, rf, rl, pad, M->d_nodes, nleaves, leaf_max, leaf_of);
-    k_emit_tris<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, n, M->d_tri, M->d_slot_of);
+    M->nLeaves = M->nNodes + 1;
+    k_emit_nodes<<<(n_inner + B - 1) / B, B, 0, st>>>(n_inner, live, newidx, slo, shi, ilo, ihi, cl, cr, rf, rl, pad, M->d_nodes, leaf_max, leaf_of);
     if (want_q) k_emit_trisq<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, leaf_of, n, M->d_triq);
     mark("emit nodes + slots");
-    unsigned nl = 0;
-    HOK(hipMemcpyAsync(&nl, nleaves, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    HOK(hipStreamSynchronize(st));
-    M->nLeaves = nl;
   }
   if (gctx().wide4 || want_q) OK(build_nodes4(M, &A)); // the traversal layout; counted in the build time
   mark("4-wide collapse");
@@ -628,26 +685,40 @@ static int build_nodes4(gvt_hip_mesh *M, BuildArena *A) {
   if (A) { // called from build_lbvh: the frontier arrays out of the build's arena
     if (!rc) rc = A->take(&fa, M->nNodes);
     if (!rc) rc = A->take(&fb, M->nNodes);
-    if (!rc) rc = A->take(&cnt, 1);
+    if (!rc) rc = A->take(&cnt, GVT_COLLAPSE_LEVELS + 1);
   } else {
     if (!rc) rc = dalloc(&fa, M->nNodes);
     if (!rc) rc = dalloc(&fb, M->nNodes);
-    if (!rc) rc = dalloc(&cnt, 1);
+    if (!rc) rc = dalloc(&cnt, GVT_COLLAPSE_LEVELS + 1);
   }
   if (!rc) {
+    // levels[l] = frontier size of level l (levels[0] = 1: the root); levels are launched in batches, the sizes read once per batch
+    std::vector<unsigned> h_levels(GVT_COLLAPSE_LEVELS + 1, 0u);
+    h_levels[0] = 1u;
     const int root = 0;
     hipError_t e = hipMemcpyAsync(fa, &root, sizeof root, hipMemcpyHostToDevice, st);
-    unsigned n_in = 1, base = 0;
-    while (e == hipSuccess && n_in) {
-      e = hipMemsetAsync(cnt, 0, sizeof(unsigned), st);
-      if (e != hipSuccess) break;
-      k_collapse4<<<(n_in + 255) / 256, 256, 0, st>>>(M->d_nodes, fa, n_in, base, fb, cnt, M->d_nodes4, M->d_nodes4q);
-      unsigned n_next = 0;
-      e = hipMemcpyAsync(&n_next, cnt, sizeof n_next, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(cnt, h_levels.data(), sizeof(unsigned) * (GVT_COLLAPSE_LEVELS + 1), hipMemcpyHostToDevice, st);
+    unsigned base = 0;
+    int level = 0;
+    bool more = true;
+    while (e == hipSuccess && more) {
+      if (level >= GVT_COLLAPSE_LEVELS) { set_error("4-wide collapse: more than %d levels", GVT_COLLAPSE_LEVELS); rc = GVT_HIP_ERR_CAPACITY; break; }
+      // first batch: the depth a tree of this size has at least (log4 of its nodes) and a few levels more; then four at a time
+      int first = 3;
+      for (size_t k = M->nNodes; k > 1; k >>= 2) first++;
+      const int batch_end = std::min(GVT_COLLAPSE_LEVELS, level == 0 ? first : level + 4);
+      const int batch_begin = level;
+      for (; level < batch_end; level++) {
+        // a level holds at most 4^level nodes (a node has at most four children) and at most every node
+        const size_t bound = level >= 16 ? M->nNodes : std::min<size_t>(M->nNodes, (size_t)1 << (2 * level));
+        k_collapse4<<<(unsigned)((bound + GVT_COLLAPSE_BLOCK - 1) / GVT_COLLAPSE_BLOCK), GVT_COLLAPSE_BLOCK, 0, st>>>(M->d_nodes, fa, cnt, level, fb, M->d_nodes4, M->d_nodes4q);
+        int *t = fa; fa = fb; fb = t;
+      }
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipMemcpyAsync(h_levels.data(), cnt, sizeof(unsigned) * (GVT_COLLAPSE_LEVELS + 1), hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipStreamSynchronize(st);
-      base += n_in;
-      n_in = n_next;
-      int *t = fa; fa = fb; fb = t;
+      for (int l = batch_begin; l < batch_end; l++) base += h_levels[l];
+      more = h_levels[batch_end] != 0u;
     }
     M->nNodes4 = base;
     if (e != hipSuccess) { set_error("4-wide collapse: %s", hipGetErrorString(e)); rc = GVT_HIP_ERR_DEVICE; }

@@ -138,3 +138,28 @@ def test_bench_script_multi_rank_branch_under_gloo(tmp_path):
         assert r["value"] > 0 and r["rays_per_step"] > 100 and r["ticks_per_step"] >= 1
     assert c4["film"] == [95, 54] and c4["domain_async"]["rays_sent_per_step"] == c4["domain_bsp"]["rays_sent_per_step"] > 0
     assert wk["scaling"] == "weak" and wk["tiles"] == 2 and wk["tris_per_tile"] == 8000 and wk["film"] == [136, 80] and len(wk["roofline_per_rank"]) == 2
+
+
+def test_bench_script_keeps_its_line_when_a_secondary_leg_fails(tmp_path):
+    """A scheduler variant that fails in the ray exchange (here: injected on every rank, as a peer's error word or a passed deadline does it)
+    must not cost the measurement made before it: the line is printed with `value`, the failed variant and `legs_error`; the legs behind it
+    (same communicator) are skipped; every rank leaves with status 0 so that the launcher does not stop rank 0 before its line is out."""
+    import json
+    import subprocess
+    import sys
+
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", OMP_NUM_THREADS="1", GVT_BENCH_FAIL_LEG="domain_bsp")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--harness", "checker", "--tris", "20000",
+                                       "--width", "96", "--height", "54", "--steps", "1", "--warmup", "0", "--weak-tris", "8000", "--config4-width", "95", "--config4-height", "54"],
+                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][1][-2000:] + outs[1][1][-2000:]
+    j = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1])
+    assert j["value"] > 0 and "domain_bsp" in j["legs_error"]
+    assert j["variants"]["domain_async"]["value"] > 0 and "injected" in j["variants"]["domain_bsp"]["failed"]
+    assert "config4_bunny_grid" not in j and "weak_soup" not in j
+    assert "domain_bsp failed" in outs[1][1]  # every rank says what it knows on stderr
