@@ -280,9 +280,10 @@ struct WaveSingle { // the launch has ONE segment: its queue planes and instance
   int pass0_begun;       // the producer of the queue (k_cam1_scatter) has already done k_wave_pass_begin's pass-0 resets
 };
 // defer_end: the caller's next kernel (k_round_report) does k_wave_end's work
+// n_dev0_multi (merged kernels): device word holding the length of the merged list where only the device knows it; n_total is then a bound
 int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
                      const gvt_hip_light *lights_host, const WaveSingle *single, unsigned *const *d_count_ptr, const unsigned char *d_mask, int n_inst,
-                     bool defer_end = false);
+                     bool defer_end = false, const unsigned *n_dev0_multi = nullptr);
 int finish_round(const WaveSet &W, size_t n_total, const TraceParams &P, const gvt_hip_light *lights_host, const void *d_qdesc, const int *d_owner, int rank,
                  unsigned *d_queue_overflow, unsigned *const *d_count_ptr, const unsigned char *d_mask);
 int convert_aos_to_planes(const gvt_hip_ray *d_src, size_t n, RayPlanes dst, size_t dst_off);

@@ -595,18 +595,34 @@ int shuffle_async(gvt_hip_top *T, gvt_hip_queue *q_in, size_t n_ub, const int *f
 // generateRays + FilterRaysLocally without a read-back: every kept queue must have room for all W*H*samples^2 rays; the queue counts
 // advance on the device only (the caller's first launch chain reads its ray count from there)
 // [first, first + count) of the generated list (count == 0: all of it): a rank's portion under the multi-rank Image scheduler
+static bool camera_keep_rect(const gvt_hip_top *T, CamArgs &A, const uint8_t *keep_mask);
+// rect: enumerate only the film rectangle the kept instances project onto (the whole list, first == count == 0)
 int camera_filter_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *const *queues, const uint8_t *keep_mask, unsigned *d_overflow,
-                        size_t first, size_t count) {
+                        size_t first, size_t count, bool rect) {
   const size_t n_all = (size_t)cam->width * cam->height * cam->samples * cam->samples;
   if (n_all > 0xffffffffull) { set_error("camera_filter: more than 2^32 rays"); return GVT_HIP_ERR_INVALID; }
-  if (!count) count = n_all - first;
   RaySrc S{};
   S.cam = make_cam_args(cam->eye, cam->focus, cam->up, cam->fov, cam->width, cam->height, cam->samples, cam->depth, cam->jitter_window_size, tile);
-  S.cam.first = (unsigned)first;
   S.from_cam = 1;
+  if (rect && !first && !count && tile == 8 && camera_keep_rect(T, S.cam, keep_mask))
+    count = (size_t)S.cam.rtpr * (size_t)((S.cam.ry1 - S.cam.ry0 + 7) / 8) * 64u * (size_t)(cam->samples * cam->samples); // (0: nothing in view, nothing launched)
+  else {
+    if (!count) count = n_all - first;
+    S.cam.first = (unsigned)first;
+  }
   return shuffle_async_src(T, S, count, nullptr, nullptr, -1, queues, keep_mask, nullptr, d_overflow, nullptr);
 }
-static bool camera_keep_rect(const gvt_hip_top *T, CamArgs &A, const uint8_t *keep_mask);
+// Upper bound of the camera rays that can have instance `inst` as their first domain: the positions of the film rectangle its box
+// projects onto (the whole list where there is no bounded projection, camera_keep_rect)
+size_t camera_instance_bound(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, size_t inst) {
+  const size_t n_all = (size_t)cam->width * cam->height * cam->samples * cam->samples;
+  if (tile != 8 || inst >= T->n) return n_all;
+  CamArgs A = make_cam_args(cam->eye, cam->focus, cam->up, cam->fov, cam->width, cam->height, cam->samples, cam->depth, cam->jitter_window_size, tile);
+  std::vector<uint8_t> only(T->n, (uint8_t)0);
+  only[inst] = 1;
+  if (!camera_keep_rect(T, A, only.data())) return n_all;
+  return std::min(n_all, (size_t)A.rtpr * (size_t)((A.ry1 - A.ry0 + 7) / 8) * 64u * (size_t)(cam->samples * cam->samples));
+}
 // clearBuffer + generateRays + FilterRaysLocally for a ONE-instance scene on one rank, with the launch chain's pass-0 resets folded
 // in (k_cam1_count / k_cam1_scatter).  q must have room for all W*H*samples^2 rays; its count lives on the device only.
 int camera_one_instance_async(gvt_hip_top *T, const gvt_hip_camera *cam, int tile, gvt_hip_queue *q, gvt_hip_fb *fb, unsigned *d_overflow, unsigned *d_moved_count) {

@@ -486,7 +486,7 @@ __global__ void k_wave_end(unsigned *c, unsigned *const *__restrict__ count_ptr,
 
 int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
                      const gvt_hip_light *lights_host, const WaveSingle *single, unsigned *const *d_count_ptr, const unsigned char *d_mask, int n_inst,
-                     bool defer_end) {
+                     bool defer_end, const unsigned *n_dev0_multi) {
   Ctx &C = gctx();
   if (!n_total) return 0;
   hipStream_t st = C.stream;
@@ -522,13 +522,16 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
   const bool use_long = C.long_steps > 0 && n >= (size_t)C.long_min_rays;
   const bool small = n <= (size_t)C.small_rays; // a wave per ray (see k_long_seed)
   const int small_grid = (int)std::min<size_t>((n + 3) / 4, (size_t)C.n_cu * 3);
+  // pass 0's ray count where only the device knows it (the chain straight behind the camera filter): the single queue's count word, or
+  // the word the caller's segment kernel left the merged list's length in (n_total is then the bound the launches are sized by)
+  const unsigned *nd0 = single ? single->n_dev : n_dev0_multi;
   for (int pass = 0; pass < passes; pass++) {
-    const unsigned *n_dev = pass ? c + ((pass & 1) ? 2 : 5) : ((single && single->n_dev) ? single->n_dev : nullptr); // count written by the previous pass's k_shade
+    const unsigned *n_dev = pass ? c + ((pass & 1) ? 2 : 5) : nd0; // count written by the previous pass's k_shade
     const unsigned *idx = pass ? ((pass & 1) ? d_idx_a : d_idx_b) : nullptr;    // its bounce list
     unsigned *next = (pass & 1) ? d_idx_b : d_idx_a;
     unsigned *c_next = c + ((pass & 1) ? 5 : 2);
     if (!(pass == 0 && single && single->pass0_begun))
-      k_wave_pass_begin<<<1, 64, 0, st>>>(c, pass, (unsigned)n, out->d_count, (single && single->n_dev) ? single->n_dev : nullptr);
+      k_wave_pass_begin<<<1, 64, 0, st>>>(c, pass, (unsigned)n, out->d_count, nd0);
     if (single) {
       // one segment (a single non-empty local queue, e.g. the one-domain benchmark): the single-mesh kernels -- no segment lookup and
       // no per-ray table loads at a refill -- with the same device-side counts
@@ -674,6 +677,9 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     A.sink = P.sink; A.update_in_place = 0;
     A.n_dev = n_dev; A.W = W; A.out_from = d_out_from; A.shadow_inst = d_shadow_inst;
     const bool direct = C.shadow_direct && pass == 0 && !small; // later passes and small rounds hold few rays: compacted slots
+    // (k_shade marks every slot below the stride -- the bound -- empty or taken; with one light the list is as long as the traced one,
+    // and where only the device knows that length the any-hit launch stops there instead of skipping empty slots up to the bound)
+    const bool direct_dev = direct && nd0 != nullptr && nL == 1;
     A.shadow_stride = direct ? (unsigned)n : 0u;
     {
       ProfScope ps(KC_SHADE);
@@ -686,11 +692,11 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
 #ifdef GVT_EXPERIMENTS
       else if (C.quad && W.quad_ok)
         k_traceq<true, true, 1, true><<<quad_grid(shadow_cap), 256, 0, st>>>(shadow, nullptr, direct ? (unsigned)shadow_cap : 0u, id, TravQ{}, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
-                                                                           c + 0, C.d_spill, C.quad_refill_min, C.quad_inner_min, direct ? nullptr : c + 1, P.sink, LongQ{}, MA);
+                                                                           c + 0, C.d_spill, C.quad_refill_min, C.quad_inner_min, direct ? (direct_dev ? nd0 : nullptr) : c + 1, P.sink, LongQ{}, MA);
 #endif
       else
       k_trace<true, true, 1, false, true, true><<<trav_grid2(shadow_cap), TRAV_BLOCK, 0, st>>>(shadow, nullptr, direct ? (unsigned)shadow_cap : 0u, id, T, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
-                                                                                              c + 0, C.d_spill, C.refill_min, C.inner_min, direct ? nullptr : c + 1, C.share, (unsigned)C.share_min_rays,
+                                                                                              c + 0, C.d_spill, C.refill_min, C.inner_min, direct ? (direct_dev ? nd0 : nullptr) : c + 1, C.share, (unsigned)C.share_min_rays,
                                                                                               P.sink, LongQ{}, MA);
     }
     HIPCHK(hipGetLastError());
