@@ -470,11 +470,6 @@ __global__ __launch_bounds__(256) void k_round_report(unsigned *const *__restric
   }
 }
 
-__global__ void k_zero_counts(unsigned *const *__restrict__ count_ptr, const unsigned char *__restrict__ mask /* null: all */, int n_inst) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_inst && (!mask || mask[i])) *count_ptr[i] = 0u;
-}
-
 // wire image of one queue: [int32 queueId][int32 nRays][nRays x 80-byte Ray] (DomainTracer.h:441-455); one thread per dword.  ALL queues
 // of a tick -- every peer, every queue -- go through ONE launch: the items travel by value in the kernel's arguments (<= WIRE_MAX per
 // launch), a thread finds its item by its dword number.
@@ -554,16 +549,9 @@ template <bool ADD> __global__ __launch_bounds__(256) void k_rect(float4 *__rest
   else buf[i] = fb[px];
 }
 // start of a frame: ray totals, flags, the work counter of the first small chain, the deposit rectangle (empty) and the kernels' tickets
-// The segments of a merged chain whose queues were filled by the camera filter without a read-back: each segment's length is its
-// queue's count word, its beginning the sum of the lengths before it; the list's length goes to *n_out.  (The host uploaded the
-// segments with the BOUNDS it knows; a handful of them: one thread.)
-__global__ void k_seg_begins(WaveSeg *segs, int n_seg, unsigned *const *__restrict__ count_ptr, unsigned *n_out) {
-  if (blockIdx.x || threadIdx.x) return;
-  unsigned run = 0;
-  for (int k = 0; k < n_seg; k++) { const unsigned n = *count_ptr[segs[k].inst]; segs[k].begin = run; segs[k].n = n; run += n; }
-  *n_out = run;
-}
-__global__ void k_zero_totals(unsigned *c, unsigned *ovf, int fb_w, int fb_h) {
+// a frame's resets in one launch: every queue.clear() (count words) and the frame's totals / flags / deposit rectangle
+__global__ void k_zero_totals(unsigned *c, unsigned *ovf, int fb_w, int fb_h, unsigned *const *__restrict__ count_ptr = nullptr, int n_inst = 0) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_inst; i += gridDim.x * blockDim.x) *count_ptr[i] = 0u;
   if (blockIdx.x) return;
   if (threadIdx.x < 4) c[16 + threadIdx.x] = 0u;
   if (threadIdx.x == 4) { *ovf = 0u; c[9] = 0u; c[0] = 0u; ovf[10] = 0u; ovf[11] = 0u; c[3] = 0u; c[20] = 0u; }
@@ -832,11 +820,8 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
     std::memcpy(one.normi.n, R->normi.data() + 9 * (size_t)i0, 36);
   }
   const bool single = one.mesh != nullptr;
-  const unsigned *n_dev0 = nullptr;
-  if (count_on_device && !single) { // several queues straight from the camera filter: lengths and beginnings from the count words
-    k_seg_begins<<<1, 64, 0, st>>>(R->d_segs, n_seg, R->d_count_ptr, C.d_counters + 22);
-    n_dev0 = C.d_counters + 22;
-  }
+  // several queues straight from the camera filter: the segments' lengths and beginnings from the count words (in the chain's first kernel)
+  const unsigned *n_dev0 = (count_on_device && !single) ? C.d_counters + 22 : nullptr;
   if ((rc = wave_trace_chain(W, N, passes, R->q_moved, d_from, P, R->lights.data(), single ? &one : nullptr, R->d_count_ptr, R->d_mask, (int)nI, defer_end && single, n_dev0))) return rc;
   // one instance in the whole scene and the terminal rule applied inside the kernels: nothing can have moved
   if (exact) {
@@ -954,16 +939,15 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   // One instance, one rank, terminal rule inside the kernels: the first (and only) launch chain takes its ray count from the queue's
   // count word on the device -- the camera filter needs no read-back and the frame has ONE host synchronisation.
   const bool one_shot = nI == 1 && R->world == 1 && C.term_sink && C.wave_single && R->meshes[0] && C.first_round_async;
-  // ... and in eight launches: the camera filter's two kernels also clear the framebuffer and do the resets (k_zero_counts,
-  // k_zero_totals, k_wave_pass_begin), the round's report does k_wave_end's work
+  // ... and in eight launches: the camera filter's two kernels also clear the framebuffer and do the resets
+  // (k_zero_totals, k_wave_pass_begin), the round's report does k_wave_end's work
   const bool lean = one_shot && C.lean_frame && R->fb->w == R->cam.width && R->fb->h == R->cam.height; // (the lean filter clears the camera's pixels only)
   for (size_t i = 0; i < nI; i++) R->queues[i]->size = 0;
   R->q_moved->size = 0;
   bool first_on_device = false; // the queues hold the camera's rays, their sizes are on the device only (R->present: bounds)
   if (!lean) {
     if ((rc = gvt_hip_fb_clear(R->fb))) return rc;
-    if (nI) k_zero_counts<<<(unsigned)((nI + 255) / 256), 256, 0, st>>>(R->d_count_ptr, nullptr, (int)nI); // every queue.clear() in one launch
-    k_zero_totals<<<1, 64, 0, st>>>(C.d_counters, R->d_overflow, R->fb->w, R->fb->h);
+    k_zero_totals<<<(unsigned)std::max<size_t>(1, (nI + 255) / 256), 256, 0, st>>>(C.d_counters, R->d_overflow, R->fb->w, R->fb->h, R->d_count_ptr, (int)nI); // + every queue.clear()
   }
   if (one_shot) {
     const size_t n_cam = (size_t)R->cam.width * R->cam.height * R->cam.samples * R->cam.samples;

@@ -466,8 +466,17 @@ extern "C" int gvt_hip_math_probe(int kind, const float *in, size_t n, float *ou
 // (closest, any) accumulated over the frame and read back with the queue sizes.
 // ------------------------------------------------------------------------------------------------
 namespace {
-__global__ void k_wave_pass_begin(unsigned *c, int pass, unsigned n_host, unsigned *out_count, const unsigned *n_dev0 = nullptr) {
+// segs (pass 0 of a merged chain whose queues were filled by the camera filter without a read-back; the host uploaded the segments with
+// the BOUNDS it knows): each segment's length is its queue's count word, its beginning the sum of the lengths before it, the list's
+// length goes to *n_dev0 (a handful of segments: one thread)
+__global__ void k_wave_pass_begin(unsigned *c, int pass, unsigned n_host, unsigned *out_count, const unsigned *n_dev0 = nullptr, WaveSeg *segs = nullptr, int n_seg = 0,
+                                  unsigned *const *__restrict__ count_ptr = nullptr) {
   if (blockIdx.x || threadIdx.x) return;
+  if (segs) {
+    unsigned run = 0;
+    for (int k = 0; k < n_seg; k++) { const unsigned n = *count_ptr[segs[k].inst]; segs[k].begin = run; segs[k].n = n; run += n; }
+    *const_cast<unsigned *>(n_dev0) = run;
+  }
   unsigned long long *tot = (unsigned long long *)(c + 16);
   const int cur = (pass & 1) ? 5 : 2, prev = (pass & 1) ? 2 : 5;
   if (pass == 0) { *out_count = 0u; c[2] = 0u; c[5] = 0u; tot[0] += n_dev0 ? *n_dev0 : n_host; }
@@ -531,7 +540,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     unsigned *next = (pass & 1) ? d_idx_b : d_idx_a;
     unsigned *c_next = c + ((pass & 1) ? 5 : 2);
     if (!(pass == 0 && single && single->pass0_begun))
-      k_wave_pass_begin<<<1, 64, 0, st>>>(c, pass, (unsigned)n, out->d_count, nd0);
+      k_wave_pass_begin<<<1, 64, 0, st>>>(c, pass, (unsigned)n, out->d_count, nd0, (pass == 0 && n_dev0_multi && !single) ? const_cast<WaveSeg *>(W.segs) : nullptr, W.n_seg, d_count_ptr);
     if (single) {
       // one segment (a single non-empty local queue, e.g. the one-domain benchmark): the single-mesh kernels -- no segment lookup and
       // no per-ray table loads at a refill -- with the same device-side counts
