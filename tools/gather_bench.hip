@@ -98,6 +98,36 @@ __global__ __launch_bounds__(256) void k_quad_lds(const Node *__restrict__ nodes
   out[tid] = acc;
 }
 
+// D: quad-cooperative fetch with LDS-DIRECT loads (gfx950: global_load_lds_dwordx4 -- the 16-byte pieces go from the L1 straight into
+// LDS, no VGPR staging, no cross-lane transpose): instruction j brings the node of the quad's lane j (its four lanes address the four
+// pieces of ONE 64-byte line: one look-up in the L1's tag pipe instead of four), lane L's piece lands at M0 + L * 16; lane j then reads its
+// node as four ds_read_b128 from tile j.  Tiles are 1024 + 64 bytes apart (a quad's four reads hit different banks).
+#define TILE_STRIDE (1024 + 64)
+__global__ __launch_bounds__(256) void k_quad_ldsdirect(const Node *__restrict__ nodes, const unsigned *__restrict__ idx, unsigned n_idx, int iters, float *out) {
+  __shared__ __attribute__((aligned(16))) unsigned char tiles[4 * 4 * TILE_STRIDE];
+  unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned cur = idx[tid % n_idx];
+  const int lane = threadIdx.x & 63, k = lane & 3, qbase = lane & ~3, wv = threadIdx.x >> 6;
+  if (n_idx == 0xffffffffu) ((volatile unsigned char *)tiles)[0] = 0; // (keeps the array: the asm below is its only writer)
+  const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)tiles + (unsigned)wv * 4u * TILE_STRIDE));
+  const float4 *mine = (const float4 *)(tiles + (wv * 4 + k) * TILE_STRIDE) + qbase;
+  float acc = 0.f;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const unsigned nj = __shfl(cur, qbase + j);
+      const float4 *p = ((const float4 *)(nodes + nj)) + k;
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(base + (unsigned)j * TILE_STRIDE), "v"(p) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float4 a = mine[0], b = mine[1], c = mine[2], d = mine[3];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the reads are done before the next step's loads overwrite the tiles
+    acc += a.x + b.y + c.z + d.w;
+    cur = __float_as_uint(d.x);
+  }
+  out[tid] = acc;
+}
+
 int main(int argc, char **argv) {
   const size_t n_nodes = argc > 1 ? atoll(argv[1]) : 3500000; // 224 MB like the 10 M-triangle tree
   const int iters = 64, blocks = 256 * 4, threads = 256;
@@ -119,17 +149,19 @@ int main(int argc, char **argv) {
   hipMemcpy(d_nodes, h.data(), n_nodes * sizeof(Node), hipMemcpyHostToDevice);
   hipMemcpy(d_idx, hidx.data(), hidx.size() * 4, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int v = 0; v < 3; v++) {
+  for (int v = 0; v < 4; v++) {
     for (int rep = 0; rep < 3; rep++) {
       hipEventRecord(e0);
       if (v == 0) k_own<<<blocks, threads>>>(d_nodes, d_idx, (unsigned)hidx.size(), iters, d_out);
       if (v == 1) k_quad<<<blocks, threads>>>(d_nodes, d_idx, (unsigned)hidx.size(), iters, d_out);
       if (v == 2) k_quad_lds<<<blocks, threads>>>(d_nodes, d_idx, (unsigned)hidx.size(), iters, d_out);
+      if (v == 3) k_quad_ldsdirect<<<blocks, threads>>>(d_nodes, d_idx, (unsigned)hidx.size(), iters, d_out);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       double fetches = (double)blocks * threads * iters;
-      std::vector<float> o(4); hipMemcpy(o.data(), d_out, 16, hipMemcpyDeviceToHost);
-      printf("variant %d rep %d: %.3f ms  %.1f Gnodes/s  %.2f TB/s  (check %.1f)\n", v, rep, ms, fetches / ms / 1e6, fetches * 64 / ms / 1e9, o[0]);
+      std::vector<float> o(hidx.size()); hipMemcpy(o.data(), d_out, 4 * o.size(), hipMemcpyDeviceToHost);
+      double sum = 0; for (float f : o) sum += f;
+      printf("variant %d rep %d: %.3f ms  %.1f Gnodes/s  %.2f TB/s  (check %.1f, sum %.1f)\n", v, rep, ms, fetches / ms / 1e6, fetches * 64 / ms / 1e9, o[0], sum);
     }
   }
   return 0;
