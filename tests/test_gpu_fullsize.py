@@ -137,6 +137,8 @@ def test_config1_bunny_conf_at_its_full_film(hip):
     fb = tr().framebuffer(True)
     assert np.array_equal(fb[..., :3].view(np.uint32), ref[..., :3].view(np.uint32)) and np.array_equal(fb[..., 3], ref[..., 3])
     assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any
+    # three instances: the first chain runs behind the camera filter on device-side counts -- one chain, one host wait for the whole frame
+    assert tr.stats["chains"] == 1 and tr.stats["host_syncs"] == 1
     tr.close()
     it = ImageTracer(sc, NORMALS_SMOOTH)
     fb = it().framebuffer(True)
