@@ -142,7 +142,7 @@ void scratch_release(int slot) {
 // ---- profiling: HIP events on the launch stream ----
 ProfScope::ProfScope(int c) : cls(c) {
   Ctx &C = g_ctx;
-  if (!C.profile || (C.profile == 2 && c != KC_CLOSEST && c != KC_ANY && c != KC_LONG)) return;
+  if (!C.profile || (C.profile == 2 && c != KC_CLOSEST && c != KC_ANY && c != KC_LONG) || (C.profile == 3 && c != KC_CLOSEST) || (C.profile == 4 && c != KC_ANY)) return;
   auto take = [&]() {
     hipEvent_t e;
     if (!C.event_pool.empty()) { e = C.event_pool.back(); C.event_pool.pop_back(); }

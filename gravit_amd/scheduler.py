@@ -245,7 +245,11 @@ class NativeTracer:
             raise capi.GvtHipError("gvt_hip_tracer_create: " + capi.last_error())
         own = np.ascontiguousarray(self.owner, dtype=np.int32)
         capi.check(self.lib.gvt_hip_tracer_set_domains(self.h, capi.ptr(own), comm.h if comm is not None else None), "gvt_hip_tracer_set_domains")
-        self.stats = {}
+        self.frame_stats = None  # the last frame's gvt_hip_frame_stats as the library filled it (`stats`: the same as a dict, made on access)
+
+    @property
+    def stats(self):
+        return self.frame_stats.as_dict() if self.frame_stats is not None else {}
 
     def __call__(self, bsp=False, composite=True, full_reduce=False, image=False):
         import ctypes as C
@@ -254,7 +258,7 @@ class NativeTracer:
         flags = ((capi.FRAME_BSP if bsp else 0) | (0 if composite else capi.FRAME_NO_COMPOSITE) | (capi.FRAME_FULL_REDUCE if full_reduce else 0) |
                  (capi.FRAME_IMAGE if image else 0))
         capi.check(self.lib.gvt_hip_tracer_frame(self.h, C.c_int(flags), C.byref(st)), "gvt_hip_tracer_frame")
-        self.stats = st.as_dict()
+        self.frame_stats = st
         return self.backend
 
     render = __call__

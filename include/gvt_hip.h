@@ -298,7 +298,8 @@ typedef struct gvt_hip_stats {
   double ms_sort; /* ray sorting inside the adapter */
   double ms_long; /* k_long_closest: parked long rays, a wave per ray (not part of ms_closest) */
 } gvt_hip_stats;
-int gvt_hip_profile(int enable);           /* 1: bracket every kernel with HIP events on the launch stream; 2: the traversal kernels only; 0: off */
+int gvt_hip_profile(int enable);           /* 1: bracket every kernel with HIP events on the launch stream; 2: the traversal kernels only; 3 / 4: the
+                                            * closest-hit / any-hit launches only (an event pair costs a few microseconds of the stream); 0: off */
 int gvt_hip_stats_read(gvt_hip_stats *);   /* synchronises */
 int gvt_hip_stats_reset(void);
 /* diagnostic, not on the hot path: per-ray visit counts of the closest-hit traversal over n object-space rays:

@@ -118,6 +118,21 @@ def test_whole_config3_frame_of_the_native_tracer_is_bit_exact(soup, hip):
     assert np.array_equal(fb.view(np.uint32), ref.view(np.uint32)), "max |diff| %g in %d pixels" % (np.abs(fb - ref).max(), (fb != ref).any(axis=2).sum())
     assert stats["rays_closest"] == st.rays_closest == 1_040_400 and stats["rays_any"] == st.rays_any > 1_000_000
     assert stats["host_syncs"] == 1 and stats["chains"] == 1
+    # gvt_hip_profile: 2 brackets the three traversal classes, 3 / 4 one of them (what bench.py's timed steps carry: an event pair costs
+    # a few microseconds of the stream); the image does not depend on it
+    seen = {}
+    for mode in (2, 3, 4):
+        hip.stats_reset()
+        hip.profile(mode)
+        try:
+            fb3 = tr().framebuffer(True)
+            seen[mode] = hip.stats()
+        finally:
+            hip.profile(False)
+        assert np.array_equal(fb, fb3)
+    assert seen[2]["ms_closest"] > 0.3 and seen[2]["ms_any"] > 0.2 and seen[2]["ms_long"] > 0.0
+    assert seen[3]["ms_closest"] > 0.3 and seen[3]["ms_any"] == 0.0 and seen[3]["ms_long"] == 0.0
+    assert seen[4]["ms_any"] > 0.2 and seen[4]["ms_closest"] == 0.0 and seen[4]["ms_long"] == 0.0
     tr.close()
 
 
