@@ -722,6 +722,11 @@ static int build_nodes4(gvt_hip_mesh *M, BuildArena *A) {
     }
     M->nNodes4 = base;
     if (e != hipSuccess) { set_error("4-wide collapse: %s", hipGetErrorString(e)); rc = GVT_HIP_ERR_DEVICE; }
+    if (getenv("GVT_HIP_BUILD_TRACE")) {
+      int depth = 0;
+      while (depth < GVT_COLLAPSE_LEVELS && h_levels[depth]) depth++;
+      fprintf(stderr, "[build] 4-wide collapse: %d levels (%zu nodes), %d launched\n", depth, (size_t)base, level);
+    }
   }
   if (!A) { hipFree(fa); hipFree(fb); hipFree(cnt); }
   if (rc) { hipFree(M->d_nodes4); M->d_nodes4 = nullptr; hipFree(M->d_nodes4q); M->d_nodes4q = nullptr; }

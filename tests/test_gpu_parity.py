@@ -127,6 +127,62 @@ def test_degenerate_inputs(hip):
     assert a.intersect(org, d)["prim"].tolist() == [0] == b.intersect(org, d)["prim"].tolist()
 
 
+def test_deep_trees_from_exponentially_spaced_clusters_and_coincident_triangles(hip, capfd, monkeypatch):
+    """Sixty clusters of small triangles at 2^-k along x, along y and along z (k = 1 .. 20, each cluster 2^-(k+6) wide) -- the Morton
+    order makes a comb, one cluster split off per level -- plus 1,500 coincident copies of one triangle (a subtree split by index alone):
+    a tree several times deeper than log4 of its size, so the 4-wide collapse needs more batches of levels than its first (lbvh.hip
+    build_nodes4) and the traversal's stack goes a long way down.  Rays start a few dozen cluster widths from their cluster (a ray from
+    across the scene cannot resolve a triangle of 1e-9: both sides' results are then rounding noise).  Hits and occlusion flags against
+    the oracle, bit for bit; the lower primID wins among the coincident triangles."""
+    import re
+
+    rng = np.random.default_rng(5)
+    verts, per, sizes = [], 400, []
+    for arm in range(3):
+        for k in range(1, 21):
+            c = np.zeros(3)
+            c[arm] = 2.0 ** -k
+            sz = 2.0 ** -(k + 6)
+            ctr = c + rng.uniform(0, sz, (per, 1, 3))
+            verts.append(ctr + rng.uniform(0, sz / 4, (per, 3, 3)))
+            sizes.append(sz)
+    one = np.array([[0.30, 0.40, 0.45], [0.36, 0.40, 0.45], [0.33, 0.46, 0.45]])
+    verts.append(np.broadcast_to(one, (1500, 3, 3)))
+    v = np.concatenate(verts).reshape(-1, 3).astype(np.float32)
+    t = np.arange(len(v), dtype=np.int32).reshape(-1, 3)
+    first_coincident = 60 * per
+    monkeypatch.setenv("GVT_HIP_BUILD_TRACE", "1")
+    capfd.readouterr()
+    ad = HipMeshAdapter(scenes.MeshData(v, t))
+    trace = capfd.readouterr().err
+    monkeypatch.delenv("GVT_HIP_BUILD_TRACE")
+    m = re.search(r"4-wide collapse: (\d+) levels \((\d+) nodes\), (\d+) launched", trace)
+    assert m, trace
+    levels, nodes4, launched = int(m.group(1)), int(m.group(2)), int(m.group(3))
+    n, first_batch = ad.info()["n_nodes"], 3  # the first batch of levels build_nodes4 launches: log4 of the node count + 3
+    while n > 1:
+        n >>= 2
+        first_batch += 1
+    assert levels >= 20 and launched > levels >= first_batch, (levels, launched, first_batch)  # more than one batch of levels
+    om = orc.Mesh(v, t)
+    tri = rng.integers(0, first_coincident, 20_000)
+    szr = np.array(sizes)[tri // per][:, None]
+    tgt = v.reshape(-1, 3, 3)[tri].mean(axis=1) + rng.uniform(-0.1, 0.1, (20_000, 3)) * szr
+    dirs = rng.normal(size=(20_000, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    org = np.concatenate([tgt - dirs * szr * rng.uniform(30, 60, (20_000, 1)), rng.uniform([0.2, 0.3, 1.5], [0.45, 0.55, 2.0], (4_000, 3))]).astype(np.float32)
+    tgt = np.concatenate([tgt, np.tile(one.mean(axis=0), (4_000, 1)) + rng.uniform(-0.02, 0.02, (4_000, 3))]).astype(np.float32)
+    d = tgt - org
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    a, b = ad.intersect(org, d), om.intersect(org, d)
+    assert_hits_equal(a, b)
+    assert (ad.occluded(org, d) == om.occluded(org, d)).all()
+    small = (a["prim"][:20_000] >= 0) & (tri // per % 20 >= 14)  # hits in the clusters of 2^-15 and below
+    assert small.sum() > 2_000 and (a["prim"][:20_000] >= 0).sum() > 12_000
+    on_stack = a["prim"][20_000:]
+    assert (on_stack[on_stack >= first_coincident] == first_coincident).all() and (on_stack == first_coincident).sum() > 1_000
+
+
 def test_mesh_create_rejects_bad_input(hip):
     from gravit_amd import capi
 
