@@ -209,6 +209,7 @@ const KnobDef g_knobs[] = {
   { "abi_lanes", &Knobs::abi_lanes_n, 0, 8, true },           { "abi_chunk", &Knobs::abi_chunk, 16384, 1 << 30, true },
   { "inject_fail_tick", &Knobs::inject_fail_tick, -1, 1 << 30, true },
   { "long_min_rays", &Knobs::long_min_rays, 0, 1 << 30, true }, { "long_auto", &Knobs::long_auto, 0, 1, true },
+  { "finish_auto", &Knobs::finish_auto, 0, 1, true },
   { "payload_overlap_kb", &Knobs::payload_overlap_kb, 0, 1 << 30, true },
   // experiments build only: the alternative was measured and lost, or the value is a tuned constant
   { "trav_kernel", &Knobs::trav_kernel, 0, 1, false },        { "wide4", &Knobs::wide4, 0, 1, false },

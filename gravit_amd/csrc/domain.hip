@@ -601,6 +601,14 @@ struct gvt_hip_tracer {
   uint64_t last_local_pending = 0;
   std::vector<size_t> present; // host-known queue sizes as of the last report
   int long_cur = 0;            // the parking threshold this tracer's frames run with (0: Knobs::long_steps), adapted frame by frame (long_auto)
+  // finish_auto (one rank, several instances): small rounds through k_finish or through per-hop merged chains, decided by timing
+  uint64_t frame_no = 0;
+  int fin_choice = -1;         // -1: probing (frames alternate), 0: per-hop chains, 1: k_finish
+  int fin_limit = 0;           // the frame in progress: rounds of at most this many rays go through k_finish
+  bool fin_eligible = false;   // the frame in progress had a round small enough for k_finish (else its time says nothing)
+  unsigned fin_probe = 0;
+  double fin_best[2] = { 1e30, 1e30 }; // fastest eligible frame seen with each variant, ms
+  int fin_n[2] = { 0, 0 };
 };
 
 extern "C" void gvt_hip_tracer_destroy(gvt_hip_tracer *R) {
@@ -801,7 +809,8 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
     P.sink.fb = R->fb->d_rgba; P.sink.n_pix = (unsigned)(R->fb->w * R->fb->h);
   }
   WaveSet W{ R->d_segs, R->d_insts, n_seg, R->all_quad ? 1 : 0, (int)nI };
-  if (C.finish_rays > 0 && N <= (size_t)C.finish_rays && P.sink.fb && !count_on_device && !exact) {
+  if (C.finish_rays > 0 && N <= (size_t)C.finish_rays && P.sink.fb && !count_on_device && !exact) R->fin_eligible = true;
+  if (R->fin_limit > 0 && N <= (size_t)R->fin_limit && P.sink.fb && !count_on_device && !exact) {
     // a small round: ONE launch follows every ray to its end on this rank (finish_kernel.inc); what remains are rays in other ranks' queues
     if ((rc = finish_round(W, N, P, R->lights.data(), R->d_qdesc, R->d_owner, R->world > 1 ? R->rank : -1, R->d_overflow, R->d_count_ptr, R->d_mask))) return rc; // (+ the traced queues' clear())
     if (chains) (*chains)++;
@@ -933,6 +942,16 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   // sparser scene has more rays beyond it (1 M-triangle soup: 4 % of the rays, k_long_closest 0.25 ms of a 1.27 ms frame).  long_auto:
   // the tracer raises the threshold from frame to frame while more than 0.3 % of a frame's closest-hit rays were parked, and lets it
   // fall back towards the knob when fewer than 0.05 % were.  Results never depend on it.
+  // small rounds: k_finish, or per-hop chains -- on one rank with several instances whichever a few timed frames say is faster here (finish_auto)
+  const auto frame_t0 = std::chrono::steady_clock::now();
+  const bool fin_auto = C.finish_auto && C.finish_rays > 0 && R->world == 1 && nI > 1;
+  int fin_variant = 1;
+  if (fin_auto && R->frame_no >= 2) {
+    if ((R->frame_no & 2047u) == 0) { R->fin_choice = -1; R->fin_n[0] = R->fin_n[1] = 0; R->fin_best[0] = R->fin_best[1] = 1e30; } // look again now and then
+    fin_variant = R->fin_choice >= 0 ? R->fin_choice : (int)(R->fin_probe & 1u);
+  }
+  R->fin_limit = fin_variant ? C.finish_rays : 0;
+  R->fin_eligible = false;
   struct LongOverride { Ctx &C; ~LongOverride() { C.long_steps_override = 0; } } long_override{ C };
   C.long_steps_override = (C.long_auto && C.long_steps > 0 && R->long_cur > C.long_steps) ? R->long_cur : 0;
   // clearBuffer + generateRays + FilterRaysLocally / shuffleDropRays (ImageTracer.h:137-146, DomainTracer.h:148-183, 204-211)
@@ -1236,6 +1255,14 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   }
   C.stats.rays_closest += S.rays_closest;
   C.stats.rays_any += S.rays_any;
+  if (fin_auto && R->frame_no >= 2 && R->fin_choice < 0 && R->fin_eligible) { // a probing frame that had a small round: its time counts
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - frame_t0).count();
+    R->fin_best[fin_variant] = std::min(R->fin_best[fin_variant], ms);
+    R->fin_n[fin_variant]++;
+    R->fin_probe++;
+    if (R->fin_n[0] >= 3 && R->fin_n[1] >= 3) R->fin_choice = R->fin_best[1] <= R->fin_best[0] ? 1 : 0;
+  }
+  R->frame_no++;
   if (out) *out = S;
   return 0;
 }

@@ -44,6 +44,9 @@ struct Knobs {
   int round_room_mb = 16384; // scheduler rounds: memory the worst-case reservation of the destination queues may add (MiB); beyond it the round shuffles with exact growth
   int finish_rays = 32768; // scheduler rounds holding at most this many rays are run by ONE kernel that follows every ray to its end on this rank (k_finish):
                          // no per-hop rounds for the few rays that move between the rank's own domains (0: off)
+  int finish_auto = 1;   // one rank, several instances: whether small rounds go through k_finish at all is decided per tracer by timing a few frames each way
+                         // (following every ray to its end in one launch wins where rays hop many times -- soup tiles --, per-hop rounds where a hop is a long
+                         // traversal of its own -- a row of bunnies); re-probed every 2048 frames.  Results never depend on it.
   int small_rays = 4096; // scheduler rounds holding at most this many rays give every ray a whole wave (k_long_closest / k_wave_any): ~40 us
                          // per traversal launch instead of the ~150 us latency floor of a one-lane-per-ray launch
   int abi_lanes_n = 4;   // gvt_hip_trace on a host RayVector: host threads (each with a context of its own) that pipeline the list's chunks (0: one shot)

@@ -314,7 +314,7 @@ int gvt_hip_wide_visit_stats(gvt_hip_mesh *, const float *org, const float *dir,
  * functions the bounce path (EmbreeMeshAdapter.cpp:289-318) is built on. */
 int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
 /* Knobs of the library (gvt_internal.h `struct Knobs` lists them with their defaults; ("defaults", 0) restores all of them).  Results never
- * depend on them -- except "skip_known", which switches between two shuffle rules with the same image (below).  The shipped surface, 15 knobs:
+ * depend on them -- except "skip_known", which switches between two shuffle rules with the same image (below).  The shipped surface, 16 knobs:
  *   behaviour    "skip_known"   1: shuffleRays' known-miss shortcut (a ray is not traced / sent again into an instance it has already crossed
  *                               without a hit on the same straight segment; image-identical) -- 0: the reference's hop-by-hop rule, ray for ray
  *                "term_sink"    1: gvt_hip_trace_queue_sink applies shuffleRays' terminal rule inside the kernels -- 0: every moved ray goes through the shuffle
@@ -324,6 +324,8 @@ int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
  *   budgets      "long_steps" / "long_min_rays" / "long_auto"  closest hit: node steps after which a ray is parked for a whole wave (0: never), launches it
  *                               applies to, and whether gvt_hip_tracer_frame raises it from frame to frame on scenes that park more than 0.3 % of their rays
  *                "small_rays" / "finish_rays"    rounds of at most so many rays: a wave per ray / the whole round in one launch (k_finish)
+ *                "finish_auto"                   1: on one rank with several instances gvt_hip_tracer_frame times a few frames with and without k_finish and keeps
+ *                                                the faster (a hop that is a long traversal of its own is better served by per-hop rounds)
  *                "round_room_mb"                 memory a round's worst-case reservation may add before it falls back to exact growth
  *                "payload_overlap_kb"            Domain scheduler: payloads of at least this size move on the communicator's own stream beside the next chain
  *                "abi_lanes" / "abi_chunk"     gvt_hip_trace on a host RayVector: pipeline lanes (0: one shot), rays per chunk

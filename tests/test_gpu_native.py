@@ -526,6 +526,40 @@ def test_parking_threshold_adapts_to_a_sparser_scene(hip):
     tr.close()
 
 
+def test_small_rounds_through_one_launch_or_per_hop_whichever_the_tracer_times_faster(hip):
+    """finish_auto (default on; one rank, several instances): frames 2.. alternate between k_finish (a small round followed to its end in
+    one launch) and per-hop merged chains until each has been timed three times, then the tracer keeps the faster.  Every frame -- probing
+    or settled, either route -- is the oracle's image bit for bit with the oracle's ray counts.  On the soup tiles the routes differ in
+    their number of launch chains (rays hop several times), which shows that the probing frames took both and that the choice settled."""
+    for sc, mode in ((scenes.bunny_grid_scene(width=760, height=432), NORMALS_SMOOTH), (scenes.soup_domains_scene(200_000, 4, 480, 270), NORMALS_FLAT)):
+        ref, st = oracle_render(sc, mode, nthreads=8)
+        pinned = {}
+        for fin in (32768, 0):  # the two routes pinned
+            hip.set_option("finish_auto", 0); hip.set_option("finish_rays", fin)
+            try:
+                tr = NativeTracer(sc, mode)
+                fb = tr().framebuffer(True)
+                assert np.array_equal(fb[..., :3].view(np.uint32), ref[..., :3].view(np.uint32))
+                assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any
+                pinned[fin] = tr.stats["chains"]
+                tr.close()
+            finally:
+                hip.set_option("defaults", 0)
+        tr = NativeTracer(sc, mode)
+        chains = []
+        for _ in range(12):
+            fb = tr().framebuffer(True)
+            assert np.array_equal(fb[..., :3].view(np.uint32), ref[..., :3].view(np.uint32))
+            assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any
+            chains.append(tr.stats["chains"])
+        tr.close()
+        assert set(chains) <= set(pinned.values())
+        if pinned[0] != pinned[32768]:
+            assert chains[:2] == [pinned[32768]] * 2 and set(chains[2:8]) == set(pinned.values()), (chains, pinned)  # probing: both routes
+            assert len(set(chains[8:])) == 1, chains  # settled
+    assert pinned[0] > pinned[32768]  # (the soup tiles: per-hop rounds need more chains)
+
+
 @pytest.mark.parametrize("case", ["partly_off_film", "box_behind_the_eye_plane", "nothing_in_view", "jitter_window"])
 def test_camera_rectangle_edge_cases(hip, case):
     """The camera filter enumerates only the film rectangle the (kept) instances' boxes project onto (sched.hip camera_keep_rect).

@@ -35,7 +35,7 @@ for name, mk, mode in cfgs:
     sc = mk()
     tris = sum(len(m.tris) for m in sc.meshes)
     for label, tr in (("rounds", NativeTracer(sc, mode)), ("reference order", ImageTracer(sc, mode))):
-        for _ in range(3):
+        for _ in range(10):  # (warm-up; the tracer's per-scene choices -- parking threshold, k_finish or per-hop rounds -- settle within eight frames)
             tr()
         capi.synchronize(); capi.stats_reset()
         n = 10
