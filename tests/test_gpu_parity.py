@@ -16,6 +16,7 @@ import pytest
 from gravit_amd import layouts, scenes
 from gravit_amd.adapter import FrameBuffer, HipMeshAdapter, RayQueue, TopLevel, camera_generate
 from gravit_amd.layouts import NORMALS_FLAT, NORMALS_SMOOTH, RAY_DTYPE
+from gravit_amd.layouts import RAY_EPSILON as RAY_EPSILON_F
 from gravit_amd.scheduler import ImageTracer
 from oracle import orc
 from tests.conftest import GOLDEN, read_ppm
@@ -183,6 +184,49 @@ def test_deep_trees_from_exponentially_spaced_clusters_and_coincident_triangles(
     assert (on_stack[on_stack >= first_coincident] == first_coincident).all() and (on_stack == first_coincident).sum() > 1_000
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_meshes_and_rays_against_the_oracle(hip, seed):
+    """Seeded fuzz of the two queries: meshes of 1 .. 3,000 triangles with shared vertices, vertex coordinates on mixed scales, zero-area
+    and duplicated triangles, slivers; rays from outside and inside the box, axis-parallel directions (zero components), directions along
+    triangle planes and through vertices, ragged counts.  Hits (t, primID, u, v) and occlusion flags against the oracle, bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    n_v = int(rng.integers(3, 2000))
+    n_t = int(rng.integers(1, 3000))
+    scale = 10.0 ** rng.integers(-3, 3)
+    v = rng.normal(size=(n_v, 3)) * scale
+    if seed % 3 == 1:  # a few vertices far out / very close together
+        v[rng.integers(0, n_v, max(1, n_v // 50))] *= 50.0
+        v[rng.integers(0, n_v, max(1, n_v // 50))] = v[0] + rng.normal(size=(max(1, n_v // 50), 3)) * scale * 1e-4
+    if seed % 4 == 2:  # axis-aligned structure: many coplanar triangles, zero-thickness boxes
+        v[:, int(rng.integers(0, 3))] = np.round(v[:, 0] / scale) * scale
+    v = v.astype(np.float32)
+    t = rng.integers(0, n_v, (n_t, 3)).astype(np.int32)  # index triples may repeat a vertex: zero-area triangles
+    if n_t > 4:
+        t[rng.integers(0, n_t, n_t // 8 + 1)] = t[rng.integers(0, n_t, n_t // 8 + 1)]  # duplicated triangles: the lower primID wins
+    mesh = scenes.MeshData(v, t)
+    ad, om = HipMeshAdapter(mesh), orc.Mesh(v, t)
+    lo, hi = v[t.reshape(-1)].min(axis=0), v[t.reshape(-1)].max(axis=0)
+    ext = np.maximum(hi - lo, 1e-6 * scale)
+    n = int(rng.integers(1, 5000))
+    org = (lo - 0.5 * ext + 2.0 * ext * rng.random((n, 3))).astype(np.float32)  # outside and inside the box
+    tgt = v[t[rng.integers(0, n_t, n)]].astype(np.float64)
+    w = rng.dirichlet([1.0, 1.0, 1.0], n)
+    kind = rng.integers(0, 5, n)
+    w[kind == 1] = [1.0, 0.0, 0.0]               # through a vertex
+    w[kind == 2, 2] = 0.0                         # through an edge
+    w[kind == 2] /= np.maximum(w[kind == 2].sum(axis=1, keepdims=True), 1e-9)
+    p = (tgt * w[:, :, None]).sum(axis=1)
+    d = p - org
+    ax = kind == 3                                # axis-parallel: two zero components
+    d[ax] = np.eye(3)[rng.integers(0, 3, ax.sum())] * rng.choice([-1.0, 1.0], (ax.sum(), 1))
+    inpl = kind == 4                              # inside the plane of the target triangle
+    d[inpl] = (tgt[inpl, 1] - tgt[inpl, 0]) + 1e-30
+    nrm = np.linalg.norm(d, axis=1, keepdims=True)
+    d = np.where(nrm > 0, d / np.maximum(nrm, 1e-300), [0.0, 0.0, 1.0]).astype(np.float32)
+    assert_hits_equal(ad.intersect(org, d), om.intersect(org, d))
+    assert (ad.occluded(org, d) == om.occluded(org, d)).all()
+
+
 def test_mesh_create_rejects_bad_input(hip):
     from gravit_amd import capi
 
@@ -222,6 +266,63 @@ def test_trace_matches_oracle_bit_exact(hip, name, mode):
     assert rays_equal_bits(sort_rays(out_g), sort_rays(out_c)), "moved_rays differ from the oracle"
     assert rays_equal_bits(rg, rc), "rayList was not updated in place like the oracle's"
     assert (out_g["type"] == 1).sum() > 0 and (out_g[out_g["type"] == 1]["t_max"] == np.float32(3.0)).all()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_adapter_calls_against_the_oracle(hip, seed):
+    """Seeded fuzz of Adapter::trace itself: a random mesh under a random translate / non-uniform scale (minv, normi as api.cpp:307-308
+    makes them), one to three lights (point, ambient, area), rays of all three types with random depth, weight, colour and `t`, flat and
+    smooth normals, Lambert / Phong / Blinn, a random [begin, end) range.  Moved rays as a set and the rayList updated in place, bit for
+    bit (Lambert; the `powf` materials within 1e-5, counts exact)."""
+    from gravit_amd.layouts import BLINN, LAMBERT, PHONG, ambient_light, area_light, default_material, point_light
+    rng = np.random.default_rng(7000 + seed)
+    n_v, n_t = int(rng.integers(30, 1500)), int(rng.integers(20, 4000))
+    v = rng.normal(size=(n_v, 3)).astype(np.float32)
+    t = rng.integers(0, n_v, (n_t, 3)).astype(np.int32)
+    mtype = (LAMBERT, LAMBERT, PHONG, BLINN)[seed % 4]
+    mat = default_material(kd=rng.uniform(0.1, 0.9, 3), mtype=mtype, ks=rng.uniform(0.1, 0.9, 3), alpha=float(rng.uniform(1.0, 30.0)))
+    mode = NORMALS_SMOOTH if seed % 2 else NORMALS_FLAT
+    mesh = scenes.MeshData(v, t, mat)
+    ad, om = HipMeshAdapter(mesh, mode), orc.Mesh(v, t, mesh_mat=mat)
+    m = scenes.mat_translate_scale(rng.uniform(-2, 2, 3), rng.uniform(0.3, 3.0, 3))
+    minv, normi = scenes.instance_matrices(m)
+    lights = [point_light(rng.uniform(-6, 6, 3), rng.uniform(0.2, 1.0, 3))]
+    if seed % 3 == 1:
+        lights.append(ambient_light(rng.uniform(0.05, 0.3, 3)))
+    if seed % 3 == 2:
+        lights.append(area_light(rng.uniform(-6, 6, 3), rng.uniform(0.2, 1.0, 3), (0.0, -1.0, 0.0), 0.7, 0.4))
+        lights.append(point_light(rng.uniform(-6, 6, 3)))
+    lights = np.concatenate(lights)
+    n = int(rng.integers(1, 6000))
+    rays = np.zeros(n, RAY_DTYPE)
+    M = m.reshape(4, 4).T.astype(np.float64)
+    world = v[t[rng.integers(0, n_t, n)]].astype(np.float64).mean(axis=1) @ M[:3, :3].T + M[:3, 3]
+    rays["origin"] = (world + rng.normal(size=(n, 3)) * 4.0).astype(np.float32)
+    d = world + rng.normal(size=(n, 3)) * 0.05 - rays["origin"]
+    rays["direction"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays["t_min"], rays["t_max"], rays["t"] = RAY_EPSILON_F, np.float32(np.finfo(np.float32).max), rng.uniform(0.1, 5.0, n).astype(np.float32)
+    rays["type"] = rng.choice([0, 0, 1, 2], n)
+    rays["depth"], rays["w"], rays["id"] = rng.integers(1, 4, n), rng.uniform(0.05, 1.0, n).astype(np.float32), rng.integers(0, 1 << 20, n)
+    rays["color"] = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    rays["rng"] = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    begin = int(rng.integers(0, max(1, n // 3)))
+    end = 0 if seed % 4 == 0 else int(rng.integers(begin, n + 1))
+    rg, rc = rays.copy(), rays.copy()
+    out_g = ad.trace(rg, m, minv, normi, lights, begin=begin, end=end, seed=seed)
+    out_c = om.trace(rc, m, minv, normi, lights, mode, seed=seed, begin=begin, end=end)
+    assert len(out_g) == len(out_c)
+    if (end or n) - begin > 500:  # the call did something: rays were hit (t updated in place), shadow rays and misses moved on
+        assert (rg["t"] != rays["t"]).sum() > 50 and (out_g["type"] == 1).sum() > 10 and (out_g["type"] != 1).sum() > 10
+    a, b = sort_rays(out_g), sort_rays(out_c)
+    if mtype == LAMBERT:
+        assert rays_equal_bits(a, b) and rays_equal_bits(rg, rc)
+    else:
+        for f in RAY_DTYPE.names:
+            if f == "color":
+                assert np.abs(a[f] - b[f]).max(initial=0.0) <= 1e-5
+            else:
+                assert a[f].tobytes() == b[f].tobytes(), f
+        assert rays_equal_bits(rg, rc)
 
 
 def test_trace_ranges_capacity_and_errors(hip):
