@@ -560,6 +560,52 @@ def test_small_rounds_through_one_launch_or_per_hop_whichever_the_tracer_times_f
     assert pinned[0] > pinned[32768]  # (the soup tiles: per-hop rounds need more chains)
 
 
+def _random_scene(seed):
+    """Two to seven instances of one to three random blobs, placed along and around the view axis so that their boxes overlap and rays
+    cross several of them (hops, known misses, shadow rays between instances); one or two point lights; a small film."""
+    from gravit_amd.layouts import default_material, point_light
+    rng = np.random.default_rng(9000 + seed)
+    meshes = []
+    for _ in range(int(rng.integers(1, 4))):
+        n_v, n_t = int(rng.integers(20, 300)), int(rng.integers(30, 900))
+        v = (rng.normal(size=(n_v, 3)) * rng.uniform(0.1, 0.4, 3)).astype(np.float32)
+        t = rng.integers(0, n_v, (n_t, 3)).astype(np.int32)
+        t = t[(t[:, 0] != t[:, 1]) & (t[:, 1] != t[:, 2]) & (t[:, 0] != t[:, 2])]
+        meshes.append(scenes.MeshData(v, np.ascontiguousarray(t), default_material(kd=rng.uniform(0.2, 0.9, 3))))
+    n_inst = int(rng.integers(2, 8))
+    inst_mesh = [int(rng.integers(0, len(meshes))) for _ in range(n_inst)]
+    mats = [scenes.mat_translate_scale(rng.normal(size=3) * (0.5, 0.5, 0.9), rng.uniform(0.5, 1.6, 3)) for _ in range(n_inst)]
+    lights = np.concatenate([point_light(rng.uniform(-3, 3, 3) + (0, 0, 3), rng.uniform(0.4, 1.0, 3)) for _ in range(int(rng.integers(1, 3)))])
+    cam = scenes.Camera(eye=tuple(rng.normal(size=3) * 0.3 + (0.0, 0.0, 4.5)), focus=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=float(np.radians(rng.uniform(25, 60))),
+                        width=int(rng.integers(8, 24)) * 8 + int(rng.integers(0, 8)), height=int(rng.integers(60, 140)))
+    return scenes._assemble(meshes, inst_mesh, mats, lights, cam, "random %d" % seed)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_scenes_through_the_native_schedulers(hip, seed):
+    """Seeded fuzz of the scheduler loop: random overlapping instances (rays hop between them, meet known misses, their shadow rays cross
+    other instances), on one rank against the oracle's restated Image scheduler and on two or three in-process ranks (asynchronous ticks
+    and BSP rounds) against its restated DomainTracer: whole float framebuffers bit for bit, ray counts and rays sent equal."""
+    sc = _random_scene(seed)
+    mode = NORMALS_SMOOTH if seed % 2 else NORMALS_FLAT
+    ref, st = oracle_render(sc, mode, nthreads=8)
+    tr = NativeTracer(sc, mode)
+    for _ in range(9):  # (through the probing frames of finish_auto as well)
+        fb = tr().framebuffer(True)
+        assert np.array_equal(fb[..., :3].view(np.uint32), ref[..., :3].view(np.uint32)) and np.array_equal(fb[..., 3], ref[..., 3])
+        assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any
+    tr.close()
+    assert st.rays_closest > 500
+    world = 2 + seed % 2
+    owner = [i % world for i in range(sc.n_inst)]
+    refd, std = oracle_render_domain(sc, owner, world, mode)
+    assert std.rays_sent > 0  # (every one of these scenes makes rays change rank: 42 .. 4,570 of them, in 3 .. 6 rounds)
+    for bsp in (False, True):
+        res = run_native_ranks(sc, owner, world, mode, bsp)
+        assert np.array_equal(res[0][0][..., :3].view(np.uint32), refd[..., :3].view(np.uint32))
+        assert sum(r[1]["rays_closest"] for r in res.values()) == std.rays_closest and sum(r[1]["rays_sent"] for r in res.values()) == std.rays_sent
+
+
 @pytest.mark.parametrize("case", ["partly_off_film", "box_behind_the_eye_plane", "nothing_in_view", "jitter_window"])
 def test_camera_rectangle_edge_cases(hip, case):
     """The camera filter enumerates only the film rectangle the (kept) instances' boxes project onto (sched.hip camera_keep_rect).
