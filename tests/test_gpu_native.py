@@ -577,7 +577,8 @@ def _random_scene(seed):
     mats = [scenes.mat_translate_scale(rng.normal(size=3) * (0.5, 0.5, 0.9), rng.uniform(0.5, 1.6, 3)) for _ in range(n_inst)]
     lights = np.concatenate([point_light(rng.uniform(-3, 3, 3) + (0, 0, 3), rng.uniform(0.4, 1.0, 3)) for _ in range(int(rng.integers(1, 3)))])
     cam = scenes.Camera(eye=tuple(rng.normal(size=3) * 0.3 + (0.0, 0.0, 4.5)), focus=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=float(np.radians(rng.uniform(25, 60))),
-                        width=int(rng.integers(8, 24)) * 8 + int(rng.integers(0, 8)), height=int(rng.integers(60, 140)))
+                        width=int(rng.integers(8, 24)) * 8 + int(rng.integers(0, 8)), height=int(rng.integers(60, 140)),
+                        depth=2 if seed % 5 == 4 else 1)  # (every fifth scene with a bounce: several deposits per pixel)
     return scenes._assemble(meshes, inst_mesh, mats, lights, cam, "random %d" % seed)
 
 
@@ -585,24 +586,26 @@ def _random_scene(seed):
 def test_random_scenes_through_the_native_schedulers(hip, seed):
     """Seeded fuzz of the scheduler loop: random overlapping instances (rays hop between them, meet known misses, their shadow rays cross
     other instances), on one rank against the oracle's restated Image scheduler and on two or three in-process ranks (asynchronous ticks
-    and BSP rounds) against its restated DomainTracer: whole float framebuffers bit for bit, ray counts and rays sent equal."""
+    and BSP rounds) against its restated DomainTracer: whole float framebuffers bit for bit (within 1e-5 where a bounce gives pixels several deposits), ray
+    counts and rays sent equal."""
     sc = _random_scene(seed)
     mode = NORMALS_SMOOTH if seed % 2 else NORMALS_FLAT
     ref, st = oracle_render(sc, mode, nthreads=8)
     tr = NativeTracer(sc, mode)
+    tol = 1e-5 if sc.camera.depth > 1 else 0.0  # bounces: a pixel gets several deposits, their float sum depends on arrival order
     for _ in range(9):  # (through the probing frames of finish_auto as well)
         fb = tr().framebuffer(True)
-        assert np.array_equal(fb[..., :3].view(np.uint32), ref[..., :3].view(np.uint32)) and np.array_equal(fb[..., 3], ref[..., 3])
+        assert np.abs(fb[..., :3] - ref[..., :3]).max() <= tol and np.array_equal(fb[..., 3], ref[..., 3])
         assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any
     tr.close()
-    assert st.rays_closest > 500
+    assert seed >= 10 or st.rays_closest > 500
     world = 2 + seed % 2
     owner = [i % world for i in range(sc.n_inst)]
     refd, std = oracle_render_domain(sc, owner, world, mode)
     assert seed >= 10 or std.rays_sent > 0  # (every one of the suite's ten scenes makes rays change rank: 42 .. 4,570 of them, in 3 .. 6 rounds)
     for bsp in (False, True):
         res = run_native_ranks(sc, owner, world, mode, bsp)
-        assert np.array_equal(res[0][0][..., :3].view(np.uint32), refd[..., :3].view(np.uint32))
+        assert np.abs(res[0][0][..., :3] - refd[..., :3]).max() <= tol
         assert sum(r[1]["rays_closest"] for r in res.values()) == std.rays_closest and sum(r[1]["rays_sent"] for r in res.values()) == std.rays_sent
 
 
