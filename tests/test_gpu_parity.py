@@ -272,7 +272,7 @@ def test_trace_matches_oracle_bit_exact(hip, name, mode):
 def test_random_adapter_calls_against_the_oracle(hip, seed):
     """Seeded fuzz of Adapter::trace itself: a random mesh under a random translate / non-uniform scale (minv, normi as api.cpp:307-308
     makes them), one to three lights (point, ambient, area), rays of all three types with random depth, weight, colour and `t`, flat and
-    smooth normals, Lambert / Phong / Blinn, a random [begin, end) range.  Moved rays as a set and the rayList updated in place, bit for
+    smooth normals (generated or the caller's), Lambert / Phong / Blinn, per-vertex colours, per-face materials, a random [begin, end) range.  Moved rays as a set and the rayList updated in place, bit for
     bit (Lambert; the `powf` materials within 1e-5, counts exact)."""
     from gravit_amd.layouts import BLINN, LAMBERT, PHONG, ambient_light, area_light, default_material, point_light
     rng = np.random.default_rng(7000 + seed)
@@ -282,8 +282,17 @@ def test_random_adapter_calls_against_the_oracle(hip, seed):
     mtype = (LAMBERT, LAMBERT, PHONG, BLINN)[seed % 4]
     mat = default_material(kd=rng.uniform(0.1, 0.9, 3), mtype=mtype, ks=rng.uniform(0.1, 0.9, 3), alpha=float(rng.uniform(1.0, 30.0)))
     mode = NORMALS_SMOOTH if seed % 2 else NORMALS_FLAT
-    mesh = scenes.MeshData(v, t, mat)
-    ad, om = HipMeshAdapter(mesh, mode), orc.Mesh(v, t, mesh_mat=mat)
+    vcol = rng.uniform(0, 1, (n_v, 3)).astype(np.float32) if seed % 6 == 3 else None            # per-vertex colours (a temporary Lambert per hit)
+    mats, fmat = None, None
+    if seed % 6 == 5:                                                                              # per-face materials, some faces without one (-1)
+        mats = np.concatenate([default_material(kd=rng.uniform(0.1, 0.9, 3), mtype=LAMBERT) for _ in range(4)])
+        fmat = rng.integers(-1, 4, n_t).astype(np.int32)
+    vnrm = None
+    if seed % 4 == 3:                                                                              # the caller's own vertex normals (not generated)
+        vnrm = rng.normal(size=(n_v, 3)).astype(np.float32)
+        vnrm /= np.linalg.norm(vnrm, axis=1, keepdims=True)
+    mesh = scenes.MeshData(v, t, mat, vnormals=vnrm, vcolors=vcol, materials=mats, face_mat=fmat)
+    ad, om = HipMeshAdapter(mesh, mode), orc.Mesh(v, t, vnormals=vnrm, vcolors=vcol, materials=mats, face_mat=fmat, mesh_mat=mat)
     m = scenes.mat_translate_scale(rng.uniform(-2, 2, 3), rng.uniform(0.3, 3.0, 3))
     minv, normi = scenes.instance_matrices(m)
     lights = [point_light(rng.uniform(-6, 6, 3), rng.uniform(0.2, 1.0, 3))]
