@@ -1,5 +1,5 @@
 """More seeds of the three seeded fuzz tests than the suite runs (tests/test_gpu_parity.py, tests/test_gpu_native.py): prints the first failure.
-   usage (GPU box): python tools/fuzz_soak.py [queries=400] [calls=200] [scenes=60]"""
+   usage (GPU box): python tools/fuzz_soak.py [queries=400] [calls=200] [scenes=60] [film=1]"""
 import os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,9 +12,16 @@ class Hip:  # the fixture's surface the tests use
     set_option = staticmethod(capi.set_option)
     stats = staticmethod(capi.stats)
 
-n = {"queries": 400, "calls": 200, "scenes": 60}
+n = {"queries": 400, "calls": 200, "scenes": 60, "film": 1}  # film=k: the random scenes' films k times wider and higher (rounds beyond the small-round kernels)
 for a in sys.argv[1:]:
     k, v = a.split("="); n[k] = int(v)
+if n["film"] > 1:
+    _base = N._random_scene
+    def _big(seed):
+        sc = _base(seed)
+        sc.camera.width *= n["film"]; sc.camera.height *= n["film"]
+        return sc
+    N._random_scene = _big
 capi.init(0)
 orc.set_skip_known_misses(1)  # as tests/conftest.py does for the GPU tests
 bad = 0
