@@ -12,6 +12,7 @@ value = (rays through the closest-hit kernel + rays through the any-hit kernel, 
 timed steps.
 
   python bench.py --gpus 1 --steps 10 --warmup 2
+  python bench.py --gpus N ...        (no launcher: the script starts its N ranks itself, spawn_ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -436,6 +437,55 @@ def inproc_ranks(args):
     print(json.dumps(out))
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it (the reference's equivalent is one `ibrun -np 2` line, CMakeLists.txt:650-654):
+    this process starts N fresh children of the same command line, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set as torch.distributed.run would, hands rank 0's standard output (the ONE JSON line) through and leaves with the first
+    non-zero status of a child.  It imports neither torch nor the library and makes no GPU call; nothing is re-executed: the children are
+    ordinary child processes.  When one rank dies the others are given a few seconds (they usually run into the exchange's error path by
+    themselves) and are then ended by their exact PIDs."""
+    import signal
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   GVT_BENCH_SELF_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))  # rank 0 prints the line; stderr of every rank is inherited
+    rc, first_exit, grace = 0, None, float(os.environ.get("GVT_BENCH_SPAWN_GRACE_S", "30"))
+    try:
+        while any(p.poll() is None for p in procs):
+            for p in procs:
+                c = p.poll()
+                if c is not None and c != 0 and rc == 0:
+                    rc, first_exit = c, time.perf_counter()
+            if first_exit is not None and time.perf_counter() - first_exit > grace:
+                break
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        rc = 130
+    for p in procs:
+        if p.poll() is None:
+            p.send_signal(signal.SIGTERM)
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+        if rc == 0 and p.returncode not in (0, None):
+            rc = p.returncode
+    if rc != 0:
+        print("bench.py: launcher: a rank left with status %d" % rc, file=sys.stderr)
+    sys.exit(rc if 0 <= rc < 256 else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -477,6 +527,9 @@ def main():
             sys.exit(2)
         return inproc_ranks(args)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)  # plain `python bench.py --gpus N`: this process becomes the launcher (it never touches the GPU)
+
     import numpy as np
     import torch
 
@@ -485,8 +538,10 @@ def main():
     local_rank = 0 if args.same_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (a launcher set it): the two must agree" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
+    if os.environ.get("GVT_BENCH_DIE_RANK") == str(rank) and world > 1:  # test hook (tests/test_domain_gloo.py): this rank dies before the rendezvous
+        sys.exit(7)
     import torch.distributed as dist
 
     on_gpu = args.harness != "checker"

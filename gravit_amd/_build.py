@@ -41,7 +41,7 @@ def source_hash():
     files = [os.path.join(root, "bench.py")]
     for base in (CSRC, os.path.join(root, "include")):
         for d, _, fs in os.walk(base):
-            if os.path.basename(d) == "build" or os.sep + "build" + os.sep in d + os.sep:
+            if "build" in os.path.relpath(d, root).split(os.sep):  # csrc/build (objects): judged on the path INSIDE the tree, wherever the tree lies
                 continue
             files += [os.path.join(d, f) for f in fs if f.endswith((".hip", ".h", ".inc"))]
     h = hashlib.sha256()

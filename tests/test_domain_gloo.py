@@ -163,3 +163,39 @@ def test_bench_script_keeps_its_line_when_a_secondary_leg_fails(tmp_path):
     assert j["variants"]["domain_async"]["value"] > 0 and "injected" in j["variants"]["domain_bsp"]["failed"]
     assert "config4_bunny_grid" not in j and "weak_soup" not in j
     assert "domain_bsp failed" in outs[1][1]  # every rank says what it knows on stderr
+
+
+def _clean_env():
+    """the environment of a caller that knows nothing of the launcher: no RANK / WORLD_SIZE / MASTER_*"""
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e["OMP_NUM_THREADS"] = "1"
+    return e
+
+
+def test_bench_script_starts_its_own_ranks_when_no_launcher_did(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE in the environment (how the driver runs the N = 1 line): the script
+    starts its two ranks itself, rank 0's single JSON line comes out of the parent's standard output, the status is 0."""
+    import json
+    import subprocess
+    import sys
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--harness", "checker", "--tris", "20000", "--width", "96", "--height", "54",
+                        "--steps", "1", "--warmup", "0", "--no-extra-legs"], env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, rank 0's"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and set(j["variants"]) == {"domain_async", "domain_bsp"}
+
+
+def test_bench_script_launcher_reports_a_failing_rank(tmp_path):
+    """a rank that dies takes the launcher's status with it (non-zero), the surviving ranks are ended by their PIDs after the grace period"""
+    import subprocess
+    import sys
+
+    env = dict(_clean_env(), GVT_BENCH_DIE_RANK="1", GVT_BENCH_SPAWN_GRACE_S="3")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--harness", "checker", "--tris", "20000", "--width", "96", "--height", "54",
+                        "--steps", "1", "--warmup", "0", "--no-extra-legs"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "a rank left with status" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
