@@ -27,7 +27,7 @@ SYMBOLS = [
     "gvt_hip_profile", "gvt_hip_stats_read", "gvt_hip_stats_reset", "gvt_hip_set_option", "gvt_hip_is_experiments_build", "gvt_hip_counters_peek", "gvt_hip_visit_stats", "gvt_hip_wide_visit_stats", "gvt_hip_image_frame",
     "gvt_hip_math_probe", "gvt_hip_ctx_create", "gvt_hip_ctx_make_current", "gvt_hip_ctx_destroy",
     "gvt_hip_comm_unique_id", "gvt_hip_comm_create", "gvt_hip_hub_create", "gvt_hip_hub_abort", "gvt_hip_hub_destroy", "gvt_hip_comm_create_local",
-    "gvt_hip_comm_destroy", "gvt_hip_comm_rank", "gvt_hip_comm_world", "gvt_hip_comm_count", "gvt_hip_comm_set_deadline_ms", "gvt_hip_comm_selftest",
+    "gvt_hip_comm_destroy", "gvt_hip_comm_rank", "gvt_hip_comm_world", "gvt_hip_comm_count", "gvt_hip_comm_reserved_cus", "gvt_hip_comm_set_deadline_ms", "gvt_hip_comm_selftest",
     "gvt_hip_tracer_create", "gvt_hip_tracer_destroy", "gvt_hip_tracer_set_camera", "gvt_hip_tracer_set_domains", "gvt_hip_tracer_frame",
 ]
 
@@ -50,7 +50,8 @@ class CameraPod(C.Structure):
 class FrameStats(C.Structure):
     _fields_ = [("rounds", C.c_uint64), ("chains", C.c_uint64), ("host_syncs", C.c_uint64), ("rays_sent", C.c_uint64),
                 ("rays_closest", C.c_uint64), ("rays_any", C.c_uint64), ("packets_bailed", C.c_uint64), ("bytes_sent", C.c_uint64),
-                ("ms_chain", C.c_double), ("ms_announce", C.c_double), ("ms_payload", C.c_double), ("ms_composite", C.c_double), ("ms_host_wait", C.c_double)]
+                ("ms_chain", C.c_double), ("ms_announce", C.c_double), ("ms_payload", C.c_double), ("ms_composite", C.c_double), ("ms_host_wait", C.c_double),
+                ("exchanges", C.c_uint64), ("rays_inline", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

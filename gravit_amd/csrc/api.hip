@@ -200,7 +200,7 @@ extern "C" int gvt_hip_stats_reset(void) {
 namespace {
 struct KnobDef { const char *name; int Knobs::*field; int lo, hi; bool shipped; };
 const KnobDef g_knobs[] = {
-  // shipped (15)
+  // shipped (18)
   { "skip_known", &Knobs::skip_known, 0, 1, true },           { "frame_timing", &Knobs::frame_timing, 0, 1, true },
   { "term_sink", &Knobs::term_sink, 0, 1, true },
   { "sort_rays", &Knobs::sort_rays, 0, 1, true },             { "leaf_max", &Knobs::leaf_max, 1, 4, true },
@@ -211,6 +211,7 @@ const KnobDef g_knobs[] = {
   { "long_min_rays", &Knobs::long_min_rays, 0, 1 << 30, true }, { "long_auto", &Knobs::long_auto, 0, 1, true },
   { "finish_auto", &Knobs::finish_auto, 0, 1, true },
   { "payload_overlap_kb", &Knobs::payload_overlap_kb, 0, 1 << 30, true },
+  { "inline_kb", &Knobs::inline_kb, 0, 1024, true },          { "comm_cus", &Knobs::comm_cus, 0, 128, true },
   // experiments build only: the alternative was measured and lost, or the value is a tuned constant
   { "trav_kernel", &Knobs::trav_kernel, 0, 1, false },        { "wide4", &Knobs::wide4, 0, 1, false },
   { "coop_fetch", &Knobs::coop_fetch, 0, 1, false },          { "fused", &Knobs::fused, 0, 1, false },

@@ -151,6 +151,8 @@ struct gvt_hip_comm {
   int connect_ms = 180000;
   hipEvent_t ev_wait = nullptr;
   double ms_host_wait = 0.0; // host time spent in bounded waits since the frame began
+  uint64_t groups = 0;       // transport groups issued since the frame began
+  int cus = 0;               // compute units reserved for `stream` (knob comm_cus at creation)
 };
 
 extern "C" gvt_hip_hub *gvt_hip_hub_create(int world) {
@@ -192,11 +194,47 @@ static gvt_hip_comm *comm_new(int rank, int world) {
   K->count = world;
   return K;
 }
+// Knob comm_cus = k > 0: the communicator's own stream may only use the device's first k compute units (CU mask; on gfx950 the mask's bits go
+// round the eight XCDs, so k = 8 is one CU of every XCD) and the calling context's stream the others -- its persistent traversal grids are
+// then sized for those (Ctx::n_cu).  A payload that moves on the communicator's stream (payload_overlap_kb) then finds CUs that no
+// persistent wave holds; without the reservation an RCCL kernel beside k_trace waits for a block of it to leave.  Off by default.
+static int comm_reserve_cus(gvt_hip_comm *K) {
+  Ctx &C = gctx();
+  const int k = C.comm_cus;
+  if (k <= 0) return 0;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, C.device));
+  const int total = prop.multiProcessorCount;
+  if (k > total / 2) { set_error("comm_cus = %d: more than half of the device's %d compute units", k, total); return GVT_HIP_ERR_INVALID; }
+  if (C.cu_reserved && C.cu_reserved != k) { set_error("comm_cus = %d, but this context's stream already leaves %d compute units free", k, C.cu_reserved); return GVT_HIP_ERR_INVALID; }
+  const int words = (total + 31) / 32;
+  std::vector<uint32_t> m_comm(words, 0u), m_comp(words, 0u);
+  for (int b = 0; b < total; b++) (b < k ? m_comm : m_comp)[b >> 5] |= 1u << (b & 31);
+  hipStream_t s = nullptr;
+  HIPCHK(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, m_comm.data()));
+  hipStreamDestroy(K->stream);
+  K->stream = s;
+  if (!C.cu_reserved) {
+    hipStream_t cs = nullptr;
+    HIPCHK(hipExtStreamCreateWithCUMask(&cs, (uint32_t)words, m_comp.data()));
+    HIPCHK(hipStreamSynchronize(C.own_stream));
+    if (C.stream == C.own_stream) C.stream = cs;
+    hipStreamDestroy(C.own_stream);
+    C.own_stream = cs;
+    C.cu_reserved = k;
+    C.n_cu = total - k;
+  }
+  K->cus = k;
+  return 0;
+}
+extern "C" int gvt_hip_comm_reserved_cus(const gvt_hip_comm *K) { return K ? K->cus : 0; }
+
 extern "C" gvt_hip_comm *gvt_hip_comm_create(const unsigned char id[128], int rank, int world) {
   if (!id) { set_error("comm_create: null id"); return nullptr; }
   if (rccl_load()) return nullptr;
   gvt_hip_comm *K = comm_new(rank, world);
   if (!K) return nullptr;
+  if (comm_reserve_cus(K)) { hipEventDestroy(K->ev_wait); hipStreamDestroy(K->stream); delete K; return nullptr; }
   ncclUniqueId u;
   std::memcpy(&u, id, 128);
   ncclResult_t r = g_rccl.CommInitRank(&K->nccl, world, u, rank);
@@ -213,6 +251,7 @@ extern "C" gvt_hip_comm *gvt_hip_comm_create(const unsigned char id[128], int ra
 extern "C" gvt_hip_comm *gvt_hip_comm_create_local(gvt_hip_hub *hub, int rank) {
   if (!hub) { set_error("comm_create_local: null hub"); return nullptr; }
   gvt_hip_comm *K = comm_new(rank, hub->world);
+  if (K && comm_reserve_cus(K)) { hipEventDestroy(K->ev_wait); hipStreamDestroy(K->stream); delete K; return nullptr; }
   if (K) K->hub = hub;
   return K;
 }
@@ -245,19 +284,44 @@ int comm_timed_out(gvt_hip_comm *K, const char *what, const char *diag, int wait
             waited_ms ? waited_ms : K->deadline_ms, what, diag && *diag ? "; " : "", diag ? diag : "");
   return GVT_HIP_ERR_TIMEOUT;
 }
-// host wait for an event with the communicator's deadline (hipEventSynchronize would wait for ever on an exchange a peer never joins)
-int bounded_event_wait(gvt_hip_comm *K, hipEvent_t ev, const char *what, const char *diag = nullptr) {
+// host wait for an event with the communicator's deadline (hipEventSynchronize would wait for ever on an exchange a peer never joins).
+// all_pairs: the awaited work sent to and received from EVERY peer (an announce exchange): only then is the communicator known to be
+// connected and the long allowance of RCCL's first connections over (a composite or an image-split frame touches some pairs only).
+int bounded_event_wait(gvt_hip_comm *K, hipEvent_t ev, const char *what, const char *diag = nullptr, bool all_pairs = false) {
   const auto t0 = std::chrono::steady_clock::now();
   const int limit_ms = (K->nccl && !K->connected) ? std::max(K->deadline_ms, K->connect_ms) : K->deadline_ms;
   int rc = 0;
   for (unsigned spins = 0;; spins++) {
     const hipError_t e = hipEventQuery(ev);
-    if (e == hipSuccess) { K->connected = true; break; }
+    if (e == hipSuccess) { if (all_pairs) K->connected = true; break; }
     if (e != hipErrorNotReady) { set_error("hipEventQuery while waiting for %s: %s", what, hipGetErrorString(e)); rc = GVT_HIP_ERR_DEVICE; break; }
     if ((spins & 63u) == 63u) {
       if (K->hub && K->hub->aborted.load()) { set_error("hub: aborted while waiting for %s", what); K->dead = true; rc = GVT_HIP_ERR_TIMEOUT; break; }
       if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(limit_ms)) { rc = comm_timed_out(K, what, diag, limit_ms); break; }
       if (spins > 4096u) std::this_thread::yield();
+    }
+  }
+  K->ms_host_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
+}
+// the same for a word of pinned host memory that a kernel behind the exchange releases (k_publish): waited for with loads
+int bounded_flag_wait(gvt_hip_comm *K, const unsigned *flag, unsigned want, hipStream_t st, const char *what, const char *diag, bool all_pairs) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const int limit_ms = (K->nccl && !K->connected) ? std::max(K->deadline_ms, K->connect_ms) : K->deadline_ms;
+  int rc = 0;
+  for (unsigned spins = 0;; spins++) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == want) { if (all_pairs) K->connected = true; break; }
+    if ((spins & 1023u) == 1023u) {
+      if (K->hub && K->hub->aborted.load()) { set_error("hub: aborted while waiting for %s", what); K->dead = true; rc = GVT_HIP_ERR_TIMEOUT; break; }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(limit_ms)) { rc = comm_timed_out(K, what, diag, limit_ms); break; }
+      if ((spins & 0xffffu) == 0xffffu) { // a stream that ended (or faulted) without the word: not a peer's doing
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) {
+          set_error("%s: the stream %s without publishing report %u", what, e == hipSuccess ? "finished" : hipGetErrorString(e), want);
+          rc = GVT_HIP_ERR_DEVICE; break;
+        }
+        std::this_thread::yield();
+      }
     }
   }
   K->ms_host_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -316,6 +380,7 @@ int hub_group_end(gvt_hip_comm *K) {
 
 int comm_group_end(gvt_hip_comm *K) {
   if (K->dead) { set_error("ray exchange: the communicator of rank %d was aborted after a deadline passed", K->rank); return GVT_HIP_ERR_TIMEOUT; }
+  if (!K->ops.empty()) K->groups++;
   if (K->hub) return hub_group_end(K);
   if (K->ops.empty()) return 0;
   NCCLCHK(g_rccl.GroupStart());
@@ -381,11 +446,22 @@ extern "C" int gvt_hip_comm_selftest(gvt_hip_comm *K, size_t bytes) {
 // device helpers of the scheduler loop
 // ------------------------------------------------------------------------------------------------
 namespace {
-#define ANN_HEAD 10 // announce row: {rays to you, bytes to you, my total outgoing rays, my local pending rays, the bounding rectangle of the
+#define ANN_HEAD 11 // announce row: {rays to you, bytes to you, my total outgoing rays, my local pending rays, the bounding rectangle of the
                     // pixels my framebuffer holds deposits in (x0, y0, x1, y1; for the composite), my error code (0: none -- a rank whose
                     // local work failed still takes part in the exchange, so that EVERY rank leaves the frame, with the same error),
-                    // my exchange number (ranks out of step are a protocol error, not a hang), rays per queue [n_inst]}
+                    // my exchange number (ranks out of step are a protocol error, not a hang), bytes of payload carried INLINE behind this
+                    // row (0: none, or too large -- it follows in the payload exchange), rays per queue [n_inst]}
+                    // The message a rank sends a peer per tick is this row followed by a fixed inline area (knob inline_kb, the same on every
+                    // rank): a tick whose pairs all have at most that much to say is ONE exchange (one ncclGroup), the rays travel with the
+                    // count exchange of SendRays (DomainTracer.h:397-415) instead of behind it (:433-463).
 #define REPORT_TAIL 13 // words behind the queue sizes in the round's report (the last one: the sequence number of a polled report)
+
+// dword w (0..19) of ray `ray`'s 80-byte wire image (actor/Ray.h:68-96; words 16..19: the stream word and the known-miss list, inside Ray::data)
+__device__ inline unsigned wire_word(const RayPlanes &q, unsigned ray, unsigned w) {
+  if (w < 16) { const float4 *pl = w < 4 ? q.p0 : w < 8 ? q.p1 : w < 12 ? q.p2 : q.p3; return ((const unsigned *)(pl + ray))[w & 3]; }
+  if (w == 16) return q.p4[ray];
+  return q.p5[3 * (size_t)ray + (w - 17)];
+}
 
 // sizes[i] = *count_ptr[i]; the announce row for every peer; totals (2 x u64) and flags copied next to them so that ONE device-to-host
 // copy carries everything the host needs from a round
@@ -398,7 +474,8 @@ __global__ __launch_bounds__(256) void k_round_report(unsigned *const *__restric
                                unsigned *overflow /* [0] flags, [4..7] rectangle, [10] this kernel's ticket */, unsigned *tail /* sizes + n_inst: tot[4], ovf trav, ovf queue, bbox[4] */,
                                int *bbox, int chain_end = 0, const unsigned char *__restrict__ chain_mask = nullptr,
                                unsigned *host_report = nullptr, unsigned host_seq = 0u, int err_code = 0, int tick = 0, const float4 *__restrict__ scan_fb = nullptr,
-                               int fb_w = 0, int fb_h = 0) {
+                               int fb_w = 0, int fb_h = 0, int msg_ints = 0 /* stride of the announce rows (row + inline area), ints */, int inl_bytes = 0,
+                               const QueueDesc *__restrict__ qd = nullptr) {
   __shared__ unsigned long long sh_out, sh_local;
   if (scan_fb) {
     __shared__ int sh_bb[4];
@@ -435,22 +512,45 @@ __global__ __launch_bounds__(256) void k_round_report(unsigned *const *__restric
   }
   __syncthreads();
   const int row = ANN_HEAD + n_inst;
+  if (msg_ints < row) msg_ints = row;
   int bb[4];
   for (int k = 0; k < 4; k++) bb[k] = __hip_atomic_load(&bbox[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int p = threadIdx.x; p < world; p += blockDim.x) {
     unsigned rays = 0, queues = 0;
     for (int i = 0; i < n_inst; i++) {
       const unsigned s = (owner[i] == p && p != rank) ? sizes[i] : 0u;
-      ann[p * row + ANN_HEAD + i] = (int)s;
+      ann[p * msg_ints + ANN_HEAD + i] = (int)s;
       rays += s; queues += s ? 1u : 0u;
     }
-    ann[p * row + 0] = (int)rays;
-    ann[p * row + 1] = (int)(rays * 80u + queues * 8u); // SendRays: packed rays + {queue number, ray count} per queue (:397-407)
-    ann[p * row + 2] = (int)sh_out;
-    ann[p * row + 3] = (int)sh_local;
-    for (int k = 0; k < 4; k++) ann[p * row + 4 + k] = bb[k];
-    ann[p * row + 8] = err_code;
-    ann[p * row + 9] = tick;
+    const unsigned bytes = rays * 80u + queues * 8u; // SendRays: packed rays + {queue number, ray count} per queue (:397-407)
+    ann[p * msg_ints + 0] = (int)rays;
+    ann[p * msg_ints + 1] = (int)bytes;
+    ann[p * msg_ints + 2] = (int)sh_out;
+    ann[p * msg_ints + 3] = (int)sh_local;
+    for (int k = 0; k < 4; k++) ann[p * msg_ints + 4 + k] = bb[k];
+    ann[p * msg_ints + 8] = err_code;
+    ann[p * msg_ints + 9] = tick;
+    ann[p * msg_ints + 10] = (bytes && bytes <= (unsigned)inl_bytes && !err_code) ? (int)bytes : 0;
+  }
+  if (inl_bytes > 0 && !err_code) {
+    // a peer's whole payload of this tick fits the inline area: packed here, in the reference's wire format, behind the row it is announced
+    // in; the queues it came from are cleared (the sender's q.second.clear(), :455) -- `sizes` keeps what they held, the host applies
+    // the same rule to it
+    __syncthreads();
+    for (int p = 0; p < world; p++) {
+      const unsigned bytes = (unsigned)ann[p * msg_ints + 10];
+      if (!bytes) continue;
+      unsigned *buf = (unsigned *)(ann + (size_t)p * msg_ints + row);
+      unsigned off = 0;
+      for (int i = 0; i < n_inst; i++) {
+        const unsigned n = (unsigned)ann[p * msg_ints + ANN_HEAD + i];
+        if (!n) continue;
+        const RayPlanes q = make_planes(qd[i].planes, qd[i].cap);
+        for (unsigned l = threadIdx.x; l < 2u + 20u * n; l += blockDim.x) buf[off + l] = l < 2 ? (l == 0 ? (unsigned)i : n) : wire_word(q, (l - 2) / 20u, (l - 2) % 20u);
+        if (threadIdx.x == 0) *count_ptr[i] = 0u;
+        off += 2u + 20u * n;
+      }
+    }
   }
   if (threadIdx.x == 0) {
     tail[0] = counters[16]; tail[1] = counters[17]; tail[2] = counters[18]; tail[3] = counters[19];
@@ -502,13 +602,8 @@ __global__ __launch_bounds__(256) void k_pack_all(const WireBatch B) {
   const unsigned l = t - I.dword0;
   if (l == 0) *I.count = 0u;
   if (l < 2) { I.buf[l] = l == 0 ? (unsigned)I.qid : I.n; return; }
-  const unsigned d = l - 2, ray = d / 20u, w = d % 20u;
-  const RayPlanes q = make_planes(I.planes, I.cap);
-  unsigned v;
-  if (w < 16) { const float4 *pl = w < 4 ? q.p0 : w < 8 ? q.p1 : w < 12 ? q.p2 : q.p3; v = ((const unsigned *)(pl + ray))[w & 3]; }
-  else if (w == 16) v = q.p4[ray];
-  else v = q.p5[3 * (size_t)ray + (w - 17)]; // the known-miss list travels with the ray (bytes 68..79)
-  I.buf[l] = v;
+  const unsigned d = l - 2;
+  I.buf[l] = wire_word(make_planes(I.planes, I.cap), d / 20u, d % 20u); // (the known-miss list travels with the ray, bytes 68..79)
 }
 // unpack: appended behind the queue's current rays.  Every thread reads the queue's count word as its base; the LAST block of the
 // launch to finish (ticket) -- every other block has read its bases by then -- advances the count words.
@@ -547,6 +642,16 @@ template <bool ADD> __global__ __launch_bounds__(256) void k_rect(float4 *__rest
   const size_t px = (size_t)(y0 + (int)(i / (unsigned)w)) * W + x0 + (int)(i % (unsigned)w);
   if (ADD) { float4 a = fb[px]; const float4 b = buf[i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; fb[px] = a; }
   else buf[i] = fb[px];
+}
+// behind an announce exchange: the peers' rows (without their inline areas) and this rank's report gathered into the host's pinned mirror,
+// the sequence word released last -- the host polls it (no device-to-host copy, no event, no interrupt between the exchange and the vote)
+__global__ __launch_bounds__(256) void k_publish(const int *__restrict__ ann_in, int msg_ints, int row, int world, const unsigned *__restrict__ report, int n_rep,
+                                                  int *h_ann, unsigned *h_report, unsigned seq) {
+  for (int k = threadIdx.x; k < world * row; k += blockDim.x) h_ann[k] = ann_in[(size_t)(k / row) * msg_ints + (k % row)];
+  for (int k = threadIdx.x; k < n_rep; k += blockDim.x) h_report[k] = report[k];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(h_report + n_rep, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // start of a frame: ray totals, flags, the work counter of the first small chain, the deposit rectangle (empty) and the kernels' tickets
 // a frame's resets in one launch: every queue.clear() (count words) and the frame's totals / flags / deposit rectangle
@@ -591,7 +696,9 @@ struct gvt_hip_tracer {
   unsigned char *d_mask = nullptr, *h_mask = nullptr;
   unsigned *d_report = nullptr, *h_report = nullptr; // sizes[n_inst] + tail[REPORT_TAIL]; the tail's last word: sequence number of a polled report
   unsigned report_seq = 0;
-  int *d_ann_out = nullptr, *d_ann_in = nullptr, *h_ann_in = nullptr; // [world][ANN_HEAD + n_inst]
+  int *d_ann_out = nullptr, *d_ann_in = nullptr; // [world][msg_ints]: the announce row (ANN_HEAD + n_inst ints) + the inline payload area
+  int *h_ann_in = nullptr;                       // [world][ANN_HEAD + n_inst]: the rows only (k_publish)
+  size_t inl_bytes = 0, msg_ints = 0;            // inline area per pair (knob inline_kb when the tables were laid out), message length in ints
   unsigned *d_overflow = nullptr;
   std::vector<void *> send_buf, recv_buf;
   std::vector<size_t> send_cap, recv_cap;
@@ -631,14 +738,17 @@ static int tracer_alloc_tables(gvt_hip_tracer *R) {
   const size_t row = ANN_HEAD + R->n_inst;
   hipFree(R->d_ann_out); hipFree(R->d_ann_in); hipHostFree(R->h_ann_in);
   R->d_ann_out = R->d_ann_in = R->h_ann_in = nullptr;
-  // the peers' announces as received and, right behind them, this rank's report: one device block, one pinned mirror, one copy per tick
-  const size_t view = sizeof(int) * W * row + sizeof(unsigned) * (n + REPORT_TAIL);
-  HIPCHK(hipMalloc((void **)&R->d_ann_out, sizeof(int) * W * row));
-  HIPCHK(hipMalloc((void **)&R->d_ann_in, view));
-  HIPCHK(hipHostMalloc((void **)&R->h_ann_in, view, hipHostMallocDefault));
-  HIPCHK(hipMemset(R->d_ann_in, 0, view));
-  std::memset(R->h_ann_in, 0, view);
-  R->d_report = (unsigned *)(R->d_ann_in + W * row);
+  R->inl_bytes = W > 1 ? ((size_t)gctx().inline_kb << 10) : 0;
+  R->msg_ints = row + R->inl_bytes / 4;
+  // the peers' messages as received and, behind them, this rank's report: one device block; the pinned mirror holds the rows and the report
+  const size_t dview = sizeof(int) * W * R->msg_ints + sizeof(unsigned) * (n + REPORT_TAIL), hview = sizeof(int) * W * row + sizeof(unsigned) * (n + REPORT_TAIL);
+  HIPCHK(hipMalloc((void **)&R->d_ann_out, sizeof(int) * W * R->msg_ints));
+  HIPCHK(hipMalloc((void **)&R->d_ann_in, dview));
+  HIPCHK(hipHostMalloc((void **)&R->h_ann_in, hview, hipHostMallocDefault));
+  HIPCHK(hipMemset(R->d_ann_out, 0, sizeof(int) * W * R->msg_ints));
+  HIPCHK(hipMemset(R->d_ann_in, 0, dview));
+  std::memset(R->h_ann_in, 0, hview);
+  R->d_report = (unsigned *)(R->d_ann_in + W * R->msg_ints);
   R->h_report = (unsigned *)(R->h_ann_in + W * row);
   R->report_seq = 0;
   for (void *p : R->send_buf) hipFree(p);
@@ -736,6 +846,15 @@ struct Report {
   uint64_t rays_closest, rays_any;
 };
 
+// segments + queue descriptors + mask (one pinned block) to the device -- skipped when they equal what the device already holds
+int round_tables_upload(gvt_hip_tracer *R, hipStream_t st) {
+  if (R->round_uploaded.size() != R->round_bytes || std::memcmp(R->round_uploaded.data(), R->h_round, R->round_bytes) != 0) {
+    HIPCHK(hipMemcpyAsync(R->d_round, R->h_round, R->round_bytes, hipMemcpyHostToDevice, st));
+    R->round_uploaded.assign((const unsigned char *)R->h_round, (const unsigned char *)R->h_round + R->round_bytes);
+  }
+  return 0;
+}
+
 int grow(void **buf, size_t *cap, size_t bytes) {
   if (bytes <= *cap) return 0;
   if (*buf) HIPCHK(hipFree(*buf));
@@ -795,10 +914,7 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
   // segments + descriptors + mask in one copy -- skipped when they equal what the device already holds (steady-state frames of a
   // one-queue scene: same pointers, same bound)
   for (size_t k = (size_t)n_seg; k < (nI ? nI : 1); k++) std::memset(&R->h_segs[k], 0, sizeof(WaveSeg));
-  if (R->round_uploaded.size() != R->round_bytes || std::memcmp(R->round_uploaded.data(), R->h_round, R->round_bytes) != 0) {
-    HIPCHK(hipMemcpyAsync(R->d_round, R->h_round, R->round_bytes, hipMemcpyHostToDevice, st));
-    R->round_uploaded.assign((const unsigned char *)R->h_round, (const unsigned char *)R->h_round + R->round_bytes);
-  }
+  if ((rc = round_tables_upload(R, st))) return rc;
   int *d_from = (int *)scratch_get(17, sizeof(int) * bound);
   if (!d_from) return GVT_HIP_ERR_DEVICE;
   TraceParams P{};
@@ -854,35 +970,44 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_e
   // launch -- many blocks scan the framebuffer, the last one to finish writes the report
   const bool scan = exchange && R->world > 1;
   const unsigned n_blk = scan ? (unsigned)std::min<size_t>(1024, ((size_t)R->fb->w * R->fb->h + 1023) / 1024) : 1u;
+  if (scan && R->inl_bytes) { // the inline pack reads the outgoing queues through the descriptor table: current? (a reserve may have moved one since the last chain)
+    for (size_t i = 0; i < nI; i++) { gvt_hip_queue *Q = R->queues[i]; R->h_qdesc[i].planes = Q->d_planes; R->h_qdesc[i].cap = Q->cap; R->h_qdesc[i].count = Q->d_count; R->h_qdesc[i].keep = 1u; }
+    int rc_up = round_tables_upload(R, st);
+    if (rc_up) return rc_up;
+  }
   k_round_report<<<n_blk, 256, 0, st>>>(R->d_count_ptr, R->d_owner, (int)nI, R->rank, R->world, R->d_report, R->d_ann_out, C.d_counters, R->d_overflow,
                                         R->d_report + nI, d_bbox, chain_end ? 1 : 0, R->d_mask, poll ? R->h_report : nullptr, poll ? ++R->report_seq : 0u, err_code, tick,
-                                        scan ? (const float4 *)R->fb->d_rgba : nullptr, R->fb->w, R->fb->h);
+                                        scan ? (const float4 *)R->fb->d_rgba : nullptr, R->fb->w, R->fb->h, (int)R->msg_ints, scan ? (int)R->inl_bytes : 0, R->d_qdesc);
   HIPCHK(hipGetLastError());
   if (exchange && R->world > 1) {
     gvt_hip_comm *K = R->comm;
+    const size_t msg = sizeof(int) * R->msg_ints;
     if (K->stream != st || timing) HIPCHK(hipEventRecord(R->ev_compute, st)); // (also the timing event at the end of this tick's local chain)
     if (K->stream != st) HIPCHK(hipStreamWaitEvent(K->stream, R->ev_compute, 0));
     if (timing) HIPCHK(hipEventRecord(R->ev_ann0, K->stream));
     comm_group_begin(K);
     for (int p = 0; p < R->world; p++) {
       if (p == R->rank) continue;
-      comm_send(K, R->d_ann_out + (size_t)p * row, sizeof(int) * row, p);
-      comm_recv(K, R->d_ann_in + (size_t)p * row, sizeof(int) * row, p);
+      comm_send(K, R->d_ann_out + (size_t)p * R->msg_ints, msg, p);
+      comm_recv(K, R->d_ann_in + (size_t)p * R->msg_ints, msg, p);
     }
     int rc = comm_group_end(K);
     if (rc) return rc;
-    // ONE copy brings the peers' announces and this rank's report (adjacent on both sides, tracer_alloc_tables; the report's last word is
-    // the polled reports' sequence number and stays the host's)
-    HIPCHK(hipMemcpyAsync(R->h_ann_in, R->d_ann_in, sizeof(int) * R->world * row + sizeof(unsigned) * (nI + REPORT_TAIL - 1), hipMemcpyDeviceToHost, K->stream));
-    HIPCHK(hipEventRecord(R->ev_report, K->stream));
-    { // bounded: a peer that never joins the exchange must not hang this rank
+    // behind the exchange ONE small kernel gathers the peers' rows and this rank's report into the pinned mirror and releases the
+    // sequence word; the host waits for that word with loads (bounded: a peer that never joins the exchange must not hang this rank)
+    const unsigned seq = ++R->report_seq;
+    k_publish<<<1, 256, 0, K->stream>>>(R->d_ann_in, (int)R->msg_ints, (int)row, R->world, R->d_report, (int)(nI + REPORT_TAIL - 1), R->h_ann_in, R->h_report, seq);
+    HIPCHK(hipGetLastError());
+    if (timing) HIPCHK(hipEventRecord(R->ev_report, K->stream));
+    {
       char diag[256];
       std::snprintf(diag, sizeof diag, "exchange %d, this rank's announce: %zu local rays pending, error word %d; last report: %u rays in the first queue", tick,
                     (size_t)R->last_local_pending, err_code, nI ? R->h_report[0] : 0u);
-      if ((rc_wait = bounded_event_wait(K, R->ev_report, "the announce exchange", diag))) return rc_wait;
+      if ((rc_wait = bounded_flag_wait(K, R->h_report + nI + REPORT_TAIL - 1, seq, K->stream, "the announce exchange", diag, true))) return rc_wait;
     }
-    if (S && timing) { // phase times of this tick (all three events are complete now)
+    if (S && timing) { // phase times of this tick
       float ms = 0.f;
+      hipEventSynchronize(R->ev_report);
       if (R->chain_timed && hipEventElapsedTime(&ms, R->ev_chain0, R->ev_compute) == hipSuccess) S->ms_chain += ms;
       if (hipEventElapsedTime(&ms, R->ev_ann0, R->ev_report) == hipSuccess) S->ms_announce += ms;
       if (R->payload_timed && hipEventElapsedTime(&ms, R->ev_pay0, R->ev_recv) == hipSuccess) S->ms_payload += ms;
@@ -927,9 +1052,14 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   // Tracer<ImageScheduler> on several ranks (ImageTracer.h:111-125): the scene is replicated, every rank takes a contiguous portion of
   // the camera's ray list and traces it to the end on its own; no ray ever changes rank; the frame ends with the composite.
   const bool image_split = (flags & GVT_HIP_FRAME_IMAGE) != 0 && R->world > 1;
+  int rc0 = 0;
   if (image_split)
     for (size_t i = 0; i < nI; i++)
       if (!R->meshes[i]) { set_error("tracer_frame: GVT_HIP_FRAME_IMAGE needs every instance's mesh on every rank (instance %zu has none)", i); return GVT_HIP_ERR_INVALID; }
+  if (R->world > 1 && R->inl_bytes != ((size_t)C.inline_kb << 10)) { // the knob moved since the tables were laid out (every rank must move it alike)
+    HIPCHK(hipStreamSynchronize(st));
+    if ((rc0 = tracer_alloc_tables(R))) return rc0;
+  }
   const int world_saved = R->world;
   std::vector<uint8_t> owned_saved = R->owned;
   struct Restore { // whatever path leaves this function: the tracer is a rank of its communicator again
@@ -1048,11 +1178,13 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     for (int p = 0; p < R->world; p++) {
       if (p == R->rank) continue;
       const int *a = pending_ann.data() + (size_t)p * row;
+      // the peer's payload arrived inside its announce (behind the row, in this rank's receive block) or in the payload exchange
+      char *src = a[10] ? (char *)(R->d_ann_in + (size_t)p * R->msg_ints + row) : (char *)R->recv_buf[p];
       size_t off = 0;
       for (size_t i = 0; i < nI; i++) {
         const unsigned n = (unsigned)a[ANN_HEAD + i];
         if (!n) continue;
-        if ((rc_ = wire_add(B, true, R->queues[i], (char *)R->recv_buf[p] + off, n, (int)i))) return rc_;
+        if ((rc_ = wire_add(B, true, R->queues[i], src + off, n, (int)i))) return rc_;
         off += 8 + 80ull * n;
       }
     }
@@ -1083,7 +1215,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   // (A rank that cannot even run the exchange -- a device fault, a dead process -- is what the deadlines are for.)
   auto failed = [&](int rc_) { if (rc_ && !local_err) { local_err = rc_; local_msg = gvt_hip_last_error(); } return rc_ != 0; };
   const bool multi = world_saved > 1;
-  if (R->comm) R->comm->ms_host_wait = 0.0;
+  if (R->comm) { R->comm->ms_host_wait = 0.0; R->comm->groups = 0; }
   // The exchanges of a frame are issued on the COMPUTE stream itself (the communicator's own stream is bound to it for the frame): a tick is
   // a short dependent sequence -- chain, report, announce, copy, pack, payload, unpack -- and every hop between two streams costs an event
   // record, a wait and the queues' hand-over latency on the device (toy two-rank frame 914 -> 670 us, profiles/r04_tick_floor.txt).  What is
@@ -1117,7 +1249,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     } else if (!local_err) {
       bool have_local = false;
       for (size_t i = 0; i < nI; i++) have_local = have_local || (R->owned[i] && R->present[i]);
-      if (!have_local) failed(unpack_pending()); // nothing to overlap the transfer with: take what arrived first
+      if (!have_local || !payload_cross) failed(unpack_pending()); // nothing to overlap a transfer with (or it is here already: inline / compute stream): take what arrived first
       if (!local_err) failed(local_chain(R, &incoming, &S.chains, S.chains == 0, first_on_device && S.chains == 0));
       if (!local_err) failed(unpack_pending());
     }
@@ -1138,10 +1270,25 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     std::vector<size_t> bytes_out(R->world, 0), bytes_in(R->world, 0);
     WireBatch PB;
     PB.n_items = 0; PB.total = 0;
+    bool any_inline = false;
     for (int p = 0; p < R->world; p++) {
       if (p == R->rank) continue;
       for (size_t i = 0; i < nI; i++) if (R->owner[i] == p && R->present[i]) bytes_out[p] += 8 + 80 * R->present[i];
       bytes_in[p] = (size_t)(unsigned)R->h_ann_in[(size_t)p * row + 1];
+      const size_t inl_in = (size_t)(unsigned)R->h_ann_in[(size_t)p * row + 10];
+      if (inl_in) { // this peer's rays are already here, behind its row
+        if (inl_in != bytes_in[p] || inl_in > R->inl_bytes) { set_error("ray exchange: rank %d announces %zu inline bytes of %zu (inline area %zu)", p, inl_in, bytes_in[p], R->inl_bytes); return GVT_HIP_ERR_DEVICE; }
+        bytes_in[p] = 0; any_inline = true;
+      }
+      if (bytes_out[p] && bytes_out[p] <= R->inl_bytes) { // k_round_report applied the same rule: these rays left inside the announce, their queues are cleared
+        S.bytes_sent += bytes_out[p];
+        for (size_t i = 0; i < nI; i++) {
+          if (R->owner[i] != p || !R->present[i]) continue;
+          S.rays_sent += R->present[i]; S.rays_inline += R->present[i];
+          R->present[i] = 0; R->queues[i]->size = 0;
+        }
+        bytes_out[p] = 0;
+      }
       // (a failure from here on -- after the announce promised these bytes -- cannot be reported before the peers have posted their
       // matching operations: it ends this rank's frame at once and the peers run into the exchange deadline)
       if ((rc = grow(&R->send_buf[p], &R->send_cap[p], bytes_out[p]))) return rc;
@@ -1164,10 +1311,13 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     for (int p = 0; p < R->world; p++)
       if (p != R->rank)
         for (size_t i = 0; i < nI; i++) incoming[i] += (unsigned)pending_ann[(size_t)p * row + ANN_HEAD + i];
-    if (any_traffic) {
-      // room for what arrives, reserved now (the unpack kernels are launched later, behind the next local chain)
+    // room for what arrives (or has arrived inline), reserved now (the unpack kernels are launched in the next tick)
+    if (any_traffic || any_inline)
       for (size_t i = 0; i < nI; i++)
         if (incoming[i] && (rc = queue_reserve(R->queues[i], R->present[i] + incoming[i]))) return rc;
+    payload_cross = false;
+    if (any_inline) payload_pending = true;
+    if (any_traffic) {
       // A payload of a megabyte or more moves on the communicator's OWN stream, while the next tick's local chain runs on the compute
       // stream (ordered by two events); smaller ones -- every late tick of a frame -- stay on the compute stream (StreamBind above).
       size_t bytes_total = 0;
@@ -1240,7 +1390,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     S.host_syncs++;
     if (C.frame_timing) { float ms = 0.f; if (hipEventElapsedTime(&ms, R->ev_comp0, R->ev_comm) == hipSuccess) S.ms_composite += ms; }
   }
-  if (R->comm) S.ms_host_wait = R->comm->ms_host_wait;
+  if (R->comm) { S.ms_host_wait = R->comm->ms_host_wait; S.exchanges = R->comm->groups; }
   const unsigned *tail = R->h_report + nI;
   S.rays_closest = (uint64_t)tail[0] | ((uint64_t)tail[1] << 32);
   S.rays_any = (uint64_t)tail[2] | ((uint64_t)tail[3] << 32);

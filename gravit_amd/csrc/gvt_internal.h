@@ -59,6 +59,10 @@ struct Knobs {
   int long_auto = 1;     // native tracer: raise the parking threshold from frame to frame while more than 0.3 % of a frame's closest-hit rays get parked (sparser scenes than the benchmark)
   int payload_overlap_kb = 1024; // Domain scheduler: a tick's payload of at least this many KiB (sent + received) moves on the communicator's own stream while the next
                          // chain runs; smaller ones stay on the compute stream (no cross-stream event pairs).  0: every payload on its own stream
+  int inline_kb = 16;    // Domain scheduler: a pair's payload of at most this many KiB per tick travels INSIDE the announce (one exchange per tick instead of two); every
+                         // rank must use the same value (the announce message has a fixed length).  0: always the two-step exchange
+  int comm_cus = 0;      // Domain scheduler: payloads that move on the communicator's own stream (payload_overlap_kb) get this many compute units to themselves:
+                         // the communicator's stream is created with a CU mask of that many CUs and the persistent traversal grids are sized for the rest (0: no reservation)
   int frame_timing = 0;  // multi-rank frames: fill gvt_hip_frame_stats' ms_chain / ms_announce / ms_payload / ms_composite (five more event calls per exchange)
   int inject_fail_tick = -1; // tests: this rank's local work "fails" at that exchange of a multi-rank frame (the announce carries the error to every rank)
   int report_poll = 1;   // one rank: a round's report is written into pinned host memory by the kernel and polled (no copy, no stream synchronisation)
@@ -88,7 +92,8 @@ struct Ctx : Knobs {
   std::vector<hipEvent_t> event_pool;
   gvt_hip_stats stats{};
   // traversal launch geometry + per-thread stack spill area
-  int n_cu = 256;
+  int n_cu = 256;        // compute units the context's launches are sized for (all of the device's, minus cu_reserved)
+  int cu_reserved = 0;   // compute units masked away from the context's stream for a communicator's own stream (knob comm_cus)
   int trav_blocks = 0;
   int *d_spill = nullptr;
   unsigned *d_counters = nullptr; // small array of device counters (work fetch, temps)

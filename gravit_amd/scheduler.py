@@ -201,6 +201,11 @@ class Comm:
         """ranks the transport itself reports (ncclCommCount; the hub's world)"""
         return self.lib.gvt_hip_comm_count(self.h)
 
+    @property
+    def reserved_cus(self):
+        """compute units reserved for the communicator's own stream (knob comm_cus when it was created)"""
+        return self.lib.gvt_hip_comm_reserved_cus(self.h)
+
     def set_deadline_ms(self, ms):
         import ctypes as C
 

@@ -238,6 +238,8 @@ int gvt_hip_comm_selftest(gvt_hip_comm *, size_t bytes);
 int gvt_hip_comm_rank(const gvt_hip_comm *);
 /* ranks the transport itself counts (ncclCommCount; the hub's world): gvt_hip_comm_create fails unless it equals `world` */
 int gvt_hip_comm_count(const gvt_hip_comm *);
+/* compute units reserved for the communicator's own stream (knob "comm_cus" of the creating context at gvt_hip_comm_create[_local]; 0: none) */
+int gvt_hip_comm_reserved_cus(const gvt_hip_comm *);
 /* deadline of every blocking point of an exchange, in milliseconds (default: GVT_HIP_EXCHANGE_TIMEOUT_MS or 20000).  A rank that waits
  * longer returns GVT_HIP_ERR_TIMEOUT with its last announce in gvt_hip_last_error(), aborts the communicator (ncclCommAbort / hub
  * abort) and must not use it again: the process reports and exits non-zero. */
@@ -274,6 +276,9 @@ typedef struct gvt_hip_frame_stats {
   double ms_payload;     /* payload exchanges, posting to arrival (overlaps the next chain) */
   double ms_composite;   /* framebuffer composite on rank 0 */
   double ms_host_wait;   /* host time blocked in the exchanges' bounded waits */
+  uint64_t exchanges;    /* transport groups (ncclGroupStart .. End) this rank issued in the frame, composite included: one per tick when every pair's
+                            payload rode inside the announce ("inline_kb"), two where a payload exchange followed */
+  uint64_t rays_inline;  /* of rays_sent: rays that travelled inside an announce */
 } gvt_hip_frame_stats;
 /* One frame: clearBuffer, generateRays + FilterRaysLocally / shuffleDropRays, rounds until every queue of every rank is empty, then
  * (Domain) the composite: the sum of the ranks' float framebuffers on rank 0 (IceTComposite.cpp:84-101).  Collective under a comm. */
@@ -314,7 +319,7 @@ int gvt_hip_wide_visit_stats(gvt_hip_mesh *, const float *org, const float *dir,
  * functions the bounce path (EmbreeMeshAdapter.cpp:289-318) is built on. */
 int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
 /* Knobs of the library (gvt_internal.h `struct Knobs` lists them with their defaults; ("defaults", 0) restores all of them).  Results never
- * depend on them -- except "skip_known", which switches between two shuffle rules with the same image (below).  The shipped surface, 16 knobs:
+ * depend on them -- except "skip_known", which switches between two shuffle rules with the same image (below).  The shipped surface, 18 knobs:
  *   behaviour    "skip_known"   1: shuffleRays' known-miss shortcut (a ray is not traced / sent again into an instance it has already crossed
  *                               without a hit on the same straight segment; image-identical) -- 0: the reference's hop-by-hop rule, ray for ray
  *                "term_sink"    1: gvt_hip_trace_queue_sink applies shuffleRays' terminal rule inside the kernels -- 0: every moved ray goes through the shuffle
@@ -328,6 +333,10 @@ int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
  *                                                the faster (a hop that is a long traversal of its own is better served by per-hop rounds)
  *                "round_room_mb"                 memory a round's worst-case reservation may add before it falls back to exact growth
  *                "payload_overlap_kb"            Domain scheduler: payloads of at least this size move on the communicator's own stream beside the next chain
+ *                "inline_kb"                     Domain scheduler: a pair's payload of at most this many KiB per tick travels inside the announce message (one exchange
+ *                                                per tick; default 16; the same on every rank; 0: the two-step exchange of SendRays, counts then rays)
+ *                "comm_cus"                      Domain scheduler: compute units reserved for the communicator's own stream (CU mask; the persistent traversal grids
+ *                                                are sized for the rest); set before gvt_hip_comm_create; default 0
  *                "abi_lanes" / "abi_chunk"     gvt_hip_trace on a host RayVector: pipeline lanes (0: one shot), rays per chunk
  *   test hook    "inject_fail_tick"
  * Everything else -- the tuned constants of the kernels (refill / phase thresholds, grid sizes, drain sharing ...) and the variants that were

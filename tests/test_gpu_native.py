@@ -66,7 +66,7 @@ def run_native_ranks(scene, owner, world, mode, bsp, full_reduce=False, image=Fa
             comm = Comm.local(hub, rank)
             tr = NativeTracer(scene, mode, owner, comm, replicate=image)
             B = tr(bsp=bsp, full_reduce=full_reduce, image=image)
-            out[rank] = (B.framebuffer(True) if rank == 0 else None, dict(tr.stats))
+            out[rank] = (B.framebuffer(True) if rank == 0 else None, dict(tr.stats, reserved_cus=comm.reserved_cus))
             tr.close()
             comm.close()
             B = tr = None
@@ -178,6 +178,51 @@ def test_known_miss_shortcut_is_image_identical(hip, case):
         assert b[1] <= a[1] and b[2] <= a[2] and b[3] <= a[3]
     if case.startswith("soup"):  # the tiles' boxes overlap: the hand-back hops are there to be skipped
         assert got[(1, True)][1] < got[(0, True)][1] and got[(1, True)][2] < got[(0, True)][2]
+
+
+def _toy_crossing_scene():
+    sc = scenes.soup_domains_scene(30000, 4, 96, 54)
+    sc.camera.eye, sc.camera.focus = (3.0, 0.6, 0.4), (0.5, 0.5, 0.5)  # along -x: rays cross the x-tiled domains one after the other
+    sc.lights["position"] = (2.0, 2.5, 1.5)
+    return sc
+
+
+@pytest.mark.parametrize("world,bsp", [(2, False), (2, True), (4, False), (3, True)])
+def test_small_payloads_ride_inside_the_announce(hip, world, bsp):
+    """inline_kb: a pair's payload of a tick that fits the inline area travels INSIDE the announce message -- SendRays' count exchange and ray
+    exchange (DomainTracer.h:397-415, :433-463) in ONE transport group per tick.  Same image, same rays crossing the same boundaries as with the
+    two-step exchange (inline_kb = 0) and as the restated DomainTracer; with a 1 KiB area a frame mixes both routes."""
+    sc = _toy_crossing_scene()
+    owner = [i % world for i in range(sc.n_inst)]
+    ref, st = oracle_render_domain(sc, owner, world, 0)
+    res = {kb: run_native_ranks(sc, owner, world, NORMALS_FLAT, bsp, opts=(("inline_kb", kb),)) for kb in (0, 1, 1024)}
+    for kb, r in res.items():
+        assert np.array_equal(r[0][0][..., :3], ref[..., :3]), kb
+        assert sum(x[1]["rays_sent"] for x in r.values()) == st.rays_sent and st.rays_sent > 100
+        assert sum(x[1]["rays_closest"] for x in r.values()) == st.rays_closest
+    sent = lambda kb, k: sum(x[1][k] for x in res[kb].values())  # noqa: E731
+    assert sent(0, "rays_inline") == 0
+    assert 0 < sent(1, "rays_inline") < sent(1, "rays_sent")           # pairs with at most 12 rays inline, the others behind the announce
+    assert sent(1024, "rays_inline") == sent(1024, "rays_sent")        # everything fits
+    for x in res[1024].values():                                         # ONE group per tick (+ at most one for the composite)
+        assert x[1]["rounds"] <= x[1]["exchanges"] <= x[1]["rounds"] + 1
+    assert all(x[1]["exchanges"] > x[1]["rounds"] + 1 for x in res[0].values())
+    if not bsp:  # what has arrived with the announce is traced in the very next tick: never more ticks than the two-step exchange needs
+        assert max(x[1]["rounds"] for x in res[1024].values()) <= max(x[1]["rounds"] for x in res[0].values())
+
+
+def test_reserved_compute_units_for_the_communicators_stream(hip):
+    """comm_cus: the communicator's own stream gets k compute units to itself (CU-masked stream), the rank's compute stream the others, the
+    persistent grids are sized for those; with payload_overlap_kb = 0 and inline_kb = 0 every payload moves on that stream beside the next
+    chain.  Same image and counts as without the reservation."""
+    sc = config5(256, 4)
+    owner = [i % 2 for i in range(sc.n_inst)]
+    ref, st = oracle_render_domain(sc, owner, 2, 0)
+    for opts in ((("comm_cus", 16), ("payload_overlap_kb", 0), ("inline_kb", 0)), (("comm_cus", 8),)):
+        res = run_native_ranks(sc, owner, 2, NORMALS_FLAT, False, opts=opts)
+        assert np.abs(res[0][0][..., :3] - ref[..., :3]).max() <= 1e-5 and np.array_equal(res[0][0][..., 3], ref[..., 3])
+        assert sum(r[1]["rays_sent"] for r in res.values()) == st.rays_sent
+        assert all(r[1]["reserved_cus"] == dict(opts)["comm_cus"] for r in res.values())
 
 
 def test_composite_rectangles_equal_the_full_reduce(hip):
