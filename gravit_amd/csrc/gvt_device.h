@@ -399,10 +399,13 @@ __host__ __device__ inline bool km_has(const uint32_t km[3], int inst) {
 __host__ __device__ inline void km_add(uint32_t km[3], int inst) { // first free entry; a full list forgets its oldest entry (forgetting only costs a trace)
   if (inst < 0 || inst >= 65535 || km_has(km, inst)) return;
   const uint32_t v = (uint32_t)(inst + 1);
-  for (int k = 0; k < 3; k++) {
-    if (!(km[k] & 0xffffu)) { km[k] |= v; return; }
-    if (!(km[k] >> 16)) { km[k] |= v << 16; return; }
-  }
+  // (written out: a loop with early returns keeps its index dynamic and the three words in scratch memory)
+  if (!(km[0] & 0xffffu)) { km[0] |= v; return; }
+  if (!(km[0] >> 16)) { km[0] |= v << 16; return; }
+  if (!(km[1] & 0xffffu)) { km[1] |= v; return; }
+  if (!(km[1] >> 16)) { km[1] |= v << 16; return; }
+  if (!(km[2] & 0xffffu)) { km[2] |= v; return; }
+  if (!(km[2] >> 16)) { km[2] |= v << 16; return; }
   km[0] = (km[0] >> 16) | (km[1] << 16);
   km[1] = (km[1] >> 16) | (km[2] << 16);
   km[2] = (km[2] >> 16) | (v << 16);
