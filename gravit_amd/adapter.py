@@ -157,6 +157,28 @@ class HipMeshAdapter:
                                                      capi.ptr(cnt), C.byref(nw)), "gvt_hip_wide_visit_stats")
         return {"width": width, "nodes_per_ray": float(cnt.mean()), "p99": float(np.percentile(cnt, 99)), "max": int(cnt.max()), "wide_nodes": int(nw.value)}
 
+    def download_nodes(self):
+        """Diagnostic: the binary LBVH as built, (n_nodes, 16) float32 rows (gvt_hip.h gvt_hip_mesh_download_nodes; child refs bit-cast in columns 12, 13)."""
+        n = self.info()["n_nodes"]
+        out = np.zeros((n, 16), np.float32)
+        capi.check(self.lib.gvt_hip_mesh_download_nodes(self.h, capi.ptr(out), C.c_size_t(n)), "gvt_hip_mesh_download_nodes")
+        return out
+
+    def upload_nodes(self, nodes):
+        """Diagnostic: replace the binary nodes (visit-count diagnostics only) by a tree over the same leaves."""
+        nodes = np.ascontiguousarray(nodes, np.float32)
+        capi.check(self.lib.gvt_hip_mesh_upload_nodes(self.h, capi.ptr(nodes), C.c_size_t(len(nodes))), "gvt_hip_mesh_upload_nodes")
+
+    def marked_visit_stats(self, org, dirs, marks, tnear=1e-6):
+        """Diagnostic: per ray, the marked binary nodes (roots of the wide nodes of a collapse the caller chose) its closest-hit traversal visits."""
+        org = capi.f32(org, (-1, 3))
+        dirs = capi.f32(dirs, (-1, 3))
+        marks = np.ascontiguousarray(marks, np.uint8)
+        cnt = np.zeros(len(org), np.uint32)
+        capi.check(self.lib.gvt_hip_marked_visit_stats(self.h, capi.ptr(org), capi.ptr(dirs), C.c_size_t(len(org)), C.c_float(tnear), capi.ptr(marks), capi.ptr(cnt)),
+                   "gvt_hip_marked_visit_stats")
+        return cnt
+
     def visit_stats(self, org, dirs, tnear=1e-6):
         """Diagnostic: per-ray (inner-node visits, leaf visits, triangle tests) of the closest-hit traversal, plus the
         number of steps a 64-lane wave executes per batch (the slowest lane's inner + leaf steps)."""

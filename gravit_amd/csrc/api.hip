@@ -759,6 +759,45 @@ extern "C" int gvt_hip_wide_visit_stats(gvt_hip_mesh *M, const float *org, const
   return rc;
 }
 
+// diagnostics behind tools/wide_dp.py: the binary LBVH as the builder left it (64-byte nodes, gvt_device.h BvhNode), and the visit count of
+// an ARBITRARY collapse of it -- marks[k] = 1 where binary node k is the root of a wide node (the caller's choice, e.g. a cost-optimal
+// collapse computed on the host); counts[j] = marked nodes ray j's closest-hit traversal visits.
+extern "C" int gvt_hip_mesh_download_nodes(gvt_hip_mesh *M, void *out, size_t n_nodes) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!M || !out || n_nodes != M->nNodes) { set_error("mesh_download_nodes: null argument or n_nodes != %zu", M ? M->nNodes : (size_t)0); return GVT_HIP_ERR_INVALID; }
+  HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  if (n_nodes) HIPCHK(hipMemcpy(out, M->d_nodes, n_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost));
+  return 0;
+}
+// (diagnostic) replaces the binary nodes by a tree of the caller's over the SAME leaves (same node count, root = node 0): only the visit-count
+// diagnostics traverse the binary tree; the 4-wide layout the product kernels use is NOT rebuilt from it
+extern "C" int gvt_hip_mesh_upload_nodes(gvt_hip_mesh *M, const void *in, size_t n_nodes) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!M || !in || n_nodes != M->nNodes) { set_error("mesh_upload_nodes: null argument or n_nodes != %zu", M ? M->nNodes : (size_t)0); return GVT_HIP_ERR_INVALID; }
+  HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  if (n_nodes) HIPCHK(hipMemcpy(M->d_nodes, in, n_nodes * sizeof(BvhNode), hipMemcpyHostToDevice));
+  return 0;
+}
+extern "C" int gvt_hip_marked_visit_stats(gvt_hip_mesh *M, const float *org, const float *dir, size_t n, float tnear, const unsigned char *marks, uint32_t *counts) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!M || !marks || (n && (!org || !dir || !counts))) { set_error("marked_visit_stats: null argument"); return GVT_HIP_ERR_INVALID; }
+  if (!n || !M->nNodes) { for (size_t i = 0; i < n; i++) counts[i] = 0; return 0; }
+  Ctx &C = g_ctx;
+  unsigned char *d_marks = nullptr;
+  HIPCHK(hipMalloc((void **)&d_marks, M->nNodes));
+  int rc = hipMemcpy(d_marks, marks, M->nNodes, hipMemcpyHostToDevice) == hipSuccess ? 0 : GVT_HIP_ERR_DEVICE;
+  RayPlanes pl;
+  if (!rc) rc = stage_od(org, dir, n, pl);
+  unsigned *d_out = rc ? nullptr : (unsigned *)scratch_get(0, n * sizeof(unsigned));
+  if (!rc && !d_out) rc = GVT_HIP_ERR_DEVICE;
+  if (!rc) rc = launch_wide_visit_stats(M, pl, n, tnear, d_marks, d_out);
+  if (!rc && hipMemcpyAsync(counts, d_out, n * sizeof(unsigned), hipMemcpyDeviceToHost, C.stream) != hipSuccess) rc = GVT_HIP_ERR_DEVICE;
+  if (hipStreamSynchronize(C.stream) != hipSuccess && !rc) rc = GVT_HIP_ERR_DEVICE;
+  hipFree(d_marks);
+  if (rc == GVT_HIP_ERR_DEVICE && !*gvt_hip_last_error()) set_error("marked_visit_stats: HIP error");
+  return rc;
+}
+
 int debug_stamps(unsigned long long *out, int reset);
 // diagnostic: the launching context's counter words (work counters, parked-ray count [3], overflow flags [8]), after a synchronisation
 extern "C" int gvt_hip_counters_peek(uint32_t out[32]) {

@@ -314,6 +314,14 @@ int gvt_hip_visit_stats(gvt_hip_mesh *, const float *org, const float *dir, size
  * 4-wide layout the traversal uses) would make each ray visit; *n_wide_nodes (optional) = nodes of that collapse. */
 int gvt_hip_wide_visit_stats(gvt_hip_mesh *, const float *org, const float *dir, size_t n, float tnear, int width, uint32_t *counts /* n */,
                              uint64_t *n_wide_nodes);
+/* diagnostics behind tools/wide_dp.py (is a cost-optimal wide collapse of the tree worth building?): the binary LBVH as built -- n_nodes x 64 bytes,
+ * per node {c0.lo.x, c0.hi.x, c0.lo.y, c0.hi.y | c1.lo.x, c1.hi.x, c1.lo.y, c1.hi.y | c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z | child0, child1 (int32; < 0: leaf), -, -} --
+ * and the visits of a collapse the CALLER chose: marks[k] = 1 where binary node k is the root of a wide node, counts[j] = marked nodes ray j visits */
+int gvt_hip_mesh_download_nodes(gvt_hip_mesh *, void *out, size_t n_nodes);
+/* ... and back: a tree of the caller's over the SAME leaves (same node count, root = node 0) for the visit-count diagnostics only -- the 4-wide layout the
+ * product kernels traverse is not rebuilt from it */
+int gvt_hip_mesh_upload_nodes(gvt_hip_mesh *, const void *in, size_t n_nodes);
+int gvt_hip_marked_visit_stats(gvt_hip_mesh *, const float *org, const float *dir, size_t n, float tnear, const unsigned char *marks /* n_nodes */, uint32_t *counts /* n */);
 /* diagnostic, not on the hot path: include/gvt_math.h evaluated on the device, element-wise over n floats -- kind 0 gvt_sinf(x),
  * 1 gvt_cosf(x), 2 (float)gvt_acos(sqrt(1.0 - x)) -- so that a test can compare the device's bits with the host's for the
  * functions the bounce path (EmbreeMeshAdapter.cpp:289-318) is built on. */
