@@ -98,7 +98,8 @@ class HipMeshAdapter:
         i = capi.MeshInfo()
         capi.check(self.lib.gvt_hip_mesh_get_info(self.h, C.byref(i)), "gvt_hip_mesh_get_info")
         return {"n_tris": i.n_tris, "n_verts": i.n_verts, "n_nodes": i.n_nodes, "n_leaves": i.n_leaves, "bbox_lo": list(i.bbox_lo),
-                "bbox_hi": list(i.bbox_hi), "build_ms": i.build_ms, "max_leaf": i.max_leaf, "bytes_nodes": i.bytes_nodes, "bytes_tris": i.bytes_tris}
+                "bbox_hi": list(i.bbox_hi), "build_ms": i.build_ms, "max_leaf": i.max_leaf, "bytes_nodes": i.bytes_nodes, "bytes_tris": i.bytes_tris,
+                "packet": int(i.packet), "sah_inner": float(i.sah_inner)}
 
     def normals(self):
         out = np.zeros((len(self.verts), 3), np.float32)

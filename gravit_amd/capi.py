@@ -39,7 +39,7 @@ class GvtHipError(RuntimeError):
 class MeshInfo(C.Structure):
     _fields_ = [("n_tris", C.c_uint64), ("n_verts", C.c_uint64), ("n_nodes", C.c_uint64), ("n_leaves", C.c_uint64),
                 ("bbox_lo", C.c_float * 3), ("bbox_hi", C.c_float * 3), ("build_ms", C.c_float), ("max_leaf", C.c_uint32),
-                ("pad", C.c_uint32), ("bytes_nodes", C.c_uint64), ("bytes_tris", C.c_uint64)]
+                ("packet", C.c_uint32), ("bytes_nodes", C.c_uint64), ("bytes_tris", C.c_uint64), ("sah_inner", C.c_float), ("pad", C.c_float)]
 
 
 class CameraPod(C.Structure):

@@ -200,7 +200,7 @@ extern "C" int gvt_hip_stats_reset(void) {
 namespace {
 struct KnobDef { const char *name; int Knobs::*field; int lo, hi; bool shipped; };
 const KnobDef g_knobs[] = {
-  // shipped (18)
+  // shipped (21)
   { "skip_known", &Knobs::skip_known, 0, 1, true },           { "frame_timing", &Knobs::frame_timing, 0, 1, true },
   { "term_sink", &Knobs::term_sink, 0, 1, true },
   { "sort_rays", &Knobs::sort_rays, 0, 1, true },             { "leaf_max", &Knobs::leaf_max, 1, 4, true },
@@ -211,11 +211,13 @@ const KnobDef g_knobs[] = {
   { "long_min_rays", &Knobs::long_min_rays, 0, 1 << 30, true }, { "long_auto", &Knobs::long_auto, 0, 1, true },
   { "finish_auto", &Knobs::finish_auto, 0, 1, true },
   { "payload_overlap_kb", &Knobs::payload_overlap_kb, 0, 1 << 30, true },
+  { "packet", &Knobs::packet, 0, 2, true },                   { "packet_sah_max", &Knobs::packet_sah_max, 0, 1 << 30, true },
+  { "packet_min_rays", &Knobs::packet_min_rays, 0, 1 << 30, true },
   { "inline_kb", &Knobs::inline_kb, 0, 1024, true },          { "comm_cus", &Knobs::comm_cus, 0, 128, true },
   // experiments build only: the alternative was measured and lost, or the value is a tuned constant
   { "trav_kernel", &Knobs::trav_kernel, 0, 1, false },        { "wide4", &Knobs::wide4, 0, 1, false },
   { "coop_fetch", &Knobs::coop_fetch, 0, 1, false },          { "fused", &Knobs::fused, 0, 1, false },
-  { "packet", &Knobs::packet, 0, 1, false },                  { "quad", &Knobs::quad, 0, 1, false },
+  { "quad", &Knobs::quad, 0, 1, false },
   { "quad_inner_min", &Knobs::quad_inner_min, 1, 16, false }, { "quad_refill_min", &Knobs::quad_refill_min, 1, 16, false },
   { "blocks_per_cu_quad", &Knobs::blocks_per_cu_quad, 1, 8, false },
   { "blocks_per_cu", &Knobs::blocks_per_cu, 1, 8, false },    { "blocks_per_cu_closest", &Knobs::blocks_per_cu_closest, 0, 8, false },
@@ -334,7 +336,7 @@ extern "C" int gvt_hip_mesh_get_info(const gvt_hip_mesh *M, gvt_hip_mesh_info *o
   std::memset(o, 0, sizeof *o);
   o->n_tris = M->nT; o->n_verts = M->nV; o->n_nodes = M->nNodes; o->n_leaves = M->nLeaves;
   for (int k = 0; k < 3; k++) { o->bbox_lo[k] = M->lo[k]; o->bbox_hi[k] = M->hi[k]; }
-  o->build_ms = M->build_ms; o->max_leaf = M->leaf_max;
+  o->build_ms = M->build_ms; o->max_leaf = M->leaf_max; o->packet = M->packet_ok ? 1u : 0u; o->sah_inner = M->sah_inner;
   o->bytes_nodes = M->nNodes * sizeof(BvhNode) + M->nNodes4 * 64; o->bytes_tris = M->nT * 64;
   return 0;
 }

@@ -947,7 +947,15 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
   const bool single = one.mesh != nullptr;
   // several queues straight from the camera filter: the segments' lengths and beginnings from the count words (in the chain's first kernel)
   const unsigned *n_dev0 = (count_on_device && !single) ? C.d_counters + 22 : nullptr;
-  if ((rc = wave_trace_chain(W, N, passes, R->q_moved, d_from, P, R->lights.data(), single ? &one : nullptr, R->d_count_ptr, R->d_mask, (int)nI, defer_end && single, n_dev0))) return rc;
+  // several queues of camera rays in tile order, every traced mesh packet-friendly (or packets forced): the merged closest-hit launch walks packets too
+  // (launches of a few hundred thousand rays over small meshes lose with packets -- 4 K waves, each a long serial walk: bunny.conf 0.243 -> 0.254 ms, the
+  // 8-bunny grid 0.368 -> 0.407 -- where the hall cut into 8 slabs, 4.2 M camera rays, gains: 7.57 -> 7.25 ms; hence packet_min_rays)
+  bool multi_packets = !single && fresh_from_camera && C.camera_tile == 8 && (C.packet == 2 || (C.packet == 1 && N >= (size_t)C.packet_min_rays));
+  for (int k = 0; k < n_seg && multi_packets; k++) {
+    const gvt_hip_mesh *Mk = R->meshes[R->h_segs[k].inst];
+    multi_packets = Mk && Mk->d_nodes4 && (C.packet == 2 || Mk->packet_ok);
+  }
+  if ((rc = wave_trace_chain(W, N, passes, R->q_moved, d_from, P, R->lights.data(), single ? &one : nullptr, R->d_count_ptr, R->d_mask, (int)nI, defer_end && single, n_dev0, multi_packets))) return rc;
   // one instance in the whole scene and the terminal rule applied inside the kernels: nothing can have moved
   if (exact) {
     if ((rc = shuffle_exact(R->top, R->q_moved, single ? nullptr : d_from, single ? one.inst : -1, R->queues.data(), R->fb))) return rc;
@@ -1236,7 +1244,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
         bool any = false;
         for (size_t i = 0; i < nI; i++) any = any || (R->owned[i] && R->present[i]);
         if (!any) break;
-        if (failed(local_chain(R, nullptr, &S.chains, S.chains == 0, first_on_device && S.chains == 0)) || failed(round_report(R, false, &S.host_syncs))) { if (!multi) return local_err; break; }
+        if (failed(local_chain(R, nullptr, &S.chains, S.chains == 0 && tick == 0, first_on_device && S.chains == 0)) || failed(round_report(R, false, &S.host_syncs))) { if (!multi) return local_err; break; }
       }
       if (R->world == 1) {
         if (image_split) { // back among the ranks: one exchange, so that rank 0 learns every rank's deposit rectangle
@@ -1250,7 +1258,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
       bool have_local = false;
       for (size_t i = 0; i < nI; i++) have_local = have_local || (R->owned[i] && R->present[i]);
       if (!have_local || !payload_cross) failed(unpack_pending()); // nothing to overlap a transfer with (or it is here already: inline / compute stream): take what arrived first
-      if (!local_err) failed(local_chain(R, &incoming, &S.chains, S.chains == 0, first_on_device && S.chains == 0));
+      if (!local_err) failed(local_chain(R, &incoming, &S.chains, S.chains == 0 && tick == 0, first_on_device && S.chains == 0));
       if (!local_err) failed(unpack_pending());
     }
     // (3)-(5) sizes + announce exchange (carrying this rank's error word), one bounded synchronisation

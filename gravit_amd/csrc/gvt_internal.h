@@ -39,8 +39,11 @@ struct Knobs {
   int long_min_rays = 65536; // ... only in launches of at least this many rays (small launches have no tail to speak of)
   int fused = 0;         // scheduler rounds: closest hit + shade + first-light shadow rays in one kernel (k_fused) instead of three launches.
                          // Measured 2.4x SLOWER than the three launches (EXPERIMENTS.md): shading inside the persistent kernel is latency-exposed
-  int packet = 0;        // scheduler rounds: camera rays in tile order (and their direct-mapped shadow rays) traversed a packet of 64 per wave (k_packet).
-                         // Off: 8 % faster on a surface mesh (bun_zipper), 2.5x-20x SLOWER on the random soups (EXPERIMENTS.md)
+  int packet = 1;        // scheduler rounds: camera rays in tile order (and their direct-mapped shadow rays) traversed a packet of 64 per wave (k_packet): 0 never,
+                         // 1 on meshes the builder found packet-friendly (gvt_hip_mesh::packet_ok), 2 always.  4-10 % faster on surfaces (bun_zipper, the hall),
+                         // 2.5x-20x SLOWER on the random soups (EXPERIMENTS.md): hence the per-mesh choice
+  int packet_min_rays = 524288; // ... and only in launches of at least this many rays (bound): a small launch is a few thousand packets, each a long serial walk
+  int packet_sah_max = 128; // meshes created afterwards: packet-friendly when sum(area(inner node)) / area(root) is at most this (lbvh.hip k_sah_sum)
   int round_room_mb = 16384; // scheduler rounds: memory the worst-case reservation of the destination queues may add (MiB); beyond it the round shuffles with exact growth
   int finish_rays = 32768; // scheduler rounds holding at most this many rays are run by ONE kernel that follows every ray to its end on this rank (k_finish):
                          // no per-hop rounds for the few rays that move between the rank's own domains (0: off)
@@ -159,6 +162,8 @@ struct gvt_hip_mesh {
   size_t nLeaves = 0;
   float lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
   float build_ms = 0.f;
+  float sah_inner = 0.f;      // sum over the inner nodes of area(node) / area(root)
+  bool packet_ok = false;     // coherent lists over this mesh are traversed a packet per wave (k_packet)
 };
 
 struct gvt_hip_queue {
@@ -291,7 +296,8 @@ struct WaveSingle { // the launch has ONE segment: its queue planes and instance
 // n_dev0_multi (merged kernels): device word holding the length of the merged list where only the device knows it; n_total is then a bound
 int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
                      const gvt_hip_light *lights_host, const WaveSingle *single, unsigned *const *d_count_ptr, const unsigned char *d_mask, int n_inst,
-                     bool defer_end = false, const unsigned *n_dev0_multi = nullptr);
+                     bool defer_end = false, const unsigned *n_dev0_multi = nullptr, bool multi_packets = false);
+// multi_packets (merged kernels, first pass): the queues hold camera rays in tile order over packet-friendly meshes -- closest hits through k_packet_multi
 int finish_round(const WaveSet &W, size_t n_total, const TraceParams &P, const gvt_hip_light *lights_host, const void *d_qdesc, const int *d_owner, int rank,
                  unsigned *d_queue_overflow, unsigned *const *d_count_ptr, const unsigned char *d_mask);
 int convert_aos_to_planes(const gvt_hip_ray *d_src, size_t n, RayPlanes dst, size_t dst_off);

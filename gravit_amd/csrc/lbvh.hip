@@ -506,6 +506,22 @@ static int build_box_levels(const float4 *lo0, const float4 *hi0, unsigned n, Bu
   return 0;
 }
 
+// The per-mesh statistic behind the packet choice: sum over the INNER nodes of area(node) / area(root), i.e. the inner nodes a random line through
+// the mesh's box pierces, in 16.16 fixed point (integer adds: the same sum whatever the order).  Every node adds the boxes of its inner children.
+__global__ __launch_bounds__(256) void k_sah_sum(const BvhNode *__restrict__ nodes, unsigned n, float inv_root_area, unsigned long long *acc) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  float s = 0.f;
+  if (i < n) {
+    const BvhNode nd = nodes[i];
+    Slot4 c;
+    slot_from(nd, 0, c); if (c.ref >= 0) s += slot_area(c);
+    slot_from(nd, 1, c); if (c.ref >= 0) s += slot_area(c);
+  }
+  unsigned long long v = (unsigned long long)(fminf(s * inv_root_area, 4.0f) * 65536.0f);
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  if (lane_id() == 0 && v) atomicAdd(acc, v);
+}
+
 int build_lbvh(gvt_hip_mesh *M) {
   Ctx &C = gctx();
   hipStream_t st = C.stream;
@@ -540,6 +556,7 @@ int build_lbvh(gvt_hip_mesh *M) {
   const int n_inner = (int)n - 1;
   const unsigned n32 = (n + 31u) / 32u;
   float pad = 0.f;
+  unsigned long long *sah_acc = nullptr, sah_host = 0ull;
 
 #define OK(x) do { if ((rc = (x)) != 0) goto done; } while (0)
 #define HOK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(_e)); rc = GVT_HIP_ERR_DEVICE; goto done; } } while (0)
@@ -649,10 +666,25 @@ int build_lbvh(gvt_hip_mesh *M) {
   }
   if (gctx().wide4 || want_q) OK(build_nodes4(M, &A)); // the traversal layout; counted in the build time
   mark("4-wide collapse");
+  { // packet-friendly?  (a surface: a few dozen inner nodes on a random line, whatever the triangle count; a soup: N^(1/3) of them)
+    const float ex = M->hi[0] - M->lo[0], ey = M->hi[1] - M->lo[1], ez = M->hi[2] - M->lo[2];
+    const float ra = ex * ey + ey * ez + ez * ex;
+    M->sah_inner = 0.f; M->packet_ok = false;
+    if (ra > 0.f && M->nNodes > 1) {
+      OK(A.take(&sah_acc, 1));
+      HOK(hipMemsetAsync(sah_acc, 0, sizeof(unsigned long long), st));
+      k_sah_sum<<<(unsigned)((M->nNodes + 255) / 256), 256, 0, st>>>(M->d_nodes, (unsigned)M->nNodes, 1.f / ra, sah_acc);
+      HOK(hipMemcpyAsync(&sah_host, sah_acc, sizeof sah_host, hipMemcpyDeviceToHost, st));
+    }
+  }
   HOK(hipEventRecord(e1, st));
   HOK(hipEventSynchronize(e1));
   HOK(hipEventElapsedTime(&M->build_ms, e0, e1));
   gctx().stats.ms_build += M->build_ms;
+  if (M->nNodes > 1) {
+    M->sah_inner = 1.f + (float)((double)sah_host / 65536.0);
+    M->packet_ok = M->sah_inner <= (float)C.packet_sah_max;
+  }
 done:
   hipStreamSynchronize(st);
   if (A.cap > ((size_t)1 << 30)) scratch_release(21); // a large scene's temporaries are not kept

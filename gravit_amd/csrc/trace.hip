@@ -60,9 +60,7 @@ struct Trav {
 
 #include "trace_wave.inc" // the wave-per-ray traversal
 
-#ifdef GVT_EXPERIMENTS
-#include "experiments/packet_kernel.inc" // k_packet: a wave walks the BVH for a packet of 64 coherent rays
-#endif
+#include "packet_kernel.inc" // k_packet: a wave walks the BVH for a packet of 64 coherent rays (meshes the builder found packet-friendly)
 
 #include "shade.inc" // Shade(), lights, the bounce direction, k_shade
 
@@ -495,7 +493,7 @@ __global__ void k_wave_end(unsigned *c, unsigned *const *__restrict__ count_ptr,
 
 int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
                      const gvt_hip_light *lights_host, const WaveSingle *single, unsigned *const *d_count_ptr, const unsigned char *d_mask, int n_inst,
-                     bool defer_end, const unsigned *n_dev0_multi) {
+                     bool defer_end, const unsigned *n_dev0_multi, bool multi_packets) {
   Ctx &C = gctx();
   if (!n_total) return 0;
   hipStream_t st = C.stream;
@@ -550,9 +548,13 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       LongQ LQ{};
       if (use_long && have4) { LQ.recs = d_long; LQ.count = c + 3; long_limits(LQ, n); }
       const bool small1 = small && have4;
-#ifdef GVT_EXPERIMENTS
-      // a coherent list (camera rays in 8x8 tiles, straight from the filter): a wave walks the tree for 64 rays at once (k_packet)
-      const bool pkt = C.packet && single->coherent && pass == 0 && have4 && !small1;
+      // a coherent list (camera rays in 8x8 tiles, straight from the filter) over a mesh the builder found packet-friendly (gvt_hip_mesh::packet_ok;
+      // knob packet: 0 never, 1 the mesh's own choice, 2 always): a wave walks the tree ONCE for 64 rays (k_packet) -- the reference chooses its packet
+      // width per build as well (EmbreeMeshAdapter.cpp:50-74)
+      const bool pkt = (C.packet == 2 || (C.packet == 1 && M->packet_ok && n >= (size_t)C.packet_min_rays)) && single->coherent && pass == 0 && have4 && !small1;
+      // ... the CLOSEST hit, that is.  Shadow rays as packets lost on both surfaces they were measured on (bun_zipper any hit 0.162 -> 0.189 ms, the hall
+      // 1.23 -> 1.33: an any-hit packet goes on until its LAST ray is occluded or through): under the per-mesh choice they stay a lane per ray; 2 forces both
+      const bool pkt_any = pkt && C.packet == 2;
       if (pkt) {
         ProfScope ps(KC_CLOSEST);
         LongQ LP{ d_long, c + 3, nullptr, 0u, 0, 0 };
@@ -560,9 +562,6 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
                                                      TermSink{}, LP, nullptr, nullptr, nullptr, c + 9);
         k_long_closest<true><<<C.n_cu * 3, 256, 0, st>>>(single->planes, d_long, c + 3, single->minv, TS, GVT_RAY_EPSILON, d_hits, c + 4); // packets that bailed out
       } else
-#else
-      const bool pkt = false;
-#endif
       if (small1) {
         ProfScope ps(KC_CLOSEST);
         k_long_seed<<<blocks_for(n), 256, 0, st>>>(d_long, c + 3, idx, (unsigned)n, n_dev);
@@ -591,7 +590,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       A.n_lights = nL; A.seed = P.seed; A.zero_word = c + 0;
       A.sink = P.sink; A.sink.from = single->inst; A.update_in_place = 0;
       A.n_dev = n_dev; A.W = WaveSet{}; A.out_from = nullptr; A.shadow_inst = nullptr; A.shadow_stride = 0;
-      if (pkt) { A.shadow_inst = d_shadow_inst; A.shadow_stride = (unsigned)n; } // shadow rays in the primaries' order: packets again
+      if (pkt_any) { A.shadow_inst = d_shadow_inst; A.shadow_stride = (unsigned)n; } // shadow rays in the primaries' order: packets again
       MeshView mv;
       mv.slots = M->d_tri; mv.slot_of = M->d_slot_of; mv.verts = M->d_verts; mv.tris = M->d_tris; mv.normals = M->d_normals; mv.vcolors = M->d_vcolors;
       mv.materials = M->d_materials; mv.n_mat = (unsigned)M->nMat; mv.face_mat = M->d_face_mat; mv.mat = M->mesh_mat;
@@ -603,8 +602,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
         ProfScope ps(KC_ANY);
         TermSink sk = P.sink;
         sk.from = single->inst;
-#ifdef GVT_EXPERIMENTS
-        if (pkt) {
+        if (pkt_any) {
           unsigned *d_retry = (unsigned *)scratch_get(18, sizeof(unsigned) * shadow_cap);
           if (!d_retry) return GVT_HIP_ERR_DEVICE;
           k_packet<true><<<blocks_for(shadow_cap), 256, 0, st>>>(shadow, (unsigned)shadow_cap, nullptr, single->minv, TS, GVT_RAY_EPSILON, nullptr, d_shadow_inst, outp, out->d_count,
@@ -612,7 +610,9 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
           // rays of packets that bailed out: one lane per ray (an empty list costs a few microseconds)
           launch_trace<true, true, 1>(have4, trav_grid2(4096), st, shadow, d_retry, 0u, single->minv, TS, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
                                       c + 0, C.d_spill, C.refill_min, C.inner_min, c + 6, C.share, (unsigned)C.share_min_rays, sk, LongQ{});
-        } else if (quad_usable(M) && !small1)
+        } else
+#ifdef GVT_EXPERIMENTS
+        if (quad_usable(M) && !small1)
           k_traceq<true, true, 1><<<quad_grid(shadow_cap), 256, 0, st>>>(shadow, nullptr, 0u, single->minv, TravQ{ M->d_nodes4q, M->d_triq }, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
                                                                        c + 0, C.d_spill, C.quad_refill_min, C.quad_inner_min, c + 1, sk, LongQ{});
         else
@@ -656,6 +656,14 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     LongQ LQ{};
     if (use_long) { LQ.recs = d_long; LQ.count = c + 3; long_limits(LQ, n); }
     MultiSrc MS{ W, nullptr, nullptr, nullptr };
+    // the round's queues hold camera rays in tile order, over packet-friendly meshes only: the closest hits a packet of 64 rays per wave
+    const bool pktm = multi_packets && pass == 0 && !small && idx == nullptr;
+    if (pktm) {
+      ProfScope ps(KC_CLOSEST);
+      LongQ LP{ d_long, c + 3, nullptr, 0u, 0, 0 };
+      k_packet_multi<<<blocks_for(n), 256, 0, st>>>(W, (unsigned)n, n_dev, GVT_RAY_EPSILON, d_hits, LP, c + 9);
+      k_long_closest<true, true><<<C.n_cu * 3, 256, 0, st>>>(none, d_long, c + 3, id, T, GVT_RAY_EPSILON, d_hits, c + 4, W); // packets that bailed out
+    } else
     if (small) {
       ProfScope ps(KC_CLOSEST);
       k_long_seed<<<blocks_for(n), 256, 0, st>>>(d_long, c + 3, idx, (unsigned)n, n_dev);
@@ -674,7 +682,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
                                                                                       c + 0, C.d_spill, C.refill_min, C.inner_min, n_dev, C.share, (unsigned)C.share_min_rays,
                                                                                       TermSink{}, LQ, MS);
     }
-    if (use_long && !small) {
+    if (use_long && !small && !pktm) {
       ProfScope ps(KC_LONG);
       k_long_closest<true, true><<<C.n_cu * 3, 256, 0, st>>>(none, d_long, c + 3, id, T, GVT_RAY_EPSILON, d_hits, c + 4, W, LQ.stk);
     }

@@ -116,8 +116,13 @@ typedef struct gvt_hip_mesh_info {
   uint64_t n_tris, n_verts, n_nodes, n_leaves;
   float bbox_lo[3], bbox_hi[3];
   float build_ms; /* device time of the LBVH build */
-  uint32_t max_leaf, pad;
+  uint32_t max_leaf;
+  uint32_t packet;   /* 1: the builder found the mesh packet-friendly -- coherent lists (camera rays in tile order and their shadow rays) are traversed a
+                        packet of 64 per wave (k_packet); 0: one lane per ray.  The reference picks its packet width per build too (EmbreeMeshAdapter.cpp:50-74) */
   uint64_t bytes_nodes, bytes_tris;
+  float sah_inner;   /* the statistic behind `packet`: sum over the inner nodes of area(node) / area(root) = inner nodes a random line through the mesh's
+                        box pierces.  A surface stays at a few dozen whatever its triangle count, a volume-filling soup grows with N^(1/3) */
+  float pad;
 } gvt_hip_mesh_info;
 int gvt_hip_mesh_get_info(const gvt_hip_mesh *, gvt_hip_mesh_info *);
 /* vertex normals in use (device -> host copy), nV*3 floats */
@@ -327,13 +332,16 @@ int gvt_hip_marked_visit_stats(gvt_hip_mesh *, const float *org, const float *di
  * functions the bounce path (EmbreeMeshAdapter.cpp:289-318) is built on. */
 int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
 /* Knobs of the library (gvt_internal.h `struct Knobs` lists them with their defaults; ("defaults", 0) restores all of them).  Results never
- * depend on them -- except "skip_known", which switches between two shuffle rules with the same image (below).  The shipped surface, 18 knobs:
+ * depend on them -- except "skip_known", which switches between two shuffle rules with the same image (below).  The shipped surface, 21 knobs:
  *   behaviour    "skip_known"   1: shuffleRays' known-miss shortcut (a ray is not traced / sent again into an instance it has already crossed
  *                               without a hit on the same straight segment; image-identical) -- 0: the reference's hop-by-hop rule, ray for ray
  *                "term_sink"    1: gvt_hip_trace_queue_sink applies shuffleRays' terminal rule inside the kernels -- 0: every moved ray goes through the shuffle
  *                "sort_rays"    1: Morton-sort a list before traversal (pays on incoherent lists; off)
  *                "frame_timing" 1: fill gvt_hip_frame_stats' per-phase milliseconds (five more event calls per exchange)
+ *                "packet"       closest hits of coherent lists (camera rays in tile order) a packet of 64 rays per wave: 0 never, 1 (default) on meshes the builder
+ *                               found packet-friendly (gvt_hip_mesh_info::packet), in launches of at least "packet_min_rays" rays, 2 always (and shadow rays too)
  *   build time   "leaf_max"     triangles per leaf of meshes created afterwards (1..4, default 2)
+ *                "packet_sah_max"  meshes created afterwards are packet-friendly when gvt_hip_mesh_info::sah_inner is at most this (default 128)
  *   budgets      "long_steps" / "long_min_rays" / "long_auto"  closest hit: node steps after which a ray is parked for a whole wave (0: never), launches it
  *                               applies to, and whether gvt_hip_tracer_frame raises it from frame to frame on scenes that park more than 0.3 % of their rays
  *                "small_rays" / "finish_rays"    rounds of at most so many rays: a wave per ray / the whole round in one launch (k_finish)

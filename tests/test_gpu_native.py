@@ -438,7 +438,7 @@ def test_top_level_bvh_with_1056_instances(hip):
 
 @pytest.mark.parametrize("opts", [dict(small_rays=0), dict(small_rays=1 << 30), dict(term_sink=0), dict(leaf_max=4, small_rays=0), dict(finish_rays=0), dict(round_room_mb=0),
                                   dict(round_room_mb=0, finish_rays=0, small_rays=0), dict(finish_rays=1 << 30), dict(finish_rays=1 << 30, leaf_max=4), dict(skip_known=0, finish_rays=0),
-                                  dict(sort_rays=1)])
+                                  dict(sort_rays=1), dict(packet=0), dict(packet=2), dict(packet=2, long_steps=0), dict(packet=2, term_sink=0), dict(packet=1, packet_min_rays=0)])
 def test_round_results_do_not_depend_on_knobs(hip, opts):
     """The round chain under every knob of the shipped library -- a wave per ray for small rounds or never, k_finish or rounds, exact
     growth, no terminal sink, the reference's hop-by-hop shuffle -- returns the oracle's image on a multi-domain depth-2 frame, on config 4
@@ -460,6 +460,32 @@ def test_round_results_do_not_depend_on_knobs(hip, opts):
         finally:
             hip.set_option("defaults", 0)
             orc.set_skip_known_misses(True)
+
+
+def test_packet_traversal_is_chosen_per_mesh(hip):
+    """The builder decides per mesh whether coherent lists are traversed a packet of 64 rays per wave (k_packet) or a lane per ray (k_trace), as the
+    reference picks its packet width per build (EmbreeMeshAdapter.cpp:50-74): from sum(area(inner node)) / area(root) -- a surface stays at a few
+    dozen, a volume-filling soup grows with N^(1/3).  Either way, forced on, forced off: the same bits (one-instance frames: the single-mesh
+    kernels; camera rays in tile order and their direct-mapped shadow rays)."""
+    from gravit_amd.adapter import HipMeshAdapter
+
+    bunny, soup = scenes.bunny_scene(320, 320), scenes.soup_scene(300_000, 320, 180)
+    ib, isoup = HipMeshAdapter(bunny.meshes[0]).info(), HipMeshAdapter(soup.meshes[0]).info()
+    assert ib["packet"] == 1 and 1.0 < ib["sah_inner"] < 128.0
+    assert isoup["packet"] == 0 and isoup["sah_inner"] > 128.0
+    for sc, mode in ((bunny, NORMALS_SMOOTH), (soup, NORMALS_FLAT)):
+        ref, st = oracle_render(sc, mode, nthreads=8)
+        for pk in (1, 0, 2):
+            try:
+                hip.set_option("packet", pk)
+                hip.set_option("packet_min_rays", 0)  # (the test's film is far below the launch size packets are kept for)
+                tr = NativeTracer(sc, mode)
+                fb = tr().framebuffer(True)
+                assert np.array_equal(fb[..., :3], ref[..., :3]) and np.array_equal(fb[..., 3], ref[..., 3]), (pk,)
+                assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any
+                tr.close()
+            finally:
+                hip.set_option("defaults", 0)
 
 
 def test_degenerate_scenes_through_the_native_tracer(hip):

@@ -1,6 +1,9 @@
 """Frame time and ray rate of the BASELINE.json configurations on ONE GPU through the native tracer (rounds; gvt_hip_tracer) and, for
 comparison, through the reference-order loop (one adapter call at a time, gvt_hip_image_frame).
-   usage (GPU box): python tools/bench_configs.py"""
+   usage (GPU box): python tools/bench_configs.py [only=1,2,5] [roofline=1] [opt=value ...]
+roofline=1 adds, per configuration, the per-class kernel times of the round chain (HIP events on the launch stream, gvt_hip_profile(2)), the dominant
+traversal class, its algorithmic bytes per ray by SURVEY 8(d)'s formula at the configuration's triangle count (the largest mesh of the scene) and the
+fraction of the 8 TB/s HBM roofline that launch class reaches; plus the builder's per-mesh packet statistic."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gravit_amd import capi, scenes
@@ -8,11 +11,19 @@ from gravit_amd.layouts import NORMALS_SMOOTH, NORMALS_FLAT
 from gravit_amd.scheduler import ImageTracer, NativeTracer
 
 capi.init(0)
-ONLY = None
-for a in sys.argv[1:]:  # opt=value: library options; only=1,2,4: a subset of the configurations
+import math
+ONLY, ROOF, FRAMES, NOREF = None, False, 10, False
+for a in sys.argv[1:]:  # opt=value: library options; only=1,2,4: a subset of the configurations; frames=N timed frames; noref=1: skip the reference-order loop
     k, v = a.split("=")
     if k == "only": ONLY = set(v.split(","))
+    elif k == "roofline": ROOF = bool(int(v))
+    elif k == "frames": FRAMES = int(v)
+    elif k == "noref": NOREF = bool(int(v))
     else: capi.set_option(k, int(v))
+
+
+def b_ray(n_tris):
+    return 32 + 16 + 32 * max(1, math.ceil(math.log2(max(n_tris, 8) / 4.0))) + 4 * 48
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
@@ -34,11 +45,14 @@ for name, mk, mode in cfgs:
         continue
     sc = mk()
     tris = sum(len(m.tris) for m in sc.meshes)
-    for label, tr in (("rounds", NativeTracer(sc, mode)), ("reference order", ImageTracer(sc, mode))):
+    for label, mk_tr in (("rounds", lambda: NativeTracer(sc, mode)), ("reference order", lambda: ImageTracer(sc, mode))):
+        if NOREF and label != "rounds":
+            continue
+        tr = mk_tr()
         for _ in range(10):  # (warm-up; the tracer's per-scene choices -- parking threshold, k_finish or per-hop rounds -- settle within eight frames)
             tr()
         capi.synchronize(); capi.stats_reset()
-        n = 10
+        n = FRAMES
         t = time.perf_counter()
         for _ in range(n):
             tr()
@@ -48,5 +62,21 @@ for name, mk, mode in cfgs:
         extra = ("%d launch chains, %d host syncs" % (tr.stats["chains"], tr.stats["host_syncs"])) if label == "rounds" else ("%d adapter calls" % tr.adapter_calls)
         print("%-70s %-16s %8.3f ms/frame %8.1f Mrays/s  (%d rays/frame, %s, %d tris, %d instances)" % (
             name, label, dt * 1e3, rays / dt / 1e6, rays, extra, tris, sc.n_inst), flush=True)
+        if ROOF and label == "rounds":
+            capi.stats_reset(); capi.profile(2)
+            for _ in range(n):
+                tr()
+            st = capi.stats(); capi.profile(False)
+            dom = "closest" if st["ms_closest"] >= st["ms_any"] else "any"
+            T = max(len(m.tris) for m in sc.meshes)
+            B = b_ray(T)
+            rays_dom = st["rays_%s" % dom]
+            ms_dom = st["ms_%s" % dom]
+            ach = rays_dom * B / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
+            infos = [a.info() for a in tr.backend.adapter_cache.values()]
+            print("    kernel classes per frame: closest %.3f ms (%d launches), long %.3f ms, any %.3f ms (%d launches); dominant: %s-hit, %d rays per frame through it, "
+                  "%d algorithmic B/ray at T = %d -> %.0f GB/s = %.3f of the 8 TB/s roofline; packet statistic per mesh: %s" % (
+                      st["ms_closest"] / n, st["launches_closest"] // n, st["ms_long"] / n, st["ms_any"] / n, st["launches_any"] // n, dom, rays_dom // n, B, T, ach, ach / 8000.0,
+                      ", ".join(sorted(set("sah %.0f -> %s" % (i["sah_inner"], "packets" if i["packet"] else "lanes") for i in infos)))), flush=True)
         if hasattr(tr, "close"):
             tr.close()
