@@ -165,6 +165,15 @@ class HipMeshAdapter:
         capi.check(self.lib.gvt_hip_mesh_download_nodes(self.h, capi.ptr(out), C.c_size_t(n)), "gvt_hip_mesh_download_nodes")
         return out
 
+    def download_wide(self):
+        """Measurement: the traversal layout -- (n4, 16) uint32 compressed 4-wide nodes and (n_tris, 16) float32 triangle slots in leaf order."""
+        i = self.info()
+        n4 = i["bytes_nodes"] // 64 - i["n_nodes"]
+        nodes4 = np.zeros((n4, 16), np.uint32)
+        slots = np.zeros((i["n_tris"], 16), np.float32)
+        capi.check(self.lib.gvt_hip_mesh_download_wide(self.h, capi.ptr(nodes4), C.c_size_t(n4), capi.ptr(slots), C.c_size_t(i["n_tris"])), "gvt_hip_mesh_download_wide")
+        return nodes4, slots
+
     def upload_nodes(self, nodes):
         """Diagnostic: replace the binary nodes (visit-count diagnostics only) by a tree over the same leaves."""
         nodes = np.ascontiguousarray(nodes, np.float32)

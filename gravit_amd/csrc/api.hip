@@ -771,6 +771,19 @@ extern "C" int gvt_hip_mesh_download_nodes(gvt_hip_mesh *M, void *out, size_t n_
   if (n_nodes) HIPCHK(hipMemcpy(out, M->d_nodes, n_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost));
   return 0;
 }
+// (measurement) the traversal layout itself -- the compressed 4-wide nodes (gvt_device.h: 64 bytes each) and the triangle slots in leaf order (64 bytes
+// each) -- for bench.py's SIMD CPU baseline (oracle/simd_baseline.c), which walks the very tree the kernels walk, on the host's cores
+extern "C" int gvt_hip_mesh_download_wide(gvt_hip_mesh *M, void *nodes4, size_t n_nodes4, void *slots, size_t n_slots) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!M || !nodes4 || !slots || n_nodes4 != M->nNodes4 || n_slots != M->nT) {
+    set_error("mesh_download_wide: null argument, or (%zu nodes, %zu slots) asked of (%zu, %zu)", n_nodes4, n_slots, M ? M->nNodes4 : (size_t)0, M ? M->nT : (size_t)0);
+    return GVT_HIP_ERR_INVALID;
+  }
+  HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  if (n_nodes4) HIPCHK(hipMemcpy(nodes4, M->d_nodes4, n_nodes4 * 64, hipMemcpyDeviceToHost));
+  if (n_slots) HIPCHK(hipMemcpy(slots, M->d_tri, n_slots * 64, hipMemcpyDeviceToHost));
+  return 0;
+}
 // (diagnostic) replaces the binary nodes by a tree of the caller's over the SAME leaves (same node count, root = node 0): only the visit-count
 // diagnostics traverse the binary tree; the 4-wide layout the product kernels use is NOT rebuilt from it
 extern "C" int gvt_hip_mesh_upload_nodes(gvt_hip_mesh *M, const void *in, size_t n_nodes) {

@@ -319,6 +319,11 @@ int gvt_hip_visit_stats(gvt_hip_mesh *, const float *org, const float *dir, size
  * 4-wide layout the traversal uses) would make each ray visit; *n_wide_nodes (optional) = nodes of that collapse. */
 int gvt_hip_wide_visit_stats(gvt_hip_mesh *, const float *org, const float *dir, size_t n, float tnear, int width, uint32_t *counts /* n */,
                              uint64_t *n_wide_nodes);
+/* measurement: the traversal layout as the kernels walk it -- (bytes_nodes / 64 - n_nodes) compressed 4-wide nodes of 64 bytes {origin.xyz, step.x | qlo.x[4], qhi.x[4],
+ * qlo.y[4], qhi.y[4] | qlo.z[4], qhi.z[4], ref0, ref1 | ref2, ref3, step.y, step.z} (child box plane = origin + q * step; ref >= 0: node, < 0: leaf, ~ref =
+ * first slot << 3 | triangles) and n_tris triangle slots of 64 bytes {v0, primID | e1 = v0 - v1, . | e2 = v2 - v0, . | .} in leaf order -- for the SIMD CPU
+ * baseline of bench.py (oracle/simd_baseline.c) */
+int gvt_hip_mesh_download_wide(gvt_hip_mesh *, void *nodes4, size_t n_nodes4, void *slots, size_t n_slots);
 /* diagnostics behind tools/wide_dp.py (is a cost-optimal wide collapse of the tree worth building?): the binary LBVH as built -- n_nodes x 64 bytes,
  * per node {c0.lo.x, c0.hi.x, c0.lo.y, c0.hi.y | c1.lo.x, c1.hi.x, c1.lo.y, c1.hi.y | c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z | child0, child1 (int32; < 0: leaf), -, -} --
  * and the visits of a collapse the CALLER chose: marks[k] = 1 where binary node k is the root of a wide node, counts[j] = marked nodes ray j visits */

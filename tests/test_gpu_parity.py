@@ -805,3 +805,27 @@ def test_trace_without_write_back_leaves_the_ray_list_alone(hip):
     assert rays_equal_bits(b, rays) and not rays_equal_bits(a, rays)  # the 68 defined bytes of every ray (numpy leaves the padding of a copy undefined)
     assert len(moved_a) == len(moved_b) and len(moved_a) > 0
     assert rays_equal_bits(sort_rays(moved_a), sort_rays(moved_b))
+
+
+def test_simd_cpu_baseline_equals_the_oracle_on_the_downloaded_tree(hip):
+    """bench.py times a SIMD CPU baseline beside the GPU number (oracle/simd_baseline.c: one ray against four quantised boxes per step over the
+    GPU-built 4-wide tree).  Its answers must be the oracle's, bit for bit, before its time means anything: closest hits and occlusion flags on
+    the bunny and on a soup, rays through the box, along the axes and from inside."""
+    from oracle import simd
+
+    from oracle import orc
+
+    for name, mesh in (("bunny", scenes.bunny_scene().meshes[0]), ("soup", scenes.soup_scene(200_000, 64, 64).meshes[0])):
+        om = orc.Mesh(mesh.verts, mesh.tris)
+        ad = HipMeshAdapter(mesh)
+        nodes4, slots = ad.download_wide()
+        assert nodes4.shape[1] == 16 and slots.shape == (len(mesh.tris), 16) and len(nodes4) > 0
+        T = simd.Tree(nodes4, slots)
+        lo, hi = om.bbox()
+        org, d = seeded_rays_at(lo, hi, 30_011, 5)
+        ref = om.intersect(org, d)
+        t, prim, u, v = T.intersect(org, d, nthreads=4)
+        assert np.array_equal(ref["prim"], prim) and np.array_equal(bits(ref["t"]), bits(t)) and np.array_equal(bits(ref["u"]), bits(u)) and np.array_equal(bits(ref["v"]), bits(v)), name
+        assert (prim >= 0).sum() > 1000
+        assert np.array_equal(om.occluded(org, d), T.occluded(org, d, nthreads=4)), name
+        assert_hits_equal(ad.intersect(org, d), ref)

@@ -30,7 +30,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(lib, s), s
     # struct sizes the ABI promises
-    assert C.sizeof(capi.MeshInfo) == 88 and C.sizeof(capi.Stats) == 16 * 8
+    assert C.sizeof(capi.MeshInfo) == 96 and C.sizeof(capi.Stats) == 16 * 8
     m = re.search(r"typedef struct gvt_hip_ray \{(.*?)\} gvt_hip_ray;", hdr, re.S)
     assert m and "float pad[4]" in m.group(1)
 
@@ -54,7 +54,7 @@ def test_no_device_is_an_error_not_a_fallback():
 
 
 def test_product_never_imports_the_oracle():
-    pat = re.compile(r"^\s*(import\s+oracle|from\s+oracle|from\s+\.+oracle|#\s*include\s*[<\"].*oracle)|liboracle|libgvtref|orc\.py", re.M)
+    pat = re.compile(r"^\s*(import\s+oracle|from\s+oracle|from\s+\.+oracle|#\s*include\s*[<\"].*oracle)|liboracle|libgvtref|libsimd_baseline|orc\.py", re.M)
     for root, _, files in os.walk(os.path.join(ROOT, "gravit_amd")):
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
@@ -144,3 +144,30 @@ def test_oracle_trace_output_contract():
     r3 = before.copy()
     out3 = om.trace(r3, sc.m[0], sc.minv[0], sc.normi[0], sc.lights, 0, begin=100, end=1177)
     assert (r3[:100]["t"] == before[:100]["t"]).all() and (r3[1177:]["t"] == before[1177:]["t"]).all() and len(out3) > 0
+
+
+def test_simd_cpu_baseline_library_loads_and_answers_a_tiny_tree():
+    """oracle/libsimd_baseline.so (bench.py's SIMD CPU baseline; measurement infrastructure, not the product, not the oracle) loads, exports its two
+    entry points and walks a hand-made one-node tree: one triangle in the unit square at z = 0, rays down the z axis."""
+    from oracle import simd
+
+    lib = simd.load()
+    assert lib.simd_intersect and lib.simd_occluded
+    node = np.zeros(16, np.uint32)
+    f = node.view(np.float32)
+    f[0], f[1], f[2], f[3] = -1.0, -1.0, -1.0, 2.0 / 255.0   # origin, step.x
+    f[14], f[15] = 2.0 / 255.0, 2.0 / 255.0                   # step.y, step.z
+    lo = np.array([0, 255, 255, 255], np.uint8).view(np.uint32)[0]      # child 0: the whole grid; children 1..3 inverted (unused)
+    hi = np.array([255, 0, 0, 0], np.uint8).view(np.uint32)[0]
+    node[4], node[5], node[6], node[7], node[8], node[9] = lo, hi, lo, hi, lo, hi
+    node[10] = np.uint32((~((0 << 3) | 1)) & 0xFFFFFFFF)                   # leaf: slot 0, one triangle
+    node[11] = node[12] = node[13] = np.uint32(0xFFFFFFFF)               # empty refs
+    v0, v1, v2 = np.array([0, 0, 0], np.float32), np.array([1, 0, 0], np.float32), np.array([0, 1, 0], np.float32)
+    slot = np.zeros(16, np.float32)
+    slot[0:3] = v0; slot.view(np.int32)[3] = 7; slot[4:7] = v0 - v1; slot[8:11] = v2 - v0
+    T = simd.Tree(node.reshape(1, 16), slot.reshape(1, 16))
+    org = np.array([[0.25, 0.25, 1.0], [0.9, 0.9, 1.0]], np.float32)
+    d = np.array([[0, 0, -1.0], [0, 0, -1.0]], np.float32)
+    t, prim, u, v = T.intersect(org, d, nthreads=2)
+    assert prim.tolist() == [7, -1] and t[0] == np.float32(1.0) and (u[0], v[0]) == (np.float32(0.25), np.float32(0.25))
+    assert T.occluded(org, d).tolist() == [True, False]
