@@ -403,8 +403,10 @@ extern "C" int gvt_hip_queue_sizes(gvt_hip_queue *const *queues, size_t n, uint6
   return 0;
 }
 
-extern "C" int gvt_hip_queue_append(gvt_hip_queue *q, const gvt_hip_ray *rays, size_t n, int src_on_device) {
+extern "C" int gvt_hip_queue_append(gvt_hip_queue *q, const gvt_hip_ray *rays, size_t n, int flags) {
   if (!q || (n && !rays)) { set_error("queue_append: null"); return GVT_HIP_ERR_INVALID; }
+  if (flags & ~(GVT_HIP_APPEND_DEVICE | GVT_HIP_APPEND_KEEP_STATE)) { set_error("queue_append: unknown flag bits %d", flags); return GVT_HIP_ERR_INVALID; }
+  const int src_on_device = flags & GVT_HIP_APPEND_DEVICE;
   if (!n) return 0;
   Ctx &C = g_ctx;
   int rc = queue_reserve(q, q->size + n);
@@ -416,7 +418,7 @@ extern "C" int gvt_hip_queue_append(gvt_hip_queue *q, const gvt_hip_ray *rays, s
     HIPCHK(hipMemcpyAsync(stage, rays, sizeof(gvt_hip_ray) * n, hipMemcpyHostToDevice, C.stream));
     d_src = (const gvt_hip_ray *)stage;
   }
-  rc = convert_aos_to_planes(d_src, n, make_planes(q->d_planes, q->cap), q->size);
+  rc = convert_aos_to_planes(d_src, n, make_planes(q->d_planes, q->cap), q->size, (flags & GVT_HIP_APPEND_KEEP_STATE) != 0);
   if (rc) return rc;
   q->size += n;
   if ((rc = set_device_u32(q->d_count, (unsigned)q->size))) return rc;
@@ -585,7 +587,7 @@ static int trace_pipelined(Ctx &C, gvt_hip_mesh *M, gvt_hip_ray *rays, size_t be
       size_t got = 0;
       const auto tc0 = std::chrono::steady_clock::now();
       if ((rc = gvt_hip_queue_clear(qin)) || (rc = gvt_hip_queue_clear(qout))) break;
-      if ((rc = gvt_hip_queue_append(qin, rays + begin + off, cn, 0))) break;
+      if ((rc = gvt_hip_queue_append(qin, rays + begin + off, cn, GVT_HIP_APPEND_KEEP_STATE))) break; // (Adapter::trace copies a forwarded ray whole, padding included, and interprets none of it)
       const auto tc1 = std::chrono::steady_clock::now();
       if ((rc = queue_reserve(qout, cn * (1 + n_lights)))) break;
       if ((rc = trace_core(M, make_planes(qin->d_planes, qin->cap), cn, begin + off, qout, P, lights))) break;
@@ -657,7 +659,7 @@ extern "C" int gvt_hip_trace_ex(gvt_hip_mesh *M, gvt_hip_ray *rays, size_t n_ray
   gvt_hip_queue *qin = C.abi_qin, *qout = C.abi_qout;
   if (!qin || !qout) return GVT_HIP_ERR_DEVICE;
   if ((rc = gvt_hip_queue_clear(qin)) || (rc = gvt_hip_queue_clear(qout))) return rc;
-  if ((rc = gvt_hip_queue_append(qin, rays + begin, n, 0))) return rc;
+  if ((rc = gvt_hip_queue_append(qin, rays + begin, n, GVT_HIP_APPEND_KEEP_STATE))) return rc; // bytes 64..79 pass through (a forwarded ray is a copy of all 80 bytes); this path never reads them
   if ((rc = queue_reserve(qout, n * (1 + n_lights)))) return rc;
   P.update_in_place = write_back ? 1 : 0;
   if ((rc = trace_core(M, make_planes(qin->d_planes, qin->cap), n, begin, qout, P, lights))) return rc;

@@ -57,8 +57,11 @@ struct Knobs {
   int abi_pipe_min = 131072; // ... lists shorter than this take the one-shot path
   int lean_frame = 1;    // one-instance scenes on one rank: framebuffer clear, counter resets and the chain's begin / end folded into the camera filter's
                          // two kernels and the round's report (8 launches per frame instead of 14)
-  int skip_known = 1;    // shuffleRays' known-miss shortcut (gvt_device.h): a ray is not traced again in an instance it has already crossed without a hit
-                         // on the same straight segment (image-identical; 0: the reference's hop-by-hop behaviour, same ray counts as its schedulers)
+  int skip_known = 0;    // shuffleRays' known-miss shortcut (gvt_device.h): a ray is not traced again in an instance it has already crossed without a hit on the
+                         // same straight segment.  OFF by default = the reference's hop-by-hop rule, ray for ray.  On, it saves the hand-back hops between
+                         // overlapping boxes (exchanges 6 / 8 / 8 -> 2 / 4 / 6 on 2 / 4 / 8 soup tiles), but it is NOT image-identical in general: a re-trace from
+                         // the advanced origin can flip an edge-grazing triangle test that missed from the earlier origin (round 5, found by the strict checker:
+                         // 9 of 575,174 shadow rays, 2 of 147,456 pixels of the hall in 8 slabs) -- an approximation a user may opt into, never the default
   int long_auto = 1;     // native tracer: raise the parking threshold from frame to frame while more than 0.3 % of a frame's closest-hit rays get parked (sparser scenes than the benchmark)
   int payload_overlap_kb = 1024; // Domain scheduler: a tick's payload of at least this many KiB (sent + received) moves on the communicator's own stream while the next
                          // chain runs; smaller ones stay on the compute stream (no cross-stream event pairs).  0: every payload on its own stream
@@ -300,6 +303,6 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
 // multi_packets (merged kernels, first pass): the queues hold camera rays in tile order over packet-friendly meshes -- closest hits through k_packet_multi
 int finish_round(const WaveSet &W, size_t n_total, const TraceParams &P, const gvt_hip_light *lights_host, const void *d_qdesc, const int *d_owner, int rank,
                  unsigned *d_queue_overflow, unsigned *const *d_count_ptr, const unsigned char *d_mask);
-int convert_aos_to_planes(const gvt_hip_ray *d_src, size_t n, RayPlanes dst, size_t dst_off);
+int convert_aos_to_planes(const gvt_hip_ray *d_src, size_t n, RayPlanes dst, size_t dst_off, bool keep_state);
 int convert_planes_to_aos(RayPlanes src, size_t src_off, size_t n, gvt_hip_ray *d_dst);
 int convert_od_to_planes(const float *d_org, const float *d_dir, size_t n, RayPlanes dst);

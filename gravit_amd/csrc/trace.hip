@@ -154,10 +154,10 @@ int trav_overflow_result() {
 size_t trav_spill_ints_per_thread() { return TRAV_SPILL; }
 int trav_block_threads() { return TRAV_BLOCK; }
 
-int convert_aos_to_planes(const gvt_hip_ray *d_src, size_t n, RayPlanes dst, size_t dst_off) {
+int convert_aos_to_planes(const gvt_hip_ray *d_src, size_t n, RayPlanes dst, size_t dst_off, bool keep_state) {
   if (!n) return 0;
   ProfScope ps(KC_CONVERT);
-  k_aos_to_planes<<<blocks_for(n), 256, 0, gctx().stream>>>((const float4 *)d_src, (unsigned)n, dst, dst_off);
+  k_aos_to_planes<<<blocks_for(n), 256, 0, gctx().stream>>>((const float4 *)d_src, (unsigned)n, dst, dst_off, keep_state ? 1 : 0);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -68,11 +68,15 @@ def _default_knobs(request):
     from gravit_amd import capi
     from oracle import orc
 
+    from tests import helpers
+
     capi.set_option("defaults", 0)
-    orc.set_skip_known_misses(True)  # the checker follows the library's default: shuffleRays' known-miss shortcut on (image-identical;
-    yield                            # the ray counts of both sides are then the shortcut's, not the reference's hop-by-hop ones)
+    orc.set_skip_known_misses(False)  # the checker is STRICT -- the reference's hop-by-hop shuffleRays, which is also the library's default -- unless a test
+    helpers.DEFAULT_RULE = "strict"   # asks for the restated shortcut (rule="shortcut", with the device's knob skip_known = 1)
+    yield
     capi.set_option("defaults", 0)
     orc.set_skip_known_misses(False)
+    helpers.DEFAULT_RULE = "asis"
 
 
 def read_ppm(path):

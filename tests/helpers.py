@@ -16,21 +16,39 @@ def oracle_camera_rays(scene):
     return orc.camera_rays(c.eye, c.focus, c.up, c.fov, c.width, c.height, c.samples, c.depth, c.jitter)
 
 
-def oracle_render(scene, mode, nthreads=8, meshes=None):
+DEFAULT_RULE = "asis"  # tests/conftest.py switches the GPU tests to "strict"
+
+
+def _by_rule(render, rule):
+    """Which shuffleRays rule the checker restates: 'strict' -- the reference's hop-by-hop rule (TracerBase.h:392-400), the library's default and
+    the GPU tests' default; 'shortcut' -- the library's opt-in known-miss shortcut (knob skip_known = 1), restated in the checker so that a
+    device running it can be compared ray for ray; 'asis' -- the checker's flag left as the caller set it (the CPU tests, where the checker is
+    also the backend under test)."""
+    rule = rule or DEFAULT_RULE
+    if rule == "asis":
+        return render()
+    assert rule in ("strict", "shortcut"), rule
+    try:
+        orc.set_skip_known_misses(rule == "shortcut")
+        return render()
+    finally:
+        orc.set_skip_known_misses(False)
+
+
+def oracle_render(scene, mode, nthreads=8, meshes=None, rule=None):
     meshes = meshes or oracle_meshes(scene)
     c = scene.camera
     rays = oracle_camera_rays(scene)
-    fb, st = orc.render_image([meshes[i] for i in scene.inst_mesh], scene.m, scene.minv, scene.normi, scene.inst_lo, scene.inst_hi,
-                              scene.lights, rays, c.width, c.height, mode, nthreads)
-    return fb, st
+    return _by_rule(lambda: orc.render_image([meshes[i] for i in scene.inst_mesh], scene.m, scene.minv, scene.normi, scene.inst_lo, scene.inst_hi,
+                                             scene.lights, rays, c.width, c.height, mode, nthreads), rule)
 
 
-def oracle_render_domain(scene, owner, P, mode, nthreads=8):
+def oracle_render_domain(scene, owner, P, mode, nthreads=8, rule=None):
     meshes = oracle_meshes(scene)
     c = scene.camera
     rays = oracle_camera_rays(scene)
-    return orc.render_domain([meshes[i] for i in scene.inst_mesh], scene.m, scene.minv, scene.normi, scene.inst_lo, scene.inst_hi,
-                             scene.lights, owner, P, rays, c.width, c.height, mode, nthreads)
+    return _by_rule(lambda: orc.render_domain([meshes[i] for i in scene.inst_mesh], scene.m, scene.minv, scene.normi, scene.inst_lo, scene.inst_hi,
+                                              scene.lights, owner, P, rays, c.width, c.height, mode, nthreads), rule)
 
 
 def sort_rays(r):

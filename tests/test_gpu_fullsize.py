@@ -185,27 +185,25 @@ def test_config4_bunny_grid_at_its_full_film_under_the_native_domain_scheduler(h
 
 def test_benchmark_soup_in_8_tiles_under_the_native_domain_scheduler_at_full_size(hip):
     """The benchmark scene itself -- 10,000,000 triangles, 1920x1080 -- cut into 8 x-y tiles, a tile per rank (8 in-process ranks,
-    asynchronous ticks, known-miss shortcut on as shipped): the composited float framebuffer against the checker's restated
-    DomainTracer with the same shortcut, bit for bit, with equal ray counts and rays sent; and against the checker's hop-by-hop run
-    (the reference's rule): the same image from more rays and more exchanges."""
+    asynchronous ticks): the composited float framebuffer against the checker's restated DomainTracer, bit for bit, with equal ray counts
+    and rays sent -- under the reference's hop-by-hop shuffle rule (the default) and under the opt-in known-miss shortcut (against its
+    restatement): on this scene the same image from fewer rays and fewer exchanges."""
     from tests.helpers import oracle_render_domain
     from tests.test_gpu_native import run_native_ranks
 
     sc = scenes.soup_domains_scene(10_000_000, 8)
     owner = list(range(8))
-    res = run_native_ranks(sc, owner, 8, NORMALS_FLAT, False)
-    fb = res[0][0]
-    ref, st = oracle_render_domain(sc, owner, 8, NORMALS_FLAT, nthreads=16)  # (the gpu-test fixture has switched the checker's shortcut on)
-    assert (ref[..., 3] > 0).sum() > 1_000_000
-    assert np.array_equal(fb[..., :3].view(np.uint32), ref[..., :3].view(np.uint32)) and np.array_equal(fb[..., 3], ref[..., 3])
-    assert sum(r[1]["rays_sent"] for r in res.values()) == st.rays_sent and st.rays_sent > 10_000
-    assert sum(r[1]["rays_closest"] for r in res.values()) == st.rays_closest and sum(r[1]["rays_any"] for r in res.values()) == st.rays_any
-    ticks = max(r[1]["rounds"] for r in res.values())
-    assert ticks <= 6
-    orc.set_skip_known_misses(False)
-    try:
-        strict, st0 = oracle_render_domain(sc, owner, 8, NORMALS_FLAT, nthreads=16)
-    finally:
-        orc.set_skip_known_misses(True)
-    assert np.array_equal(strict.view(np.uint32), ref.view(np.uint32))
+    out = {}
+    for rule, skip in (("strict", 0), ("shortcut", 1)):
+        res = run_native_ranks(sc, owner, 8, NORMALS_FLAT, False, opts=(("skip_known", skip),))
+        fb = res[0][0]
+        ref, st = oracle_render_domain(sc, owner, 8, NORMALS_FLAT, nthreads=16, rule=rule)
+        assert (ref[..., 3] > 0).sum() > 1_000_000
+        assert np.array_equal(fb[..., :3].view(np.uint32), ref[..., :3].view(np.uint32)) and np.array_equal(fb[..., 3], ref[..., 3])
+        assert sum(r[1]["rays_sent"] for r in res.values()) == st.rays_sent and st.rays_sent > 10_000
+        assert sum(r[1]["rays_closest"] for r in res.values()) == st.rays_closest and sum(r[1]["rays_any"] for r in res.values()) == st.rays_any
+        out[rule] = (ref, st, max(r[1]["rounds"] for r in res.values()))
+    assert out["shortcut"][2] <= 6 < out["strict"][2]
+    assert np.array_equal(out["strict"][0].view(np.uint32), out["shortcut"][0].view(np.uint32))
+    st0, st = out["strict"][1], out["shortcut"][1]
     assert st0.rays_sent > st.rays_sent and st0.rays_closest > st.rays_closest and st0.rounds > st.rounds

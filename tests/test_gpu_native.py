@@ -138,26 +138,25 @@ def test_soup_domains_with_cross_traffic_native(hip):
         assert sum(r[1]["rays_sent"] for r in res.values()) == st.rays_sent and st.rays_sent > 1000
 
 
-@pytest.mark.parametrize("case", ["soup2", "soup4", "soup8", "config4", "config5"])
-def test_known_miss_shortcut_is_image_identical(hip, case):
-    """shuffleRays' known-miss shortcut (gvt_device.h; default on): a ray is not traced again, nor sent again, in an instance it has
-    already crossed without a hit on the same straight segment.  Against the reference's hop-by-hop behaviour (skip_known = 0, the
-    checker in its default mode): the composited float framebuffer is the same bit for bit (config 5: several deposits per pixel
-    meet in another order, 1e-5, equal deposit counts), fewer rays are traced and sent, fewer exchanges are needed -- and in both
-    modes the ray counts are the checker's."""
-    from oracle import orc
-
+@pytest.mark.parametrize("case", ["soup2", "soup4", "soup8", "config4", "config5", "config5_8"])
+def test_known_miss_shortcut_against_the_reference_rule(hip, case):
+    """shuffleRays' known-miss shortcut (gvt_device.h; knob skip_known, OFF by default): a ray is not traced again, nor sent again, in an instance
+    it has already crossed without a hit on the same straight segment.  In both modes the device's image and ray counts are the checker's for
+    the same rule (the reference's hop-by-hop rule by default; the restated shortcut).  Between the modes: fewer rays traced and sent, fewer
+    exchanges -- and the same image EXCEPT where a re-trace from the advanced origin flips an edge-grazing triangle test that missed from the
+    earlier origin: the reference then finds a hit (and its shadow rays deposit) that the shortcut never looks for.  Rare (config5_8: 2 of
+    147,456 pixels; none in the other cases), which is why the shortcut is an opt-in approximation and not the default."""
     sc, mode, world, exact = {
         "soup2": lambda: (scenes.soup_domains_scene(400_000, 2, 480, 270), NORMALS_FLAT, 2, True),
         "soup4": lambda: (scenes.soup_domains_scene(400_000, 4, 480, 270), NORMALS_FLAT, 4, True),
         "soup8": lambda: (scenes.soup_domains_scene(400_000, 8, 480, 270), NORMALS_FLAT, 8, True),
         "config4": lambda: (scenes.bunny_grid_scene(width=475, height=270), NORMALS_SMOOTH, 8, True),
-        "config5": lambda: (config5(256, 4), NORMALS_FLAT, 4, False)}[case]()
+        "config5": lambda: (config5(256, 4), NORMALS_FLAT, 4, False),
+        "config5_8": lambda: (config5(384, 8), NORMALS_FLAT, 8, False)}[case]()
     owner = [i % world for i in range(sc.n_inst)]
     got = {}
     for skip in (0, 1):
-        orc.set_skip_known_misses(bool(skip))
-        ref, st = oracle_render_domain(sc, owner, world, mode)
+        ref, st = oracle_render_domain(sc, owner, world, mode, rule="shortcut" if skip else "strict")
         for bsp in (True, False):
             res = run_native_ranks(sc, owner, world, mode, bsp, opts=(("skip_known", skip),))
             fb = res[0][0]
@@ -173,8 +172,12 @@ def test_known_miss_shortcut_is_image_identical(hip, case):
             got[(skip, bsp)] = (fb, max(r[1]["rounds"] for r in res.values()), st.rays_sent, st.rays_closest)
     for bsp in (True, False):
         a, b = got[(0, bsp)], got[(1, bsp)]
-        assert np.array_equal(a[0][..., 3], b[0][..., 3])
-        assert np.array_equal(a[0], b[0]) if exact else np.abs(a[0] - b[0]).max() <= 1e-5
+        flipped = a[0][..., 3] != b[0][..., 3]  # pixels whose deposit COUNT differs: an edge-grazing flip of the reference's re-trace
+        assert flipped.sum() <= max(2, flipped.size // 20000)
+        if case != "config5_8":
+            assert not flipped.any()
+        same = ~flipped
+        assert np.array_equal(a[0][same], b[0][same]) if exact else np.abs(a[0][same] - b[0][same]).max() <= 1e-5
         assert b[1] <= a[1] and b[2] <= a[2] and b[3] <= a[3]
     if case.startswith("soup"):  # the tiles' boxes overlap: the hand-back hops are there to be skipped
         assert got[(1, True)][1] < got[(0, True)][1] and got[(1, True)][2] < got[(0, True)][2]
@@ -437,18 +440,16 @@ def test_top_level_bvh_with_1056_instances(hip):
 
 
 @pytest.mark.parametrize("opts", [dict(small_rays=0), dict(small_rays=1 << 30), dict(term_sink=0), dict(leaf_max=4, small_rays=0), dict(finish_rays=0), dict(round_room_mb=0),
-                                  dict(round_room_mb=0, finish_rays=0, small_rays=0), dict(finish_rays=1 << 30), dict(finish_rays=1 << 30, leaf_max=4), dict(skip_known=0, finish_rays=0),
+                                  dict(round_room_mb=0, finish_rays=0, small_rays=0), dict(finish_rays=1 << 30), dict(finish_rays=1 << 30, leaf_max=4), dict(skip_known=1, finish_rays=0), dict(skip_known=1),
                                   dict(sort_rays=1), dict(packet=0), dict(packet=2), dict(packet=2, long_steps=0), dict(packet=2, term_sink=0), dict(packet=1, packet_min_rays=0)])
 def test_round_results_do_not_depend_on_knobs(hip, opts):
     """The round chain under every knob of the shipped library -- a wave per ray for small rounds or never, k_finish or rounds, exact
-    growth, no terminal sink, the reference's hop-by-hop shuffle -- returns the oracle's image on a multi-domain depth-2 frame, on config 4
+    growth, no terminal sink, the known-miss shortcut (against the checker's restatement of it) -- returns the oracle's image on a multi-domain depth-2 frame, on config 4
     and on a soup (the variants that lost -- merged kernels for one queue, compacted shadow slots, non-lean frames, k_fused / k_packet /
     k_traceq -- tests/experiment_cases.py, against the experiments build)."""
     for sc, mode, tol in ((config5(192, 4), NORMALS_FLAT, 1e-5), (scenes.bunny_grid_scene(width=380, height=216), NORMALS_SMOOTH, 0.0),
                           (scenes.soup_scene(100_000, 160, 90), NORMALS_FLAT, 0.0)):
-        from oracle import orc
-        orc.set_skip_known_misses(bool(opts.get("skip_known", 1)))
-        ref, st = oracle_render(sc, mode, nthreads=8)
+        ref, st = oracle_render(sc, mode, nthreads=8, rule="shortcut" if opts.get("skip_known", 0) else "strict")
         try:
             for k, v in opts.items():
                 hip.set_option(k, v)
@@ -459,7 +460,6 @@ def test_round_results_do_not_depend_on_knobs(hip, opts):
             tr.close()
         finally:
             hip.set_option("defaults", 0)
-            orc.set_skip_known_misses(True)
 
 
 def test_packet_traversal_is_chosen_per_mesh(hip):

@@ -535,8 +535,8 @@ def test_queue_roundtrip_and_camera(hip):
     cpu = oracle_camera_rays(sc)
     assert rays_equal_bits(dev, cpu), "camera rays differ from gvtPerspectiveCamera::generateRays restated"
     q2 = RayQueue(16)
-    q2.append(cpu[:1000])
-    q2.append(cpu[1000:1003])
+    q2.append(cpu[:1000], keep_state=True)   # (rays in the library's own format: the oracle's camera rays carry their stream words)
+    q2.append(cpu[1000:1003], keep_state=True)
     assert len(q2) == 1003 and rays_equal_bits(q2.to_numpy(), cpu[:1003])
     q2.clear()
     assert len(q2) == 0 and len(q2.to_numpy()) == 0
@@ -561,7 +561,7 @@ def test_toplevel_shuffle_matches_oracle(hip):
     assert (top.order() == order).all()
     cpu = oracle_camera_rays(sc)
     q = RayQueue()
-    q.append(cpu)
+    q.append(cpu, keep_state=True)
     queues = [RayQueue() for _ in range(sc.n_inst)]
     fb = FrameBuffer(150, 150)
     top.shuffle(q, -1, queues, fb)
@@ -829,3 +829,34 @@ def test_simd_cpu_baseline_equals_the_oracle_on_the_downloaded_tree(hip):
         assert (prim >= 0).sum() > 1000
         assert np.array_equal(om.occluded(org, d), T.occluded(org, d, nthreads=4)), name
         assert_hits_equal(ad.intersect(org, d), ref)
+
+
+def test_host_appended_rays_start_fresh_whatever_their_padding_holds(hip):
+    """gvt_hip_queue_append without GVT_HIP_APPEND_KEEP_STATE: bytes 64..79 of a host ray are NOT read as scheduler state.  The reference's
+    Ray(origin, dir, ...) constructor never writes data[64..79] (Ray.h:106-116), so a GraviT host hands over stack garbage there; read as a
+    known-miss list, a 16-bit entry equal to an instance number + 1 would let shuffleRays walk the ray through that instance without tracing
+    it.  Camera rays of a scene of overlapping instances with every such entry poisoned (all instances 'already crossed') are shuffled
+    exactly like clean ones; with the flag the same bytes ARE state and the shuffle walks through the boxes."""
+    hip.set_option("skip_known", 1)  # the shortcut on: the setting under which a known-miss list is read at all
+    sc = scenes.simple_scene(96, 96)
+    top = TopLevel(sc.inst_lo, sc.inst_hi)
+    clean = oracle_camera_rays(sc)
+    clean["rng"] = 0
+    clean["known"] = 0
+    dirty = clean.copy()
+    dirty["rng"] = 0xDEADBEEF
+    dirty["known"] = np.arange(1, 7, dtype=np.uint16)[None, :]  # instances 0..5 "known missed"
+
+    def shuffled(rays, keep):
+        q = RayQueue()
+        q.append(rays, keep_state=keep)
+        queues = [RayQueue() for _ in range(sc.n_inst)]
+        top.shuffle(q, -1, queues, FrameBuffer(96, 96))
+        return [qq.to_numpy() for qq in queues]
+
+    a, b = shuffled(clean, False), shuffled(dirty, False)
+    assert sum(len(x) for x in a) > 1000
+    for x, y in zip(a, b):
+        assert len(x) == len(y) and np.array_equal(sort_rays(x).view(np.uint8).reshape(-1, 80), sort_rays(y).view(np.uint8).reshape(-1, 80))
+    c = shuffled(dirty, True)  # the same bytes taken as state: rays bound for instances 0..5 are walked past them
+    assert [len(x) for x in c] != [len(x) for x in a]

@@ -305,9 +305,10 @@ def test_round2_definitions_are_stable():
     assert (st.rays_closest, st.rays_any, st.rays_sent, st.rounds) == (rec["rays_closest"], rec["rays_any"], rec["rays_sent"], rec["rounds"])
 
 
-def test_known_miss_shortcut_of_the_checker_is_image_identical_and_off_by_default():
-    """The build's shortcut of shuffleRays (gvt_oracle.c "known misses"; not reference behaviour): off by default -- every pinning test
-    above runs the reference's hop-by-hop rule -- and, switched on, it changes no bit of the image while fewer rays are traced and sent."""
+def test_known_miss_shortcut_of_the_checker_is_off_by_default_and_image_identical_on_the_soup_tiles():
+    """The build's shortcut of shuffleRays (gvt_oracle.c "known misses"; not reference behaviour, an opt-in approximation of the library: a
+    re-trace can flip an edge-grazing triangle test, tests/test_gpu_native.py case config5_8): off by default -- every pinning test above runs
+    the reference's hop-by-hop rule -- and, switched on, it changes no bit of THIS image while fewer rays are traced and sent."""
     from gravit_amd import scenes
     from tests.helpers import oracle_render_domain
 
