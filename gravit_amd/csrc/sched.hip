@@ -706,7 +706,13 @@ extern "C" int gvt_hip_shuffle(gvt_hip_top *T, gvt_hip_queue *q_in, int from, gv
   S.q = make_planes(q_in->d_planes, q_in->cap);
   S.from_cam = 0;
   int rc = shuffle_impl(T, S, q_in->size, from, queues, keep_mask, fb);
-  if (rc) return rc;
+  if (rc) { // (the classify step has already advanced origins in place: a failed shuffle CONSUMES q_in too -- it is cleared, never left half-walked for a second attempt)
+    const std::string why = gvt_hip_last_error();
+    q_in->size = 0;
+    hipMemsetAsync(q_in->d_count, 0, sizeof(unsigned), gctx().stream);
+    set_error("%s; q_in has been cleared (its rays are lost)", why.c_str());
+    return rc;
+  }
   q_in->size = 0; // rays.clear(), TracerBase.h:411
   HIPCHK(hipMemsetAsync(q_in->d_count, 0, sizeof(unsigned), gctx().stream));
   return 0;

@@ -194,7 +194,7 @@ int gvt_hip_camera_generate_tiled(gvt_hip_queue *q, const float eye[3], const fl
 gvt_hip_top *gvt_hip_top_create(const float *inst_lo, const float *inst_hi, size_t n_inst);
 void gvt_hip_top_destroy(gvt_hip_top *);
 int gvt_hip_top_order(const gvt_hip_top *, int32_t *order_out /* n_inst */);
-/* shuffleRays(rays, from): consumes q_in; a ray whose next instance is i is advanced
+/* shuffleRays(rays, from): consumes q_in (also when it fails: q_in is then cleared, its rays are lost); a ray whose next instance is i is advanced
  * (origin += dir * t * 0.95f) and appended to queues[i] -- unless keep_mask!=NULL and keep_mask[i]==0
  * (Tracer<DomainScheduler>::shuffleDropRays, DomainTracer.h:148-183); SHADOW rays that hit no further
  * instance deposit color*w into fb (fb may be NULL only if deposit is impossible, i.e. from<0 drop mode). */

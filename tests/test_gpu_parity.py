@@ -851,7 +851,7 @@ def test_host_appended_rays_start_fresh_whatever_their_padding_holds(hip):
         q = RayQueue()
         q.append(rays, keep_state=keep)
         queues = [RayQueue() for _ in range(sc.n_inst)]
-        top.shuffle(q, -1, queues, FrameBuffer(96, 96))
+        top.shuffle(q, 12, queues, FrameBuffer(96, 96))  # as rays that leave instance 12 (the camera's own shuffle, from -1, reads no list)
         return [qq.to_numpy() for qq in queues]
 
     a, b = shuffled(clean, False), shuffled(dirty, False)
