@@ -773,10 +773,15 @@ def main():
         variants = {}
         primary = "image_replicated" if image_split else ("domain_bsp" if args.bsp else "domain_async")
         todo = [("domain_async", "domain", False), ("domain_bsp", "domain", True)] + ([("image_replicated", "image", False)] if args.harness == "native" else [])
+        if args.harness == "native" and on_gpu:  # the opt-in known-miss shortcut of shuffleRays (skip_known = 1; not image-identical in general): fewer ticks
+            todo.append(("domain_async_known_miss_shortcut", "domain", False))
         for name, kind, bsp_v in todo:
             if legs_error is not None:
                 break
             made = None
+            shortcut = name.endswith("known_miss_shortcut")
+            if shortcut:
+                capi.set_option("skip_known", 1)
             if args.harness == "native":
                 if (kind == "image") == image_split:
                     tr_v = tracer  # same scene and tracer as the primary variant
@@ -805,6 +810,9 @@ def main():
                 legs_error = str(e)
                 variants[name] = {"failed": legs_error, "is_value": name == primary}
                 continue
+            finally:
+                if shortcut:
+                    capi.set_option("skip_known", int(dict(o.split("=") for o in args.opt).get("skip_known", 0)))
             res_v["is_value"] = name == primary
             variants[name] = res_v
             if made is not None and hasattr(made, "close"):

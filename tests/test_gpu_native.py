@@ -709,7 +709,8 @@ def test_camera_rectangle_edge_cases(hip, case):
     assert sum(r[1]["rays_closest"] for r in res.values()) == std.rays_closest and sum(r[1]["rays_sent"] for r in res.values()) == std.rays_sent
 
 
-def test_bench_script_native_multi_process_plumbing(hip, tmp_path):
+@pytest.mark.parametrize("launcher", ["torch.distributed.run", "none"])
+def test_bench_script_native_multi_process_plumbing(hip, tmp_path, launcher):
     """bench.py's N > 1 branch with the NATIVE harness, two processes on this one GPU: RCCL refuses two ranks on one device, so
     --fake-comm leaves the communicator out (every rank renders every scene alone: the numbers mean nothing) -- what runs is the
     script's own plumbing around the library: rendezvous, the three scheduler variants, the config-4 and weak-soup legs with
@@ -722,13 +723,16 @@ def test_bench_script_native_multi_process_plumbing(hip, tmp_path):
 
     from tests.conftest import ROOT
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-gpu", "--fake-comm", "--tris", "200000", "--weak-tris", "100000", "--width", "480", "--height", "270",
-                        "--steps", "2", "--warmup", "1"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    # launcher "none": plain `python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment -- the script starts its two ranks itself (spawn_ranks: the
+    # parent touches no GPU, the children are ordinary child processes) and hands rank 0's line through
+    pre = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] if launcher != "none" else [sys.executable]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run(pre + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-gpu", "--fake-comm", "--tris", "200000", "--weak-tris", "100000", "--width", "480", "--height", "270",
+                              "--steps", "2", "--warmup", "1"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
     j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["harness"] == "native" and j["roofline"]["frac"] > 0
-    assert set(j["variants"]) == {"domain_async", "domain_bsp", "image_replicated"}
+    assert set(j["variants"]) == {"domain_async", "domain_bsp", "image_replicated", "domain_async_known_miss_shortcut"}
     c4, wk = j["config4_bunny_grid"], j["weak_soup"]
     assert c4["film"] == [1900, 1080] and c4["domain_async"]["rays_per_step"] > 100_000 and c4["domain_bsp"]["value"] > 0
     assert wk["tiles"] == 2 and wk["tris_per_tile"] == 100000 and wk["value"] > 0 and len(wk["roofline_per_rank"]) == 2 and all(r["frac"] > 0 for r in wk["roofline_per_rank"])

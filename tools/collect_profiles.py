@@ -2,7 +2,7 @@
    usage: python tools/collect_profiles.py <tag>"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = os.path.join(ROOT, "gpurun_out", "refresh_" + tag)
 dst = os.path.join(ROOT, "profiles")
 commit = open(os.path.join(dst, ".profiled_commit")).read().strip()
@@ -29,6 +29,15 @@ for n in (2, 4, 8):
         rows.append("%d %-18s %8.3f %6.1f %7.1f %6.1f %10d %11d | %5.2f %8.2f %7.2f %9.2f %9.2f" % (
             n, name, v["ms_per_step"], v.get("ticks_per_step", 0), v.get("launch_chains_per_step", 0), v.get("host_syncs_per_step", 0),
             v.get("rays_sent_per_step", 0), v.get("bytes_sent_per_step", 0), ph["chain"], ph["announce"], ph["payload"], ph["composite"], ph["host_wait"]))
+    ps = os.path.join(src, "inproc_s_%d.log" % n)
+    if os.path.exists(ps):  # the same with the opt-in known-miss shortcut (skip_known = 1)
+        for name, v in last_json(ps)["variants"].items():
+            if name == "image_replicated":
+                continue
+            ph = v["phase_ms_per_step_max_over_ranks"]
+            rows.append("%d %-18s %8.3f %6.1f %7.1f %6.1f %10d %11d | %5.2f %8.2f %7.2f %9.2f %9.2f" % (
+                n, name + "+skip", v["ms_per_step"], v.get("ticks_per_step", 0), v.get("launch_chains_per_step", 0), v.get("host_syncs_per_step", 0),
+                v.get("rays_sent_per_step", 0), v.get("bytes_sent_per_step", 0), ph["chain"], ph["announce"], ph["payload"], ph["composite"], ph["host_wait"]))
     c4, wk = j.get("config4_bunny_grid"), j.get("weak_soup")
     if c4:
         for name in ("domain_async", "domain_bsp"):
@@ -42,8 +51,8 @@ d8 = last_json(os.path.join(src, "domains8.log"))
 open(os.path.join(dst, tag + "_domain_ticks.txt"), "w").write(
     "# bench.py --inproc-ranks N --steps 10 --warmup 2 at %s (source hash %s): the native multi-rank frame loop with N in-process ranks sharing ONE MI355X (hub transport).\n"
     "# Tick counts, rays / bytes sent and the per-phase times (max over ranks, ms per frame; frame_timing on: five more event calls per tick) of the config-3 soup cut into N x-y tiles;\n"
-    "# NOT a scaling number: the ranks' launch chains serialise on one device.  Known-miss shortcut ON (the default); with skip_known = 0 -- the reference's hop-by-hop rule -- the\n"
-    "# same scenes took 6 / 8 / 8 ticks and sent 5,578 / 9,412 / 25,626 rays (round 3's table, re-measured this round at 93933e1: 4.26 / 8.18 / 12.9 ms per frame).\n"
+    "# NOT a scaling number: the ranks' launch chains serialise on one device.  Default = the reference's hop-by-hop shuffle rule; rows '+skip': the opt-in known-miss shortcut\n"
+    "# (skip_known = 1: fewer hand-back hops between overlapping tiles, not image-identical in general -- DESIGN 6).  Payloads of at most inline_kb = 16 KiB per pair ride inside the announce.\n"
     "# N variant            ms/frame  ticks  chains  syncs  rays_sent  bytes_sent | chain announce payload composite host_wait\n" % (commit, h) + "\n".join(rows) +
     "\n# the extra legs of the same invocation (BASELINE configs[3] at its 1900x1080 film; the weak-scaling soup):\n" + "\n".join(legs) +
     "\n# bench.py --domains 8 (one rank owns all 8 tiles): %.3f ms per frame, %s launch chains, %s host synchronisations\n"

@@ -1,6 +1,6 @@
 """Kernel timeline of ONE frame of a BASELINE configuration through the native tracer (rocprofv3 kernel trace).
    GPU box:  cd /tmp && rocprofv3 --kernel-trace --output-format csv -d OUT -o tl -- python3 $REPO/tools/config_timeline.py run <config> [opt=value ...]
-             python3 tools/config_timeline.py parse OUT        (config: 1 = bunny.conf, 4 = bunny grid, 5 = hall, 58 = hall in 8 slabs)"""
+             python3 tools/config_timeline.py parse OUT        (config: 1 = bunny.conf, 4 = bunny grid, 5 = hall, 58 = hall in 8 slabs, d8 = the benchmark soup in 8 domains)"""
 import csv, glob, os, re, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if sys.argv[1] == "run":
@@ -14,9 +14,10 @@ if sys.argv[1] == "run":
     golden = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
     hall = lambda n: (lambda one: one if n <= 1 else scenes.split_into_domains(one, n))(scenes.cathedral_scene(1024, 1024, samples=2, depth=2, eye=(0.0, 1.5, 13.0), light=(0.0, 2.5, 12.0)))
     sc, mode = {"1": lambda: (scenes.load_conf(os.path.join(golden, "bunny.conf")), NORMALS_SMOOTH), "4": lambda: (scenes.bunny_grid_scene(), NORMALS_SMOOTH),
-                "5": lambda: (hall(1), NORMALS_FLAT), "58": lambda: (hall(8), NORMALS_FLAT)}[cfg]()
+                "5": lambda: (hall(1), NORMALS_FLAT), "58": lambda: (hall(8), NORMALS_FLAT),
+                "d8": lambda: (scenes.soup_domains_scene(10_000_000, 8, 1920, 1080), NORMALS_FLAT)}[cfg]()   # bench.py --domains 8
     tr = NativeTracer(sc, mode)
-    for _ in range(6):
+    for _ in range(14):  # (finish_auto has settled by then)
         tr()
     capi.synchronize()
 else:
