@@ -24,7 +24,7 @@ if n["film"] > 1:
     N._random_scene = _big
 capi.init(0)
 import tests.helpers as _H
-_H.DEFAULT_RULE = "both"  # as tests/conftest.py does for the GPU tests: images against the STRICT checker (the reference's rule), ray counts against the restated shortcut
+_H.DEFAULT_RULE = "strict"  # as tests/conftest.py does for the GPU tests: the STRICT checker (the reference's hop-by-hop shuffle rule, the library's default)
 bad = 0
 for name, fn, cnt, base in (("queries", P.test_random_meshes_and_rays_against_the_oracle, n["queries"], 100), ("calls", P.test_random_adapter_calls_against_the_oracle, n["calls"], 100),
                             ("scenes", N.test_random_scenes_through_the_native_schedulers, n["scenes"], 100)):
