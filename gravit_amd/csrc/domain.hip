@@ -91,13 +91,16 @@ int rccl_load() {
     }                                                                                                      \
   } while (0)
 
-__global__ __launch_bounds__(256) void k_add_f32(float *__restrict__ dst, const float *__restrict__ src, unsigned long long n4) {
-  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  float4 a = ((float4 *)dst)[i];
-  const float4 b = ((const float4 *)src)[i];
-  a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-  ((float4 *)dst)[i] = a;
+// the in-process transport's receive side: every message a rank takes in one group, copied (or added, float by float) by ONE launch
+#define HUB_ITEMS 16
+struct HubItem { unsigned *dst; const unsigned *src; unsigned long long words; int accumulate; };
+struct HubBatch { int n; HubItem it[HUB_ITEMS]; };
+__global__ __launch_bounds__(256) void k_hub_gather(const HubBatch B) {
+  const HubItem I = B.it[blockIdx.y];
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < I.words; i += (unsigned long long)gridDim.x * blockDim.x) {
+    if (I.accumulate) ((float *)I.dst)[i] += ((const float *)I.src)[i];
+    else I.dst[i] = I.src[i];
+  }
 }
 } // namespace
 
@@ -117,6 +120,10 @@ struct gvt_hip_hub {
     std::atomic<int> state{ 0 }; // 0 empty, 1 posted (ptr / bytes / ready valid), 2 consumed (copied valid)
   };
   std::unique_ptr<Slot[]> slots; // [dst * world + src]; a slot has ONE writer per state: the sender for 0 -> 1 and 2 -> 0, the receiver for 1 -> 2
+  // ONE event pair per RANK and group, not per message: a rank records `sent[r]` once when its outgoing buffers are complete and `taken[r]` once
+  // behind the one kernel that gathers everything it receives (the slots point at them).  An 8-rank announce was 7 records + 7 copies + 7 records
+  // per rank and tick; it is 1 + 1 kernel + 1.
+  std::unique_ptr<hipEvent_t[]> sent, taken;
   std::atomic<bool> aborted{ false };
 };
 namespace {
@@ -160,6 +167,8 @@ extern "C" gvt_hip_hub *gvt_hip_hub_create(int world) {
   gvt_hip_hub *H = new gvt_hip_hub();
   H->world = world;
   H->slots.reset(new gvt_hip_hub::Slot[(size_t)world * world]);
+  H->sent.reset(new hipEvent_t[world]());
+  H->taken.reset(new hipEvent_t[world]());
   return H;
 }
 extern "C" void gvt_hip_hub_abort(gvt_hip_hub *H) { // every rank waiting in an exchange sees it (a rank failed)
@@ -167,7 +176,7 @@ extern "C" void gvt_hip_hub_abort(gvt_hip_hub *H) { // every rank waiting in an 
 }
 extern "C" void gvt_hip_hub_destroy(gvt_hip_hub *H) {
   if (!H) return;
-  for (size_t k = 0; k < (size_t)H->world * H->world; k++) { auto &s = H->slots[k]; if (s.ready) hipEventDestroy(s.ready); if (s.copied) hipEventDestroy(s.copied); }
+  for (int r = 0; r < H->world; r++) { if (H->sent[r]) hipEventDestroy(H->sent[r]); if (H->taken[r]) hipEventDestroy(H->taken[r]); }
   delete H;
 }
 
@@ -342,28 +351,51 @@ int hub_group_end(gvt_hip_comm *K) {
     if (H->aborted.load()) { set_error("hub: aborted"); K->dead = true; return GVT_HIP_ERR_TIMEOUT; }
     return comm_timed_out(K, what, nullptr);
   };
-  // 1. post every send (the slot is free: the previous group waited for its consumption)
+  bool any_send = false, any_recv = false;
+  for (auto &o : K->ops) { any_send = any_send || o.send; any_recv = any_recv || !o.send; }
+  if (!H->sent[me]) { HIPCHK(hipEventCreateWithFlags(&H->sent[me], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&H->taken[me], hipEventDisableTiming)); }
+  // 1. post every send behind ONE event (the slots are free: the previous group waited for their consumption)
+  if (any_send) HIPCHK(hipEventRecord(H->sent[me], K->stream));
   for (auto &o : K->ops) {
     if (!o.send) continue;
     gvt_hip_hub::Slot &s = H->slots[(size_t)o.peer * W + me];
     if (!hub_await(H, s.state, 0, K->deadline_ms)) return gone("a free send slot (in-process transport)");
-    if (!s.ready) { hipEventCreateWithFlags(&s.ready, hipEventDisableTiming); hipEventCreateWithFlags(&s.copied, hipEventDisableTiming); }
-    HIPCHK(hipEventRecord(s.ready, K->stream));
+    s.ready = H->sent[me];
     s.ptr = o.ptr; s.bytes = o.bytes;
     s.state.store(1, std::memory_order_release);
   }
-  // 2. every receive: wait for the matching send, copy behind its event
+  // 2. every receive: wait for the matching send, then ONE kernel gathers them all (word copies, or float adds for a reduce) behind the senders' events
+  HubBatch B;
+  B.n = 0;
+  unsigned long long max_words = 0;
+  auto flush = [&]() -> int {
+    if (!B.n) return 0;
+    const unsigned gx = (unsigned)std::min<unsigned long long>(4096ull, (max_words + 255ull) / 256ull);
+    k_hub_gather<<<dim3(gx ? gx : 1u, (unsigned)B.n), 256, 0, K->stream>>>(B);
+    HIPCHK(hipGetLastError());
+    B.n = 0; max_words = 0;
+    return 0;
+  };
   for (auto &o : K->ops) {
     if (o.send) continue;
     gvt_hip_hub::Slot &s = H->slots[(size_t)me * W + o.peer];
     if (!hub_await(H, s.state, 1, K->deadline_ms)) return gone("a peer's matching send (in-process transport)");
     if (s.bytes != o.bytes) { set_error("hub: rank %d expects %zu bytes from %d, which sends %zu", me, o.bytes, o.peer, s.bytes); H->aborted.store(true); return GVT_HIP_ERR_INVALID; }
+    if (o.bytes & 3u) { set_error("hub: message of %zu bytes is not a multiple of 4", o.bytes); H->aborted.store(true); return GVT_HIP_ERR_INVALID; }
     HIPCHK(hipStreamWaitEvent(K->stream, s.ready, 0));
     if (o.bytes) {
-      if (o.accumulate) k_add_f32<<<(unsigned)((o.bytes / 16 + 255) / 256), 256, 0, K->stream>>>((float *)o.ptr, (const float *)s.ptr, o.bytes / 16);
-      else HIPCHK(hipMemcpyAsync(o.ptr, s.ptr, o.bytes, hipMemcpyDeviceToDevice, K->stream));
+      if (B.n == HUB_ITEMS || o.accumulate) { int rc = flush(); if (rc) return rc; } // (adds into one destination from several peers: one launch each, in rank order)
+      B.it[B.n++] = HubItem{ (unsigned *)o.ptr, (const unsigned *)s.ptr, (unsigned long long)(o.bytes / 4), o.accumulate };
+      max_words = std::max<unsigned long long>(max_words, o.bytes / 4);
+      if (o.accumulate) { int rc = flush(); if (rc) return rc; }
     }
-    HIPCHK(hipEventRecord(s.copied, K->stream));
+  }
+  { int rc = flush(); if (rc) return rc; }
+  if (any_recv) HIPCHK(hipEventRecord(H->taken[me], K->stream));
+  for (auto &o : K->ops) {
+    if (o.send) continue;
+    gvt_hip_hub::Slot &s = H->slots[(size_t)me * W + o.peer];
+    s.copied = H->taken[me];
     s.state.store(2, std::memory_order_release);
   }
   // 3. own sends consumed: later work on this stream must not overwrite a buffer that is still being read
