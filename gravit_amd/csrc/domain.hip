@@ -675,15 +675,61 @@ template <bool ADD> __global__ __launch_bounds__(256) void k_rect(float4 *__rest
   if (ADD) { float4 a = fb[px]; const float4 b = buf[i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; fb[px] = a; }
   else buf[i] = fb[px];
 }
-// behind an announce exchange: the peers' rows (without their inline areas) and this rank's report gathered into the host's pinned mirror,
-// the sequence word released last -- the host polls it (no device-to-host copy, no event, no interrupt between the exchange and the vote)
-__global__ __launch_bounds__(256) void k_publish(const int *__restrict__ ann_in, int msg_ints, int row, int world, const unsigned *__restrict__ report, int n_rep,
-                                                  int *h_ann, unsigned *h_report, unsigned seq) {
-  for (int k = threadIdx.x; k < world * row; k += blockDim.x) h_ann[k] = ann_in[(size_t)(k / row) * msg_ints + (k % row)];
-  for (int k = threadIdx.x; k < n_rep; k += blockDim.x) h_report[k] = report[k];
-  __threadfence_system();
+// behind an announce exchange, ONE launch of `world` blocks: block `rank` gathers the peers' rows (without their inline areas) and this rank's
+// report into the host's pinned mirror and releases the sequence word last -- the host polls it (no device-to-host copy, no event, no interrupt
+// between the exchange and the vote); block p != rank appends the payload peer p sent INLINE behind its row to this rank's queues, where it
+// arrived (no separate unpack launch, and the append overlaps the host's wake-up).  Slots are deterministic: a queue's incoming rays lie behind
+// its current ones in peer order; every thread reads the count words as its base and the LAST block to finish advances them (ticket).
+__global__ __launch_bounds__(256) void k_publish(const int *__restrict__ ann_in, int msg_ints, int row, int world, int rank, const unsigned *__restrict__ report, int n_rep,
+                                                  int *h_ann, unsigned *h_report, unsigned seq, const QueueDesc *__restrict__ qd, int n_inst, unsigned *__restrict__ err,
+                                                  unsigned *ticket) {
+  const int p = (int)blockIdx.x;
+  if (p == rank) {
+    for (int k = threadIdx.x; k < world * row; k += blockDim.x) h_ann[k] = ann_in[(size_t)(k / row) * msg_ints + (k % row)];
+    for (int k = threadIdx.x; k < n_rep; k += blockDim.x) h_report[k] = report[k];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(h_report + n_rep, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else if (qd && ann_in[(size_t)p * msg_ints + 10] > 0) {
+    const int *head = ann_in + (size_t)p * msg_ints;
+    const unsigned *buf = (const unsigned *)(head + row);
+    unsigned off = 0;
+    for (int i = 0; i < n_inst; i++) {
+      const unsigned n = (unsigned)head[ANN_HEAD + i];
+      if (!n) continue;
+      unsigned prior = 0; // rays of earlier peers' inline payloads bound for the same queue
+      for (int pp = 0; pp < p; pp++)
+        if (pp != rank && ann_in[(size_t)pp * msg_ints + 10] > 0) prior += (unsigned)ann_in[(size_t)pp * msg_ints + ANN_HEAD + i];
+      const QueueDesc Q = qd[i];
+      const unsigned long long base = (unsigned long long)__hip_atomic_load(Q.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + prior;
+      const RayPlanes q = make_planes(Q.planes, Q.cap);
+      if (threadIdx.x < 2 && buf[off + threadIdx.x] != (threadIdx.x == 0 ? (unsigned)i : n)) atomicOr(err, 2u); // in-band header disagrees with the row
+      if (base + n > Q.cap) { if (threadIdx.x == 0) atomicOr(err, 1u); }
+      else
+        for (unsigned l = threadIdx.x; l < 20u * n; l += blockDim.x) {
+          const unsigned ray = l / 20u, w = l % 20u, v = buf[off + 2u + l];
+          const unsigned long long slot = base + ray;
+          if (w < 16) { float4 *pl = w < 4 ? q.p0 : w < 8 ? q.p1 : w < 12 ? q.p2 : q.p3; ((unsigned *)(pl + slot))[w & 3] = v; }
+          else if (w == 16) q.p4[slot] = v;
+          else q.p5[3 * (size_t)slot + (w - 17)] = v;
+        }
+      off += 2u + 20u * n;
+    }
+  }
+  if (!qd) return;
+  __shared__ unsigned sh_ticket;
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(h_report + n_rep, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) { __threadfence(); sh_ticket = atomicAdd(ticket, 1u); }
+  __syncthreads();
+  if (sh_ticket != gridDim.x - 1) return;
+  __threadfence();
+  for (int i = threadIdx.x; i < n_inst; i += blockDim.x) {
+    unsigned tot = 0;
+    for (int pp = 0; pp < world; pp++)
+      if (pp != rank && ann_in[(size_t)pp * msg_ints + 10] > 0) tot += (unsigned)ann_in[(size_t)pp * msg_ints + ANN_HEAD + i];
+    if (tot) atomicAdd(qd[i].count, tot);
+  }
+  if (threadIdx.x == 0) *ticket = 0u;
 }
 // start of a frame: ray totals, flags, the work counter of the first small chain, the deposit rectangle (empty) and the kernels' tickets
 // a frame's resets in one launch: every queue.clear() (count words) and the frame's totals / flags / deposit rectangle
@@ -691,7 +737,7 @@ __global__ void k_zero_totals(unsigned *c, unsigned *ovf, int fb_w, int fb_h, un
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_inst; i += gridDim.x * blockDim.x) *count_ptr[i] = 0u;
   if (blockIdx.x) return;
   if (threadIdx.x < 4) c[16 + threadIdx.x] = 0u;
-  if (threadIdx.x == 4) { *ovf = 0u; c[9] = 0u; c[0] = 0u; ovf[10] = 0u; ovf[11] = 0u; c[3] = 0u; c[20] = 0u; }
+  if (threadIdx.x == 4) { *ovf = 0u; c[9] = 0u; c[0] = 0u; ovf[10] = 0u; ovf[11] = 0u; ovf[12] = 0u; c[3] = 0u; c[20] = 0u; }
   if (threadIdx.x == 5) { int *bb = (int *)(ovf + 4); bb[0] = fb_w; bb[1] = fb_h; bb[2] = 0; bb[3] = 0; }
 }
 } // namespace
@@ -930,9 +976,10 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
     if (want > R->queues[i]->cap) growth += (want - R->queues[i]->cap) * GVT_QUEUE_BYTES_PER_RAY;
   }
   const bool exact = growth > ((size_t)(C.round_room_mb > 0 ? C.round_room_mb : 1) << 20) && !count_on_device;
+  const size_t inline_room = (R->world > 1 && R->owned.size()) ? (size_t)(R->world - 1) * (R->inl_bytes / 80) : 0; // what k_publish may append behind this tick's exchange
   for (size_t i = 0; i < nI; i++) {
     const size_t stay = R->h_mask[i] ? 0 : R->present[i];
-    if ((rc = queue_reserve(R->queues[i], stay + (exact ? 0 : bound) + (extra_in ? (*extra_in)[i] : 0)))) return rc;
+    if ((rc = queue_reserve(R->queues[i], stay + (exact ? 0 : bound) + (extra_in ? (*extra_in)[i] : 0) + (R->owned[i] ? inline_room : 0)))) return rc;
   }
   for (int k = 0; k < n_seg; k++) { // (a reserve above may have moved a traced queue)
     gvt_hip_queue *q = R->queues[R->h_segs[k].inst];
@@ -1011,6 +1058,11 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_e
   const bool scan = exchange && R->world > 1;
   const unsigned n_blk = scan ? (unsigned)std::min<size_t>(1024, ((size_t)R->fb->w * R->fb->h + 1023) / 1024) : 1u;
   if (scan && R->inl_bytes) { // the inline pack reads the outgoing queues through the descriptor table: current? (a reserve may have moved one since the last chain)
+    // ... and k_publish appends what arrives inline to the owned queues: room for every peer's full inline area, beyond what they hold (a tick
+    // in which a chain ran has it already: local_chain reserves the same slack on top of the round's bound)
+    const size_t inline_room = (size_t)(R->world - 1) * (R->inl_bytes / 80);
+    for (size_t i = 0; i < nI; i++)
+      if (R->owned[i]) { int rc_q = queue_reserve(R->queues[i], R->queues[i]->size + inline_room); if (rc_q) return rc_q; }
     for (size_t i = 0; i < nI; i++) { gvt_hip_queue *Q = R->queues[i]; R->h_qdesc[i].planes = Q->d_planes; R->h_qdesc[i].cap = Q->cap; R->h_qdesc[i].count = Q->d_count; R->h_qdesc[i].keep = 1u; }
     int rc_up = round_tables_upload(R, st);
     if (rc_up) return rc_up;
@@ -1036,7 +1088,8 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_e
     // behind the exchange ONE small kernel gathers the peers' rows and this rank's report into the pinned mirror and releases the
     // sequence word; the host waits for that word with loads (bounded: a peer that never joins the exchange must not hang this rank)
     const unsigned seq = ++R->report_seq;
-    k_publish<<<1, 256, 0, K->stream>>>(R->d_ann_in, (int)R->msg_ints, (int)row, R->world, R->d_report, (int)(nI + REPORT_TAIL - 1), R->h_ann_in, R->h_report, seq);
+    k_publish<<<(unsigned)R->world, 256, 0, K->stream>>>(R->d_ann_in, (int)R->msg_ints, (int)row, R->world, R->rank, R->d_report, (int)(nI + REPORT_TAIL - 1), R->h_ann_in, R->h_report,
+                                                         seq, R->inl_bytes ? R->d_qdesc : nullptr, (int)nI, R->d_overflow, R->d_overflow + 12);
     HIPCHK(hipGetLastError());
     if (timing) HIPCHK(hipEventRecord(R->ev_report, K->stream));
     {
@@ -1218,8 +1271,8 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     for (int p = 0; p < R->world; p++) {
       if (p == R->rank) continue;
       const int *a = pending_ann.data() + (size_t)p * row;
-      // the peer's payload arrived inside its announce (behind the row, in this rank's receive block) or in the payload exchange
-      char *src = a[10] ? (char *)(R->d_ann_in + (size_t)p * R->msg_ints + row) : (char *)R->recv_buf[p];
+      if (a[10]) continue; // arrived inside the announce: k_publish appended it where it arrived
+      char *src = (char *)R->recv_buf[p];
       size_t off = 0;
       for (size_t i = 0; i < nI; i++) {
         const unsigned n = (unsigned)a[ANN_HEAD + i];
@@ -1310,15 +1363,18 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     std::vector<size_t> bytes_out(R->world, 0), bytes_in(R->world, 0);
     WireBatch PB;
     PB.n_items = 0; PB.total = 0;
-    bool any_inline = false;
     for (int p = 0; p < R->world; p++) {
       if (p == R->rank) continue;
       for (size_t i = 0; i < nI; i++) if (R->owner[i] == p && R->present[i]) bytes_out[p] += 8 + 80 * R->present[i];
       bytes_in[p] = (size_t)(unsigned)R->h_ann_in[(size_t)p * row + 1];
       const size_t inl_in = (size_t)(unsigned)R->h_ann_in[(size_t)p * row + 10];
-      if (inl_in) { // this peer's rays are already here, behind its row
+      if (inl_in) { // this peer's rays are already here: k_publish has appended them to their queues on the device
         if (inl_in != bytes_in[p] || inl_in > R->inl_bytes) { set_error("ray exchange: rank %d announces %zu inline bytes of %zu (inline area %zu)", p, inl_in, bytes_in[p], R->inl_bytes); return GVT_HIP_ERR_DEVICE; }
-        bytes_in[p] = 0; any_inline = true;
+        bytes_in[p] = 0;
+        for (size_t i = 0; i < nI; i++) {
+          const unsigned n_in = (unsigned)R->h_ann_in[(size_t)p * row + ANN_HEAD + i];
+          if (n_in) { R->present[i] += n_in; R->queues[i]->size = R->present[i]; }
+        }
       }
       if (bytes_out[p] && bytes_out[p] <= R->inl_bytes) { // k_round_report applied the same rule: these rays left inside the announce, their queues are cleared
         S.bytes_sent += bytes_out[p];
@@ -1349,14 +1405,13 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     if ((rc = wire_flush(PB, false))) return rc;
     pending_ann.assign(R->h_ann_in, R->h_ann_in + (size_t)R->world * row);
     for (int p = 0; p < R->world; p++)
-      if (p != R->rank)
+      if (p != R->rank && !pending_ann[(size_t)p * row + 10]) // (inline payloads are in their queues already)
         for (size_t i = 0; i < nI; i++) incoming[i] += (unsigned)pending_ann[(size_t)p * row + ANN_HEAD + i];
-    // room for what arrives (or has arrived inline), reserved now (the unpack kernels are launched in the next tick)
-    if (any_traffic || any_inline)
+    // room for what arrives in the payload exchange, reserved now (the unpack kernel is launched in the next tick)
+    if (any_traffic)
       for (size_t i = 0; i < nI; i++)
         if (incoming[i] && (rc = queue_reserve(R->queues[i], R->present[i] + incoming[i]))) return rc;
     payload_cross = false;
-    if (any_inline) payload_pending = true;
     if (any_traffic) {
       // A payload of a megabyte or more moves on the communicator's OWN stream, while the next tick's local chain runs on the compute
       // stream (ordered by two events); smaller ones -- every late tick of a frame -- stay on the compute stream (StreamBind above).
