@@ -341,13 +341,15 @@ def measure_variant(run_frame, frame_stats, steps, warmup, barrier, reduce_sum, 
             sums[k] = sums.get(k, 0) + v
     barrier()
     elapsed = time.perf_counter() - t0
-    tot = reduce_sum([float(sums.get(k, 0)) for k in ("rays_closest", "rays_any", "rays_sent", "bytes_sent")])
-    mx = reduce_max([elapsed] + [float(sums.get(k, 0.0)) for k in PHASES] + [float(sums.get(k, 0)) for k in ("rounds", "chains", "host_syncs")])
+    tot = reduce_sum([float(sums.get(k, 0)) for k in ("rays_closest", "rays_any", "rays_sent", "bytes_sent", "rays_inline")])
+    mx = reduce_max([elapsed] + [float(sums.get(k, 0.0)) for k in PHASES] + [float(sums.get(k, 0)) for k in ("rounds", "chains", "host_syncs", "exchanges")])
     ticks = mx[1 + len(PHASES)] / steps
     res = {"value": (tot[0] + tot[1]) / mx[0] / 1e6, "unit": "Mrays/s", "ms_per_step": mx[0] / steps * 1e3,
            "ticks_per_step": ticks, "ms_per_tick": (mx[0] / steps * 1e3 / ticks) if ticks else None,
            "launch_chains_per_step": mx[2 + len(PHASES)] / steps, "host_syncs_per_step": mx[3 + len(PHASES)] / steps,
            "rays_sent_per_step": tot[2] / steps, "bytes_sent_per_step": tot[3] / steps,
+           "rays_sent_inline_per_step": tot[4] / steps,  # of rays_sent: rays that travelled inside an announce (one transport group per tick)
+           "transport_groups_per_step": mx[4 + len(PHASES)] / steps,  # ncclGroupStart .. End per rank and frame (max over ranks), composite included
            "phase_ms_per_step_max_over_ranks": {k[3:]: mx[1 + i] / steps for i, k in enumerate(PHASES)}}
     return res, sums, mx[0], tot
 
@@ -445,6 +447,7 @@ def run_inproc(scene, owner, N, mode, call, replicate, args, roofline=False):
            "launch_chains_per_step": mx("chains") / args.steps, "host_syncs_per_step": mx("host_syncs") / args.steps,
            "rays_per_step": (tot("rays_closest") + tot("rays_any")) / args.steps,
            "rays_sent_per_step": tot("rays_sent") / args.steps, "bytes_sent_per_step": tot("bytes_sent") / args.steps,
+           "rays_sent_inline_per_step": tot("rays_inline") / args.steps, "transport_groups_per_step": mx("exchanges") / args.steps,
            "phase_ms_per_step_max_over_ranks": {k[3:]: mx(k) / args.steps for k in PHASES}}
     if roofline:
         res["roofline_per_rank"] = [per_rank[r][2] for r in range(N)]
