@@ -42,6 +42,10 @@ struct Knobs {
   int packet = 1;        // scheduler rounds: camera rays in tile order (and their direct-mapped shadow rays) traversed a packet of 64 per wave (k_packet): 0 never,
                          // 1 on meshes the builder found packet-friendly (gvt_hip_mesh::packet_ok), 2 always.  4-10 % faster on surfaces (bun_zipper, the hall),
                          // 2.5x-20x SLOWER on the random soups (EXPERIMENTS.md): hence the per-mesh choice
+  int fused1 = 0;        // experiments build: one-instance depth-1 frames with one point / ambient light and a Lambert mesh material run the whole adapter call in ONE
+                         // launch (k_frame1: closest hit -> lean shade -> the lane goes on with its shadow ray -> deposit).  Bit-exact, and SLOWER: 1.19-1.27 ms per
+                         // benchmark frame against 0.94 for the three launches (EXPERIMENTS.md round 5): closest-hit and any-hit work co-resident costs more than the tails
+  int fused1_min_rays = 65536; // ... in launches of at least this many rays
   int packet_min_rays = 524288; // ... and only in launches of at least this many rays (bound): a small launch is a few thousand packets, each a long serial walk
   int packet_sah_max = 128; // meshes created afterwards: packet-friendly when sum(area(inner node)) / area(root) is at most this (lbvh.hip k_sah_sum)
   int round_room_mb = 16384; // scheduler rounds: memory the worst-case reservation of the destination queues may add (MiB); beyond it the round shuffles with exact growth
@@ -111,6 +115,8 @@ struct Ctx : Knobs {
   // light list of the last trace call (uploaded only when it changes)
   std::vector<unsigned char> lights_cached;
   const void *lights_cached_dst = nullptr;
+  std::vector<unsigned char> frame1_cached; // k_frame1's shading constants as last uploaded (trace.hip)
+  const void *frame1_cached_dst = nullptr;
   // staging queues of gvt_hip_trace (host RayVector in / out)
   gvt_hip_queue *abi_qin = nullptr, *abi_qout = nullptr;
   std::vector<Ctx *> abi_lanes; // contexts of the pipelined host path's lanes (api.hip trace_pipelined), created on first use

@@ -67,6 +67,10 @@ struct Trav {
 #include "finish_kernel.inc" // k_finish: a small round in one launch, every ray followed to its end on this rank
 
 #ifdef GVT_EXPERIMENTS
+#include "experiments/fused_lean.inc" // k_frame1: closest hit + Lambert / point-light shade + shadow ray + deposit of a one-instance depth-1 frame in ONE launch (measured slower, EXPERIMENTS.md; knob `fused1`)
+#endif
+
+#ifdef GVT_EXPERIMENTS
 #include "experiments/fused_kernel.inc" // k_fused: the one-kernel closest + shade + shadow variant (measured slower, EXPERIMENTS.md; knob `fused`)
 #endif
 
@@ -555,6 +559,34 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       // ... the CLOSEST hit, that is.  Shadow rays as packets lost on both surfaces they were measured on (bun_zipper any hit 0.162 -> 0.189 ms, the hall
       // 1.23 -> 1.33: an any-hit packet goes on until its LAST ray is occluded or through): under the per-mesh choice they stay a lane per ray; 2 forces both
       const bool pkt_any = pkt && C.packet == 2;
+#ifdef GVT_EXPERIMENTS
+      // the whole adapter call in ONE launch (experiments/fused_lean.inc; measured 1.19-1.27 ms per benchmark frame against 0.94 for the three launches) where the frame is the simple case: one instance in the scene, camera rays, depth 1, one
+      // point / ambient light, a Lambert mesh material, the terminal sink on
+      const bool lean1 = C.fused1 && !pkt && single->coherent && pass == 0 && passes == 1 && have4 && !small1 && nL == 1 && lights_host[0].type != GVT_HIP_LIGHT_AREA &&
+                         P.sink.fb && P.sink.top.n_inst == 1 && !M->d_vcolors && !M->d_face_mat && M->mesh_mat.type == 0 && n >= (size_t)C.fused1_min_rays;
+      if (lean1) {
+        ProfScope ps(KC_CLOSEST);
+        Frame1Shade K;
+        std::memset(&K, 0, sizeof K);
+        K.normi = single->normi; K.kd[0] = M->mesh_mat.kd[0]; K.kd[1] = M->mesh_mat.kd[1]; K.kd[2] = M->mesh_mat.kd[2]; K.normal_mode = P.normal_mode;
+        K.slot_of = M->d_slot_of; K.tri_idx = M->d_tris; K.normals = M->d_normals; K.p3 = single->planes.p3; K.light = lights_host[0]; K.fb = P.sink.fb; K.n_pix = P.sink.n_pix;
+        Frame1Shade *d_K = (Frame1Shade *)scratch_get(22, sizeof K);
+        if (!d_K) return GVT_HIP_ERR_DEVICE;
+        if (C.frame1_cached_dst != d_K || C.frame1_cached.size() != sizeof K || std::memcmp(C.frame1_cached.data(), &K, sizeof K) != 0) { // (uploaded when it changes: steady-state frames skip it)
+          C.frame1_cached.assign((const unsigned char *)&K, (const unsigned char *)&K + sizeof K);
+          C.frame1_cached_dst = d_K;
+          HIPCHK(hipMemcpyAsync(d_K, C.frame1_cached.data(), sizeof K, hipMemcpyHostToDevice, st));
+          HIPCHK(hipStreamSynchronize(st)); // pageable source
+        }
+        Frame1Args F;
+        F.p0 = single->planes.p0; F.p1 = single->planes.p1; F.n = (unsigned)n; F.n_dev = n_dev; F.minv = single->minv; F.nodes4 = M->d_nodes4; F.tris = M->d_tri;
+        F.tnear = GVT_RAY_EPSILON; F.counter = c + 0; F.spill_base = C.d_spill; F.refill_min = C.refill_min; F.inner_min = C.inner_min; F.shade = d_K;
+        k_frame1<<<trav_grid2(n, true), TRAV_BLOCK, 0, st>>>(F);
+        HIPCHK(hipGetLastError());
+        C.stats.launches_closest++;
+        continue;
+      }
+#endif
       if (pkt) {
         ProfScope ps(KC_CLOSEST);
         LongQ LP{ d_long, c + 3, nullptr, 0u, 0, 0 };

@@ -81,11 +81,11 @@ def test_quad_kernel_on_surface_meshes_and_deep_stacks(hip, name):
 
 @pytest.mark.parametrize("opts", [dict(first_round_async=0), dict(wave_single=0), dict(shadow_direct=0), dict(small_rays=1 << 30, wave_single=0), dict(blocks_per_cu_closest=0, term_sink=0),
                                   dict(lean_frame=0), dict(report_poll=0), dict(lean_frame=0, report_poll=0, first_round_async=0), dict(sort_rays=1, camera_tile=0),
-                                  dict(packet=2), dict(packet=2, camera_tile=0), dict(first_round_async=1, packet=2), dict(fused=1), dict(quad=1, leaf_max=4),
+                                  dict(packet=2), dict(packet=2, camera_tile=0), dict(first_round_async=1, packet=2), dict(fused=1), dict(fused1=1, fused1_min_rays=0), dict(fused1=1, fused1_min_rays=0, packet=0), dict(quad=1, leaf_max=4),
                                   dict(quad=1, leaf_max=2, small_rays=0), dict(quad=1, leaf_max=4, wave_single=0, shadow_direct=0)])
 def test_round_results_do_not_depend_on_experimental_variants(hip, opts):
     for sc, mode, tol in ((config5(192, 4), NORMALS_FLAT, 1e-5), (scenes.bunny_grid_scene(width=380, height=216), NORMALS_SMOOTH, 0.0),
-                          (scenes.soup_scene(100_000, 160, 90), NORMALS_FLAT, 0.0)):
+                          (scenes.soup_scene(100_000, 160, 90), NORMALS_FLAT, 0.0), (scenes.bunny_scene(256, 256), NORMALS_SMOOTH, 0.0)):
         ref, st = oracle_render(sc, mode, nthreads=8)
         try:
             for k, v in opts.items():
