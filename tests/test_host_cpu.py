@@ -171,3 +171,69 @@ def test_simd_cpu_baseline_library_loads_and_answers_a_tiny_tree():
     t, prim, u, v = T.intersect(org, d, nthreads=2)
     assert prim.tolist() == [7, -1] and t[0] == np.float32(1.0) and (u[0], v[0]) == (np.float32(0.25), np.float32(0.25))
     assert T.occluded(org, d).tolist() == [True, False]
+
+
+def test_cost_optimal_wide_collapse_tool_on_a_random_tree(tmp_path):
+    """tools/wide_dp.c (the measurement tool behind profiles/r05_wide_dp.txt): on a random binary tree the dynamic programme's collapse never has
+    more than W children per wide node, covers the tree (every leaf is reached through marked roots), costs no more than the greedy collapse the
+    4-wide layout is built with, and its PLOC rebuild returns a tree over the same leaves."""
+    import ctypes as C
+    import subprocess
+    import sys
+
+    so = str(tmp_path / "libwide_dp.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tools", "wide_dp.c"), "-lm"])
+    lib = C.CDLL(so)
+    rng = np.random.default_rng(7)
+    n_leaves = 2000
+    pts = rng.random((n_leaves, 3)).astype(np.float32)
+    nodes = []
+    sys.setrecursionlimit(20000)
+
+    def rec(idx):  # random-split binary tree; returns (ref, lo, hi); leaf refs are negative like the library's
+        if len(idx) == 1:
+            return ~int(idx[0] * 8 + 1), pts[idx[0]] - 0.01, pts[idx[0]] + 0.01
+        ax = int(np.argmax(pts[idx].max(0) - pts[idx].min(0)))
+        order = idx[np.argsort(pts[idx, ax])]
+        h = int(rng.integers(1, len(order)))
+        me = len(nodes)
+        nodes.append(None)
+        a, b = rec(order[:h]), rec(order[h:])
+        row = np.zeros(16, np.float32)
+        for s_, (_, lo, hi) in enumerate((a, b)):
+            row[4 * s_:4 * s_ + 4] = (lo[0], hi[0], lo[1], hi[1])
+            row[8 + 2 * s_:10 + 2 * s_] = (lo[2], hi[2])
+        row.view(np.int32)[12:14] = (a[0], b[0])
+        nodes[me] = row
+        return me, np.minimum(a[1], b[1]), np.maximum(a[2], b[2])
+
+    rec(np.arange(n_leaves))
+    tree = np.ascontiguousarray(np.stack(nodes))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+
+    def sah(marks):  # sum of the marked nodes' areas (the root's from its children's union), as the tool defines its cost
+        area = np.zeros(len(tree))
+        r = tree[0]
+        d = [max(r[1], r[5]) - min(r[0], r[4]), max(r[3], r[7]) - min(r[2], r[6]), max(r[9], r[11]) - min(r[8], r[10])]
+        area[0] = d[0] * d[1] + d[1] * d[2] + d[2] * d[0]
+        for k, row in enumerate(tree):
+            c = row.view(np.int32)[12:14]
+            for s_ in range(2):
+                if c[s_] >= 0:
+                    dx, dy, dz = row[4 * s_ + 1] - row[4 * s_], row[4 * s_ + 3] - row[4 * s_ + 2], row[9 + 2 * s_] - row[8 + 2 * s_]
+                    area[c[s_]] = dx * dy + dy * dz + dz * dx
+        return float(area[marks.astype(bool)].sum() / area[0])
+
+    for W in (4, 8):
+        marks, greedy, st = np.zeros(len(tree), np.uint8), np.zeros(len(tree), np.uint8), np.zeros(4 + 17)
+        assert lib.wide_dp(p(tree), C.c_int64(len(tree)), C.c_int(W), p(marks), p(st)) == 0
+        assert lib.wide_greedy(p(tree), C.c_int64(len(tree)), C.c_int(W), p(greedy)) == 0
+        assert marks[0] == 1 and greedy[0] == 1
+        assert st[4 + W + 1:].sum() == 0 and st[4:4 + W + 1].sum() == st[0] == marks.sum()     # every wide node has 2..W children
+        assert abs(st[1] - (marks.sum() - 1 + n_leaves)) < 0.5                                  # children = the other roots + all leaves: the tree is covered
+        assert abs(sah(marks) - st[2]) < 1e-3 * st[2] and sah(marks) <= sah(greedy) * (1 + 1e-6)  # never dearer than the greedy collapse
+    out = np.zeros_like(tree)
+    assert lib.ploc_rebuild(p(tree), C.c_int64(len(tree)), C.c_int(8), p(out)) == 0
+    refs = out.view(np.int32)[:, 12:14].reshape(-1)
+    assert sorted(refs[refs < 0].tolist()) == sorted(tree.view(np.int32)[:, 12:14].reshape(-1)[tree.view(np.int32)[:, 12:14].reshape(-1) < 0].tolist())
+    assert sorted(refs[refs >= 0].tolist()) == list(range(1, len(tree)))                         # every inner node but the root is some node's child

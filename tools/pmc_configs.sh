@@ -2,12 +2,12 @@
 # rocprofv3 counter passes over ONE configuration of tools/bench_configs.py (counters for the configurations packets and child
 # ordering were judged on):  bash tools/pmc_configs.sh <config number> <tag>   -> gpurun_out/pmc_cfg<N>/, summary profiles/<tag>_pmc_cfg<N>.json
 # Separate passes per counter group (FETCH_SIZE and WRITE_SIZE do not share a pass), never combined with a trace domain; the program follows `--`.
-CFG=$1; TAG=${2:-r05}
+CFG=$1; TAG=${2:-r05}; shift; shift   # further arguments: opt=value for tools/bench_configs.py (GVT_HIP_LIB in the environment selects the library)
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/pmc_cfg$CFG
+OUT=$REPO/gpurun_out/pmc_${TAG}_cfg$CFG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="only=$CFG frames=5 noref=1"
+ARGS="only=$CFG frames=5 noref=1 $@"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $REPO/tools/bench_configs.py $ARGS roofline=1 > $OUT/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES" \
          "TCP_TCP_LATENCY_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum"; do
@@ -34,7 +34,7 @@ for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
         e[0] += float(r["Counter_Value"] or 0); e[1] += 1
 res = {}
 for k, cs in pmc.items():
-    if not k.startswith(("k_trace", "k_packet", "k_long", "k_shade", "k_wave_any")): continue
+    if not k.startswith(("k_trace", "k_packet", "k_long", "k_shade", "k_wave_any", "k_frame1", "k_finish")): continue
     e = {c: v[0] / max(1, v[1]) for c, v in cs.items()}   # per launch
     e["launches_counted"] = max(v[1] for v in cs.values())
     if k in dur: e["avg_launch_us_trace_pass"] = sum(dur[k]) / len(dur[k]) / 1e3; e["launches_trace_pass"] = len(dur[k])
