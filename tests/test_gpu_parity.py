@@ -223,8 +223,12 @@ def test_random_meshes_and_rays_against_the_oracle(hip, seed):
     d[inpl] = (tgt[inpl, 1] - tgt[inpl, 0]) + 1e-30
     nrm = np.linalg.norm(d, axis=1, keepdims=True)
     d = np.where(nrm > 0, d / np.maximum(nrm, 1e-300), [0.0, 0.0, 1.0]).astype(np.float32)
-    assert_hits_equal(ad.intersect(org, d), om.intersect(org, d))
-    assert (ad.occluded(org, d) == om.occluded(org, d)).all()
+    # the reference is the DEFINITION: the arg-min of the triangle test over all triangles (the checker's brute-force loop), not the checker's own
+    # tree -- where the test's t is noise (a ray through a vertex almost in the triangle's plane) a tree's culling order decides between duplicates
+    brute = om.intersect(org, d, use_bvh=False)
+    assert_hits_equal(ad.intersect(org, d), brute)
+    assert_hits_equal(om.intersect(org, d), brute)
+    assert (ad.occluded(org, d) == om.occluded(org, d, use_bvh=False)).all()
 
 
 def test_mesh_create_rejects_bad_input(hip):
