@@ -60,6 +60,9 @@ static inline int tri_test_raw(V3 O, V3 D, V3 v0, V3 e1, V3 e2, V3 Ng, float tne
   return *absDen * tnear < *T;
 }
 
+/* the cull distance: the best t with the relative slack of the kernels and the oracle (csrc/gvt_device.h cull_bound, gvt_oracle.c box_test) */
+static inline float sb_cull(float bt) { return fmaf(fabsf(bt), 0x1p-10f, bt); }
+
 static inline __m128 q4(uint32_t q) { return _mm_cvtepi32_ps(_mm_cvtepu8_epi32(_mm_cvtsi32_si128((int)q))); } /* four 8-bit planes -> four floats */
 
 static void trace_one(const Job *J, size_t j, unsigned long long *n_node, unsigned long long *n_leaf) {
@@ -79,7 +82,7 @@ static void trace_one(const Job *J, size_t j, unsigned long long *n_node, unsign
   int32_t cur = J->has_nodes ? 0 : INT32_MIN;
   int done = !J->has_nodes;
   /* the next stack entry that can still hold something nearer than the best hit (any hit: the next entry) */
-#define SB_POP() { cur = INT32_MIN; while (sp) { sp--; if (J->any || st_tn[sp] <= bt) { cur = st_ref[sp]; break; } } if (cur == INT32_MIN) break; }
+#define SB_POP() { cur = INT32_MIN; while (sp) { sp--; if (J->any || st_tn[sp] <= sb_cull(bt)) { cur = st_ref[sp]; break; } } if (cur == INT32_MIN) break; }
   while (!done) {
     if (cur >= 0) {
       (*n_node)++;
@@ -97,7 +100,7 @@ static void trace_one(const Job *J, size_t j, unsigned long long *n_node, unsign
                    fz = _mm_fmadd_ps(q4(qfz), _mm_set1_ps(sz), _mm_set1_ps(bzf));
       const __m128 tnr = _mm_max_ps(_mm_max_ps(nx, ny), _mm_max_ps(nz, _mm_setzero_ps()));
       const __m128 tfr = _mm_mul_ps(_mm_min_ps(_mm_min_ps(fx, fy), fz), _mm_set1_ps(1.0000004f));
-      const __m128 lim = _mm_set1_ps(J->any ? SB_FLT_MAX : bt);
+      const __m128 lim = _mm_set1_ps(J->any ? SB_FLT_MAX : sb_cull(bt));
       const int mask = _mm_movemask_ps(_mm_cmple_ps(tnr, _mm_min_ps(tfr, lim)));
       if (!mask) { SB_POP(); continue; }
       float tn[4];

@@ -225,10 +225,21 @@ def test_random_meshes_and_rays_against_the_oracle(hip, seed):
     d = np.where(nrm > 0, d / np.maximum(nrm, 1e-300), [0.0, 0.0, 1.0]).astype(np.float32)
     # the reference is the DEFINITION: the arg-min of the triangle test over all triangles (the checker's brute-force loop), not the checker's own
     # tree -- where the test's t is noise (a ray through a vertex almost in the triangle's plane) a tree's culling order decides between duplicates
-    brute = om.intersect(org, d, use_bvh=False)
-    assert_hits_equal(ad.intersect(org, d), brute)
-    assert_hits_equal(om.intersect(org, d), brute)
-    assert (ad.occluded(org, d) == om.occluded(org, d, use_bvh=False)).all()
+    # (every tree culls against the best hit with a relative slack of 2^-10 for that: gvt_device.h cull_bound.)  What no tree can return is a "hit" the
+    # triangle test reports FAR from its triangle -- a ray almost in the plane of a triangle it passes at a distance: den ~ 0, t, u, v garbage;
+    # the brute-force loop tests that triangle, a tree never enters its box (fuzz seed 295: a hit point 9 units outside the box of a 20-unit triangle
+    # at t = 1,650).  Such rays are compared tree against tree; their number is bounded.
+    brute, got, tree = om.intersect(org, d, use_bvh=False), ad.intersect(org, d), om.intersect(org, d)
+    hp = org.astype(np.float64) + d.astype(np.float64) * brute["t"].astype(np.float64)[:, None]
+    tv = v[t[np.maximum(brute["prim"], 0)]].astype(np.float64)
+    off = np.maximum(tv.min(axis=1) - hp, hp - tv.max(axis=1)).max(axis=1)  # how far outside its triangle's box the brute-force hit point lies
+    garbage = (brute["prim"] >= 0) & (off > np.abs(brute["t"]) * 2.0 ** -11)
+    assert garbage.sum() <= max(2, n // 500)
+    assert_hits_equal(got[~garbage], brute[~garbage])
+    assert_hits_equal(tree[~garbage], brute[~garbage])
+    assert_hits_equal(got[garbage], tree[garbage])
+    occ = om.occluded(org, d, use_bvh=False)
+    assert (ad.occluded(org, d)[~garbage] == occ[~garbage]).all() and (om.occluded(org, d)[~garbage] == occ[~garbage]).all()
 
 
 def test_mesh_create_rejects_bad_input(hip):
