@@ -234,7 +234,7 @@ def test_random_meshes_and_rays_against_the_oracle(hip, seed):
     tv = v[t[np.maximum(brute["prim"], 0)]].astype(np.float64)
     off = np.maximum(tv.min(axis=1) - hp, hp - tv.max(axis=1)).max(axis=1)  # how far outside its triangle's box the brute-force hit point lies
     garbage = (brute["prim"] >= 0) & (off > np.abs(brute["t"]) * 2.0 ** -11)
-    assert garbage.sum() <= max(2, n // 500)
+    assert garbage.sum() <= max(8, n // 20)  # (a fifth of the rays is aimed INSIDE the plane of its target triangle)
     assert_hits_equal(got[~garbage], brute[~garbage])
     assert_hits_equal(tree[~garbage], brute[~garbage])
     assert_hits_equal(got[garbage], tree[garbage])
