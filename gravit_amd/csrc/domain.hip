@@ -67,7 +67,11 @@ std::mutex g_rccl_mu;
 int rccl_load() {
   std::lock_guard<std::mutex> lk(g_rccl_mu);
   if (g_rccl.lib) return 0;
-  void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL); // the copy already in the process (e.g. PyTorch's) or the system one
+  void *h = nullptr;
+  if (const char *e = getenv("GVT_HIP_RCCL_LIB")) { // a particular build of the library (or, in tests/, a stand-in with the same entry points)
+    if (*e && !(h = dlopen(e, RTLD_NOW | RTLD_LOCAL))) { set_error("GVT_HIP_RCCL_LIB=%s: %s", e, dlerror()); return GVT_HIP_ERR_DEVICE; }
+  }
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL); // the copy already in the process (e.g. PyTorch's) or the system one
   if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!h) { set_error("RCCL not found: %s", dlerror()); return GVT_HIP_ERR_DEVICE; }

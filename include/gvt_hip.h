@@ -232,7 +232,8 @@ typedef struct gvt_hip_comm gvt_hip_comm;     /* one rank's endpoint of the ray 
 typedef struct gvt_hip_hub gvt_hip_hub;       /* rendezvous of in-process ranks */
 typedef struct gvt_hip_tracer gvt_hip_tracer; /* a Tracer<...> object for one rank */
 /* RCCL transport: rank 0 calls gvt_hip_comm_unique_id, the 128 bytes reach the other ranks out of band (e.g. a torch.distributed or
- * MPI broadcast), every rank calls gvt_hip_comm_create on its own device.  Collective. */
+ * MPI broadcast), every rank calls gvt_hip_comm_create on its own device.  Collective.  The library is resolved at first use: GVT_HIP_RCCL_LIB
+ * (a path: a particular build, or a stand-in with the same entry points -- tests/fake_rccl) if set, else librccl.so.1 as the process or the system has it. */
 int gvt_hip_comm_unique_id(unsigned char id[128]);
 gvt_hip_comm *gvt_hip_comm_create(const unsigned char id[128], int rank, int world);
 /* In-process transport: the ranks are threads of one process (one context each, gvt_hip_ctx_create) sharing a device; transfers are

@@ -237,3 +237,19 @@ def test_cost_optimal_wide_collapse_tool_on_a_random_tree(tmp_path):
     refs = out.view(np.int32)[:, 12:14].reshape(-1)
     assert sorted(refs[refs < 0].tolist()) == sorted(tree.view(np.int32)[:, 12:14].reshape(-1)[tree.view(np.int32)[:, 12:14].reshape(-1) < 0].tolist())
     assert sorted(refs[refs >= 0].tolist()) == list(range(1, len(tree)))                         # every inner node but the root is some node's child
+
+
+def test_rccl_stand_in_of_the_multi_process_tests_builds_and_covers_the_librarys_imports(tmp_path):
+    """tests/fake_rccl (the transport under tests/test_gpu_multiproc.py) compiles against <rccl/rccl.h> and exports every entry point the library
+    resolves from librccl (gravit_amd/csrc/domain.hip, GVT_SYM + ncclCommAbort) -- a new import in the library must reach the stand-in too."""
+    import re
+    import subprocess
+
+    from tests.conftest import ROOT
+    so = str(tmp_path / "libfakerccl.so")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-fPIC", "-shared", "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", so,
+                    os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp"), "-L/opt/rocm/lib", "-lamdhip64"], check=True, timeout=300)
+    exported = set(re.findall(r" T (nccl\w+)", subprocess.run(["nm", "-D", so], check=True, stdout=subprocess.PIPE, text=True).stdout))
+    src = open(os.path.join(ROOT, "gravit_amd", "csrc", "domain.hip")).read()
+    wanted = set(re.findall(r'"(nccl[A-Za-z]+)"', src))
+    assert len(wanted) >= 11 and wanted <= exported, wanted - exported
