@@ -949,6 +949,12 @@ def main():
         }
         if world > 1 and args.harness == "native":
             out["config"]["rccl_comm_count"] = comm.count if comm is not None else None  # == WORLD_SIZE (gvt_hip_comm_create refuses anything else)
+            # what moved the rays: RCCL as the process resolves it, a library named by GVT_HIP_RCCL_LIB (tests: a stand-in), or nothing (--fake-comm)
+            out["config"]["transport"] = "none (--fake-comm)" if args.fake_comm else ("GVT_HIP_RCCL_LIB=" + os.path.basename(os.environ["GVT_HIP_RCCL_LIB"])
+                                                                                       if os.environ.get("GVT_HIP_RCCL_LIB") else "librccl.so.1")
+            if args.same_gpu or args.fake_comm or os.environ.get("GVT_HIP_RCCL_LIB"):
+                out["config"]["rehearsal"] = "not a measurement: " + ", ".join(x for x in ("--same-gpu" if args.same_gpu else "", "--fake-comm" if args.fake_comm else "",
+                                                                                             "GVT_HIP_RCCL_LIB set" if os.environ.get("GVT_HIP_RCCL_LIB") else "") if x)
         if variants is not None:
             out["config"]["bytes_sent_per_step"] = ([v for v in variants.values() if v["is_value"]] or [{}])[0].get("bytes_sent_per_step")
         if variants is not None:

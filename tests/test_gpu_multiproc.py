@@ -76,5 +76,6 @@ def test_bench_script_starts_its_ranks_and_exchanges_over_the_rccl_leg(hip, tmp_
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["harness"] == "native" and j["config"]["rccl_comm_count"] == 2
     assert set(j["variants"]) == {"domain_async", "domain_bsp", "image_replicated", "domain_async_known_miss_shortcut"}
     assert all("failed" not in v for v in j["variants"].values()), j["variants"]
+    assert j["config"]["transport"] == "GVT_HIP_RCCL_LIB=libfakerccl.so" and "not a measurement" in j["config"]["rehearsal"]  # the line says what it is
     assert j["variants"]["domain_async"]["rays_sent_per_step"] > 0 and j["variants"]["domain_async"]["transport_groups_per_step"] > 0
     assert j["config4_bunny_grid"]["domain_async"]["value"] > 0 and j["weak_soup"]["tiles"] == 2 and j["weak_soup"]["value"] > 0
