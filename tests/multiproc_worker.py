@@ -81,6 +81,22 @@ def main():
         report.append({"case": "image scheduler, replicated", "max_abs_err": err})
     tr.close()
     dist.barrier()
+    # the reference's own distributed CTest (`ibrun -np 2 gvtSimple / gvtFileLoad -image / -domain`, CMakeLists.txt:644-688): rank 0's PPM against the
+    # golden image, gvtImageDiff -tolerance 300
+    from tests.conftest import GOLDEN, read_ppm
+    for gname, builder in (("simple", scenes.simple_scene), ("bunny", scenes.bunny_scene)):
+        for sched in ("image", "domain"):
+            sc = builder()
+            image = sched == "image"
+            tr = NativeTracer(sc, NORMALS_SMOOTH, [0] * sc.n_inst if image else [i % world for i in range(sc.n_inst)], comm, replicate=image)
+            B = tr(bsp=not image, image=image)
+            if rank == 0:
+                gold = read_ppm(os.path.join(GOLDEN, "ref_%s.ppm" % gname)).astype(np.int64)
+                diff = int(np.abs(B.fb.ppm_bytes().astype(np.int64).reshape(gold.shape) - gold).sum())
+                assert diff < 300, (gname, sched, diff)
+                report.append({"case": "reference CTest: %s -%s, %d ranks" % (gname, sched, world), "ppm_sum_abs_diff": diff})
+            tr.close()
+            dist.barrier()
     comm.close()
     if rank == 0:
         with open(sys.argv[1], "w") as f:

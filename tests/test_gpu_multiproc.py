@@ -42,7 +42,7 @@ def free_port():
 @pytest.mark.parametrize("world", [2, 3])
 def test_domain_and_image_schedulers_across_processes(hip, tmp_path, world):
     """config 4, the config-5 slabs (payloads behind the announce, on the communicator's stream, nothing inline) and the soup tiles under the
-    native Domain scheduler, and the replicated Image scheduler, on `world` processes: rank 0's composited image equals the checker's
+    native Domain scheduler, the replicated Image scheduler, and the reference's own four CTest runs against its golden PPMs, on `world` processes: rank 0's composited image equals the checker's
     restated DomainTracer; rays sent / traced add up over the ranks to the checker's counts; a second frame of the same tracer agrees."""
     out = tmp_path / "verdict.json"
     env = rank_env(tmp_path, {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()), "WORLD_SIZE": str(world)})
@@ -58,7 +58,8 @@ def test_domain_and_image_schedulers_across_processes(hip, tmp_path, world):
             raise
     assert all(p.returncode == 0 for p in procs), "\n---\n".join(lg[-3000:] for lg in logs)
     verdict = json.loads(out.read_text())
-    assert verdict["world"] == world and len(verdict["cases"]) == 6
+    assert verdict["world"] == world and len(verdict["cases"]) == 10
+    assert all(c["ppm_sum_abs_diff"] < 300 for c in verdict["cases"] if "ppm_sum_abs_diff" in c)  # the reference's own distributed CTest, four runs
     by = {c["case"]: c for c in verdict["cases"]}
     assert by["config5 in 4 slabs, nothing inline"]["rays_inline"] == 0 and by["config4 asynchronous"]["rays_inline"] > 0
     assert all(c.get("rays_sent", 1) > 0 for c in verdict["cases"])

@@ -3,6 +3,7 @@ Domain scheduler's ray exchange through the library's own transport.  On the one
 threads of one process, each with its own context (stream, scratch, counters), joined by the in-process transport -- the same
 protocol (announce + payload in the reference's wire format, termination from the announces) that runs over RCCL on 8 GPUs; RCCL
 itself is exercised as far as one GPU allows (communicator of one rank)."""
+import os
 import threading
 
 import numpy as np
@@ -66,7 +67,7 @@ def run_native_ranks(scene, owner, world, mode, bsp, full_reduce=False, image=Fa
             comm = Comm.local(hub, rank)
             tr = NativeTracer(scene, mode, owner, comm, replicate=image)
             B = tr(bsp=bsp, full_reduce=full_reduce, image=image)
-            out[rank] = (B.framebuffer(True) if rank == 0 else None, dict(tr.stats, reserved_cus=comm.reserved_cus))
+            out[rank] = (B.framebuffer(True) if rank == 0 else None, dict(tr.stats, reserved_cus=comm.reserved_cus), B.fb.ppm_bytes().copy() if rank == 0 else None)
             tr.close()
             comm.close()
             B = tr = None
@@ -124,6 +125,27 @@ def test_native_domain_scheduler_config5(hip, size, n_dom, world, bsp, overlap_k
     assert sum(r[1]["rays_sent"] for r in res.values()) == st.rays_sent and st.rays_sent > 10_000
     assert sum(r[1]["rays_closest"] for r in res.values()) == st.rays_closest
     assert sum(r[1]["rays_any"] for r in res.values()) == st.rays_any
+
+
+@pytest.mark.parametrize("name,builder", [("simple", scenes.simple_scene), ("bunny", scenes.bunny_scene)])
+@pytest.mark.parametrize("scheduler,world", [("image", 1), ("domain", 1), ("image", 2), ("domain", 2)])
+def test_reference_ctest_matrix_on_the_native_schedulers(hip, name, builder, scheduler, world):
+    """The reference's own CTest (CMakeLists.txt:644-688): gvtSimple / gvtFileLoad bunny.obj, -image and -domain, alone and as `ibrun -np 2`
+    (:650-654), each image against Test/CTESTtest/data/<name>.ppm with gvtImageDiff -tolerance 300 (sum of |byte differences| over the file) -- here
+    through the native schedulers on one rank and on two in-process ranks (two PROCESSES over the RCCL leg: tests/test_gpu_multiproc.py).
+    Domain: mpiInstanceMap round-robin (DomainTracer.h:130-142); Image: the scene on every rank, the camera's list split (ImageTracer.h:111-125)."""
+    from tests.conftest import GOLDEN, read_ppm
+    sc = builder()
+    image = scheduler == "image"
+    gold = read_ppm(os.path.join(GOLDEN, "ref_%s.ppm" % name)).astype(np.int64)
+    if world == 1:
+        tr = NativeTracer(sc, NORMALS_SMOOTH) if image else NativeTracer(sc, NORMALS_SMOOTH, [0] * sc.n_inst, None)
+        ppm = tr(bsp=not image).fb.ppm_bytes().copy()  # IceTComposite::write (:131-157), by the library
+        tr.close()
+    else:
+        owner = [0] * sc.n_inst if image else [i % world for i in range(sc.n_inst)]
+        ppm = run_native_ranks(sc, owner, world, NORMALS_SMOOTH, bsp=not image, image=image)[0][2]
+    assert np.abs(ppm.astype(np.int64).reshape(gold.shape) - gold).sum() < 300
 
 
 def test_soup_domains_with_cross_traffic_native(hip):
