@@ -268,6 +268,16 @@ class NativeTracer:
 
     render = __call__
 
+    def set_camera(self, cam):
+        """gvt_hip_tracer_set_camera: the next frame's camera (a moving camera re-uses the tracer, its queues and its framebuffer: same film size)."""
+        import ctypes as C
+
+        if (cam.width, cam.height) != (self.scene.camera.width, self.scene.camera.height):
+            raise ValueError("set_camera: the film size belongs to the tracer's framebuffer")
+        pod = capi.CameraPod((C.c_float * 3)(*cam.eye), (C.c_float * 3)(*cam.focus), (C.c_float * 3)(*cam.up), cam.fov, cam.width, cam.height,
+                             cam.samples, cam.depth, cam.jitter)
+        capi.check(self.lib.gvt_hip_tracer_set_camera(self.h, C.byref(pod)), "gvt_hip_tracer_set_camera")
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.gvt_hip_tracer_destroy(self.h)

@@ -148,6 +148,84 @@ def test_reference_ctest_matrix_on_the_native_schedulers(hip, name, builder, sch
     assert np.abs(ppm.astype(np.int64).reshape(gold.shape) - gold).sum() < 300
 
 
+def _camera_path(sc):
+    """a camera that moves between frames: sideways and closer (a larger film rectangle: queues grow), looking away (a frame without a single ray),
+    back to the start, another field of view, 2x2 samples (four times the rays), depth 2 (bounces: RNG stream words), and the start again"""
+    from dataclasses import replace
+    c = sc.camera
+    eye, foc = np.array(c.eye, np.float64), np.array(c.focus, np.float64)
+    view = foc - eye
+    side = np.cross(view, np.array(c.up, np.float64)); side /= np.linalg.norm(side)
+    return [c,
+            replace(c, eye=tuple(eye + 0.35 * view + 0.2 * np.linalg.norm(view) * side), focus=tuple(foc)),
+            replace(c, focus=tuple(eye - view)),
+            c,
+            replace(c, fov=float(c.fov) * 0.6),
+            replace(c, samples=2),
+            replace(c, depth=2),
+            c]
+
+
+@pytest.mark.parametrize("name,world", [("grid", 1), ("grid", 2), ("bunny", 1)])
+def test_a_moving_camera_reuses_the_tracer(hip, name, world):
+    """gvt_hip_tracer_set_camera between frames (an interactive GraviT application moves its camera every frame; the tracer, its queues, tables and
+    framebuffer stay): every frame of the path equals the checker's image for that camera -- one rank (rounds; "bunny": the lean one-instance frame)
+    and two in-process ranks (Domain scheduler); the frames that return to the first camera equal the first frame bit for bit."""
+    from dataclasses import replace
+    sc = scenes.bunny_grid_scene(width=380, height=216) if name == "grid" else scenes.bunny_scene(256, 256)
+    path = _camera_path(sc)
+    owner = [i % world for i in range(sc.n_inst)]
+    refs = []
+    for cam in path:
+        s2 = replace(sc, camera=cam)
+        refs.append(oracle_render(s2, NORMALS_SMOOTH)[0] if world == 1 else oracle_render_domain(s2, owner, world, NORMALS_SMOOTH)[0])
+    assert (refs[0][..., 3] > 0).sum() > 500 and not refs[2][..., 3].any() and refs[5][..., 3].max() >= 4
+    frames, errs = {}, []
+    hub = capi.load().gvt_hip_hub_create(world) if world > 1 else None
+
+    def rank_main(rank):
+        ctx = None
+        try:
+            ctx = Context(0) if world > 1 else None
+            comm = Comm.local(hub, rank) if world > 1 else None
+            tr = NativeTracer(sc, NORMALS_SMOOTH, owner, comm)
+            out = []
+            for cam in path:
+                tr.set_camera(cam)
+                B = tr(bsp=False)
+                out.append(B.framebuffer(True).copy() if rank == 0 else None)
+            frames[rank] = out
+            tr.close()
+            if comm is not None:
+                comm.close()
+            B = tr = None
+        except Exception:  # noqa: BLE001
+            import traceback
+            errs.append(traceback.format_exc())
+            if hub is not None:
+                capi.load().gvt_hip_hub_abort(hub)
+        finally:
+            import gc
+            gc.collect()
+            if ctx is not None:
+                ctx.close()
+
+    if world == 1:
+        rank_main(0)
+    else:
+        th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join(timeout=600) for t in th]
+        capi.load().gvt_hip_hub_destroy(hub)
+    assert not errs, errs[0]
+    got = frames[0]
+    for k, (fb, ref) in enumerate(zip(got, refs)):
+        tol = 1e-5 if path[k].depth > 1 else 0.0
+        assert np.abs(fb[..., :3] - ref[..., :3]).max() <= tol, k
+        assert np.array_equal(fb[..., 3], ref[..., 3]), k
+    assert np.array_equal(got[3], got[0]) and np.array_equal(got[7], got[0])
+
+
 def test_soup_domains_with_cross_traffic_native(hip):
     sc = scenes.soup_domains_scene(200_000, 4, 320, 180)
     sc.camera.eye, sc.camera.focus = (3.0, 0.6, 0.4), (0.5, 0.5, 0.5)  # along -x: rays cross the x-tiled domains

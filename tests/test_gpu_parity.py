@@ -569,6 +569,54 @@ def test_queue_roundtrip_and_camera(hip):
     assert rays_equal_bits(t[key(t)], ref2[key(ref2)])
 
 
+def test_entry_points_no_other_test_calls(hip):
+    """Four entries of include/gvt_hip.h that the bindings reach only through their wider siblings: gvt_hip_camera_generate (= _tiled with no
+    tiles), gvt_hip_trace_queue (= _sink without a sink), gvt_hip_queue_sizes (n queues in one round trip) and gvt_hip_set_stream (a caller's
+    hipStream_t instead of the context's own)."""
+    import ctypes as C
+
+    from gravit_amd import capi
+    lib = capi.load()
+    sc = scenes.bunny_scene(96, 64)
+    cam = sc.camera
+    qa, qb = RayQueue(), RayQueue()
+    capi.check(lib.gvt_hip_camera_generate(qa.h, capi.ptr(capi.f32(cam.eye, 3)), capi.ptr(capi.f32(cam.focus, 3)), capi.ptr(capi.f32(cam.up, 3)), C.c_float(cam.fov),
+                                           C.c_int(cam.width), C.c_int(cam.height), C.c_int(cam.samples), C.c_int(cam.depth), C.c_float(cam.jitter)), "gvt_hip_camera_generate")
+    camera_generate(qb, cam, tile=0)
+    rays = qa.to_numpy()
+    assert len(rays) == 96 * 64 and rays_equal_bits(rays, qb.to_numpy()) and rays_equal_bits(rays, oracle_camera_rays(sc))
+    # sizes of several queues at once
+    qs = [qa, qb, RayQueue(), RayQueue(8)]
+    qs[3].append(rays[:5], keep_state=True)
+    arr = (C.c_void_p * len(qs))(*[q.h for q in qs])
+    out = (C.c_uint64 * len(qs))()
+    capi.check(lib.gvt_hip_queue_sizes(arr, C.c_size_t(len(qs)), out), "gvt_hip_queue_sizes")
+    assert list(out) == [len(q) for q in qs] == [6144, 6144, 0, 5]
+    # Adapter::trace on queues, without a sink, on the caller's stream; the same call with the (empty) sink on the context's own stream
+    ad = HipMeshAdapter(sc.meshes[0], NORMALS_SMOOTH)
+    f32 = lambda a, n: capi.ptr(capi.f32(a, n))  # noqa: E731
+    lights = np.ascontiguousarray(sc.lights)
+    hip_rt = C.CDLL("libamdhip64.so")  # the runtime the library itself is linked against (already in the process)
+    st = C.c_void_p()
+    assert hip_rt.hipStreamCreate(C.byref(st)) == 0 and st.value
+    capi.set_stream(st.value)
+    try:
+        out_a = RayQueue()
+        capi.check(lib.gvt_hip_trace_queue(ad.h, qa.h, out_a.h, f32(sc.m[0], 16), f32(sc.minv[0], 16), f32(sc.normi[0], 9), capi.ptr(lights), C.c_size_t(len(lights)),
+                                           C.c_int(NORMALS_SMOOTH), C.c_uint32(0)), "gvt_hip_trace_queue")
+        moved_a = out_a.to_numpy()
+    finally:
+        capi.set_stream(None)
+        assert hip_rt.hipStreamDestroy(st) == 0
+    out_b = RayQueue()
+    ad.trace_queue(qb, out_b, sc.m[0], sc.minv[0], sc.normi[0], sc.lights, seed=0)
+    moved_b = out_b.to_numpy()
+    assert len(qa) == 0 and len(qb) == 0  # consumed, like ImageTracer.h:248
+    ref = oracle_meshes(sc)[0].trace(oracle_camera_rays(sc), sc.m[0], sc.minv[0], sc.normi[0], sc.lights, NORMALS_SMOOTH)
+    assert len(moved_a) > 1000 and rays_equal_bits(sort_rays(moved_a), sort_rays(moved_b)) and rays_equal_bits(sort_rays(moved_a), sort_rays(ref))
+    ad.close()
+
+
 def test_toplevel_shuffle_matches_oracle(hip):
     sc = scenes.simple_scene(150, 150)
     top = TopLevel(sc.inst_lo, sc.inst_hi)
