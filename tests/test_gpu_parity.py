@@ -382,6 +382,20 @@ def test_trace_ranges_capacity_and_errors(hip):
                              capi.ptr(capi.f32(sc.m[0])), capi.ptr(capi.f32(sc.minv[0])), capi.ptr(capi.f32(sc.normi[0])),
                              capi.ptr(np.ascontiguousarray(sc.lights)), C.c_size_t(1), C.c_int(0), C.c_uint32(0)) == -1
     assert b"range" in lib.gvt_hip_last_error()
+    # sizes beyond the 32-bit slot counters are refused before anything is allocated (a 65536 x 65536 film = 2^32 camera rays; a queue of 2^32 rays = 344 GB)
+    q = RayQueue()
+    with pytest.raises(capi.GvtHipError, match="32-bit"):
+        q.reserve(1 << 32)
+    q.append(rays[:10], keep_state=True)
+    assert len(q) == 10  # the queue is as usable as before
+    huge = scenes.Camera((0, 0, 3), (0, 0, 0), (0, 1, 0), 0.5, 65536, 65536)
+    with pytest.raises(capi.GvtHipError, match="32-bit"):
+        camera_generate(q, huge)
+    top = TopLevel(sc.inst_lo, sc.inst_hi)
+    pod = capi.CameraPod((C.c_float * 3)(0, 0, 3), (C.c_float * 3)(0, 0, 0), (C.c_float * 3)(0, 1, 0), 0.5, 65536, 65536, 1, 1, 0.0)
+    qs = (C.c_void_p * 1)(q.h)
+    assert lib.gvt_hip_camera_filter(top.h, C.byref(pod), C.c_int(8), qs, None) == -1 and b"2^32" in lib.gvt_hip_last_error()
+    assert len(q) == 10 and len(ad.trace(rays.copy()[:100], sc.m[0], sc.minv[0], sc.normi[0], sc.lights)) > 0  # and the library goes on
 
 
 def test_shadow_rays_that_hit_are_dropped_and_secondary_weight(hip):
