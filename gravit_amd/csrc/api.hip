@@ -213,6 +213,7 @@ const KnobDef g_knobs[] = {
   { "payload_overlap_kb", &Knobs::payload_overlap_kb, 0, 1 << 30, true },
   { "packet", &Knobs::packet, 0, 2, true },                   { "packet_sah_max", &Knobs::packet_sah_max, 0, 1 << 30, true },
   { "packet_min_rays", &Knobs::packet_min_rays, 0, 1 << 30, true },
+  { "shadow_order", &Knobs::shadow_order, 0, 1, true },       { "shadow_order_min_rays", &Knobs::shadow_order_min_rays, 0, 1 << 30, true },
 
   { "inline_kb", &Knobs::inline_kb, 0, 1024, true },          { "comm_cus", &Knobs::comm_cus, 0, 128, true },
   // experiments build only: the alternative was measured and lost, or the value is a tuned constant
@@ -231,6 +232,7 @@ const KnobDef g_knobs[] = {
   { "shadow_direct", &Knobs::shadow_direct, 0, 1, false },    { "top_ordered", &Knobs::top_ordered, 0, 1, false },
   { "top_lds", &Knobs::top_lds, 0, 1, false },                { "camera_tile", &Knobs::camera_tile, 0, 8, false },
   { "abi_pipe_min", &Knobs::abi_pipe_min, 0, 1 << 30, false },
+  { "shadow_cls_lo", &Knobs::shadow_cls_lo, 0, 255, false },  { "shadow_cls_shift", &Knobs::shadow_cls_shift, 0, 6, false },
   { "fused1", &Knobs::fused1, 0, 1, false },                  { "fused1_min_rays", &Knobs::fused1_min_rays, 0, 1 << 30, false },
 };
 } // namespace

@@ -18,6 +18,10 @@ struct PendingEvent {
 };
 
 // tuning knobs (gvt_hip_set_option); results never depend on them.  "defaults" restores this initial state.
+// the shadow list of a single-mesh round in SHADOW_CLASSES regions (class = how long the primaries of a 64-ray tile took), their ray counts in the
+// context's counter words SHADOW_CLS_WORD.. (reset with the pass's other counters)
+#define SHADOW_CLASSES 8
+#define SHADOW_CLS_WORD 24
 struct Knobs {
   int trav_kernel = 1;   // 1 = persistent waves with lane refill (k_trace), 0 = one 64-ray batch at a time (k_closest/k_any)
   int blocks_per_cu = 4; // k_trace grid: resident 256-thread blocks per CU
@@ -46,6 +50,10 @@ struct Knobs {
                          // launch (k_frame1: closest hit -> lean shade -> the lane goes on with its shadow ray -> deposit).  Bit-exact, and SLOWER: 1.19-1.27 ms per
                          // benchmark frame against 0.94 for the three launches (EXPERIMENTS.md round 5): closest-hit and any-hit work co-resident costs more than the tails
   int fused1_min_rays = 65536; // ... in launches of at least this many rays
+  int shadow_order = 1;  // single-mesh rounds with one light: the shadow rays are listed by the step count of their primaries' tiles, the longest first (shade.inc);
+                         // 0: in arrival order.  The any-hit launch's drain is then left to short rays: 0.318 -> 0.281 ms in tools/order_probe.py
+  int shadow_cls_lo = 24, shadow_cls_shift = 3; // ... class of a 64-ray tile = (node steps of its longest primary - lo) >> shift, clamped to 0..7 (tuned constants)
+  int shadow_order_min_rays = 262144; // ... in launches of at least this many rays (a small launch has no drain worth ordering)
   int packet_min_rays = 524288; // ... and only in launches of at least this many rays (bound): a small launch is a few thousand packets, each a long serial walk
   int packet_sah_max = 128; // meshes created afterwards: packet-friendly when sum(area(inner node)) / area(root) is at most this (lbvh.hip k_sah_sum)
   int round_room_mb = 16384; // scheduler rounds: memory the worst-case reservation of the destination queues may add (MiB); beyond it the round shuffles with exact growth

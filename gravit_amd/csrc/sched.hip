@@ -317,6 +317,7 @@ __global__ __launch_bounds__(TOP_BLOCK) void k_cam1_scatter(CamArgs A, unsigned 
     unsigned long long *tot = (unsigned long long *)(c + 16); // k_wave_pass_begin, pass 0 (trace.hip)
     *moved_count = 0u; c[2] = 0u; c[5] = 0u; tot[0] += total;
     c[0] = 0u; c[1] = 0u; c[3] = 0u; c[4] = 0u; c[6] = 0u;
+    for (int k = 0; k < SHADOW_CLASSES; k++) c[SHADOW_CLS_WORD + k] = 0u;
   }
 }
 

@@ -365,7 +365,7 @@ int trace_core(gvt_hip_mesh *M, RayPlanes in, size_t n, uint64_t index_base, gvt
       rc = launch_closest(M, in, idx, n_active, true, P.minv, GVT_RAY_EPSILON, d_hits, pass == 0);
     if (rc) return rc;
     if (pass > 0) HIPCHK(hipMemsetAsync(c_shadow, 0, 2 * sizeof(unsigned), st)); // c_shadow, c_next adjacent (pass 0: k_trace_begin)
-    ShadeArgs A;
+    ShadeArgs A{};
     A.in = in; A.idx = idx; A.n = (unsigned)n_active; A.index_base = index_base; A.hits = d_hits;
     A.first_pass = (pass == 0); A.carried_rng = P.carried_rng; A.out = outp; A.out_count = out->d_count; A.shadow = shadow; A.shadow_count = c_shadow;
     A.next_idx = next; A.next_count = c_next; A.lights = d_lights; A.normi = P.normi; A.normal_mode = P.normal_mode;
@@ -485,6 +485,7 @@ __global__ void k_wave_pass_begin(unsigned *c, int pass, unsigned n_host, unsign
   else { tot[1] += c[1]; tot[0] += c[prev]; c[cur] = 0u; }
   c[20] += c[3]; // rays parked by the launch before (the frame's total: the tracer adapts its parking threshold to it)
   c[0] = 0u; c[1] = 0u; c[3] = 0u; c[4] = 0u; c[6] = 0u;
+  for (int k = 0; k < SHADOW_CLASSES; k++) c[SHADOW_CLS_WORD + k] = 0u; // the shadow list's class counts (shade.inc)
 }
 // end of a round's chain: the last pass's shadow rays into the frame total; and the traced queues' clear() (count words of the
 // queues whose mask byte is set) in the same launch
@@ -505,7 +506,17 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
   const size_t n = n_total;
   gvt_hip_hit *d_hits = (gvt_hip_hit *)scratch_get(0, sizeof(gvt_hip_hit) * n);
   const size_t shadow_cap = n * (size_t)(nL > 0 ? nL : 1);
-  float4 *d_shadow = (float4 *)scratch_get(2, sizeof(float4) * 4 * shadow_cap);
+  // a single-mesh round with one light: the shadow rays listed by how long their primaries' tiles took, the longest first (knob shadow_order; shade.inc) --
+  // SHADOW_CLASSES regions of `cls_stride` slots; not for packets (no per-ray step counts) nor small rounds (a wave per ray)
+  const bool by_class = single && single->mesh->d_nodes4 && C.shadow_order && nL == 1 && n >= (size_t)C.shadow_order_min_rays && n > (size_t)C.small_rays &&
+                        C.long_steps > 0 && n >= (size_t)C.long_min_rays &&
+                        !((C.packet == 2 || (C.packet == 1 && single->mesh->packet_ok && n >= (size_t)C.packet_min_rays)) && single->coherent);
+  const size_t cls_stride = (n + 63) & ~(size_t)63;
+  const size_t shadow_slots = by_class ? cls_stride * SHADOW_CLASSES : shadow_cap;
+  if (shadow_slots >= 0xffffffffull) { set_error("round: %zu shadow slots exceed the 32-bit slot counters", shadow_slots); return GVT_HIP_ERR_INVALID; }
+  float4 *d_shadow = (float4 *)scratch_get(2, sizeof(float4) * 4 * shadow_slots);
+  unsigned char *d_steps = by_class ? (unsigned char *)scratch_get(19, n) : nullptr;
+  if (by_class && !d_steps) return GVT_HIP_ERR_DEVICE;
   unsigned *d_idx_a = (unsigned *)scratch_get(3, sizeof(unsigned) * n);
   unsigned *d_idx_b = (unsigned *)scratch_get(4, sizeof(unsigned) * n);
   gvt_hip_light *d_lights = (gvt_hip_light *)scratch_get(5, sizeof(gvt_hip_light) * (nL > 0 ? nL : 1));
@@ -523,7 +534,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       HIPCHK(hipStreamSynchronize(st)); // pageable source: finish the copy before `cached` can change (first frame only)
     }
   }
-  RayPlanes shadow = make_planes(d_shadow, shadow_cap);
+  RayPlanes shadow = make_planes(d_shadow, shadow_slots);
   shadow.p4 = nullptr; shadow.p5 = nullptr;
   RayPlanes outp = make_planes(out->d_planes, out->cap);
   RayPlanes none{};
@@ -551,6 +562,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       Trav TS{ M->d_nodes, M->d_tri, M->d_nodes4 };
       LongQ LQ{};
       if (use_long && have4) { LQ.recs = d_long; LQ.count = c + 3; long_limits(LQ, n); }
+      LQ.steps_out = by_class ? d_steps : nullptr;
       const bool small1 = small && have4;
       // a coherent list (camera rays in 8x8 tiles, straight from the filter) over a mesh the builder found packet-friendly (gvt_hip_mesh::packet_ok;
       // knob packet: 0 never, 1 the mesh's own choice, 2 always): a wave walks the tree ONCE for 64 rays (k_packet) -- the reference chooses its packet
@@ -615,7 +627,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
         ProfScope ps(KC_LONG);
         k_long_closest<true><<<C.n_cu * 3, 256, 0, st>>>(single->planes, d_long, c + 3, single->minv, TS, GVT_RAY_EPSILON, d_hits, c + 4, WaveSet{}, LQ.stk);
       }
-      ShadeArgs A;
+      ShadeArgs A{};
       A.in = single->planes; A.idx = idx; A.n = (unsigned)n; A.index_base = 0; A.hits = d_hits;
       A.first_pass = (pass == 0); A.carried_rng = 1; A.out = outp; A.out_count = out->d_count; A.shadow = shadow; A.shadow_count = c + 1;
       A.next_idx = next; A.next_count = c_next; A.lights = d_lights; A.normi = single->normi; A.normal_mode = P.normal_mode;
@@ -623,6 +635,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       A.sink = P.sink; A.sink.from = single->inst; A.update_in_place = 0;
       A.n_dev = n_dev; A.W = WaveSet{}; A.out_from = nullptr; A.shadow_inst = nullptr; A.shadow_stride = 0;
       if (pkt_any) { A.shadow_inst = d_shadow_inst; A.shadow_stride = (unsigned)n; } // shadow rays in the primaries' order: packets again
+      A.steps = d_steps; A.cls_cnt = by_class ? c + SHADOW_CLS_WORD : nullptr; A.cls_stride = (unsigned)cls_stride; A.cls_lo = C.shadow_cls_lo; A.cls_shift = C.shadow_cls_shift;
       MeshView mv;
       mv.slots = M->d_tri; mv.slot_of = M->d_slot_of; mv.verts = M->d_verts; mv.tris = M->d_tris; mv.normals = M->d_normals; mv.vcolors = M->d_vcolors;
       mv.materials = M->d_materials; mv.n_mat = (unsigned)M->nMat; mv.face_mat = M->d_face_mat; mv.mat = M->mesh_mat;
@@ -650,8 +663,12 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
         else
 #endif
         if (small1) k_wave_any<false><<<(int)std::min<size_t>((shadow_cap + 3) / 4, (size_t)C.n_cu * 3), 256, 0, st>>>(shadow, c + 1, single->minv, TS, GVT_RAY_EPSILON, outp, out->d_count, c + 0, sk, MultiSrc{});
-        else launch_trace<true, true, 1>(have4, trav_grid2(shadow_cap), st, shadow, nullptr, 0u, single->minv, TS, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
-                                         c + 0, C.d_spill, C.refill_min, C.inner_min, c + 1, C.share, (unsigned)C.share_min_rays, sk, LongQ{});
+        else {
+          MultiSrc by{};
+          if (by_class) { by.cls_cnt = c + SHADOW_CLS_WORD; by.cls_stride = (unsigned)cls_stride; }
+          launch_trace<true, true, 1>(have4, trav_grid2(shadow_cap), st, shadow, nullptr, 0u, single->minv, TS, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
+                                      c + 0, C.d_spill, C.refill_min, C.inner_min, c + 1, C.share, (unsigned)C.share_min_rays, sk, LongQ{}, by);
+        }
       }
       HIPCHK(hipGetLastError());
       C.stats.launches_closest++;
@@ -718,7 +735,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       ProfScope ps(KC_LONG);
       k_long_closest<true, true><<<C.n_cu * 3, 256, 0, st>>>(none, d_long, c + 3, id, T, GVT_RAY_EPSILON, d_hits, c + 4, W, LQ.stk);
     }
-    ShadeArgs A;
+    ShadeArgs A{};
     A.in = none; A.idx = idx; A.n = (unsigned)n; A.index_base = 0; A.hits = d_hits;
     A.first_pass = (pass == 0); A.carried_rng = 1; A.out = outp; A.out_count = out->d_count; A.shadow = shadow; A.shadow_count = c + 1;
     A.next_idx = next; A.next_count = c_next; A.lights = d_lights; A.normi = P.normi; A.normal_mode = P.normal_mode;

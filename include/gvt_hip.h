@@ -354,6 +354,9 @@ int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
  *                "frame_timing" 1: fill gvt_hip_frame_stats' per-phase milliseconds (five more event calls per exchange)
  *                "packet"       closest hits of coherent lists (camera rays in tile order) a packet of 64 rays per wave: 0 never, 1 (default) on meshes the builder
  *                               found packet-friendly (gvt_hip_mesh_info::packet), in launches of at least "packet_min_rays" rays, 2 always (and shadow rays too)
+ *                "shadow_order" 1 (default): a single-mesh round with one light lists its shadow rays by how many node steps the primaries of their 64-ray tile
+ *                               took, the longest first (a shadow ray's step count follows its primary's), so that the any-hit launch's drain is left to
+ *                               short rays -- in launches of at least "shadow_order_min_rays" rays; 0: in arrival order.  Results do not depend on it
  *   build time   "leaf_max"     triangles per leaf of meshes created afterwards (1..4, default 2)
  *                "packet_sah_max"  meshes created afterwards are packet-friendly when gvt_hip_mesh_info::sah_inner is at most this (default 128)
  *   budgets      "long_steps" / "long_min_rays" / "long_auto"  closest hit: node steps after which a ray is parked for a whole wave (0: never), launches it

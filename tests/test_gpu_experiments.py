@@ -34,8 +34,8 @@ def test_shipped_library_refuses_the_experiment_knobs(hip):
             hip.set_option(k, v)
     for k, v in (("trav_kernel", 1), ("wide4", 1), ("coop_fetch", 0), ("fused", 0), ("quad", 0), ("refill_min", 16), ("inner_min", 32), ("share", 1)):
         hip.set_option(k, v)  # their shipped values are accepted
-    # the shipped surface: 21 knobs (behaviour switches, budgets, test hooks)
-    for k, v in (("packet", 0), ("packet", 2), ("packet_sah_max", 64), ("packet_min_rays", 0), ("inline_kb", 0), ("comm_cus", 8), ("skip_known", 0), ("frame_timing", 1), ("term_sink", 0), ("sort_rays", 1), ("leaf_max", 4), ("long_steps", 64), ("long_min_rays", 0), ("long_auto", 0), ("finish_auto", 0), ("payload_overlap_kb", 0),
+    # the shipped surface: 23 knobs (behaviour switches, budgets, test hooks)
+    for k, v in (("shadow_order", 0), ("shadow_order_min_rays", 0), ("packet", 0), ("packet", 2), ("packet_sah_max", 64), ("packet_min_rays", 0), ("inline_kb", 0), ("comm_cus", 8), ("skip_known", 0), ("frame_timing", 1), ("term_sink", 0), ("sort_rays", 1), ("leaf_max", 4), ("long_steps", 64), ("long_min_rays", 0), ("long_auto", 0), ("finish_auto", 0), ("payload_overlap_kb", 0),
                  ("small_rays", 0), ("finish_rays", 0), ("round_room_mb", 0), ("abi_lanes", 0), ("abi_chunk", 65536), ("inject_fail_tick", -1)):
         hip.set_option(k, v)
     hip.set_option("defaults", 0)

@@ -541,7 +541,8 @@ def test_top_level_bvh_with_1056_instances(hip):
 
 @pytest.mark.parametrize("opts", [dict(small_rays=0), dict(small_rays=1 << 30), dict(term_sink=0), dict(leaf_max=4, small_rays=0), dict(finish_rays=0), dict(round_room_mb=0),
                                   dict(round_room_mb=0, finish_rays=0, small_rays=0), dict(finish_rays=1 << 30), dict(finish_rays=1 << 30, leaf_max=4), dict(skip_known=1, finish_rays=0), dict(skip_known=1),
-                                  dict(sort_rays=1), dict(packet=0), dict(packet=2), dict(packet=2, long_steps=0), dict(packet=2, term_sink=0), dict(packet=1, packet_min_rays=0)])
+                                  dict(sort_rays=1), dict(packet=0), dict(packet=2), dict(packet=2, long_steps=0), dict(packet=2, term_sink=0), dict(packet=1, packet_min_rays=0),
+                                  dict(shadow_order=0), dict(shadow_order=1, shadow_order_min_rays=0, long_min_rays=0), dict(shadow_order=1, shadow_order_min_rays=0, long_min_rays=0, packet=0, term_sink=0)])
 def test_round_results_do_not_depend_on_knobs(hip, opts):
     """The round chain under every knob of the shipped library -- a wave per ray for small rounds or never, k_finish or rounds, exact
     growth, no terminal sink, the known-miss shortcut (against the checker's restatement of it) -- returns the oracle's image on a multi-domain depth-2 frame, on config 4
@@ -560,6 +561,37 @@ def test_round_results_do_not_depend_on_knobs(hip, opts):
             tr.close()
         finally:
             hip.set_option("defaults", 0)
+
+
+def test_shadow_rays_are_listed_by_their_primaries_step_counts(hip):
+    """knob shadow_order: a single-mesh round with one light writes its shadow rays into eight regions, by the node steps the longest primary of their 64-ray
+    tile took (the closest-hit launch leaves a byte per ray), and the any-hit launch walks the regions from the longest class down.  Same image, same ray
+    counts, with the knob on and off; the regions' counts add up to the shadow rays traced; depth 2 (a second pass over an index list) and a mesh with
+    packets (no per-ray step counts: the knob does not apply) likewise."""
+    for sc, mode, depth2 in ((scenes.soup_scene(100_000, 320, 180), NORMALS_FLAT, False), (scenes.soup_scene(100_000, 160, 90), NORMALS_FLAT, True), (scenes.bunny_scene(256, 256), NORMALS_SMOOTH, False)):
+        if depth2:
+            from dataclasses import replace
+            sc = replace(sc, camera=replace(sc.camera, depth=2))
+        ref, st = oracle_render(sc, mode, nthreads=8)
+        imgs = {}
+        for on in (0, 1):
+            try:
+                hip.set_option("shadow_order", on); hip.set_option("shadow_order_min_rays", 0); hip.set_option("long_min_rays", 0); hip.set_option("packet_min_rays", 0)
+                tr = NativeTracer(sc, mode)
+                imgs[on] = tr().framebuffer(True).copy()
+                assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any
+                classes = hip.counters_peek()[24:32]
+                packets = tr.backend.adapter(0).info()["packet"]
+                if on and not packets and not depth2:
+                    assert sum(classes) == st.rays_any and sum(1 for c in classes if c) >= 2, classes
+                if not on or packets:
+                    assert not any(classes), classes
+                tr.close()
+            finally:
+                hip.set_option("defaults", 0)
+        tol = 1e-5 if depth2 else 0.0
+        assert np.abs(imgs[1][..., :3] - ref[..., :3]).max() <= tol and np.array_equal(imgs[1][..., 3], ref[..., 3])
+        assert np.abs(imgs[0] - imgs[1]).max() <= tol
 
 
 def test_packet_traversal_is_chosen_per_mesh(hip):
