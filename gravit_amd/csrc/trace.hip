@@ -665,9 +665,9 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
         if (small1) k_wave_any<false><<<(int)std::min<size_t>((shadow_cap + 3) / 4, (size_t)C.n_cu * 3), 256, 0, st>>>(shadow, c + 1, single->minv, TS, GVT_RAY_EPSILON, outp, out->d_count, c + 0, sk, MultiSrc{});
         else {
           MultiSrc by{};
-          if (by_class) { by.cls_cnt = c + SHADOW_CLS_WORD; by.cls_stride = (unsigned)cls_stride; }
+          if (by_class) { by.cls_cnt = c + SHADOW_CLS_WORD; by.cls_stride = (unsigned)cls_stride; by.cls_total = c + 1; }
           launch_trace<true, true, 1>(have4, trav_grid2(shadow_cap), st, shadow, nullptr, 0u, single->minv, TS, GVT_RAY_EPSILON, nullptr, nullptr, outp, out->d_count,
-                                      c + 0, C.d_spill, C.refill_min, C.inner_min, c + 1, C.share, (unsigned)C.share_min_rays, sk, LongQ{}, by);
+                                      c + 0, C.d_spill, C.refill_min, C.inner_min, by_class ? nullptr : c + 1, C.share, (unsigned)C.share_min_rays, sk, LongQ{}, by);
         }
       }
       HIPCHK(hipGetLastError());
