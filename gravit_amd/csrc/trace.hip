@@ -508,10 +508,12 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
   const size_t shadow_cap = n * (size_t)(nL > 0 ? nL : 1);
   // a single-mesh round with one light: the shadow rays listed by how long their primaries' tiles took, the longest first (knob shadow_order; shade.inc) --
   // SHADOW_CLASSES regions of `cls_stride` slots; not for packets (no per-ray step counts) nor small rounds (a wave per ray)
-  const bool by_class = single && single->mesh->d_nodes4 && C.shadow_order && nL == 1 && n >= (size_t)C.shadow_order_min_rays && n > (size_t)C.small_rays &&
+  const bool by_class_wanted = single && single->mesh->d_nodes4 && C.shadow_order && nL == 1 && n >= (size_t)C.shadow_order_min_rays && n > (size_t)C.small_rays &&
                         C.long_steps > 0 && n >= (size_t)C.long_min_rays &&
                         !((C.packet == 2 || (C.packet == 1 && single->mesh->packet_ok && n >= (size_t)C.packet_min_rays)) && single->coherent);
   const size_t cls_stride = (n + 63) & ~(size_t)63;
+  // (every region has room for the whole list -- 8 x 64 bytes per ray: 0.5 GB at the benchmark's 1.04 M rays; beyond 8 GiB the list stays in arrival order)
+  const bool by_class = by_class_wanted && cls_stride * SHADOW_CLASSES * 64 <= ((size_t)8 << 30);
   const size_t shadow_slots = by_class ? cls_stride * SHADOW_CLASSES : shadow_cap;
   if (shadow_slots >= 0xffffffffull) { set_error("round: %zu shadow slots exceed the 32-bit slot counters", shadow_slots); return GVT_HIP_ERR_INVALID; }
   float4 *d_shadow = (float4 *)scratch_get(2, sizeof(float4) * 4 * shadow_slots);
