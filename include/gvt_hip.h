@@ -344,7 +344,7 @@ int gvt_hip_marked_visit_stats(gvt_hip_mesh *, const float *org, const float *di
  * functions the bounce path (EmbreeMeshAdapter.cpp:289-318) is built on. */
 int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
 /* Knobs of the library (gvt_internal.h `struct Knobs` lists them with their defaults; ("defaults", 0) restores all of them).  Results never
- * depend on them -- except "skip_known" = 1, an opt-in approximation of the shuffle rule (below).  The shipped surface, 21 knobs:
+ * depend on them -- except "skip_known" = 1, an opt-in approximation of the shuffle rule (below).  The shipped surface, 23 knobs:
  *   behaviour    "skip_known"   0 (default): the reference's hop-by-hop shuffleRays, ray for ray -- 1: the known-miss shortcut (a ray is not traced / sent again into an
  *                               instance it has already crossed without a hit on the same straight segment).  The shortcut saves the hand-back hops between
  *                               overlapping boxes but is an APPROXIMATION: where a re-trace from the advanced origin would flip an edge-grazing triangle test,
