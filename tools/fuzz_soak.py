@@ -1,5 +1,5 @@
 """More seeds of the three seeded fuzz tests than the suite runs (tests/test_gpu_parity.py, tests/test_gpu_native.py): prints the first failure.
-   usage (GPU box): python tools/fuzz_soak.py [queries=400] [calls=200] [scenes=60] [film=1]"""
+   usage (GPU box): python tools/fuzz_soak.py [queries=400] [calls=200] [scenes=60] [film=1] [option=value ...]"""
 import os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,8 +13,11 @@ class Hip:  # the fixture's surface the tests use
     stats = staticmethod(capi.stats)
 
 n = {"queries": 400, "calls": 200, "scenes": 60, "film": 1}  # film=k: the random scenes' films k times wider and higher (rounds beyond the small-round kernels)
+lib_opts = {}  # any other name=value: a library option, set again before every seed (e.g. shadow_order_min_rays=0 long_min_rays=0: the class-ordered shadow list on small frames)
 for a in sys.argv[1:]:
-    k, v = a.split("="); n[k] = int(v)
+    k, v = a.split("=")
+    if k in n: n[k] = int(v)
+    else: lib_opts[k] = int(v)
 if n["film"] > 1:
     _base = N._random_scene
     def _big(seed):
@@ -30,6 +33,8 @@ for name, fn, cnt, base in (("queries", P.test_random_meshes_and_rays_against_th
                             ("scenes", N.test_random_scenes_through_the_native_schedulers, n["scenes"], 100)):
     for s in range(base, base + cnt):
         try:
+            for k_, v_ in lib_opts.items():
+                capi.set_option(k_, v_)
             fn(Hip, s)
         except Exception:  # noqa: BLE001
             bad += 1
