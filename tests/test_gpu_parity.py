@@ -235,9 +235,20 @@ def test_random_meshes_and_rays_against_the_oracle(hip, seed):
     off = np.maximum(tv.min(axis=1) - hp, hp - tv.max(axis=1)).max(axis=1)  # how far outside its triangle's box the brute-force hit point lies
     garbage = (brute["prim"] >= 0) & (off > np.abs(brute["t"]) * 2.0 ** -11)
     assert garbage.sum() <= max(8, n // 20)  # (a fifth of the rays is aimed INSIDE the plane of its target triangle)
-    assert_hits_equal(got[~garbage], brute[~garbage])
-    assert_hits_equal(tree[~garbage], brute[~garbage])
-    assert_hits_equal(got[garbage], tree[garbage])
+    assert_hits_equal(got[~garbage], brute[~garbage])  # the device against the definition
+    assert_hits_equal(tree[~garbage], brute[~garbage])  # the checker's own tree against the definition (its boxes are widened sideways by 2^-11 of the distance for this:
+                                                         # oracle/gvt_oracle.c box_test; soak seeds 2044 / 3662 / 4948 / 8347)
+    # garbage: whether a tree enters the far triangle's box is the tree's business -- the device returns the definition's hit or the checker tree's
+    same = lambda x, y: (x["prim"] == y["prim"]) & (bits(x["t"]) == bits(y["t"])) & (bits(x["u"]) == bits(y["u"])) & (bits(x["v"]) == bits(y["v"]))  # noqa: E731
+    g_ok = same(got, brute) | same(got, tree)
+    # ... or, rarely (soak seeds 3358 / 4948 / 6715), a third garbage hit of the same ray that only its padded boxes reach: then it must be what the triangle test
+    # says for the triangle it names, and not nearer than the definition's
+    for i in np.nonzero(garbage & ~g_ok)[0]:
+        assert got["prim"][i] >= 0 and got["t"][i] >= brute["t"][i], i
+        one_tri = orc.Mesh(v, t[got["prim"][i]:got["prim"][i] + 1]).intersect(org[i:i + 1], d[i:i + 1], use_bvh=False)
+        assert bits(one_tri["t"])[0] == bits(got["t"])[i] and bits(one_tri["u"])[0] == bits(got["u"])[i] and bits(one_tri["v"])[0] == bits(got["v"])[i], i
+        g_ok[i] = True
+    assert g_ok[garbage].all()
     occ = om.occluded(org, d, use_bvh=False)
     assert (ad.occluded(org, d)[~garbage] == occ[~garbage]).all() and (om.occluded(org, d)[~garbage] == occ[~garbage]).all()
 
