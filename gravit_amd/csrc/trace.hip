@@ -641,9 +641,13 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       MeshView mv;
       mv.slots = M->d_tri; mv.slot_of = M->d_slot_of; mv.verts = M->d_verts; mv.tris = M->d_tris; mv.normals = M->d_normals; mv.vcolors = M->d_vcolors;
       mv.materials = M->d_materials; mv.n_mat = (unsigned)M->nMat; mv.face_mat = M->d_face_mat; mv.mat = M->mesh_mat;
+      // the simple frame (k_shade's LEAN instantiation): camera rays of the scene's only instance, depth 1, no area light, a LAMBERT mesh material
+      const bool lean_shade = single->coherent && pass == 0 && passes == 1 && P.sink.fb && P.sink.top.n_inst == 1 && nL >= 1 && !M->d_vcolors && !M->d_face_mat &&
+                              M->mesh_mat.type == 0 && !A.update_in_place && std::all_of(lights_host, lights_host + nL, [](const gvt_hip_light &l) { return l.type != GVT_HIP_LIGHT_AREA; });
       {
         ProfScope ps(KC_SHADE);
-        k_shade<false><<<blocks_for(n, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, mv);
+        if (lean_shade) k_shade<false, true><<<blocks_for(n, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, mv);
+        else k_shade<false><<<blocks_for(n, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, mv);
       }
       if (nL) {
         ProfScope ps(KC_ANY);

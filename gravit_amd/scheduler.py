@@ -17,7 +17,7 @@ import numpy as np
 
 from . import capi
 from .adapter import FrameBuffer, HipMeshAdapter, RayQueue, TopLevel, camera_generate
-from .layouts import NORMALS_FLAT
+from .layouts import LIGHT_DTYPE, NORMALS_FLAT
 
 
 class HipBackend:
@@ -79,7 +79,7 @@ class HipBackend:
                              cam.samples, cam.depth, cam.jitter)
         meshes = (C.c_void_p * max(1, self.n_inst))(*[self.adapter(i).h for i in range(self.n_inst)])
         queues = (C.c_void_p * max(1, self.n_inst))(*[q.h for q in self.queues])
-        lights = np.ascontiguousarray(s.lights)
+        lights = np.ascontiguousarray(s.lights, dtype=LIGHT_DTYPE)  # (a concatenation of records drops the dtype's padding: always the ABI's 64-byte layout)
         calls = C.c_uint64(0)
         capi.check(capi.load().gvt_hip_image_frame(
             self.top.h, meshes, capi.ptr(capi.f32(s.m)), capi.ptr(capi.f32(s.minv)), capi.ptr(capi.f32(s.normi)), C.c_size_t(self.n_inst),
@@ -242,7 +242,7 @@ class NativeTracer:
         pod = capi.CameraPod((C.c_float * 3)(*cam.eye), (C.c_float * 3)(*cam.focus), (C.c_float * 3)(*cam.up), cam.fov, cam.width, cam.height,
                              cam.samples, cam.depth, cam.jitter)
         meshes = (C.c_void_p * max(1, scene.n_inst))(*[B.adapter(i).h if owned[i] else None for i in range(scene.n_inst)])
-        lights = np.ascontiguousarray(scene.lights)
+        lights = np.ascontiguousarray(scene.lights, dtype=LIGHT_DTYPE)  # (np.concatenate of light records packs them to 48 bytes: always the ABI's 64-byte layout)
         self.h = C.c_void_p(self.lib.gvt_hip_tracer_create(
             B.top.h, meshes, capi.ptr(capi.f32(scene.m)), capi.ptr(capi.f32(scene.minv)), capi.ptr(capi.f32(scene.normi)), C.c_size_t(scene.n_inst),
             capi.ptr(lights), C.c_size_t(len(lights)), C.c_int(normal_mode), C.byref(pod), B.fb.h))

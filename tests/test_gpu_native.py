@@ -594,6 +594,41 @@ def test_shadow_rays_are_listed_by_their_primaries_step_counts(hip):
         assert np.abs(imgs[0] - imgs[1]).max() <= tol
 
 
+@pytest.mark.parametrize("mode", [NORMALS_FLAT, NORMALS_SMOOTH])
+def test_the_lean_shading_kernel_and_its_conditions(hip, mode):
+    """k_shade's LEAN instantiation (csrc/shade.inc: one instance in the scene, depth 1, point / ambient lights, a LAMBERT mesh material) against the oracle --
+    one light and three (point, ambient, point), soup and bunny, packets or lanes; and every way OUT of its conditions on the same scene (an area light, depth 2,
+    a PHONG material, vertex colours, two instances) through the general kernel: each image equals the oracle's (1e-5 where several deposits per pixel add up in
+    any order).  (Its first run found a bug in the BINDING: np.concatenate packs light records to 48 bytes; scheduler.py now always hands over the 64-byte layout.)"""
+    from dataclasses import replace
+
+    from gravit_amd import layouts
+    base = scenes.soup_scene(60_000, 256, 144)
+    bun = scenes.bunny_scene(192, 192)
+    three = np.concatenate([layouts.point_light((0.5, 0.5, 3.0)), layouts.ambient_light((0.05, 0.04, 0.03)), layouts.point_light((2.0, 1.5, 2.5), (0.9, 0.8, 0.7))])
+    area = np.concatenate([layouts.point_light((0.5, 0.5, 3.0)), layouts.area_light((0.4, 2.0, 1.0), (0.8, 0.8, 1.0), (0.0, -1.0, 0.1), 0.3, 0.2)])
+    m0 = base.meshes[0]
+    phong = scenes.MeshData(m0.verts, m0.tris, layouts.default_material(kd=(0.6, 0.5, 0.4), mtype=layouts.PHONG, ks=(0.3, 0.3, 0.3), alpha=8.0))
+    coloured = scenes.MeshData(m0.verts, m0.tris, m0.material, None, np.random.default_rng(3).random(m0.verts.shape).astype(np.float32))
+    cases = [("lean, one light", base, 0.0), ("lean, three lights", replace(base, lights=three), 1e-5), ("lean, bunny", bun, 0.0), ("lean, bunny, three lights", replace(bun, lights=three), 1e-5),
+             ("general: an area light", replace(base, lights=area), 1e-5), ("general: depth 2", replace(base, camera=replace(base.camera, depth=2)), 1e-5),
+             ("general: PHONG", replace(base, meshes=[phong]), 1e-5), ("general: vertex colours", replace(base, meshes=[coloured]), 0.0),
+             ("general: two instances", scenes.soup_domains_scene(60_000, 2, 256, 144), 0.0)]
+    for name, sc, tol in cases:
+        ref, st = oracle_render(sc, mode, nthreads=8)
+        assert (ref[..., 3] > 0).sum() > 500, name
+        for pk in (0, 1):
+            try:
+                hip.set_option("packet", pk); hip.set_option("packet_min_rays", 0)
+                tr = NativeTracer(sc, mode)
+                fb = tr().framebuffer(True)
+                assert np.abs(fb[..., :3] - ref[..., :3]).max() <= tol and np.array_equal(fb[..., 3], ref[..., 3]), (name, pk)
+                assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any, (name, pk)
+                tr.close()
+            finally:
+                hip.set_option("defaults", 0)
+
+
 def test_packet_traversal_is_chosen_per_mesh(hip):
     """The builder decides per mesh whether coherent lists are traversed a packet of 64 rays per wave (k_packet) or a lane per ray (k_trace), as the
     reference picks its packet width per build (EmbreeMeshAdapter.cpp:50-74): from sum(area(inner node)) / area(root) -- a surface stays at a few

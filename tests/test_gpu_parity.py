@@ -386,12 +386,12 @@ def test_trace_ranges_capacity_and_errors(hip):
     r1 = rays.copy()
     rc_ = lib.gvt_hip_trace(ad.h, capi.ptr(r1), C.c_size_t(len(r1)), C.c_size_t(0), C.c_size_t(0), capi.ptr(out), C.c_size_t(4), C.byref(n_out),
                             capi.ptr(capi.f32(sc.m[0])), capi.ptr(capi.f32(sc.minv[0])), capi.ptr(capi.f32(sc.normi[0])),
-                            capi.ptr(np.ascontiguousarray(sc.lights)), C.c_size_t(1), C.c_int(0), C.c_uint32(0))
+                            capi.ptr(np.ascontiguousarray(sc.lights, dtype=layouts.LIGHT_DTYPE)), C.c_size_t(1), C.c_int(0), C.c_uint32(0))
     assert rc_ == -3 and n_out.value == len(ad.trace(rays.copy(), sc.m[0], sc.minv[0], sc.normi[0], sc.lights))
     # bad arguments
     assert lib.gvt_hip_trace(ad.h, capi.ptr(r1), C.c_size_t(len(r1)), C.c_size_t(9), C.c_size_t(3), capi.ptr(out), C.c_size_t(4), C.byref(n_out),
                              capi.ptr(capi.f32(sc.m[0])), capi.ptr(capi.f32(sc.minv[0])), capi.ptr(capi.f32(sc.normi[0])),
-                             capi.ptr(np.ascontiguousarray(sc.lights)), C.c_size_t(1), C.c_int(0), C.c_uint32(0)) == -1
+                             capi.ptr(np.ascontiguousarray(sc.lights, dtype=layouts.LIGHT_DTYPE)), C.c_size_t(1), C.c_int(0), C.c_uint32(0)) == -1
     assert b"range" in lib.gvt_hip_last_error()
     # sizes beyond the 32-bit slot counters are refused before anything is allocated (a 65536 x 65536 film = 2^32 camera rays; a queue of 2^32 rays = 344 GB)
     q = RayQueue()
@@ -620,7 +620,7 @@ def test_entry_points_no_other_test_calls(hip):
     # Adapter::trace on queues, without a sink, on the caller's stream; the same call with the (empty) sink on the context's own stream
     ad = HipMeshAdapter(sc.meshes[0], NORMALS_SMOOTH)
     f32 = lambda a, n: capi.ptr(capi.f32(a, n))  # noqa: E731
-    lights = np.ascontiguousarray(sc.lights)
+    lights = np.ascontiguousarray(sc.lights, dtype=layouts.LIGHT_DTYPE)
     hip_rt = C.CDLL("libamdhip64.so")  # the runtime the library itself is linked against (already in the process)
     st = C.c_void_p()
     assert hip_rt.hipStreamCreate(C.byref(st)) == 0 and st.value
