@@ -1038,7 +1038,13 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
     const gvt_hip_mesh *Mk = R->meshes[R->h_segs[k].inst];
     multi_packets = Mk && Mk->d_nodes4 && (C.packet == 2 || Mk->packet_ok);
   }
-  if ((rc = wave_trace_chain(W, N, passes, R->q_moved, d_from, P, R->lights.data(), single ? &one : nullptr, R->d_count_ptr, R->d_mask, (int)nI, defer_end && single, n_dev0, multi_packets))) return rc;
+  // every mesh of the round a plain LAMBERT one (no vertex colours, no per-face materials): with depth 1 and no area light the merged chain shades with k_shade's lean instantiation too
+  bool simple_meshes = !single;
+  for (int k = 0; k < n_seg && simple_meshes; k++) {
+    const gvt_hip_mesh *Mk = R->meshes[R->h_segs[k].inst];
+    simple_meshes = Mk && !Mk->d_vcolors && !Mk->d_face_mat && Mk->mesh_mat.type == 0;
+  }
+  if ((rc = wave_trace_chain(W, N, passes, R->q_moved, d_from, P, R->lights.data(), single ? &one : nullptr, R->d_count_ptr, R->d_mask, (int)nI, defer_end && single, n_dev0, multi_packets, simple_meshes))) return rc;
   // one instance in the whole scene and the terminal rule applied inside the kernels: nothing can have moved
   if (exact) {
     if ((rc = shuffle_exact(R->top, R->q_moved, single ? nullptr : d_from, single ? one.inst : -1, R->queues.data(), R->fb))) return rc;

@@ -313,7 +313,7 @@ struct WaveSingle { // the launch has ONE segment: its queue planes and instance
 // n_dev0_multi (merged kernels): device word holding the length of the merged list where only the device knows it; n_total is then a bound
 int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
                      const gvt_hip_light *lights_host, const WaveSingle *single, unsigned *const *d_count_ptr, const unsigned char *d_mask, int n_inst,
-                     bool defer_end = false, const unsigned *n_dev0_multi = nullptr, bool multi_packets = false);
+                     bool defer_end = false, const unsigned *n_dev0_multi = nullptr, bool multi_packets = false, bool simple_meshes = false);
 // multi_packets (merged kernels, first pass): the queues hold camera rays in tile order over packet-friendly meshes -- closest hits through k_packet_multi
 int finish_round(const WaveSet &W, size_t n_total, const TraceParams &P, const gvt_hip_light *lights_host, const void *d_qdesc, const int *d_owner, int rank,
                  unsigned *d_queue_overflow, unsigned *const *d_count_ptr, const unsigned char *d_mask);

@@ -498,7 +498,7 @@ __global__ void k_wave_end(unsigned *c, unsigned *const *__restrict__ count_ptr,
 
 int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue *out, int *d_out_from, const TraceParams &P,
                      const gvt_hip_light *lights_host, const WaveSingle *single, unsigned *const *d_count_ptr, const unsigned char *d_mask, int n_inst,
-                     bool defer_end, const unsigned *n_dev0_multi, bool multi_packets) {
+                     bool defer_end, const unsigned *n_dev0_multi, bool multi_packets, bool simple_meshes) {
   Ctx &C = gctx();
   if (!n_total) return 0;
   hipStream_t st = C.stream;
@@ -753,9 +753,12 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     // and where only the device knows that length the any-hit launch stops there instead of skipping empty slots up to the bound)
     const bool direct_dev = direct && nd0 != nullptr && nL == 1;
     A.shadow_stride = direct ? (unsigned)n : 0u;
+    // (k_shade's LEAN instantiation for the merged chain: depth 1, no area light, plain LAMBERT meshes; a missing ray still walks the instances ahead of it)
+    const bool lean_multi = simple_meshes && pass == 0 && passes == 1 && nL >= 1 && std::all_of(lights_host, lights_host + nL, [](const gvt_hip_light &l) { return l.type != GVT_HIP_LIGHT_AREA; });
     {
       ProfScope ps(KC_SHADE);
-      k_shade<true><<<blocks_for(n, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, MeshView{});
+      if (lean_multi) k_shade<true, true><<<blocks_for(n, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, MeshView{});
+      else k_shade<true><<<blocks_for(n, SHADE_BLOCK), SHADE_BLOCK, 0, st>>>(A, MeshView{});
     }
     if (nL) {
       ProfScope ps(KC_ANY);
