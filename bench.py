@@ -299,6 +299,58 @@ def two_frames_in_flight(scene, steps, rays_per_frame):
                     "to last end; never `value`" % steps}
 
 
+def one_rank_reference(sc, mode, harness, on_gpu, capi, skip_known=0, skip_known_restore=0):
+    """Rank 0 of an N > 1 run: the SAME scene rendered by ONE rank -- every domain local, no communicator, no exchange -- on this rank's own device,
+    as the thing every multi-rank variant's composited framebuffer must equal (the reference never runs distributed without diffing the image
+    afterwards: CMakeLists.txt:650-654 `ibrun -np 2 ...`, :664-682 gvtImageDiff).  Returns (float framebuffer un-clamped, rays through the
+    closest-hit kernels, rays through the any-hit kernels) of one frame."""
+    if harness == "native":
+        from gravit_amd.scheduler import NativeTracer
+
+        capi.set_option("skip_known", int(skip_known))
+        try:
+            tr = NativeTracer(sc, mode)
+            tr()
+            fb, st = tr.backend.framebuffer(False), dict(tr.stats)
+            tr.close()
+        finally:
+            capi.set_option("skip_known", int(skip_known_restore))
+        return fb, int(st["rays_closest"]), int(st["rays_any"])
+    from gravit_amd.scheduler import ImageTracer  # the Python harness: the reference-order loop over one backend that holds every instance
+
+    if on_gpu:
+        t = ImageTracer(sc, mode)
+        c0 = capi.stats()
+        t()
+        c1 = capi.stats()
+        return t.backend.framebuffer(False), int(c1["rays_closest"] - c0["rays_closest"]), int(c1["rays_any"] - c0["rays_any"])
+    from tests.oracle_backend import OracleBackend
+
+    be = OracleBackend(sc, mode, None)
+    ImageTracer(sc, mode, backend=be)()
+    return be.framebuffer(False), int(be.rays_closest), int(be.rays_any)
+
+
+def frame_parity(name, got, ref, rays_got, rays_ref):
+    """One variant's composited framebuffer (rank 0, un-clamped float sums + the deposit count in alpha) against the one-rank render of the same
+    scene, and the rays traced per frame summed over the ranks against the one-rank counts (the strict shuffle rule moves the same rays through the same
+    instances however they are spread over ranks)."""
+    import numpy as np
+
+    got = np.asarray(got, np.float32).reshape(-1, 4)
+    ref = np.asarray(ref, np.float32).reshape(-1, 4)
+    if os.environ.get("GVT_BENCH_BREAK_PARITY") == name:  # test hook (tests/test_domain_gloo.py): one pixel of this variant's image is damaged before the comparison
+        got = got.copy()
+        got[int(np.argmax(ref[:, 3] > 0)), 0] += 0.25
+    same = bool(np.array_equal(got, ref))
+    return {"checked": "rank 0's composited framebuffer vs the same scene rendered by ONE rank (all domains local, no exchange) on rank 0's device",
+            "bit_exact": same, "lit_pixels": int((ref[:, 3] > 0).sum()), "lit_pixels_got": int((got[:, 3] > 0).sum()),
+            "deposits": float(ref[:, 3].astype(np.float64).sum()), "deposits_got": float(got[:, 3].astype(np.float64).sum()),
+            "max_abs_diff": float(np.abs(got - ref).max()) if got.size else 0.0, "pixels_differ": int((got != ref).any(axis=1).sum()),
+            "rays_closest": [int(round(rays_got[0])), int(rays_ref[0])], "rays_any": [int(round(rays_got[1])), int(rays_ref[1])],
+            "rays_equal": bool(int(round(rays_got[0])) == int(rays_ref[0]) and int(round(rays_got[1])) == int(rays_ref[1]))}
+
+
 PHASES = ("ms_chain", "ms_announce", "ms_payload", "ms_composite", "ms_host_wait")
 
 
@@ -332,6 +384,7 @@ def measure_variant(run_frame, frame_stats, steps, warmup, barrier, reduce_sum, 
     barrier()  # the ranks prepared their scenes at their own pace: start together, inside the exchange's deadline
     for _ in range(warmup):
         frame()
+    frame_stats()  # (a harness that counts through running totals hands out differences: what the warm-up traced is not the timed steps')
     barrier()
     sums = {}
     t0 = time.perf_counter()
@@ -557,6 +610,7 @@ def main():
                          "checker: the Python loops over the CPU checker backend -- no GPU, rehearses this script's N>1 plumbing under gloo")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (gvt_hip_set_option), for experiments")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="N>1: skip the per-variant image check against rank 0's one-rank render of the same scene")
     ap.add_argument("--no-abi-path", action="store_true")
     ap.add_argument("--no-sustained", action="store_true", help="skip the `sustained` key (>= 2000 frames / 2.5 s of the same frame back to back)")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
@@ -768,6 +822,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(x) for x in t]
 
+    # N > 1: every variant and leg is VERIFIED in the same invocation -- rank 0 renders the variant's scene once more with a one-rank tracer of its own
+    # (no communicator) and compares the composited framebuffer bit for bit, and the rays traced (summed over the ranks) with the one-rank counts
+    do_parity = world > 1 and not args.no_parity and not args.fake_comm
+    parity_bad = []  # names of the variants / legs whose image or ray counts differ: the line is still printed, rank 0 leaves with status 4
+    ref_cache = {}
+    skip_known_user = int(dict(o.split("=") for o in args.opt).get("skip_known", 0))
+
+    def variant_parity(name, backend_v, sc_v, mode_v, tot_v, skip_known=0):
+        """rank 0 only (the other ranks go on to the next barrier and wait there)"""
+        if not do_parity or rank != 0:
+            return None
+        t_p = time.perf_counter()
+        key = (id(sc_v), mode_v, int(skip_known))
+        if key not in ref_cache:
+            ref_cache[key] = one_rank_reference(sc_v, mode_v, args.harness, on_gpu, capi, skip_known, skip_known_user) + (sc_v,)  # (the scene stays alive: its id is the key)
+        ref_fb, ref_c, ref_a, _ = ref_cache[key]
+        got = backend_v.framebuffer(False)
+        par = frame_parity(name, got, ref_fb, (tot_v[0] / args.steps, tot_v[1] / args.steps), (ref_c, ref_a))
+        if skip_known:  # the opt-in shortcut against the reference's hop-by-hop rule (not image-identical in general, DESIGN 6): reported, not required
+            strict = ref_cache.get((id(sc_v), mode_v, 0))
+            if strict is not None:
+                a, b = np.asarray(got, np.float32).reshape(-1, 4), np.asarray(strict[0], np.float32).reshape(-1, 4)
+                par["vs_strict_rule"] = {"bit_exact": bool(np.array_equal(a, b)), "pixels_differ": int((a != b).any(axis=1).sum()), "max_abs_diff": float(np.abs(a - b).max())}
+        par["seconds"] = time.perf_counter() - t_p
+        if not (par["bit_exact"] and par["rays_equal"]):
+            parity_bad.append(name)
+        return par
+
     variants = None
     if world > 1 and on_gpu and args.harness == "native":
         capi.set_option("frame_timing", 1)  # the variants and the extra legs carry the per-phase breakdown (five more event calls per exchange); `value` above ran without
@@ -808,7 +890,7 @@ def main():
                     last["c"], last["a"] = c, a
                     return d
             try:
-                res_v, _, _, _ = measure_variant(run_v, stats_v, args.steps, args.warmup, barrier, reduce_sum, reduce_max, rank, world, name)
+                res_v, _, _, tot_v = measure_variant(run_v, stats_v, args.steps, args.warmup, barrier, reduce_sum, reduce_max, rank, world, name)
             except LegFailed as e:
                 legs_error = str(e)
                 variants[name] = {"failed": legs_error, "is_value": name == primary}
@@ -818,8 +900,15 @@ def main():
                     capi.set_option("skip_known", int(dict(o.split("=") for o in args.opt).get("skip_known", 0)))
             res_v["is_value"] = name == primary
             variants[name] = res_v
+            par = variant_parity(name, tr_v.backend, tr_v.scene if args.harness == "native" else scene, NORMALS_FLAT, tot_v, 1 if shortcut else 0)
+            if par is not None:
+                res_v["parity"] = par
             if made is not None and hasattr(made, "close"):
                 made.close()
+
+    primary_parity = None
+    if world > 1 and variants is None:  # --single-variant: the one variant that ran is checked like the others
+        primary_parity = variant_parity("primary", tracer.backend, scene, NORMALS_FLAT, (rays_closest, rays_any))
 
     # N > 1, two more keys of the same line (never `value`): BASELINE configs[3] -- the 8-bunny grid under the Domain scheduler, the
     # configuration BASELINE.json names for the scaling curve -- and the weak-scaling soup (N tiles of 10 M triangles each)
@@ -832,14 +921,15 @@ def main():
                 """(run_frame, frame_stats, close) of one Domain-scheduler variant on scene sc"""
                 if args.harness == "native":
                     t = NativeTracer(sc, mode, own, comm)
-                    return (lambda: t(bsp=bsp_v)), (lambda: t.stats), t.close
+                    return (lambda composite=True: t(bsp=bsp_v, composite=composite)), (lambda: t.stats), t.close, t.backend
                 be = None if on_gpu else OracleBackend(sc, mode, [o == rank for o in own])
                 t = DomainTracer(sc, own, dist, torch, dev, mode, backend=be, overlap=not bsp_v)
                 last = {"c": 0, "a": 0}
 
-                def run():
+                def run(composite=True):
                     t()
-                    t.composite(download=False)
+                    if composite:
+                        t.composite(download=False)
 
                 def stats():
                     c, a = getattr(t.backend, "rays_closest", 0), getattr(t.backend, "rays_any", 0)
@@ -849,15 +939,18 @@ def main():
                     d = {"rays_closest": c - last["c"], "rays_any": a - last["a"], "rays_sent": getattr(t, "rays_sent", 0), "rounds": getattr(t, "rounds", 0)}
                     last["c"], last["a"] = c, a
                     return d
-                return run, stats, (lambda: None)
+                return run, stats, (lambda: None), t.backend
 
             sc4 = scenes.bunny_grid_scene(width=args.config4_width, height=args.config4_height)
             own4 = own_map(sc4.n_inst)
             leg = {"workload": CONFIG4_NOTE, "film": [args.config4_width, args.config4_height]}
             for name, bsp_v in (("domain_async", False), ("domain_bsp", True)):
-                run_v, stats_v, close_v = tracer_for(sc4, NORMALS_SMOOTH, own4, bsp_v)
+                run_v, stats_v, close_v, be_v = tracer_for(sc4, NORMALS_SMOOTH, own4, bsp_v)
                 leg[name], _, _, tot4 = measure_variant(run_v, stats_v, args.steps, args.warmup, barrier, reduce_sum, reduce_max, rank, world, "config4_bunny_grid " + name)
                 leg[name]["rays_per_step"] = (tot4[0] + tot4[1]) / args.steps
+                par = variant_parity("config4_bunny_grid " + name, be_v, sc4, NORMALS_SMOOTH, tot4)
+                if par is not None:
+                    leg[name]["parity"] = par
                 close_v()
             extra["config4_bunny_grid"] = leg
             sc4 = None
@@ -869,7 +962,7 @@ def main():
             dist.all_gather_object(boxes, (mine.inst_lo[rank].tolist(), mine.inst_hi[rank].tolist()))
             mine.inst_lo[:] = np.array([b[0] for b in boxes], np.float32)
             mine.inst_hi[:] = np.array([b[1] for b in boxes], np.float32)
-            run_v, stats_v, close_v = tracer_for(mine, NORMALS_FLAT, own_map(world) if args.fake_comm else list(range(world)), False)
+            run_v, stats_v, close_v, be_w = tracer_for(mine, NORMALS_FLAT, own_map(world) if args.fake_comm else list(range(world)), False)
             if on_gpu:
                 capi.stats_reset()
 
@@ -900,6 +993,43 @@ def main():
             dist.all_gather_object(roofs, roof)
             weak.update({"workload": WEAK_NOTE % (args.weak_tris, ww, wh), "scaling": "weak", "tiles": world, "tris_per_tile": args.weak_tris, "film": [ww, wh],
                          "rays_per_step": (totw[0] + totw[1]) / args.steps, "roofline_per_rank": roofs})
+            if do_parity:
+                # no rank holds the whole N x 10 M-triangle scene, so the check is the composite's bookkeeping: every deposit adds 1.0 to a pixel's alpha
+                # (IceTComposite::localAdd) -- one more frame WITHOUT the composite gives every rank's own deposits, their sum over the ranks must be what
+                # rank 0's composited framebuffer holds, and no rank may have lost a shadow ray (deposits <= shadow rays traced)
+                def alpha_sum():
+                    device_sync()
+                    if on_gpu:
+                        a = be_w.fb_tensor(torch, dev).view(-1, 4)[:, 3]
+                        r = [float(a.double().sum().item()), float((a > 0).sum().item())]
+                        torch.cuda.synchronize()
+                        return r
+                    a = be_w.framebuffer(False)[..., 3]
+                    return [float(a.astype(np.float64).sum()), float((a > 0).sum())]
+
+                try:
+                    barrier()
+                    run_v(composite=False)
+                    stats_v()
+                    own = alpha_sum()
+                    own_tot = reduce_sum([own[0]])[0]
+                    barrier()
+                    run_v()
+                    d_last = stats_v()
+                    any_tot = reduce_sum([float(d_last.get("rays_any", 0))])[0]
+                    comp = alpha_sum()
+                except Exception as e:  # noqa: BLE001
+                    if type(e).__name__ != "GvtHipError":
+                        raise
+                    raise LegFailed("weak_soup (deposit check): %s" % e) from e
+                if rank == 0:
+                    ok = comp[0] == own_tot and 0 < own_tot <= any_tot
+                    weak["parity"] = {"checked": "deposit counts: alpha of rank 0's composited framebuffer vs the sum over the ranks of their own deposits (a frame without the composite); "
+                                                 "no rank holds the whole scene, so there is no one-rank image to compare with",
+                                      "deposits_composited": comp[0], "deposits_summed_over_ranks": own_tot, "lit_pixels_composited": int(comp[1]),
+                                      "shadow_rays_traced": any_tot, "deposits_equal": bool(ok)}
+                    if not ok:
+                        parity_bad.append("weak_soup")
             extra["weak_soup"] = weak
             close_v()
             mine = None
@@ -960,6 +1090,23 @@ def main():
         if variants is not None:
             out["variants"] = variants  # Domain asynchronous / Domain BSP / replicated Image, each: ticks, ms per tick, rays and bytes sent, per-phase ms
         out.update(extra)  # config4_bunny_grid, weak_soup
+        if world > 1:
+            checked = {}
+            if primary_parity is not None:
+                checked["primary"] = primary_parity
+            for k, v in (variants or {}).items():
+                if "parity" in v:
+                    checked[k] = v["parity"]
+            for k, v in extra.get("config4_bunny_grid", {}).items():
+                if isinstance(v, dict) and "parity" in v:
+                    checked["config4_bunny_grid " + k] = v["parity"]
+            if "parity" in extra.get("weak_soup", {}):
+                checked["weak_soup"] = extra["weak_soup"]["parity"]
+            out["parity"] = {"checked": "every variant's composited framebuffer on rank 0 against the same scene rendered by ONE rank on rank 0's device, bit for bit, and the rays "
+                                        "traced summed over the ranks against the one-rank counts; weak_soup: deposit counts (details: each variant's `parity`)",
+                             "bit_exact": (not parity_bad and bool(checked)) if do_parity else None, "failed": parity_bad,
+                             "variants": {k: {kk: v.get(kk) for kk in ("bit_exact", "rays_equal", "deposits_equal", "max_abs_diff", "lit_pixels") if kk in v} for k, v in checked.items()},
+                             "skipped": None if do_parity else ("--no-parity" if args.no_parity else "--fake-comm")}
         if legs_error is not None:
             out["legs_error"] = legs_error  # a secondary measurement failed in the ray exchange; it and what was behind it are missing, `value` was measured before
         if on_gpu:
@@ -1027,13 +1174,37 @@ def main():
                                                    adapter=tracer.backend.adapter(0) if args.harness == "native" else None)
             except Exception as e:  # the checker is optional for the measurement itself
                 out["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        if world > 1 and not args.no_cpu_baseline:
+            # the CPU column of the N > 1 line: the same one-GPU workload (the un-cut soup, the whole film) on rank 0's host cores while the other ranks wait at
+            # the last barrier; rank 0's own one-rank render of that scene (the image variant's reference) is compared with the CPU oracle's frame on the way
+            try:
+                one = [v for v in ref_cache.values() if v[3].n_inst == 1 and len(v[3].meshes[0].tris) == args.tris]
+                sc1 = one[0][3] if one else scenes.soup_scene(args.tris, args.width, args.height)
+                ad1 = None
+                if on_gpu and args.harness == "native":
+                    from gravit_amd.adapter import HipMeshAdapter
+                    ad1 = HipMeshAdapter(sc1.meshes[0])
+                side = {}
+                out["cpu_baseline"] = cpu_baseline(sc1, args.cpu_row_stride, host_cores(), gpu_fb=one[0][0] if (one and on_gpu) else None, parity_out=side, adapter=ad1)
+                out["cpu_baseline"]["note"] = "rank 0's host cores, the one-GPU workload (soup-%d un-cut, %dx%d), after the timed regions of every rank" % (args.tris, args.width, args.height)
+                if "parity" in side:
+                    out["parity"]["one_rank_render_vs_cpu_oracle"] = side["parity"]
+                if ad1 is not None:
+                    ad1.close()
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
+    bad_status = 4 if (rank == 0 and parity_bad) else 0  # an image or a ray count that differs from the one-rank render: the line is out, the run is NOT a success
+    if bad_status:
+        print("bench.py: parity FAILED for %s (see `parity` in the line)" % ", ".join(parity_bad), file=sys.stderr, flush=True)
     if world > 1:
         if legs_error is not None:  # the communicator was aborted: no tear-down through it, no barrier a missing peer would hang
             sys.stderr.flush()
-            os._exit(0)  # (every rank: a non-zero worker would make the launcher stop rank 0 before its line is out)
+            os._exit(bad_status)  # (every other rank 0: a non-zero worker would make the launcher stop rank 0 before its line is out)
         dist.barrier()
         dist.destroy_process_group()
+    if bad_status:
+        sys.exit(bad_status)
 
 
 if __name__ == "__main__":

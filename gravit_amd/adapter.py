@@ -46,11 +46,11 @@ class RayQueue:
     def append(self, rays, keep_state=False):
         """host rays; keep_state: they are rays this library exported (bytes 64..79 = stream word + known misses), else they start fresh"""
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
-        capi.check(self.lib.gvt_hip_queue_append(self.h, capi.ptr(rays), C.c_size_t(len(rays)), C.c_int(2 if keep_state else 0)), "gvt_hip_queue_append")
+        capi.check(self.lib.gvt_hip_queue_append_flags(self.h, capi.ptr(rays), C.c_size_t(len(rays)), C.c_int(2 if keep_state else 0)), "gvt_hip_queue_append_flags")
 
     def append_device(self, dptr, n, keep_state=True):
         """n 80-byte rays at device address dptr (a received wire buffer: the rays keep their state)."""
-        capi.check(self.lib.gvt_hip_queue_append(self.h, C.c_void_p(dptr), C.c_size_t(n), C.c_int(1 | (2 if keep_state else 0))), "gvt_hip_queue_append")
+        capi.check(self.lib.gvt_hip_queue_append_flags(self.h, C.c_void_p(dptr), C.c_size_t(n), C.c_int(1 | (2 if keep_state else 0))), "gvt_hip_queue_append_flags")
 
     def export_device(self, dptr, cap):
         n = C.c_size_t(0)

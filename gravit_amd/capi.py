@@ -12,12 +12,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GVT_HIP_LIB") or os.path.join(HERE, "libgvt_hip.so")  # GVT_HIP_LIB: an alternative build (A/B measurements)
 
 # every symbol include/gvt_hip.h declares
+ABI_VERSION = 6  # GVT_HIP_ABI_VERSION of include/gvt_hip.h this file mirrors (tests/test_host_cpu.py compares the two)
+
 SYMBOLS = [
     "gvt_hip_init", "gvt_hip_set_stream", "gvt_hip_synchronize", "gvt_hip_last_error",
     "gvt_hip_mesh_create", "gvt_hip_mesh_destroy", "gvt_hip_trace_ex", "gvt_hip_mesh_get_info", "gvt_hip_mesh_get_normals",
     "gvt_hip_trace", "gvt_hip_intersect", "gvt_hip_occluded",
     "gvt_hip_queue_create", "gvt_hip_queue_destroy", "gvt_hip_queue_reserve", "gvt_hip_queue_clear", "gvt_hip_queue_size",
-    "gvt_hip_queue_append", "gvt_hip_queue_export", "gvt_hip_trace_queue", "gvt_hip_trace_queue_sink",
+    "gvt_hip_queue_append", "gvt_hip_queue_append_flags", "gvt_hip_abi_version", "gvt_hip_queue_export", "gvt_hip_trace_queue", "gvt_hip_trace_queue_sink",
     "gvt_hip_camera_generate",
     "gvt_hip_camera_generate_tiled",
     "gvt_hip_camera_filter",
@@ -85,6 +87,8 @@ def load():
         for s in SYMBOLS:
             getattr(lib, s)  # AttributeError if the ABI is incomplete
         lib.gvt_hip_last_error.restype = C.c_char_p
+        if lib.gvt_hip_abi_version() != ABI_VERSION:  # the out-structs below (MeshInfo, Stats, FrameStats) mirror ONE revision of include/gvt_hip.h
+            raise GvtHipError("%s is ABI revision %d, this binding was written against %d: rebuild the library (python -m gravit_amd._build)" % (LIB_PATH, lib.gvt_hip_abi_version(), ABI_VERSION))
         for f in ("gvt_hip_mesh_create", "gvt_hip_queue_create", "gvt_hip_top_create", "gvt_hip_fb_create", "gvt_hip_fb_device_ptr", "gvt_hip_ctx_create",
                   "gvt_hip_comm_create", "gvt_hip_hub_create", "gvt_hip_comm_create_local", "gvt_hip_tracer_create"):
             getattr(lib, f).restype = C.c_void_p

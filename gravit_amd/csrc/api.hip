@@ -200,7 +200,7 @@ extern "C" int gvt_hip_stats_reset(void) {
 namespace {
 struct KnobDef { const char *name; int Knobs::*field; int lo, hi; bool shipped; };
 const KnobDef g_knobs[] = {
-  // shipped (21)
+  // shipped (24)
   { "skip_known", &Knobs::skip_known, 0, 1, true },           { "frame_timing", &Knobs::frame_timing, 0, 1, true },
   { "term_sink", &Knobs::term_sink, 0, 1, true },
   { "sort_rays", &Knobs::sort_rays, 0, 1, true },             { "leaf_max", &Knobs::leaf_max, 1, 4, true },
@@ -216,6 +216,7 @@ const KnobDef g_knobs[] = {
   { "shadow_order", &Knobs::shadow_order, 0, 1, true },       { "shadow_order_min_rays", &Knobs::shadow_order_min_rays, 0, 1 << 30, true },
 
   { "inline_kb", &Knobs::inline_kb, 0, 1024, true },          { "comm_cus", &Knobs::comm_cus, 0, 128, true },
+  { "comm_stream", &Knobs::comm_stream, 0, 1, true },
   // experiments build only: the alternative was measured and lost, or the value is a tuned constant
   { "trav_kernel", &Knobs::trav_kernel, 0, 1, false },        { "wide4", &Knobs::wide4, 0, 1, false },
   { "coop_fetch", &Knobs::coop_fetch, 0, 1, false },          { "fused", &Knobs::fused, 0, 1, false },
@@ -407,7 +408,13 @@ extern "C" int gvt_hip_queue_sizes(gvt_hip_queue *const *queues, size_t n, uint6
   return 0;
 }
 
-extern "C" int gvt_hip_queue_append(gvt_hip_queue *q, const gvt_hip_ray *rays, size_t n, int flags) {
+extern "C" int gvt_hip_abi_version(void) { return GVT_HIP_ABI_VERSION; }
+
+extern "C" int gvt_hip_queue_append_flags(gvt_hip_queue *q, const gvt_hip_ray *rays, size_t n, int flags);
+extern "C" int gvt_hip_queue_append(gvt_hip_queue *q, const gvt_hip_ray *rays, size_t n, int src_on_device) {
+  return gvt_hip_queue_append_flags(q, rays, n, src_on_device ? (GVT_HIP_APPEND_DEVICE | GVT_HIP_APPEND_KEEP_STATE) : 0);
+}
+extern "C" int gvt_hip_queue_append_flags(gvt_hip_queue *q, const gvt_hip_ray *rays, size_t n, int flags) {
   if (!q || (n && !rays)) { set_error("queue_append: null"); return GVT_HIP_ERR_INVALID; }
   if (flags & ~(GVT_HIP_APPEND_DEVICE | GVT_HIP_APPEND_KEEP_STATE)) { set_error("queue_append: unknown flag bits %d", flags); return GVT_HIP_ERR_INVALID; }
   const int src_on_device = flags & GVT_HIP_APPEND_DEVICE;

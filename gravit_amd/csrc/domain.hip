@@ -781,6 +781,8 @@ struct gvt_hip_tracer {
   int *d_ann_out = nullptr, *d_ann_in = nullptr; // [world][msg_ints]: the announce row (ANN_HEAD + n_inst ints) + the inline payload area
   int *h_ann_in = nullptr;                       // [world][ANN_HEAD + n_inst]: the rows only (k_publish)
   size_t inl_bytes = 0, msg_ints = 0;            // inline area per pair (knob inline_kb when the tables were laid out), message length in ints
+  bool layout_agreed = false;                    // the ranks have compared their message layout since the tables were last laid out (tracer_handshake)
+  int *d_hs = nullptr, *h_hs = nullptr;          // [world + 1][4]: this rank's layout word quadruple, then every peer's
   unsigned *d_overflow = nullptr;
   std::vector<void *> send_buf, recv_buf;
   std::vector<size_t> send_cap, recv_cap;
@@ -808,7 +810,7 @@ extern "C" void gvt_hip_tracer_destroy(gvt_hip_tracer *R) {
   gvt_hip_queue_destroy(R->q_moved);
   hipFree(R->d_insts); hipFree(R->d_round); hipHostFree(R->h_round); hipFree(R->d_count_ptr); hipFree(R->d_owner);
   hipFree(R->d_ann_out); hipFree(R->d_ann_in); hipHostFree(R->h_ann_in); // (d_report / h_report live behind the announces)
-  hipFree(R->d_overflow);
+  hipFree(R->d_overflow); hipFree(R->d_hs); hipHostFree(R->h_hs);
   for (void *p : R->send_buf) hipFree(p);
   for (void *p : R->recv_buf) hipFree(p);
   for (hipEvent_t e : { R->ev_compute, R->ev_report, R->ev_pack, R->ev_recv, R->ev_comm, R->ev_chain0, R->ev_ann0, R->ev_pay0, R->ev_comp0 }) if (e) hipEventDestroy(e);
@@ -833,6 +835,14 @@ static int tracer_alloc_tables(gvt_hip_tracer *R) {
   R->d_report = (unsigned *)(R->d_ann_in + W * R->msg_ints);
   R->h_report = (unsigned *)(R->h_ann_in + W * row);
   R->report_seq = 0;
+  R->layout_agreed = false;
+  hipFree(R->d_hs); hipHostFree(R->h_hs);
+  R->d_hs = R->h_hs = nullptr;
+  if (W > 1) {
+    HIPCHK(hipMalloc((void **)&R->d_hs, sizeof(int) * 4 * (W + 1)));
+    HIPCHK(hipHostMalloc((void **)&R->h_hs, sizeof(int) * 4 * (W + 1), hipHostMallocDefault));
+    HIPCHK(hipMemset(R->d_hs, 0, sizeof(int) * 4 * (W + 1)));
+  }
   for (void *p : R->send_buf) hipFree(p);
   for (void *p : R->recv_buf) hipFree(p);
   R->send_buf.assign(W, nullptr); R->recv_buf.assign(W, nullptr);
@@ -1101,7 +1111,11 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_e
     k_publish<<<(unsigned)R->world, 256, 0, K->stream>>>(R->d_ann_in, (int)R->msg_ints, (int)row, R->world, R->rank, R->d_report, (int)(nI + REPORT_TAIL - 1), R->h_ann_in, R->h_report,
                                                          seq, R->inl_bytes ? R->d_qdesc : nullptr, (int)nI, R->d_overflow, R->d_overflow + 12);
     HIPCHK(hipGetLastError());
-    if (timing) HIPCHK(hipEventRecord(R->ev_report, K->stream));
+    if (timing || K->stream != st) HIPCHK(hipEventRecord(R->ev_report, K->stream));
+    // The host leaves the wait below when block `rank` of k_publish has released the sequence word; the blocks that append the INLINE payloads to the owned
+    // queues and advance their count words may still run.  On the compute stream the next chain is ordered behind them anyway; with the exchange on the
+    // communicator's own stream (knob comm_stream / GVT_HIP_COMM_STREAM) the compute stream is told to wait for the whole of k_publish.
+    if (K->stream != st) HIPCHK(hipStreamWaitEvent(st, R->ev_report, 0));
     {
       char diag[256];
       std::snprintf(diag, sizeof diag, "exchange %d, this rank's announce: %zu local rays pending, error word %d; last report: %u rays in the first queue", tick,
@@ -1145,6 +1159,43 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_e
 }
 } // namespace
 
+// The announce message of a tick has a FIXED length on every rank: row (ANN_HEAD + n_inst ints) + the inline area (knob inline_kb of the rank's context when its
+// tables were laid out).  Ranks that disagree would post sends and receives of different sizes: the in-process transport reports that, RCCL hangs until the
+// deadline or corrupts the row.  So the first frame behind every (re)layout starts with ONE exchange of 16 bytes per pair -- {magic, inline bytes,
+// instances, ABI revision}, a size that cannot disagree -- and a rank that finds a peer laid out differently leaves with GVT_HIP_ERR_INVALID (every rank sees
+// the same disagreement: nobody is left inside the frame's exchanges).  Under RCCL this is also where the pairs connect (the long allowance of bounded_event_wait).
+static int tracer_handshake(gvt_hip_tracer *R) {
+  gvt_hip_comm *K = R->comm;
+  const int W = R->world;
+  if (!K || W < 2 || R->layout_agreed) return 0;
+  if (K->dead) { set_error("ray exchange: the communicator of rank %d was aborted after a deadline passed", K->rank); return GVT_HIP_ERR_TIMEOUT; }
+  int *mine = R->h_hs;
+  mine[0] = 0x47565448; mine[1] = (int)R->inl_bytes; mine[2] = (int)R->n_inst; mine[3] = GVT_HIP_ABI_VERSION;
+  HIPCHK(hipMemcpyAsync(R->d_hs, mine, 16, hipMemcpyHostToDevice, K->stream));
+  comm_group_begin(K);
+  for (int p = 0; p < W; p++) {
+    if (p == R->rank) continue;
+    comm_send(K, R->d_hs, 16, p);
+    comm_recv(K, R->d_hs + 4 * (p + 1), 16, p);
+  }
+  int rc = comm_group_end(K);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(R->h_hs + 4, R->d_hs + 4, sizeof(int) * 4 * W, hipMemcpyDeviceToHost, K->stream));
+  HIPCHK(hipEventRecord(K->ev_wait, K->stream));
+  if ((rc = bounded_event_wait(K, K->ev_wait, "the layout handshake of the frame's first exchange", nullptr, true))) return rc;
+  for (int p = 0; p < W; p++) {
+    if (p == R->rank) continue;
+    const int *h = R->h_hs + 4 * (p + 1);
+    if (h[0] != mine[0] || h[1] != mine[1] || h[2] != mine[2] || h[3] != mine[3]) {
+      set_error("ray exchange: rank %d is laid out differently from rank %d: inline area %d vs %d bytes (knob inline_kb must be the same on every rank), %d vs %d instances, "
+                "ABI revision %d vs %d%s", p, R->rank, h[1], mine[1], h[2], mine[2], h[3], mine[3], h[0] != mine[0] ? " (no handshake word: another protocol)" : "");
+      return GVT_HIP_ERR_INVALID;
+    }
+  }
+  R->layout_agreed = true;
+  return 0;
+}
+
 extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_stats *out) {
   if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
   if (!R) { set_error("tracer_frame: null"); return GVT_HIP_ERR_INVALID; }
@@ -1163,6 +1214,8 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     HIPCHK(hipStreamSynchronize(st));
     if ((rc0 = tracer_alloc_tables(R))) return rc0;
   }
+  if ((rc0 = tracer_handshake(R))) return rc0;
+  if (R->comm) { R->comm->ms_host_wait = 0.0; R->comm->groups = 0; } // (the frame's own counts: the once-per-layout handshake is not one of its ticks)
   const int world_saved = R->world;
   std::vector<uint8_t> owned_saved = R->owned;
   struct Restore { // whatever path leaves this function: the tracer is a rank of its communicator again
@@ -1318,14 +1371,14 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   // (A rank that cannot even run the exchange -- a device fault, a dead process -- is what the deadlines are for.)
   auto failed = [&](int rc_) { if (rc_ && !local_err) { local_err = rc_; local_msg = gvt_hip_last_error(); } return rc_ != 0; };
   const bool multi = world_saved > 1;
-  if (R->comm) { R->comm->ms_host_wait = 0.0; R->comm->groups = 0; }
   // The exchanges of a frame are issued on the COMPUTE stream itself (the communicator's own stream is bound to it for the frame): a tick is
   // a short dependent sequence -- chain, report, announce, copy, pack, payload, unpack -- and every hop between two streams costs an event
   // record, a wait and the queues' hand-over latency on the device (toy two-rank frame 914 -> 670 us, profiles/r04_tick_floor.txt).  What is
   // given up is the overlap of a SMALL payload with the next chain; a payload of a megabyte or more (knob payload_overlap_kb, sent +
   // received) still moves on the communicator's own stream while the next chain runs.  GVT_HIP_COMM_STREAM=1: everything on that stream, as in round 3.
   struct StreamBind { gvt_hip_comm *K; hipStream_t saved; ~StreamBind() { if (K) K->stream = saved; } } stream_bind{ nullptr, nullptr };
-  static const bool own_comm_stream = getenv("GVT_HIP_COMM_STREAM") != nullptr;
+  static const bool env_comm_stream = getenv("GVT_HIP_COMM_STREAM") != nullptr;
+  const bool own_comm_stream = env_comm_stream || C.comm_stream != 0;
   const size_t payload_overlap_min = (size_t)C.payload_overlap_kb << 10;
   if (R->comm && !own_comm_stream) { stream_bind.K = R->comm; stream_bind.saved = R->comm->stream; R->comm->stream = st; }
   int tick = 0;

@@ -81,6 +81,8 @@ struct Knobs {
                          // rank must use the same value (the announce message has a fixed length).  0: always the two-step exchange
   int comm_cus = 0;      // Domain scheduler: payloads that move on the communicator's own stream (payload_overlap_kb) get this many compute units to themselves:
                          // the communicator's stream is created with a CU mask of that many CUs and the persistent traversal grids are sized for the rest (0: no reservation)
+  int comm_stream = 0;   // Domain scheduler: 1 = every exchange of a frame on the communicator's OWN stream, ordered against the compute stream by events (round 3's
+                         // arrangement; also GVT_HIP_COMM_STREAM in the environment); 0 = on the compute stream itself, only large payloads beside it (payload_overlap_kb)
   int frame_timing = 0;  // multi-rank frames: fill gvt_hip_frame_stats' ms_chain / ms_announce / ms_payload / ms_composite (five more event calls per exchange)
   int inject_fail_tick = -1; // tests: this rank's local work "fails" at that exchange of a multi-rank frame (the announce carries the error to every rank)
   int report_poll = 1;   // one rank: a round's report is written into pinned host memory by the kernel and polled (no copy, no stream synchronisation)
@@ -111,6 +113,7 @@ struct Ctx : Knobs {
   gvt_hip_stats stats{};
   // traversal launch geometry + per-thread stack spill area
   int n_cu = 256;        // compute units the context's launches are sized for (all of the device's, minus cu_reserved)
+  bool shadow_order_denied = false; // the class-ordered shadow list (8 x the plain one) could not be allocated once: this context lists shadow rays in arrival order
   int cu_reserved = 0;   // compute units masked away from the context's stream for a communicator's own stream (knob comm_cus)
   int trav_blocks = 0;
   int *d_spill = nullptr;

@@ -510,15 +510,28 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
   // SHADOW_CLASSES regions of `cls_stride` slots; not for packets (no per-ray step counts) nor small rounds (a wave per ray)
   const bool by_class_wanted = single && single->mesh->d_nodes4 && C.shadow_order && nL == 1 && n >= (size_t)C.shadow_order_min_rays && n > (size_t)C.small_rays &&
                         C.long_steps > 0 && n >= (size_t)C.long_min_rays &&
-                        !((C.packet == 2 || (C.packet == 1 && single->mesh->packet_ok && n >= (size_t)C.packet_min_rays)) && single->coherent);
+                        !((C.packet == 2 || (C.packet == 1 && single->mesh->packet_ok && n >= (size_t)C.packet_min_rays)) && single->coherent)
+#ifdef GVT_EXPERIMENTS
+                        && !quad_usable(single->mesh) // (k_traceq walks the shadow list as one contiguous run counted by c[1])
+#endif
+      ;
   const size_t cls_stride = (n + 63) & ~(size_t)63;
   // (every region has room for the whole list -- 8 x 64 bytes per ray: 0.5 GB at the benchmark's 1.04 M rays; beyond 8 GiB the list stays in arrival order)
-  const bool by_class = by_class_wanted && cls_stride * SHADOW_CLASSES * 64 <= ((size_t)8 << 30);
-  const size_t shadow_slots = by_class ? cls_stride * SHADOW_CLASSES : shadow_cap;
+  // The ordering is an optimisation whose results do not depend on it: it must never make a frame fail that fits without it.  A device that cannot
+  // give the 8x list falls back to arrival order with the plain n-slot list, for this context from then on (no allocation attempt per frame).
+  bool by_class = by_class_wanted && !C.shadow_order_denied && cls_stride * SHADOW_CLASSES * 64 <= ((size_t)8 << 30);
+  size_t shadow_slots = by_class ? cls_stride * SHADOW_CLASSES : shadow_cap;
   if (shadow_slots >= 0xffffffffull) { set_error("round: %zu shadow slots exceed the 32-bit slot counters", shadow_slots); return GVT_HIP_ERR_INVALID; }
   float4 *d_shadow = (float4 *)scratch_get(2, sizeof(float4) * 4 * shadow_slots);
-  unsigned char *d_steps = by_class ? (unsigned char *)scratch_get(19, n) : nullptr;
-  if (by_class && !d_steps) return GVT_HIP_ERR_DEVICE;
+  unsigned char *d_steps = (by_class && d_shadow) ? (unsigned char *)scratch_get(19, n) : nullptr;
+  if (by_class && (!d_shadow || !d_steps)) {
+    (void)hipGetLastError(); // (the failed hipMalloc's sticky-less error)
+    C.shadow_order_denied = true;
+    by_class = false;
+    d_steps = nullptr;
+    shadow_slots = shadow_cap;
+    d_shadow = (float4 *)scratch_get(2, sizeof(float4) * 4 * shadow_slots);
+  }
   unsigned *d_idx_a = (unsigned *)scratch_get(3, sizeof(unsigned) * n);
   unsigned *d_idx_b = (unsigned *)scratch_get(4, sizeof(unsigned) * n);
   gvt_hip_light *d_lights = (gvt_hip_light *)scratch_get(5, sizeof(gvt_hip_light) * (nL > 0 ? nL : 1));

@@ -23,6 +23,8 @@ HipMeshAdapter::HipMeshAdapter(std::shared_ptr<gvt::render::data::primitives::Da
     : Adapter(m), mesh_(nullptr), normal_mode_(normal_mode), trace_calls_(0) {
   std::shared_ptr<Mesh> mesh = std::dynamic_pointer_cast<Mesh>(m);
   if (!mesh) throw std::runtime_error("HipMeshAdapter: mesh pointer in the database is null"); // GVT_ASSERT, EmbreeMeshAdapter.cpp:128
+  if (gvt_hip_abi_version() != GVT_HIP_ABI_VERSION) // the library on the loader's path is another revision than the header this file was compiled against
+    throw std::runtime_error("HipMeshAdapter: libgvt_hip.so is ABI revision " + std::to_string(gvt_hip_abi_version()) + ", built against " + std::to_string(GVT_HIP_ABI_VERSION));
   mesh->generateNormals();                                                                       // :129 (mutates the shared Mesh)
 
   const size_t nV = mesh->vertices.size(), nT = mesh->faces.size();

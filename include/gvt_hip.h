@@ -31,6 +31,13 @@
 extern "C" {
 #endif
 
+/* ABI revision of this header: bumped whenever an entry point changes meaning or an out-struct (gvt_hip_mesh_info, gvt_hip_stats, gvt_hip_frame_stats)
+ * changes size.  A binding compares it with gvt_hip_abi_version() of the library it loaded before its first call (gravit_amd/capi.py, HipMeshAdapter.cpp do):
+ * a caller built against another revision would have out-structs written past their end or flags read with another meaning, silently.
+ *   6: gvt_hip_queue_append keeps its round-4 meaning (4th argument: the source is device memory); the flag word lives in gvt_hip_queue_append_flags */
+#define GVT_HIP_ABI_VERSION 6
+int gvt_hip_abi_version(void); /* GVT_HIP_ABI_VERSION the library was built from; no device access */
+
 #define GVT_HIP_OK 0
 #define GVT_HIP_ERR_INVALID (-1)  /* bad argument */
 #define GVT_HIP_ERR_DEVICE (-2)   /* HIP runtime error */
@@ -163,7 +170,11 @@ int gvt_hip_queue_size(gvt_hip_queue *, size_t *n);          /* host-side count,
  * through an instance without tracing it. */
 #define GVT_HIP_APPEND_DEVICE 1
 #define GVT_HIP_APPEND_KEEP_STATE 2
-int gvt_hip_queue_append(gvt_hip_queue *, const gvt_hip_ray *rays, size_t n, int flags);
+int gvt_hip_queue_append_flags(gvt_hip_queue *, const gvt_hip_ray *rays, size_t n, int flags);
+/* The entry point of the earlier revisions, with the meaning it had there: src_on_device != 0 -- `rays` is a wire image in device memory (what an exchange
+ * delivered; this library exported it): its state bytes 64..79 are kept, = GVT_HIP_APPEND_DEVICE | GVT_HIP_APPEND_KEEP_STATE; src_on_device == 0 -- host
+ * rays, taken as FRESH (= flags 0).  A caller written against the boolean keeps working; new code uses gvt_hip_queue_append_flags. */
+int gvt_hip_queue_append(gvt_hip_queue *, const gvt_hip_ray *rays, size_t n, int src_on_device);
 /* copy the queue out as 80-byte rays (host or device destination) */
 int gvt_hip_queue_export(gvt_hip_queue *, gvt_hip_ray *dst, size_t cap, size_t *n, int dst_on_device);
 /* Adapter::trace on device queues: consumes q_in (left empty, like ImageTracer.h:248), appends to q_out */
@@ -370,6 +381,8 @@ int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
  *                                                per tick; default 16; the same on every rank; 0: the two-step exchange of SendRays, counts then rays)
  *                "comm_cus"                      Domain scheduler: compute units reserved for the communicator's own stream (CU mask; the persistent traversal grids
  *                                                are sized for the rest); set before gvt_hip_comm_create; default 0
+ *                "comm_stream"                   Domain scheduler: 1 = every exchange of a frame on the communicator's own stream, ordered against the compute stream
+ *                                                by events (also GVT_HIP_COMM_STREAM in the environment); default 0: on the compute stream, large payloads beside it
  *                "abi_lanes" / "abi_chunk"     gvt_hip_trace on a host RayVector: pipeline lanes (0: one shot), rays per chunk
  *   test hook    "inject_fail_tick"
  * Everything else -- the tuned constants of the kernels (refill / phase thresholds, grid sizes, drain sharing ...) and the variants that were

@@ -138,6 +138,34 @@ def test_bench_script_multi_rank_branch_under_gloo(tmp_path):
         assert r["value"] > 0 and r["rays_per_step"] > 100 and r["ticks_per_step"] >= 1
     assert c4["film"] == [95, 54] and c4["domain_async"]["rays_sent_per_step"] == c4["domain_bsp"]["rays_sent_per_step"] > 0
     assert wk["scaling"] == "weak" and wk["tiles"] == 2 and wk["tris_per_tile"] == 8000 and wk["film"] == [136, 80] and len(wk["roofline_per_rank"]) == 2
+    # the line verifies itself (the reference never runs distributed without diffing the image, CMakeLists.txt:650-688): every variant's composited image
+    # against rank 0's one-rank render of the same scene, the rays traced against the one-rank counts, the weak leg's deposit counts; and it carries the CPU column
+    par = j["parity"]
+    assert par["bit_exact"] is True and par["failed"] == [] and par["skipped"] is None
+    assert set(par["variants"]) == {"domain_async", "domain_bsp", "config4_bunny_grid domain_async", "config4_bunny_grid domain_bsp", "weak_soup"}
+    for name, r in (("domain_async", v["domain_async"]), ("domain_bsp", v["domain_bsp"]), ("c4a", c4["domain_async"]), ("c4b", c4["domain_bsp"])):
+        p_ = r["parity"]
+        assert p_["bit_exact"] and p_["rays_equal"] and p_["max_abs_diff"] == 0.0 and p_["lit_pixels"] == p_["lit_pixels_got"] > 100, (name, p_)
+        assert p_["rays_closest"][0] == p_["rays_closest"][1] > 0 and p_["rays_any"][0] == p_["rays_any"][1] > 0
+    assert wk["parity"]["deposits_equal"] and wk["parity"]["deposits_composited"] == wk["parity"]["deposits_summed_over_ranks"] > 0
+    cb = j["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and "rank 0" in cb["note"]
+
+
+def test_bench_script_fails_loudly_when_a_variant_image_differs(tmp_path):
+    """One damaged pixel in one variant's composited image (test hook GVT_BENCH_BREAK_PARITY): the line is still printed, says which variant failed, and
+    the run leaves with a non-zero status -- through the script's own launcher too."""
+    import json
+    import subprocess
+    import sys
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--harness", "checker", "--tris", "20000", "--width", "96", "--height", "54",
+                        "--steps", "1", "--warmup", "0", "--no-extra-legs", "--no-cpu-baseline"], env=dict(_clean_env(), GVT_BENCH_BREAK_PARITY="domain_bsp"), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 4, p.stderr[-3000:]
+    j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["value"] > 0 and j["parity"]["bit_exact"] is False and j["parity"]["failed"] == ["domain_bsp"]
+    assert j["variants"]["domain_bsp"]["parity"]["pixels_differ"] == 1 and j["variants"]["domain_async"]["parity"]["bit_exact"]
+    assert "parity FAILED for domain_bsp" in p.stderr
 
 
 def test_bench_script_keeps_its_line_when_a_secondary_leg_fails(tmp_path):

@@ -80,3 +80,16 @@ def test_bench_script_starts_its_ranks_and_exchanges_over_the_rccl_leg(hip, tmp_
     assert j["config"]["transport"] == "GVT_HIP_RCCL_LIB=libfakerccl.so" and "not a measurement" in j["config"]["rehearsal"]  # the line says what it is
     assert j["variants"]["domain_async"]["rays_sent_per_step"] > 0 and j["variants"]["domain_async"]["transport_groups_per_step"] > 0
     assert j["config4_bunny_grid"]["domain_async"]["value"] > 0 and j["weak_soup"]["tiles"] == 2 and j["weak_soup"]["value"] > 0
+    # the line verifies itself: every variant's composited image bit for bit against rank 0's one-rank render, ray counts equal, deposit counts of the weak leg
+    par = j["parity"]
+    assert par["bit_exact"] is True and par["failed"] == [], par
+    assert set(par["variants"]) == {"domain_async", "domain_bsp", "image_replicated", "domain_async_known_miss_shortcut", "config4_bunny_grid domain_async",
+                                    "config4_bunny_grid domain_bsp", "weak_soup"}
+    for name in ("domain_async", "domain_bsp", "image_replicated", "domain_async_known_miss_shortcut"):
+        p_ = j["variants"][name]["parity"]
+        assert p_["bit_exact"] and p_["rays_equal"] and p_["lit_pixels"] > 1000, (name, p_)
+    assert "vs_strict_rule" in j["variants"]["domain_async_known_miss_shortcut"]["parity"]
+    assert j["weak_soup"]["parity"]["deposits_equal"]
+    assert par["one_rank_render_vs_cpu_oracle"]["bit_exact"] is True  # rank 0's own render of the un-cut soup against the CPU oracle's frame
+    cb = j["cpu_baseline"]
+    assert cb["value"] > 0 and cb["simd"]["value"] > 0 and "rank 0" in cb["note"] and j["roofline"]["frac"] > 0

@@ -314,6 +314,22 @@ def test_small_payloads_ride_inside_the_announce(hip, world, bsp):
         assert max(x[1]["rounds"] for x in res[1024].values()) <= max(x[1]["rounds"] for x in res[0].values())
 
 
+@pytest.mark.parametrize("world,bsp", [(2, False), (3, False), (2, True)])
+def test_exchanges_on_the_communicators_own_stream(hip, world, bsp):
+    """comm_stream = 1 (GVT_HIP_COMM_STREAM): the announce, k_publish's inline appends and the payloads run on the communicator's own stream; the compute
+    stream waits for the WHOLE of k_publish (not only for the block that releases the host's sequence word) before the next chain reads the queues
+    (an all-inline tick used to leave that unordered).  Same image and counts as the restated DomainTracer, frame after frame."""
+    sc = _toy_crossing_scene()
+    owner = [i % world for i in range(sc.n_inst)]
+    ref, st = oracle_render_domain(sc, owner, world, 0)
+    for kb in (1024, 16, 0):
+        for _ in range(3):
+            r = run_native_ranks(sc, owner, world, NORMALS_FLAT, bsp, opts=(("comm_stream", 1), ("inline_kb", kb)))
+            assert np.array_equal(r[0][0][..., :3], ref[..., :3]) and np.array_equal(r[0][0][..., 3], ref[..., 3]), kb
+            assert sum(x[1]["rays_sent"] for x in r.values()) == st.rays_sent
+            assert sum(x[1]["rays_closest"] for x in r.values()) == st.rays_closest and sum(x[1]["rays_any"] for x in r.values()) == st.rays_any
+
+
 def test_reserved_compute_units_for_the_communicators_stream(hip):
     """comm_cus: the communicator's own stream gets k compute units to itself (CU-masked stream), the rank's compute stream the others, the
     persistent grids are sized for those; with payload_overlap_kb = 0 and inline_kb = 0 every payload moves on that stream beside the next
@@ -403,6 +419,54 @@ def test_a_failing_rank_ends_the_frame_on_every_rank_and_the_next_frame_works(hi
     assert all("rank 1 reported error" in msgs[r] for r in (0, 2)), msgs
     ref, _ = oracle_render_domain(sc, owner, world, 0)
     assert np.abs(fbs[0][..., :3] - ref[..., :3]).max() <= 1e-5 and np.array_equal(fbs[0][..., 3], ref[..., 3])
+
+
+def test_ranks_that_disagree_on_the_message_layout_are_told_so(hip):
+    """inline_kb differs between two ranks: the announce messages would have different lengths (RCCL: a hang or a corrupt row).  The frame's first exchange
+    is a 16-byte layout handshake; both ranks come back with GVT_HIP_ERR_INVALID naming the knob, nobody waits for a deadline; with the knob
+    agreed again the same tracers render the oracle's image."""
+    sc = _toy_crossing_scene()
+    owner = [i % 2 for i in range(sc.n_inst)]
+    hub = capi.load().gvt_hip_hub_create(2)
+    msgs, fbs, errs = {}, {}, []
+    sync = threading.Barrier(2)
+
+    def rank_main(rank):
+        ctx = None
+        try:
+            ctx = Context(0)
+            capi.set_option("inline_kb", 16 if rank == 0 else 4)
+            comm = Comm.local(hub, rank)
+            tr = NativeTracer(sc, NORMALS_FLAT, owner, comm)
+            try:
+                tr()
+                msgs[rank] = "no error"
+            except capi.GvtHipError as e:
+                msgs[rank] = str(e)
+            capi.set_option("inline_kb", 16)
+            sync.wait(timeout=60)
+            B = tr()
+            fbs[rank] = B.framebuffer(True) if rank == 0 else None
+            tr.close(); comm.close()
+            B = tr = None
+        except Exception:  # noqa: BLE001
+            import traceback
+            errs.append(traceback.format_exc())
+            capi.load().gvt_hip_hub_abort(hub)
+        finally:
+            import gc
+            gc.collect()
+            if ctx is not None:
+                ctx.close()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    capi.load().gvt_hip_hub_destroy(hub)
+    assert not errs, errs[0]
+    assert all("laid out differently" in msgs[r] and "inline_kb" in msgs[r] for r in (0, 1)), msgs
+    ref, _ = oracle_render_domain(sc, owner, 2, 0)
+    assert np.array_equal(fbs[0][..., :3], ref[..., :3])
 
 
 def test_a_rank_that_never_joins_runs_its_peer_into_the_deadline(hip):

@@ -29,6 +29,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = capi.load()
     for s in declared:
         assert hasattr(lib, s), s
+    assert lib.gvt_hip_abi_version() == capi.ABI_VERSION == int(re.search(r"#define GVT_HIP_ABI_VERSION (\d+)", hdr).group(1))
     # struct sizes the ABI promises
     assert C.sizeof(capi.MeshInfo) == 96 and C.sizeof(capi.Stats) == 16 * 8
     m = re.search(r"typedef struct gvt_hip_ray \{(.*?)\} gvt_hip_ray;", hdr, re.S)
@@ -253,3 +254,43 @@ def test_rccl_stand_in_of_the_multi_process_tests_builds_and_covers_the_librarys
     src = open(os.path.join(ROOT, "gravit_amd", "csrc", "domain.hip")).read()
     wanted = set(re.findall(r'"(nccl[A-Za-z]+)"', src))
     assert len(wanted) >= 11 and wanted <= exported, wanted - exported
+
+
+def test_read_ply_ascii_binary_and_colors(tmp_path):
+    """scenes.read_ply_full against tiny committed PLY files in the three encodings PlyReader.cpp:54-176 takes through ply.c; colours only when the
+    vertex element has more than five properties (PlyReader.cpp:123), as /255 floats; the reference's bun_zipper.ply (where the GraviT tree is present)
+    reproduces the committed bun_zipper.npz."""
+    import os
+
+    from gravit_amd import scenes
+    from tests.conftest import GOLDEN
+
+    verts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1.5]], np.float32)
+    cols = np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [128, 64, 32], [10, 20, 30]], np.float32) / np.float32(255.0)
+    tris = np.array([[0, 1, 2], [0, 2, 3], [1, 4, 2], [3, 2, 4]], np.int32)
+    for name in ("tiny_ascii.ply", "tiny_le.ply", "tiny_be.ply"):
+        v, t, c = scenes.read_ply_full(os.path.join(GOLDEN, name))
+        assert v.dtype == np.float32 and t.dtype == np.int32 and c.dtype == np.float32, name
+        assert np.array_equal(v, verts) and np.array_equal(t, tris) and np.array_equal(c, cols), name
+    v, t, c = scenes.read_ply_full(os.path.join(GOLDEN, "tiny_nocolor.ply"))
+    assert np.array_equal(v, verts) and np.array_equal(t, tris) and c is None
+    v2, t2 = scenes.load_mesh_file(os.path.join(GOLDEN, "tiny_le.ply"))
+    assert np.array_equal(v2, verts) and np.array_equal(t2, tris)
+    bad = tmp_path / "quad.ply"
+    bad.write_bytes(b"ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\nelement face 1\n"
+                    b"property list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3\n")
+    with pytest.raises(ValueError):
+        scenes.read_ply(str(bad))
+    oob = tmp_path / "oob.ply"
+    oob.write_bytes(b"ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nelement face 1\n"
+                    b"property list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n1 1 0\n3 0 1 7\n")
+    with pytest.raises(ValueError):
+        scenes.read_ply(str(oob))
+    ref = "/root/reference/data/geom/bunny/reconstruction/bun_zipper.ply"
+    if os.path.exists(ref):
+        z = np.load(os.path.join(GOLDEN, "bun_zipper.npz"))
+        v, t = scenes.read_ply(ref)
+        keys = list(z.keys())
+        vk = [k for k in keys if z[k].dtype.kind == "f" and z[k].ndim == 2][0]
+        tk = [k for k in keys if z[k].dtype.kind in "iu" and z[k].ndim == 2][0]
+        assert np.array_equal(v, z[vk]) and np.array_equal(t, z[tk].astype(np.int32))
