@@ -410,8 +410,11 @@ extern "C" int gvt_hip_queue_sizes(gvt_hip_queue *const *queues, size_t n, uint6
 
 extern "C" int gvt_hip_abi_version(void) { return GVT_HIP_ABI_VERSION; }
 
-extern "C" int gvt_hip_queue_append_flags(gvt_hip_queue *q, const gvt_hip_ray *rays, size_t n, int flags);
 extern "C" int gvt_hip_queue_append(gvt_hip_queue *q, const gvt_hip_ray *rays, size_t n, int src_on_device) {
+  if (src_on_device != 0 && src_on_device != 1) { // a caller of revision 5 passing its flag word: an error, never a host pointer read as device memory
+    set_error("queue_append: the 4th argument is the boolean src_on_device (0 / 1), got %d; flag words go to gvt_hip_queue_append_flags", src_on_device);
+    return GVT_HIP_ERR_INVALID;
+  }
   return gvt_hip_queue_append_flags(q, rays, n, src_on_device ? (GVT_HIP_APPEND_DEVICE | GVT_HIP_APPEND_KEEP_STATE) : 0);
 }
 extern "C" int gvt_hip_queue_append_flags(gvt_hip_queue *q, const gvt_hip_ray *rays, size_t n, int flags) {
@@ -598,7 +601,7 @@ static int trace_pipelined(Ctx &C, gvt_hip_mesh *M, gvt_hip_ray *rays, size_t be
       size_t got = 0;
       const auto tc0 = std::chrono::steady_clock::now();
       if ((rc = gvt_hip_queue_clear(qin)) || (rc = gvt_hip_queue_clear(qout))) break;
-      if ((rc = gvt_hip_queue_append(qin, rays + begin + off, cn, GVT_HIP_APPEND_KEEP_STATE))) break; // (Adapter::trace copies a forwarded ray whole, padding included, and interprets none of it)
+      if ((rc = gvt_hip_queue_append_flags(qin, rays + begin + off, cn, GVT_HIP_APPEND_KEEP_STATE))) break; // (Adapter::trace copies a forwarded ray whole, padding included, and interprets none of it)
       const auto tc1 = std::chrono::steady_clock::now();
       if ((rc = queue_reserve(qout, cn * (1 + n_lights)))) break;
       if ((rc = trace_core(M, make_planes(qin->d_planes, qin->cap), cn, begin + off, qout, P, lights))) break;
@@ -670,7 +673,7 @@ extern "C" int gvt_hip_trace_ex(gvt_hip_mesh *M, gvt_hip_ray *rays, size_t n_ray
   gvt_hip_queue *qin = C.abi_qin, *qout = C.abi_qout;
   if (!qin || !qout) return GVT_HIP_ERR_DEVICE;
   if ((rc = gvt_hip_queue_clear(qin)) || (rc = gvt_hip_queue_clear(qout))) return rc;
-  if ((rc = gvt_hip_queue_append(qin, rays + begin, n, GVT_HIP_APPEND_KEEP_STATE))) return rc; // bytes 64..79 pass through (a forwarded ray is a copy of all 80 bytes); this path never reads them
+  if ((rc = gvt_hip_queue_append_flags(qin, rays + begin, n, GVT_HIP_APPEND_KEEP_STATE))) return rc; // bytes 64..79 pass through (a forwarded ray is a copy of all 80 bytes); this path never reads them
   if ((rc = queue_reserve(qout, n * (1 + n_lights)))) return rc;
   P.update_in_place = write_back ? 1 : 0;
   if ((rc = trace_core(M, make_planes(qin->d_planes, qin->cap), n, begin, qout, P, lights))) return rc;

@@ -173,7 +173,8 @@ int gvt_hip_queue_size(gvt_hip_queue *, size_t *n);          /* host-side count,
 int gvt_hip_queue_append_flags(gvt_hip_queue *, const gvt_hip_ray *rays, size_t n, int flags);
 /* The entry point of the earlier revisions, with the meaning it had there: src_on_device != 0 -- `rays` is a wire image in device memory (what an exchange
  * delivered; this library exported it): its state bytes 64..79 are kept, = GVT_HIP_APPEND_DEVICE | GVT_HIP_APPEND_KEEP_STATE; src_on_device == 0 -- host
- * rays, taken as FRESH (= flags 0).  A caller written against the boolean keeps working; new code uses gvt_hip_queue_append_flags. */
+ * rays, taken as FRESH (= flags 0); any other value: GVT_HIP_ERR_INVALID (a revision-5 caller's flag word is refused, not misread).  A caller written
+ * against the boolean keeps working; new code uses gvt_hip_queue_append_flags. */
 int gvt_hip_queue_append(gvt_hip_queue *, const gvt_hip_ray *rays, size_t n, int src_on_device);
 /* copy the queue out as 80-byte rays (host or device destination) */
 int gvt_hip_queue_export(gvt_hip_queue *, gvt_hip_ray *dst, size_t cap, size_t *n, int dst_on_device);

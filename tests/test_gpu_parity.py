@@ -948,3 +948,12 @@ def test_host_appended_rays_start_fresh_whatever_their_padding_holds(hip):
         assert len(x) == len(y) and np.array_equal(sort_rays(x).view(np.uint8).reshape(-1, 80), sort_rays(y).view(np.uint8).reshape(-1, 80))
     c = shuffled(dirty, True)  # the same bytes taken as state: rays bound for instances 0..5 are walked past them
     assert [len(x) for x in c] != [len(x) for x in a]
+    # the entry point of the earlier ABI revisions keeps its boolean: 0 = host rays (fresh), 1 = a device wire image (state kept); a flag word is refused
+    import ctypes as C
+    lib = hip.load()
+    q = RayQueue()
+    d = np.ascontiguousarray(dirty[:256])
+    assert lib.gvt_hip_queue_append(q.h, hip.ptr(d), C.c_size_t(len(d)), C.c_int(2)) == -1 and "gvt_hip_queue_append_flags" in hip.last_error()
+    assert lib.gvt_hip_queue_append(q.h, hip.ptr(d), C.c_size_t(len(d)), C.c_int(0)) == 0
+    got = q.to_numpy()
+    assert len(got) == 256 and not got["known"].any() and np.array_equal(got["origin"], d["origin"])

@@ -12,11 +12,11 @@ python3 -c "from tests.test_gpu_multiproc import build_fake_rccl; print(build_fa
 export GVT_HIP_RCCL_LIB=$REPO/tests/fake_rccl/libfakerccl.so TMPDIR=/tmp/mpf_$$ FAKE_RCCL_TIMEOUT_S=600 HSA_ENABLE_IPC_MODE_LEGACY=0
 mkdir -p $TMPDIR
 OUT=gpurun_out/${TAG}_multiproc_fullsize_$N
-t0=$(date +%s.%N)
+t0=$(date +%s)
 timeout -k 10 900 python3 bench.py --gpus $N --same-gpu "$@" > $OUT.json 2> $OUT.err
 rc=$?
-t1=$(date +%s.%N)
-echo "bench.py --gpus $N --same-gpu $@: exit status $rc, wall $(echo "$t1 - $t0" | bc) s" | tee $OUT.txt
+t1=$(date +%s)
+echo "bench.py --gpus $N --same-gpu $@: exit status $rc, wall $((t1 - t0)) s" | tee $OUT.txt
 python3 - $OUT.json >> $OUT.txt <<'PY'
 import json, sys
 lines = [l for l in open(sys.argv[1]) if l.startswith("{")]
