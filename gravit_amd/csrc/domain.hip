@@ -841,8 +841,8 @@ static int tracer_alloc_tables(gvt_hip_tracer *R) {
   if (W > 1) {
     HIPCHK(hipMalloc((void **)&R->d_hs, sizeof(int) * 4 * (W + 1)));
     HIPCHK(hipHostMalloc((void **)&R->h_hs, sizeof(int) * 4 * (W + 1), hipHostMallocDefault));
-    HIPCHK(hipMemset(R->d_hs, 0, sizeof(int) * 4 * (W + 1)));
   }
+  HIPCHK(hipStreamSynchronize(nullptr)); // the memsets above run on the null stream and may return before they are done; the frame's streams do not wait for it (non-blocking)
   for (void *p : R->send_buf) hipFree(p);
   for (void *p : R->recv_buf) hipFree(p);
   R->send_buf.assign(W, nullptr); R->recv_buf.assign(W, nullptr);
