@@ -712,6 +712,8 @@ int sort_pairs_u32(unsigned *keys_in, unsigned *keys_out, unsigned *vals_in, uns
 // Compressed 4-wide collapse of the emitted binary tree (the traversal layout of k_trace's wide4 variant)
 static int build_nodes4(gvt_hip_mesh *M, BuildArena *A) {
   if (M->d_nodes4 || !M->nNodes) return 0;
+  // k_trace addresses a node by a 32-bit BYTE offset (index << 6, trace_lane.inc): 2^26 nodes is the layout's limit (a mesh of ~130 M triangles)
+  if (M->nNodes >= ((size_t)1 << 26)) { set_error("mesh: %zu tree nodes exceed the traversal layout's 2^26 (cut the mesh into several instances)", M->nNodes); return GVT_HIP_ERR_CAPACITY; }
   Ctx &C = gctx();
   hipStream_t st = C.stream;
   int *fa = nullptr, *fb = nullptr;

@@ -84,15 +84,19 @@ int trav_grid(size_t n) {
   return (int)(need < (size_t)C.trav_blocks ? (need ? need : 1) : (size_t)C.trav_blocks);
 }
 
-template <bool ANY, bool XFORM, int MODE, typename... Args> void launch_trace(bool have_nodes4, int grid, hipStream_t st, Args... args) {
+template <bool ANY, bool XFORM, int MODE, typename... Args> void launch_trace(bool have_nodes4, int grid, hipStream_t st, RayPlanes q, const unsigned *idx, unsigned n, Mat4 minv, Args... args) {
+  // k_trace never reads the matrix's bottom row (an instance matrix is affine); it carries the direction transform's `translation x 0` terms there instead
+  // (xfm_vector: m[12..14] * 0.0f, kept for parity with glm's mat4 * vec4(d, 0)): kernel arguments live in SCALAR registers, where the products computed on
+  // the device sat in three vector registers for the whole launch -- spilled to scratch in the shipped closest-hit kernel
+  minv.m[3] = minv.m[12] * 0.0f; minv.m[7] = minv.m[13] * 0.0f; minv.m[11] = minv.m[14] * 0.0f;
 #ifdef GVT_EXPERIMENTS
   if (!(gctx().wide4 && have_nodes4)) { // the uncompressed binary nodes
-    if (gctx().coop_fetch) k_trace<ANY, XFORM, MODE, true, false><<<grid, TRAV_BLOCK, 0, st>>>(args...);
-    else k_trace<ANY, XFORM, MODE, false, false><<<grid, TRAV_BLOCK, 0, st>>>(args...);
+    if (gctx().coop_fetch) k_trace<ANY, XFORM, MODE, true, false><<<grid, TRAV_BLOCK, 0, st>>>(q, idx, n, minv, args...);
+    else k_trace<ANY, XFORM, MODE, false, false><<<grid, TRAV_BLOCK, 0, st>>>(q, idx, n, minv, args...);
     return;
   }
 #endif
-  k_trace<ANY, XFORM, MODE, false, true><<<grid, TRAV_BLOCK, 0, st>>>(args...); // a mesh without 4-wide nodes has no triangles: every ray retires as a miss
+  k_trace<ANY, XFORM, MODE, false, true><<<grid, TRAV_BLOCK, 0, st>>>(q, idx, n, minv, args...); // a mesh without 4-wide nodes has no triangles: every ray retires as a miss
 }
 
 // scratch of a closest-hit launch's parked rays: n records, then LONG_SAVE stack entries for each of the first LONG_STK_CAP of them
