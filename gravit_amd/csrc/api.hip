@@ -58,11 +58,48 @@ static int ctx_setup(Ctx &C, int device) {
   return 0;
 }
 
+// The first launch from a translation unit loads its code object, rocPRIM sets itself up at its first call: the FIRST acceleration-structure build of a
+// process used to take 13-18 ms where the second takes 4 (10 M triangles).  gvt_hip_init pays that once, off every build's clock: a 2,048-triangle mesh is
+// built (every kernel of lbvh.hip + the radix sort and scan) and a handful of rays traced through it (trace.hip, api.hip), then everything is released and the
+// statistics start from zero.  GVT_HIP_NO_WARMUP=1 skips it.
+static void drain_events();
+static void warm_up() {
+  if (getenv("GVT_HIP_NO_WARMUP")) return;
+  const size_t nT = 2048;
+  std::vector<float> v(nT * 9);
+  std::vector<int32_t> t(nT * 3);
+  uint32_t r = 12345u;
+  for (size_t i = 0; i < nT; i++) {
+    float c[3];
+    for (int k = 0; k < 3; k++) { r = r * 1664525u + 1013904223u; c[k] = (float)(r >> 8) * (1.0f / 16777216.0f); }
+    for (int j = 0; j < 3; j++)
+      for (int k = 0; k < 3; k++) { r = r * 1664525u + 1013904223u; v[9 * i + 3 * j + k] = c[k] + ((float)(r >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.02f; }
+    t[3 * i] = (int32_t)(3 * i); t[3 * i + 1] = (int32_t)(3 * i + 1); t[3 * i + 2] = (int32_t)(3 * i + 2);
+  }
+  gvt_hip_mesh *m = gvt_hip_mesh_create(v.data(), nT * 3, t.data(), nT, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
+  if (m) {
+    float org[64 * 3], dir[64 * 3];
+    gvt_hip_hit hits[64];
+    int32_t occ[64];
+    for (int i = 0; i < 64; i++) { org[3 * i] = (float)(i % 8) / 8.f; org[3 * i + 1] = (float)(i / 8) / 8.f; org[3 * i + 2] = 2.f; dir[3 * i] = 0.f; dir[3 * i + 1] = 0.f; dir[3 * i + 2] = -1.f; }
+    gvt_hip_intersect(m, org, dir, 64, 0.f, hits);
+    gvt_hip_occluded(m, org, dir, 64, 0.f, occ);
+    gvt_hip_mesh_destroy(m);
+  }
+  Ctx &C = g_default_ctx;
+  hipStreamSynchronize(C.stream);
+  drain_events();
+  C.stats = gvt_hip_stats{};
+  set_error("%s", ""); // (a failed warm-up is not an error of the caller's: the first real call reports its own)
+}
+
 extern "C" int gvt_hip_init(int device) {
   Ctx &C = g_default_ctx;
   if (C.ready && C.device == device) { if (!tl_ctx) HIPCHK(hipSetDevice(device)); return 0; }
   if (C.ready) { set_error("gvt_hip_init: already initialised on device %d", C.device); return GVT_HIP_ERR_INVALID; }
-  return ctx_setup(C, device);
+  const int rc = ctx_setup(C, device);
+  if (!rc && !tl_ctx) warm_up();
+  return rc;
 }
 
 // ---- additional contexts: one per thread that wants its own stream / scratch / statistics (e.g. several ranks of a scheduler in

@@ -99,19 +99,46 @@ __device__ inline unsigned long long expand21(unsigned v) { // 21 bits -> every 
   return x;
 }
 
-__global__ __launch_bounds__(256) void k_morton(const float *__restrict__ verts, const int *__restrict__ tris, unsigned n, float3 blo,
-                                                float3 inv_ext, unsigned long long *__restrict__ keys, unsigned *__restrict__ vals) {
+// The last <= 32 boxes of the scene-box reduction folded into ONE record on the device: scene[0..2] = lo, [3..5] = hi, [6] = 1 / largest extent (the Morton
+// scale), [7] = pad (what keeps the slab test conservative w.r.t. the triangle test's rounding).  The kernels behind it read the record; the host fetches it with
+// the node count later -- a build used to stop here for a read-back (copy, synchronisation, launch latency: ~100 us of a 4.2 ms build)
+__global__ void k_scene_box(const float4 *__restrict__ lo, const float4 *__restrict__ hi, unsigned cnt, float *__restrict__ scene) {
+  float l[3] = { GVT_FLT_MAX, GVT_FLT_MAX, GVT_FLT_MAX }, h[3] = { -GVT_FLT_MAX, -GVT_FLT_MAX, -GVT_FLT_MAX };
+  for (unsigned i = threadIdx.x; i < cnt; i += 64) {
+    const float4 a = lo[i], b = hi[i];
+    l[0] = fminf(l[0], a.x); l[1] = fminf(l[1], a.y); l[2] = fminf(l[2], a.z);
+    h[0] = fmaxf(h[0], b.x); h[1] = fmaxf(h[1], b.y); h[2] = fmaxf(h[2], b.z);
+  }
+  for (int off = 32; off > 0; off >>= 1)
+    for (int k = 0; k < 3; k++) { l[k] = fminf(l[k], __shfl_xor(l[k], off)); h[k] = fmaxf(h[k], __shfl_xor(h[k], off)); }
+  if (threadIdx.x) return;
+  float ext = 0.f;
+  for (int k = 0; k < 3; k++) { scene[k] = l[k]; scene[3 + k] = h[k]; ext = fmaxf(ext, fabsf(l[k])); ext = fmaxf(ext, fabsf(h[k])); }
+  // ONE scale for the three axes (the largest extent): Morton cells are cubes whatever the shape of the mesh's box.  Normalising
+  // every axis by its own extent made the cells of a 1 : 2 : 4 box -- a tile of a domain decomposition -- as elongated as the
+  // box, and the tree's nodes with them (same box, A/B: 8 soup tiles 1.70 -> 1.66 ms, bunny.conf 0.343 -> 0.327, the cube-shaped soup unchanged)
+  const float em = fmaxf(h[0] - l[0], fmaxf(h[1] - l[1], h[2] - l[2]));
+  scene[6] = em > 0 ? 1.f / em : 0.f;
+  scene[7] = ext * 1e-5f;
+}
+
+// key = the top `bits` bits of the 63-bit Morton code of the triangle's centre (bits a multiple of 3, chosen by the host from the triangle count: cells 64 times
+// finer per axis than the mean triangle spacing -- the radix sort then runs ceil(bits / 8) passes instead of 8; triangles of one cell keep their input order,
+// Karras' tie-break)
+__global__ __launch_bounds__(256) void k_morton(const float *__restrict__ verts, const int *__restrict__ tris, unsigned n, const float *__restrict__ scene, int bits,
+                                                unsigned long long *__restrict__ keys, unsigned *__restrict__ vals) {
   unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float lo[3], hi[3];
   tri_box(verts, tris, i, lo, hi);
-  float cx = (0.5f * (lo[0] + hi[0]) - blo.x) * inv_ext.x;
-  float cy = (0.5f * (lo[1] + hi[1]) - blo.y) * inv_ext.y;
-  float cz = (0.5f * (lo[2] + hi[2]) - blo.z) * inv_ext.z;
+  const float iso = scene[6];
+  float cx = (0.5f * (lo[0] + hi[0]) - scene[0]) * iso;
+  float cy = (0.5f * (lo[1] + hi[1]) - scene[1]) * iso;
+  float cz = (0.5f * (lo[2] + hi[2]) - scene[2]) * iso;
   unsigned qx = (unsigned)fminf(fmaxf(cx * 2097152.f, 0.f), 2097151.f);
   unsigned qy = (unsigned)fminf(fmaxf(cy * 2097152.f, 0.f), 2097151.f);
   unsigned qz = (unsigned)fminf(fmaxf(cz * 2097152.f, 0.f), 2097151.f);
-  keys[i] = (expand21(qx) << 2) | (expand21(qy) << 1) | expand21(qz);
+  keys[i] = ((expand21(qx) << 2) | (expand21(qy) << 1) | expand21(qz)) >> (63 - bits);
   vals[i] = i;
 }
 
@@ -167,12 +194,8 @@ struct BoxLevels {
   const float4 *hi[GVT_BOX_LEVELS];
   int n_levels;
 };
-__global__ __launch_bounds__(256) void k_node_boxes(int n_inner, const int *__restrict__ rfirst, const int *__restrict__ rlast, BoxLevels T,
-                                                    float4 *__restrict__ ilo, float4 *__restrict__ ihi) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_inner) return;
-  unsigned a = (unsigned)rfirst[i];
-  const unsigned e = (unsigned)rlast[i] + 1u;
+#define NB_CHUNK 1024 // k_node_boxes_chunk's chunk of sorted triangles (68 KB of LDS per block: two blocks per CU)
+__device__ inline void node_box_from_table(unsigned a, const unsigned e, const BoxLevels &T, float4 &out_lo, float4 &out_hi) {
   float lx = GVT_FLT_MAX, ly = GVT_FLT_MAX, lz = GVT_FLT_MAX, hx = -GVT_FLT_MAX, hy = -GVT_FLT_MAX, hz = -GVT_FLT_MAX;
   int L = 0;
   unsigned S = 1u;
@@ -188,8 +211,98 @@ __global__ __launch_bounds__(256) void k_node_boxes(int n_inner, const int *__re
     L--; S /= 32u;
   }
 #undef GVT_TAKE
-  ilo[i] = make_float4(lx, ly, lz, 0.f);
-  ihi[i] = make_float4(hx, hy, hz, 0.f);
+  out_lo = make_float4(lx, ly, lz, 0.f);
+  out_hi = make_float4(hx, hy, hz, 0.f);
+}
+// every inner node from the table (meshes too small for the chunked path; and the definition the chunked path is tested against)
+__global__ __launch_bounds__(256) void k_node_boxes(int n_inner, const int *__restrict__ rfirst, const int *__restrict__ rlast, BoxLevels T,
+                                                    float4 *__restrict__ ilo, float4 *__restrict__ ihi) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_inner) return;
+  float4 lo, hi;
+  node_box_from_table((unsigned)rfirst[i], (unsigned)rlast[i] + 1u, T, lo, hi);
+  ilo[i] = lo; ihi[i] = hi;
+}
+
+// Boxes of the inner nodes whose Karras range lies inside ONE aligned chunk of NB_CHUNK sorted triangles, bottom-up in LDS (Karras' walk with arrival
+// counters -- in LDS, where an atomic costs a few cycles and needs no cross-XCD visibility; the same walk over the whole tree in global memory was 71 of the
+// 95 ms of round 1's build): the block loads its chunk's triangle boxes, every inner node inside the chunk tells its children who their parent is, then every
+// leaf walks up: the first child to arrive at a node stops, the second one unions the two boxes and goes on, until the parent is a node that spans a chunk
+// boundary (no parent recorded).  min / max are exact: the boxes are the ones the range-union table gives.  Nodes that DO span a boundary (the spines, ~3 % of
+// the nodes) are listed per block for k_node_boxes_spine.
+#define NB_THREADS 1024 // one sorted triangle / one node per thread: 16 waves per block keep enough loads in flight (at 256 threads x 4 the kernel ran at 1.5 TB/s)
+__global__ __launch_bounds__(NB_THREADS) void k_node_boxes_chunk(int n, const int *__restrict__ child_l, const int *__restrict__ child_r, const int *__restrict__ rfirst,
+                                                          const int *__restrict__ rlast, const float4 *__restrict__ slo, const float4 *__restrict__ shi,
+                                                          float4 *__restrict__ ilo, float4 *__restrict__ ihi, int *__restrict__ spine, unsigned *__restrict__ spine_n) {
+  __shared__ float lb[6][NB_CHUNK]; // the chunk's triangle boxes, one plane per component (conflict free)
+  __shared__ float nb[6][NB_CHUNK]; // node boxes (node c0 + k at k)
+  __shared__ int cl_s[NB_CHUNK], cr_s[NB_CHUNK];
+  __shared__ short par_leaf[NB_CHUNK], par_node[NB_CHUNK]; // parent (local node number) of leaf / node k, -1: none inside the chunk
+  __shared__ unsigned arrived[NB_CHUNK];
+  __shared__ unsigned s_spine;
+  constexpr int PER = NB_CHUNK / NB_THREADS;
+  const int c0 = (int)blockIdx.x * NB_CHUNK, c1 = min(c0 + NB_CHUNK, n);
+  if (threadIdx.x == 0) s_spine = 0u;
+#pragma unroll
+  for (int m = 0; m < PER; m++) {
+    const int k = (int)threadIdx.x + NB_THREADS * m, i = c0 + k;
+    par_leaf[k] = -1; par_node[k] = -1; arrived[k] = 0u; cl_s[k] = 0; cr_s[k] = 0;
+    if (i < c1) {
+      const float4 a = slo[i], b = shi[i];
+      lb[0][k] = a.x; lb[1][k] = a.y; lb[2][k] = a.z; lb[3][k] = b.x; lb[4][k] = b.y; lb[5][k] = b.z;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < PER; m++) {
+    const int k = (int)threadIdx.x + NB_THREADS * m, i = c0 + k;
+    if (i >= c1 || i >= n - 1) continue;
+    if (rfirst[i] >= c0 && rlast[i] < c1) { // inside: its children lie inside too
+      const int l = child_l[i], r = child_r[i];
+      cl_s[k] = l; cr_s[k] = r;
+      if (l < 0) par_leaf[~l - c0] = (short)k; else par_node[l - c0] = (short)k;
+      if (r < 0) par_leaf[~r - c0] = (short)k; else par_node[r - c0] = (short)k;
+    } else spine[(size_t)blockIdx.x * NB_CHUNK + atomicAdd(&s_spine, 1u)] = i; // (LDS atomic; the order within the block's list does not matter)
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int m = 0; m < PER; m++) {
+    const int k = (int)threadIdx.x + NB_THREADS * m;
+    if (c0 + k >= c1) continue;
+    int p = par_leaf[k];
+    while (p >= 0) {
+      // (release: this thread's box of the child it comes from is in LDS before the count; acquire: the sibling's is visible to the second arrival)
+      if (__hip_atomic_fetch_add(&arrived[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
+      const int l = cl_s[p], r = cr_s[p];
+      const float(*pl)[NB_CHUNK] = l < 0 ? lb : nb;
+      const float(*pr)[NB_CHUNK] = r < 0 ? lb : nb;
+      const int il = (l < 0 ? ~l : l) - c0, ir = (r < 0 ? ~r : r) - c0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) { nb[c][p] = fminf(pl[c][il], pr[c][ir]); nb[3 + c][p] = fmaxf(pl[3 + c][il], pr[3 + c][ir]); }
+      p = par_node[p];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < PER; m++) { // the finished nodes, coalesced
+    const int k = (int)threadIdx.x + NB_THREADS * m;
+    if (arrived[k] == 2u) {
+      ilo[c0 + k] = make_float4(nb[0][k], nb[1][k], nb[2][k], 0.f);
+      ihi[c0 + k] = make_float4(nb[3][k], nb[4][k], nb[5][k], 0.f);
+    }
+  }
+  if (threadIdx.x == 0) spine_n[blockIdx.x] = s_spine;
+}
+// the nodes that span a chunk boundary, block by block from k_node_boxes_chunk's lists: the range-union table's walk (node_box_from_table), a wave per list
+__global__ __launch_bounds__(64) void k_node_boxes_spine(const int *__restrict__ spine, const unsigned *__restrict__ spine_n, const int *__restrict__ rfirst,
+                                                         const int *__restrict__ rlast, BoxLevels T, float4 *__restrict__ ilo, float4 *__restrict__ ihi) {
+  const unsigned cnt = spine_n[blockIdx.x];
+  for (unsigned k = threadIdx.x; k < cnt; k += 64) {
+    const int i = spine[(size_t)blockIdx.x * NB_CHUNK + k];
+    float4 lo, hi;
+    node_box_from_table((unsigned)rfirst[i], (unsigned)rlast[i] + 1u, T, lo, hi);
+    ilo[i] = lo; ihi[i] = hi;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_mark_live(int n_inner, const int *__restrict__ rfirst, const int *__restrict__ rlast,
@@ -210,10 +323,11 @@ __global__ __launch_bounds__(256) void k_emit_nodes(int n_inner, const unsigned 
                                                     const float4 *__restrict__ slo, const float4 *__restrict__ shi,
                                                     const float4 *__restrict__ ilo, const float4 *__restrict__ ihi,
                                                     const int *__restrict__ child_l, const int *__restrict__ child_r, const int *__restrict__ rfirst,
-                                                    const int *__restrict__ rlast, float pad, BvhNode *__restrict__ nodes, int leaf_max,
+                                                    const int *__restrict__ rlast, const float *__restrict__ scene, BvhNode *__restrict__ nodes, int leaf_max,
                                                     unsigned *__restrict__ leaf_of) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_inner || !live[i]) return;
+  const float pad = scene[7];
   int cl = child_l[i], cr = child_r[i];
   float4 al, ah, bl, bh;
   child_box(cl, slo, shi, ilo, ihi, al, ah);
@@ -313,7 +427,8 @@ __device__ inline float slot_area(const Slot4 &c) {
 // reset, a launch, a copy and a host synchronisation (14 levels at 10 M triangles).
 #define GVT_COLLAPSE_BLOCK 512
 #define GVT_COLLAPSE_LEVELS 96
-__global__ __launch_bounds__(GVT_COLLAPSE_BLOCK) void k_collapse4(const BvhNode *__restrict__ nodes, const int *__restrict__ fin, unsigned *__restrict__ levels, int level,
+__global__ __launch_bounds__(GVT_COLLAPSE_BLOCK, 4) void k_collapse4( // (4 waves per SIMD = two 512-thread blocks per CU: 128 registers; unbounded the compiler took 132 and ONE block was resident)
+    const BvhNode *__restrict__ nodes, const int *__restrict__ fin, unsigned *__restrict__ levels, int level,
                                                                   int *__restrict__ fout, uint4 *__restrict__ nodes4, uint4 *__restrict__ nodes4q) {
   const unsigned n_in = levels[level];
   if (blockIdx.x * blockDim.x >= n_in) return; // (block-uniform)
@@ -561,42 +676,40 @@ int build_lbvh(gvt_hip_mesh *M) {
   const unsigned n32 = (n + 31u) / 32u;
   float pad = 0.f;
   unsigned long long *sah_acc = nullptr, sah_host = 0ull;
+  float *d_scene = nullptr;
+  float *h_scene = (float *)(C.h_pinned + 32); // pinned words 32..39 of the context: an asynchronous copy into pageable memory would wait for the device at once
+  // Morton key width: 3 x (bits per axis), the cells 64 times finer per axis than the mean triangle spacing n^(1/3) -- 42 bits at 10 M triangles (6 radix
+  // passes of 8 bits instead of the 8 the full 63 need), 36 at 70 K; never fewer than 30, never more than 63
+  int key_bits = 18;
+  for (unsigned k = n; k > 1; k >>= 3) key_bits += 3;
+  key_bits = key_bits < 30 ? 30 : (key_bits > 63 ? 63 : key_bits);
 
 #define OK(x) do { if ((rc = (x)) != 0) goto done; } while (0)
 #define HOK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(_e)); rc = GVT_HIP_ERR_DEVICE; goto done; } } while (0)
 
   { // every temporary of the build, with 256-byte slack each (sizes of the library calls queried first)
     if ((int)n > leaf_max) {
-      HOK(rocprim::radix_sort_pairs(nullptr, tb_sort, keys, keys2, vals, sorted, n, 0, 63, st));
+      HOK(rocprim::radix_sort_pairs(nullptr, tb_sort, keys, keys2, vals, sorted, n, 0, key_bits, st));
       HOK(rocprim::exclusive_scan(nullptr, tb_scan, live, newidx, 0u, (size_t)(n > 1 ? n - 1 : 1), rocprim::plus<unsigned>(), st));
     }
-    const size_t per_tri = 6 * sizeof(float4) + 2 * sizeof(unsigned long long) + 9 * sizeof(unsigned) + 2 * sizeof(int);
+    const size_t per_tri = 6 * sizeof(float4) + 2 * sizeof(unsigned long long) + 9 * sizeof(unsigned) + 4 * sizeof(int); // (+ k_node_boxes_chunk's spine lists)
     const size_t levels = 4 * sizeof(float4) * ((size_t)n / 31 + 64 * GVT_BOX_LEVELS);
     A.cap = per_tri * ((size_t)n + 1) + levels + tb_sort + tb_scan + 64 * 256 + 4096;
     A.base = (char *)scratch_get(21, A.cap);
     if (!A.base) { rc = GVT_HIP_ERR_DEVICE; goto done; }
   }
   mark("arena");
-  OK(A.take(&plo, n32)); OK(A.take(&phi, n32));
+  OK(A.take(&plo, n32)); OK(A.take(&phi, n32)); OK(A.take(&d_scene, 8));
   k_tri_bounds32<<<G, B, 0, st>>>(M->d_verts, M->d_tris, n, plo, phi);
-  { // scene box: 32:1 reductions (the first one straight from the vertices), the last <= 32 boxes on the host
+  { // scene box: 32:1 reductions (the first one straight from the vertices), the last <= 32 boxes by one wave; the record stays on the device (k_scene_box)
     BoxLevels T;
     OK(build_box_levels(plo, phi, n32, A, T, st));
     unsigned cnt = n32;
     for (int l = 1; l < T.n_levels; l++) cnt = (cnt + 31u) / 32u;
-    std::vector<float4> hl(cnt), hh(cnt);
-    HOK(hipMemcpyAsync(hl.data(), T.lo[T.n_levels - 1], sizeof(float4) * cnt, hipMemcpyDeviceToHost, st));
-    HOK(hipMemcpyAsync(hh.data(), T.hi[T.n_levels - 1], sizeof(float4) * cnt, hipMemcpyDeviceToHost, st));
-    HOK(hipStreamSynchronize(st));
-    for (int k = 0; k < 3; k++) { M->lo[k] = GVT_FLT_MAX; M->hi[k] = -GVT_FLT_MAX; }
-    for (unsigned i = 0; i < cnt; i++) {
-      M->lo[0] = fminf(M->lo[0], hl[i].x); M->lo[1] = fminf(M->lo[1], hl[i].y); M->lo[2] = fminf(M->lo[2], hl[i].z);
-      M->hi[0] = fmaxf(M->hi[0], hh[i].x); M->hi[1] = fmaxf(M->hi[1], hh[i].y); M->hi[2] = fmaxf(M->hi[2], hh[i].z);
-    }
-    float ext = 0.f;
-    for (int k = 0; k < 3; k++) { ext = fmaxf(ext, fabsf(M->lo[k])); ext = fmaxf(ext, fabsf(M->hi[k])); }
-    pad = ext * 1e-5f; // keeps the slab test conservative w.r.t. the triangle test's rounding
+    k_scene_box<<<1, 64, 0, st>>>(T.lo[T.n_levels - 1], T.hi[T.n_levels - 1], cnt, d_scene);
+    HOK(hipMemcpyAsync(h_scene, d_scene, 8 * sizeof(float), hipMemcpyDeviceToHost, st)); // complete at the build's next synchronisation (the node count's, or below)
   }
+#define SCENE_TO_HOST() do { for (int k_ = 0; k_ < 3; k_++) { M->lo[k_] = h_scene[k_]; M->hi[k_] = h_scene[3 + k_]; } pad = h_scene[7]; } while (0)
   mark("scene box");
   OK(dalloc(&M->d_tri, (size_t)4 * n));
   OK(dalloc(&M->d_slot_of, n));
@@ -611,6 +724,7 @@ int build_lbvh(gvt_hip_mesh *M) {
       for (unsigned i = 0; i < n; i++) id[i] = i;
       HOK(hipMemcpyAsync(sorted, id.data(), sizeof(unsigned) * n, hipMemcpyHostToDevice, st));
       HOK(hipStreamSynchronize(st));
+      SCENE_TO_HOST();
     }
     float4 *tlo = nullptr, *thi = nullptr; // n <= 4 triangle boxes
     OK(A.take(&tlo, n)); OK(A.take(&thi, n));
@@ -625,20 +739,10 @@ int build_lbvh(gvt_hip_mesh *M) {
     }
   } else {
     OK(A.take(&keys, n)); OK(A.take(&keys2, n)); OK(A.take(&vals, n)); OK(A.take(&sorted, n));
-    {
-      float3 blo = make_float3(M->lo[0], M->lo[1], M->lo[2]);
-      float ex = M->hi[0] - M->lo[0], ey = M->hi[1] - M->lo[1], ez = M->hi[2] - M->lo[2];
-      // ONE scale for the three axes (the largest extent): Morton cells are cubes whatever the shape of the mesh's box.  Normalising
-      // every axis by its own extent made the cells of a 1 : 2 : 4 box -- a tile of a domain decomposition -- as elongated as the
-      // box, and the tree's nodes with them (same box, A/B: 8 soup tiles 1.70 -> 1.66 ms, bunny.conf 0.343 -> 0.327, the cube-shaped soup unchanged)
-      const float em = fmaxf(ex, fmaxf(ey, ez));
-      const float iso = em > 0 ? 1.f / em : 0.f;
-      float3 inv = make_float3(iso, iso, iso);
-      k_morton<<<G, B, 0, st>>>(M->d_verts, M->d_tris, n, blo, inv, keys, vals);
-    }
+    k_morton<<<G, B, 0, st>>>(M->d_verts, M->d_tris, n, d_scene, key_bits, keys, vals);
     {
       OK(A.take((char **)&tmp, tb_sort));
-      HOK(rocprim::radix_sort_pairs(tmp, tb_sort, keys, keys2, vals, sorted, n, 0, 63, st));
+      HOK(rocprim::radix_sort_pairs(tmp, tb_sort, keys, keys2, vals, sorted, n, 0, key_bits, st));
     }
     mark("morton + sort");
     OK(A.take(&cl, n)); OK(A.take(&cr, n)); OK(A.take(&rf, n)); OK(A.take(&rl, n));
@@ -649,7 +753,14 @@ int build_lbvh(gvt_hip_mesh *M) {
     {
       BoxLevels T;
       OK(build_box_levels(slo, shi, n, A, T, st));
-      k_node_boxes<<<(n_inner + B - 1) / B, B, 0, st>>>(n_inner, rf, rl, T, ilo, ihi);
+      if (n >= 4 * NB_CHUNK && !getenv("GVT_HIP_NODE_BOXES_TABLE")) {
+        const unsigned n_chunks = (n + NB_CHUNK - 1) / NB_CHUNK;
+        int *spine = nullptr;
+        unsigned *spine_n = nullptr;
+        OK(A.take(&spine, (size_t)n_chunks * NB_CHUNK)); OK(A.take(&spine_n, n_chunks));
+        k_node_boxes_chunk<<<n_chunks, NB_THREADS, 0, st>>>((int)n, cl, cr, rf, rl, slo, shi, ilo, ihi, spine, spine_n); // nodes inside one chunk of sorted triangles: in LDS
+        k_node_boxes_spine<<<n_chunks, 64, 0, st>>>(spine, spine_n, rf, rl, T, ilo, ihi);                          // the spines across chunk boundaries: the range-union table
+      } else k_node_boxes<<<(n_inner + B - 1) / B, B, 0, st>>>(n_inner, rf, rl, T, ilo, ihi);
     }
     k_mark_live<<<(n_inner + B - 1) / B, B, 0, st>>>(n_inner, rf, rl, live, leaf_max);
     {
@@ -657,14 +768,14 @@ int build_lbvh(gvt_hip_mesh *M) {
       HOK(rocprim::exclusive_scan(tmp2, tb_scan, live, newidx, 0u, (size_t)n_inner, rocprim::plus<unsigned>(), st));
     }
     mark("karras + boxes + scan");
-    unsigned last_idx = 0, last_live = 0;
-    HOK(hipMemcpyAsync(&last_idx, newidx + (n_inner - 1), sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    HOK(hipMemcpyAsync(&last_live, live + (n_inner - 1), sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HOK(hipMemcpyAsync(C.h_pinned + 40, newidx + (n_inner - 1), sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HOK(hipMemcpyAsync(C.h_pinned + 41, live + (n_inner - 1), sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HOK(hipStreamSynchronize(st));
-    M->nNodes = (size_t)last_idx + last_live;
+    SCENE_TO_HOST();
+    M->nNodes = (size_t)C.h_pinned[40] + C.h_pinned[41];
     OK(dalloc(&M->d_nodes, M->nNodes));
     M->nLeaves = M->nNodes + 1;
-    k_emit_nodes<<<(n_inner + B - 1) / B, B, 0, st>>>(n_inner, live, newidx, slo, shi, ilo, ihi, cl, cr, rf, rl, pad, M->d_nodes, leaf_max, leaf_of);
+    k_emit_nodes<<<(n_inner + B - 1) / B, B, 0, st>>>(n_inner, live, newidx, slo, shi, ilo, ihi, cl, cr, rf, rl, d_scene, M->d_nodes, leaf_max, leaf_of);
     if (want_q) k_emit_trisq<<<G, B, 0, st>>>(M->d_verts, M->d_tris, sorted, leaf_of, n, M->d_triq);
     mark("emit nodes + slots");
   }
@@ -696,6 +807,7 @@ done:
   return rc;
 #undef OK
 #undef HOK
+#undef SCENE_TO_HOST
 }
 
 // radix sort of (key, value) pairs on the adapter stream; temporary storage from the grow-only scratch arena

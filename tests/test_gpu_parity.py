@@ -957,3 +957,31 @@ def test_host_appended_rays_start_fresh_whatever_their_padding_holds(hip):
     assert lib.gvt_hip_queue_append(q.h, hip.ptr(d), C.c_size_t(len(d)), C.c_int(0)) == 0
     got = q.to_numpy()
     assert len(got) == 256 and not got["known"].any() and np.array_equal(got["origin"], d["origin"])
+
+
+@pytest.mark.parametrize("case", ["soup-300k", "bun_zipper", "clustered"])
+def test_builder_node_boxes_in_lds_equal_the_range_union_table(hip, case, monkeypatch):
+    """The builder's inner-node boxes come from two routes: nodes whose Karras range lies inside one chunk of 1,024 sorted triangles are unioned bottom-up in LDS
+    (k_node_boxes_chunk), the spines across chunk boundaries from the base-32 range-union table (k_node_boxes_spine).  Forcing the table for EVERY node
+    (GVT_HIP_NODE_BOXES_TABLE, the round-5 path) must give the same tree bit for bit -- every binary node with both child boxes, and the triangle slots -- on a soup, a
+    surface and a mesh with everything crowded into a corner (many equal Morton keys: the tie-break's deep, lopsided subtrees)."""
+    if case == "soup-300k":
+        v, t = scenes.triangle_soup(300_000, seed=7)
+    elif case == "bun_zipper":
+        z = np.load(os.path.join(GOLDEN, "bun_zipper.npz"))
+        v, t = z["verts"], z["tris"]
+    else:
+        rng = np.random.default_rng(3)
+        c = np.concatenate([rng.random((40_000, 1, 3)) * 1e-4, rng.random((5_000, 1, 3))]).astype(np.float32)  # 40 K triangles in a 1e-4 corner of the unit box
+        v = (c + (rng.random((len(c), 3, 3)).astype(np.float32) - 0.5) * np.float32(2e-5)).reshape(-1, 3)
+        t = np.arange(len(c) * 3, dtype=np.int32).reshape(-1, 3)
+    m = scenes.MeshData(np.ascontiguousarray(v, np.float32), np.ascontiguousarray(t, np.int32))
+    a = HipMeshAdapter(m)
+    na, (wa, sa) = a.download_nodes(), a.download_wide()
+    monkeypatch.setenv("GVT_HIP_NODE_BOXES_TABLE", "1")
+    b = HipMeshAdapter(m)
+    nb, (wb, sb) = b.download_nodes(), b.download_wide()
+    assert len(na) == len(nb) > 1000 and np.array_equal(na.view(np.uint32), nb.view(np.uint32))
+    # (the 4-wide collapse numbers a level's nodes in block-arrival order: its array is a permutation from build to build; the slots are not)
+    assert wa.shape == wb.shape and np.array_equal(sa.view(np.uint32), sb.view(np.uint32))
+    a.close(); b.close()
