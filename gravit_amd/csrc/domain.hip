@@ -490,7 +490,14 @@ namespace {
                     // The message a rank sends a peer per tick is this row followed by a fixed inline area (knob inline_kb, the same on every
                     // rank): a tick whose pairs all have at most that much to say is ONE exchange (one ncclGroup), the rays travel with the
                     // count exchange of SendRays (DomainTracer.h:397-415) instead of behind it (:433-463).
-#define REPORT_TAIL 13 // words behind the queue sizes in the round's report (the last one: the sequence number of a polled report)
+#define REPORT_TAIL 15 // words behind the queue sizes in the round's report (the last one: the sequence number of a polled report); [12]: the speculative part
+                       // enqueued behind this report's exchange is VALID (k_publish decides, host and device read the same word); [13]: rays the speculative
+                       // chain in front of this report traced (0: none ran)
+// Device words of a tracer's speculation (gvt_hip_tracer::d_spec): [0] k_round_report: this rank announced a payload beyond the inline area, or an error (the
+// next tick needs the host); [1] k_publish: the speculative part behind this exchange is valid; [2] k_spec_begin: rays of the speculative chain
+#define SPEC_SLOW 0
+#define SPEC_VALID 1
+#define SPEC_N 2
 
 // dword w (0..19) of ray `ray`'s 80-byte wire image (actor/Ray.h:68-96; words 16..19: the stream word and the known-miss list, inside Ray::data)
 __device__ inline unsigned wire_word(const RayPlanes &q, unsigned ray, unsigned w) {
@@ -511,8 +518,13 @@ __global__ __launch_bounds__(256) void k_round_report(unsigned *const *__restric
                                int *bbox, int chain_end = 0, const unsigned char *__restrict__ chain_mask = nullptr,
                                unsigned *host_report = nullptr, unsigned host_seq = 0u, int err_code = 0, int tick = 0, const float4 *__restrict__ scan_fb = nullptr,
                                int fb_w = 0, int fb_h = 0, int msg_ints = 0 /* stride of the announce rows (row + inline area), ints */, int inl_bytes = 0,
-                               const QueueDesc *__restrict__ qd = nullptr) {
+                               const QueueDesc *__restrict__ qd = nullptr, unsigned *spec = nullptr /* SPEC_* words */, int speculative = 0) {
   __shared__ unsigned long long sh_out, sh_local;
+  if (speculative && !spec[SPEC_VALID]) return; // enqueued ahead of the host's knowledge and the exchange in front called for the host: nothing happened
+  if (speculative && scan_fb && spec[SPEC_N] == 0u) { // the speculative round held no ray: no new deposit, the rectangle stands -- one block reports, nobody scans
+    if (blockIdx.x) return;
+    scan_fb = nullptr;
+  }
   if (scan_fb) {
     __shared__ int sh_bb[4];
     __shared__ unsigned sh_ticket;
@@ -594,7 +606,14 @@ __global__ __launch_bounds__(256) void k_round_report(unsigned *const *__restric
     for (int k = 0; k < 4; k++) tail[6 + k] = (unsigned)bb[k];
     tail[10] = counters[9]; // packets handed over by k_packet
     tail[11] = counters[20] + counters[3]; // closest-hit rays parked for k_long_closest so far this frame (earlier launches + the last one)
+    tail[12] = 0u;
+    tail[13] = (speculative && spec) ? spec[SPEC_N] : 0u;
     counters[0] = 0u;       // the work counter of the next small chain (k_finish starts from 0 without a memset in front)
+    if (spec) { // does the tick behind this one need the host?  (a pair's payload beyond the inline area, or this rank's error)
+      unsigned slow = err_code ? 1u : 0u;
+      for (int p = 0; p < world; p++) if (p != rank && ann[p * msg_ints + 1] > 0 && ann[p * msg_ints + 10] == 0) slow = 1u;
+      spec[SPEC_SLOW] = slow;
+    }
   }
   if (host_report) { // one rank: the report goes straight into the host's pinned copy, the sequence word last -- the host polls it
     __syncthreads(); // instead of a device-to-host copy + a stream synchronisation (an interrupt and a wake-up per round)
@@ -686,11 +705,33 @@ template <bool ADD> __global__ __launch_bounds__(256) void k_rect(float4 *__rest
 // its current ones in peer order; every thread reads the count words as its base and the LAST block to finish advances them (ticket).
 __global__ __launch_bounds__(256) void k_publish(const int *__restrict__ ann_in, int msg_ints, int row, int world, int rank, const unsigned *__restrict__ report, int n_rep,
                                                   int *h_ann, unsigned *h_report, unsigned seq, const QueueDesc *__restrict__ qd, int n_inst, unsigned *__restrict__ err,
-                                                  unsigned *ticket) {
+                                                  unsigned *ticket, unsigned *spec = nullptr, const int *__restrict__ owner = nullptr, unsigned spec_max = 0u,
+                                                  WaveSeg *__restrict__ spec_segs = nullptr) {
   const int p = (int)blockIdx.x;
   if (p == rank) {
     for (int k = threadIdx.x; k < world * row; k += blockDim.x) h_ann[k] = ann_in[(size_t)(k / row) * msg_ints + (k % row)];
     for (int k = threadIdx.x; k < n_rep; k += blockDim.x) h_report[k] = report[k];
+    if (spec) {
+      // Is the speculative part enqueued behind this exchange (the next tick's small round + report) valid?  Not if this tick needs the host: a payload beyond
+      // the inline area out (k_round_report's word) or in, an error anywhere, or more local rays than one k_finish launch takes.  The rays the next round
+      // holds are known exactly: this rank's own queues as reported + what the peers sent inline (the other blocks of this launch append them).
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned bad = spec[SPEC_SLOW];
+        unsigned long long rays = 0ull;
+        for (int pp = 0; pp < world && !bad; pp++) {
+          if (pp == rank) continue;
+          const int *a = ann_in + (size_t)pp * msg_ints;
+          if (a[8] != 0 || (a[1] > 0 && a[10] == 0)) bad = 1u;
+          if (a[10] > 0) rays += (unsigned)a[0];
+        }
+        for (int i = 0; i < n_inst && !bad; i++) if (owner[i] == rank) rays += report[i];
+        if (rays > spec_max) bad = 1u;
+        const unsigned valid = bad ? 0u : 1u;
+        spec[SPEC_VALID] = valid;
+        h_report[n_inst + 12] = valid; // (n_rep = n_inst + REPORT_TAIL - 1: the word lies inside the copied range; this store comes after the copy)
+      }
+    }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(h_report + n_rep, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -734,6 +775,28 @@ __global__ __launch_bounds__(256) void k_publish(const int *__restrict__ ann_in,
     if (tot) atomicAdd(qd[i].count, tot);
   }
   if (threadIdx.x == 0) *ticket = 0u;
+  if (spec) {
+    // Head of the next tick's SPECULATIVE part (k_finish + k_round_report are enqueued behind this launch before the host has read it): if block `rank` found it
+    // valid -- every block took its ticket after its work, this is the last one -- the segment table of the small round is filled from the count words of this
+    // rank's queues, which are then cleared: the rays now belong to the launch, exactly what the host-driven round does with its host-known sizes (finish_round)
+    __syncthreads(); // (the count words above are final)
+    if (threadIdx.x == 0) {
+      unsigned run = 0u;
+      if (spec[SPEC_VALID]) {
+        int k = 0;
+        for (int i = 0; i < n_inst; i++) {
+          if (owner[i] != rank) continue;
+          const unsigned n = __hip_atomic_load(qd[i].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          WaveSeg sg;
+          sg.planes = qd[i].planes; sg.cap = qd[i].cap; sg.begin = run; sg.n = n; sg.inst = i; sg.pad = 0;
+          spec_segs[k++] = sg;
+          run += n;
+          *qd[i].count = 0u;
+        }
+      }
+      spec[SPEC_N] = run;
+    }
+  }
 }
 // start of a frame: ray totals, flags, the work counter of the first small chain, the deposit rectangle (empty) and the kernels' tickets
 // a frame's resets in one launch: every queue.clear() (count words) and the frame's totals / flags / deposit rectangle
@@ -781,6 +844,13 @@ struct gvt_hip_tracer {
   int *d_ann_out = nullptr, *d_ann_in = nullptr; // [world][msg_ints]: the announce row (ANN_HEAD + n_inst ints) + the inline payload area
   int *h_ann_in = nullptr;                       // [world][ANN_HEAD + n_inst]: the rows only (k_publish)
   size_t inl_bytes = 0, msg_ints = 0;            // inline area per pair (knob inline_kb when the tables were laid out), message length in ints
+  double tick_us[8] = { 0 }; uint64_t tick_n[8] = { 0 }; double comp_us = 0; // GVT_HIP_SPEC_TRACE: host time from one announce's arrival to the next, by tick number
+  uint64_t n_spec_enqueued = 0, n_spec_valid = 0, n_exchanges = 0; // since creation (GVT_HIP_SPEC_TRACE prints them when the tracer goes)
+  size_t spec_recent_rays = 0;                   // rays of this rank's latest small round (sizes the speculative k_finish grid)
+  bool sizes_exact = true;                       // no launch chain has run since the host last read the queue sizes
+  bool spec_enqueued_last = false;               // a speculative part was enqueued behind the last announce exchange
+  unsigned *d_spec = nullptr;                    // SPEC_* words of the speculative part of a tick
+  WaveSeg *d_spec_segs = nullptr;                // its segment table (filled by k_spec_begin from the count words)
   bool layout_agreed = false;                    // the ranks have compared their message layout since the tables were last laid out (tracer_handshake)
   int *d_hs = nullptr, *h_hs = nullptr;          // [world + 1][4]: this rank's layout word quadruple, then every peer's
   unsigned *d_overflow = nullptr;
@@ -804,13 +874,21 @@ struct gvt_hip_tracer {
 
 extern "C" void gvt_hip_tracer_destroy(gvt_hip_tracer *R) {
   if (!R) return;
+  if (getenv("GVT_HIP_SPEC_TRACE") && R->n_exchanges)
+    fprintf(stderr, "[tracer rank %d] %llu announce exchanges, speculative part enqueued behind %llu, valid %llu\n", R->rank, (unsigned long long)R->n_exchanges,
+            (unsigned long long)R->n_spec_enqueued, (unsigned long long)R->n_spec_valid);
+  if (getenv("GVT_HIP_SPEC_TRACE") && R->tick_n[0]) {
+    fprintf(stderr, "[tracer rank %d] mean us from frame start / previous announce to the announce of tick:", R->rank);
+    for (int k = 0; k < 8 && R->tick_n[k]; k++) fprintf(stderr, " %d: %.1f", k, R->tick_us[k] / (double)R->tick_n[k]);
+    fprintf(stderr, "; last announce to frame end %.1f\n", R->comp_us / (double)R->tick_n[0]);
+  }
   if (gctx().ready) hipStreamSynchronize(gctx().stream);
   if (R->comm && !R->comm->dead) hipStreamSynchronize(R->comm->stream);
   for (auto q : R->queues) gvt_hip_queue_destroy(q);
   gvt_hip_queue_destroy(R->q_moved);
   hipFree(R->d_insts); hipFree(R->d_round); hipHostFree(R->h_round); hipFree(R->d_count_ptr); hipFree(R->d_owner);
   hipFree(R->d_ann_out); hipFree(R->d_ann_in); hipHostFree(R->h_ann_in); // (d_report / h_report live behind the announces)
-  hipFree(R->d_overflow); hipFree(R->d_hs); hipHostFree(R->h_hs);
+  hipFree(R->d_overflow); hipFree(R->d_hs); hipHostFree(R->h_hs); hipFree(R->d_spec); hipFree(R->d_spec_segs);
   for (void *p : R->send_buf) hipFree(p);
   for (void *p : R->recv_buf) hipFree(p);
   for (hipEvent_t e : { R->ev_compute, R->ev_report, R->ev_pack, R->ev_recv, R->ev_comm, R->ev_chain0, R->ev_ann0, R->ev_pay0, R->ev_comp0 }) if (e) hipEventDestroy(e);
@@ -890,14 +968,15 @@ extern "C" gvt_hip_tracer *gvt_hip_tracer_create(gvt_hip_top *T, gvt_hip_mesh *c
   ok = ok && hipMalloc((void **)&R->d_insts, sizeof(WaveInst) * n1) == hipSuccess && hipMalloc(&R->d_round, R->round_bytes) == hipSuccess &&
        hipHostMalloc(&R->h_round, R->round_bytes, hipHostMallocDefault) == hipSuccess &&
        hipMalloc((void **)&R->d_count_ptr, sizeof(unsigned *) * n1) == hipSuccess && hipMalloc((void **)&R->d_owner, sizeof(int) * n1) == hipSuccess &&
-       hipMalloc((void **)&R->d_overflow, 64) == hipSuccess;
+       hipMalloc((void **)&R->d_overflow, 64) == hipSuccess && hipMalloc((void **)&R->d_spec, 64) == hipSuccess &&
+       hipMalloc((void **)&R->d_spec_segs, sizeof(WaveSeg) * n1) == hipSuccess;
   if (ok) {
     R->h_segs = (WaveSeg *)R->h_round; R->d_segs = (WaveSeg *)R->d_round;
     R->h_qdesc = (QueueDesc *)(R->h_segs + n1); R->d_qdesc = (QueueDesc *)(R->d_segs + n1);
     R->h_mask = (unsigned char *)(R->h_qdesc + n1); R->d_mask = (unsigned char *)(R->d_qdesc + n1);
     ok = hipMemcpy(R->d_insts, insts.data(), sizeof(WaveInst) * n1, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(R->d_count_ptr, cptr.data(), sizeof(unsigned *) * n1, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemset(R->d_owner, 0, sizeof(int) * n1) == hipSuccess && hipMemset(R->d_overflow, 0, 64) == hipSuccess;
+         hipMemset(R->d_owner, 0, sizeof(int) * n1) == hipSuccess && hipMemset(R->d_overflow, 0, 64) == hipSuccess && hipMemset(R->d_spec, 0, 64) == hipSuccess;
   }
   for (hipEvent_t *e : { &R->ev_pack })
     ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
@@ -957,6 +1036,22 @@ int grow(void **buf, size_t *cap, size_t bytes) {
   return 0;
 }
 
+// Capacity a speculative part needs WITHOUT any reallocation (nothing may move while it is in flight): this rank's own queues take what the peers send inline
+// behind the next exchange, the outgoing ones what one k_finish launch can emit.  The host-driven paths reserve the same minima, so this normally holds.
+static size_t spec_emit_bound(const gvt_hip_tracer *R) {
+  const int passes = R->cam.depth > 1 ? R->cam.depth : 1;
+  return (size_t)gctx().finish_rays * (size_t)(1 + (int)R->lights.size() * passes);
+}
+static bool spec_room(const gvt_hip_tracer *R) {
+  const size_t inline_room = (size_t)(R->world - 1) * (R->inl_bytes / 80), emit = spec_emit_bound(R);
+  for (size_t i = 0; i < R->n_inst; i++) {
+    const gvt_hip_queue *Q = R->queues[i];
+    if (Q->cap < (R->owned[i] ? 2 * inline_room : emit)) return false;
+    if (R->h_qdesc[i].planes != Q->d_planes || R->h_qdesc[i].cap != Q->cap) return false; // (the device's table must be the current one: no upload from here)
+  }
+  return R->round_uploaded.size() == R->round_bytes && std::memcmp(R->round_uploaded.data(), R->h_round, R->round_bytes) == 0;
+}
+
 // (1) of a round: the merged launch chain over this rank's non-empty queues + the shuffle of everything that moved.  Host-known
 // sizes in R->present; on return they are stale until the next report.  extra_in[i]: rays about to be appended to queue i by a
 // pending unpack (room is reserved for them too).
@@ -991,10 +1086,12 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
   }
   const bool exact = growth > ((size_t)(C.round_room_mb > 0 ? C.round_room_mb : 1) << 20) && !count_on_device;
   const size_t inline_room = (R->world > 1 && R->owned.size()) ? (size_t)(R->world - 1) * (R->inl_bytes / 80) : 0; // what k_publish may append behind this tick's exchange
+  const size_t spec_emit = (R->world > 1 && C.spec_ticks && R->inl_bytes) ? spec_emit_bound(R) : 0;                 // ... and what a speculative round behind it may emit (spec_room)
   for (size_t i = 0; i < nI; i++) {
     const size_t stay = R->h_mask[i] ? 0 : R->present[i];
-    if ((rc = queue_reserve(R->queues[i], stay + (exact ? 0 : bound) + (extra_in ? (*extra_in)[i] : 0) + (R->owned[i] ? inline_room : 0)))) return rc;
+    if ((rc = queue_reserve(R->queues[i], stay + std::max(exact ? (size_t)0 : bound, R->owned[i] ? (size_t)0 : spec_emit) + (extra_in ? (*extra_in)[i] : 0) + (R->owned[i] ? 2 * inline_room : 0)))) return rc;
   }
+  R->sizes_exact = false;
   for (int k = 0; k < n_seg; k++) { // (a reserve above may have moved a traced queue)
     gvt_hip_queue *q = R->queues[R->h_segs[k].inst];
     R->h_segs[k].planes = q->d_planes; R->h_segs[k].cap = q->cap;
@@ -1065,8 +1162,12 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
 }
 
 // (3)+(4)+(5): report kernel -> [announce exchange] -> ONE device-to-host copy -> ONE host synchronisation
-int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_end = false, int err_code = 0, int tick = 0, gvt_hip_frame_stats *S = nullptr) {
+// skip_kernel: the speculative part enqueued behind the previous exchange was valid -- this tick's round and its k_round_report have already run on the device.
+// allow_spec: enqueue the NEXT tick's speculative part behind this exchange; *spec_valid: it was enqueued and the exchange left it valid.
+int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_end = false, int err_code = 0, int tick = 0, gvt_hip_frame_stats *S = nullptr,
+                 bool skip_kernel = false, bool allow_spec = false, bool *spec_valid = nullptr) {
   Ctx &C = gctx();
+  if (spec_valid) *spec_valid = false;
   const size_t nI = R->n_inst, row = ANN_HEAD + nI;
   hipStream_t st = C.stream;
   int *d_bbox = (int *)(R->d_overflow + 4);
@@ -1077,20 +1178,33 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_e
   // launch -- many blocks scan the framebuffer, the last one to finish writes the report
   const bool scan = exchange && R->world > 1;
   const unsigned n_blk = scan ? (unsigned)std::min<size_t>(1024, ((size_t)R->fb->w * R->fb->h + 1023) / 1024) : 1u;
-  if (scan && R->inl_bytes) { // the inline pack reads the outgoing queues through the descriptor table: current? (a reserve may have moved one since the last chain)
+  if (scan && R->inl_bytes && !skip_kernel) { // the inline pack reads the outgoing queues through the descriptor table: current? (a reserve may have moved one since the last chain)
     // ... and k_publish appends what arrives inline to the owned queues: room for every peer's full inline area, beyond what they hold (a tick
-    // in which a chain ran has it already: local_chain reserves the same slack on top of the round's bound)
+    // in which a chain ran has it already: local_chain reserves the same slack on top of the round's bound) -- twice over, and the outgoing queues room for
+    // one k_finish launch's emissions: what a speculative part behind this exchange needs without reallocating (spec_room)
     const size_t inline_room = (size_t)(R->world - 1) * (R->inl_bytes / 80);
     for (size_t i = 0; i < nI; i++)
       if (R->owned[i]) { int rc_q = queue_reserve(R->queues[i], R->queues[i]->size + inline_room); if (rc_q) return rc_q; }
+    // (what a speculative part behind this exchange needs beyond that -- spec_room -- is reserved by local_chain, or here when no chain has run since the last
+    //  report: only then are the host's sizes the device's, and a reallocation copies what the host knows of)
+    if (C.spec_ticks && R->sizes_exact) {
+      const size_t emit = spec_emit_bound(R);
+      for (size_t i = 0; i < nI; i++) {
+        int rc_q = queue_reserve(R->queues[i], R->queues[i]->size + (R->owned[i] ? 2 * inline_room : emit));
+        if (rc_q) return rc_q;
+      }
+    }
     for (size_t i = 0; i < nI; i++) { gvt_hip_queue *Q = R->queues[i]; R->h_qdesc[i].planes = Q->d_planes; R->h_qdesc[i].cap = Q->cap; R->h_qdesc[i].count = Q->d_count; R->h_qdesc[i].keep = 1u; }
     int rc_up = round_tables_upload(R, st);
     if (rc_up) return rc_up;
   }
-  k_round_report<<<n_blk, 256, 0, st>>>(R->d_count_ptr, R->d_owner, (int)nI, R->rank, R->world, R->d_report, R->d_ann_out, C.d_counters, R->d_overflow,
-                                        R->d_report + nI, d_bbox, chain_end ? 1 : 0, R->d_mask, poll ? R->h_report : nullptr, poll ? ++R->report_seq : 0u, err_code, tick,
-                                        scan ? (const float4 *)R->fb->d_rgba : nullptr, R->fb->w, R->fb->h, (int)R->msg_ints, scan ? (int)R->inl_bytes : 0, R->d_qdesc);
-  HIPCHK(hipGetLastError());
+  if (!skip_kernel) {
+    k_round_report<<<n_blk, 256, 0, st>>>(R->d_count_ptr, R->d_owner, (int)nI, R->rank, R->world, R->d_report, R->d_ann_out, C.d_counters, R->d_overflow,
+                                          R->d_report + nI, d_bbox, chain_end ? 1 : 0, R->d_mask, poll ? R->h_report : nullptr, poll ? ++R->report_seq : 0u, err_code, tick,
+                                          scan ? (const float4 *)R->fb->d_rgba : nullptr, R->fb->w, R->fb->h, (int)R->msg_ints, scan ? (int)R->inl_bytes : 0, R->d_qdesc,
+                                          scan ? R->d_spec : nullptr, 0);
+    HIPCHK(hipGetLastError());
+  }
   if (exchange && R->world > 1) {
     gvt_hip_comm *K = R->comm;
     const size_t msg = sizeof(int) * R->msg_ints;
@@ -1108,9 +1222,36 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_e
     // behind the exchange ONE small kernel gathers the peers' rows and this rank's report into the pinned mirror and releases the
     // sequence word; the host waits for that word with loads (bounded: a peer that never joins the exchange must not hang this rank)
     const unsigned seq = ++R->report_seq;
+    // The NEXT tick's speculative part goes behind this exchange, before the host has seen its result: k_spec_begin (segments from the count words) -> k_finish
+    // (the small round) -> k_round_report (the next announce's rows + inline pack).  k_publish decides on the device whether it is valid -- no payload beyond the
+    // inline area either way, no error, at most finish_rays local rays -- and tells the host in the report; a void part leaves no trace.  The sequence of
+    // EXCHANGES is untouched (the next one is posted by the host as before): this is local to the rank, the peers cannot tell.
+    const bool spec_now = allow_spec && C.spec_ticks && !timing && K->stream == st && R->inl_bytes > 0 && C.finish_rays > 0 && C.term_sink && !err_code &&
+                          finish_lights_resident(R->lights.data(), (int)R->lights.size()) && spec_room(R);
     k_publish<<<(unsigned)R->world, 256, 0, K->stream>>>(R->d_ann_in, (int)R->msg_ints, (int)row, R->world, R->rank, R->d_report, (int)(nI + REPORT_TAIL - 1), R->h_ann_in, R->h_report,
-                                                         seq, R->inl_bytes ? R->d_qdesc : nullptr, (int)nI, R->d_overflow, R->d_overflow + 12);
+                                                         seq, R->inl_bytes ? R->d_qdesc : nullptr, (int)nI, R->d_overflow, R->d_overflow + 12,
+                                                         spec_now ? R->d_spec : nullptr, R->d_owner, (unsigned)(C.finish_rays > 0 ? C.finish_rays : 0), R->d_spec_segs);
     HIPCHK(hipGetLastError());
+    if (spec_now) {
+      int n_own = 0;
+      for (size_t i = 0; i < nI; i++) n_own += R->owned[i] ? 1 : 0;
+      TraceParams P{};
+      P.normal_mode = R->normal_mode; P.seed = 0; P.n_lights = (int)R->lights.size(); P.update_in_place = 0; P.carried_rng = 1;
+      P.sink = TermSink{};
+      P.sink.top = R->top->dev(); P.sink.from = -1; P.sink.fb = R->fb->d_rgba; P.sink.n_pix = (unsigned)(R->fb->w * R->fb->h);
+      WaveSet W{ R->d_spec_segs, R->d_insts, n_own, R->all_quad ? 1 : 0, (int)nI };
+      // (the launch's grid: persistent waves pull rays from a counter, any size is correct; sized for twice what this rank's rounds have held lately, so that
+      //  ranks sharing one device -- in-process ranks -- do not each claim all of it for a few hundred rays)
+      const size_t grid_rays = std::min<size_t>((size_t)C.finish_rays, std::max<size_t>(1024, 2 * R->spec_recent_rays));
+      int rc_s = n_own ? finish_round(W, grid_rays, P, R->lights.data(), R->d_qdesc, R->d_owner, R->rank, R->d_overflow, nullptr, nullptr, R->d_spec) : 0;
+      if (rc_s) return rc_s;
+      k_round_report<<<n_blk, 256, 0, st>>>(R->d_count_ptr, R->d_owner, (int)nI, R->rank, R->world, R->d_report, R->d_ann_out, C.d_counters, R->d_overflow,
+                                            R->d_report + nI, d_bbox, 0, R->d_mask, nullptr, 0u, 0, tick + 1, (const float4 *)R->fb->d_rgba, R->fb->w, R->fb->h,
+                                            (int)R->msg_ints, (int)R->inl_bytes, R->d_qdesc, R->d_spec, 1);
+      HIPCHK(hipGetLastError());
+    }
+    R->spec_enqueued_last = spec_now;
+    R->n_exchanges++; R->n_spec_enqueued += spec_now ? 1 : 0;
     if (timing || K->stream != st) HIPCHK(hipEventRecord(R->ev_report, K->stream));
     // The host leaves the wait below when block `rank` of k_publish has released the sequence word; the blocks that append the INLINE payloads to the owned
     // queues and advance their count words may still run.  On the compute stream the next chain is ordered behind them anyway; with the exchange on the
@@ -1149,7 +1290,9 @@ int round_report(gvt_hip_tracer *R, bool exchange, uint64_t *syncs, bool chain_e
     HIPCHK(hipStreamSynchronize(st));
   }
   if (syncs) (*syncs)++;
+  if (spec_valid && exchange && R->world > 1) { *spec_valid = R->spec_enqueued_last && R->h_report[nI + 12] != 0u; R->n_spec_valid += *spec_valid ? 1 : 0; }
   for (size_t i = 0; i < nI; i++) { R->present[i] = R->h_report[i]; R->queues[i]->size = R->h_report[i]; }
+  R->sizes_exact = !(spec_valid && *spec_valid); // (a valid speculative part is a chain in flight)
   R->q_moved->size = 0;
   const unsigned *tail = R->h_report + nI;
   if (tail[4]) { set_error("BVH traversal stack overflow: results of this frame are incomplete"); return GVT_HIP_ERR_DEVICE; }
@@ -1249,6 +1392,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   const bool lean = one_shot && C.lean_frame && R->fb->w == R->cam.width && R->fb->h == R->cam.height; // (the lean filter clears the camera's pixels only)
   for (size_t i = 0; i < nI; i++) R->queues[i]->size = 0;
   R->q_moved->size = 0;
+  R->sizes_exact = true; R->spec_enqueued_last = false;
   bool first_on_device = false; // the queues hold the camera's rays, their sizes are on the device only (R->present: bounds)
   if (!lean) {
     if ((rc = gvt_hip_fb_clear(R->fb))) return rc;
@@ -1381,6 +1525,10 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   const bool own_comm_stream = env_comm_stream || C.comm_stream != 0;
   const size_t payload_overlap_min = (size_t)C.payload_overlap_kb << 10;
   if (R->comm && !own_comm_stream) { stream_bind.K = R->comm; stream_bind.saved = R->comm->stream; R->comm->stream = st; }
+  static const bool spec_trace = getenv("GVT_HIP_SPEC_TRACE") != nullptr;
+  auto t_mark = frame_t0;
+  bool last_round_small = false; // this tick's host-driven round held at most finish_rays rays (one k_finish launch)
+  bool spec_valid = false; // the speculative part enqueued behind the last exchange was valid: the device has already run this tick's round and k_round_report
   int tick = 0;
   for (;; tick++) {
     // (1) local work: one merged chain (asynchronous ticks), or chains until the local queues are dry (BSP rounds / one rank)
@@ -1402,16 +1550,32 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
         } else if (local_err) return local_err;
         break;
       }
+    } else if (spec_valid) {
+      // (nothing to launch: k_spec_begin -> k_finish -> k_round_report of this tick sit behind the last exchange; the exchange in front of them left them valid)
     } else if (!local_err) {
       bool have_local = false;
       for (size_t i = 0; i < nI; i++) have_local = have_local || (R->owned[i] && R->present[i]);
+      {
+        size_t n_loc = 0;
+        for (size_t i = 0; i < nI; i++) if (R->owned[i]) n_loc += R->present[i] + incoming[i];
+        last_round_small = n_loc <= (size_t)(C.finish_rays > 0 ? C.finish_rays : 0);
+        if (last_round_small) R->spec_recent_rays = n_loc;
+      }
       if (!have_local || !payload_cross) failed(unpack_pending()); // nothing to overlap a transfer with (or it is here already: inline / compute stream): take what arrived first
       if (!local_err) failed(local_chain(R, &incoming, &S.chains, S.chains == 0 && tick == 0, first_on_device && S.chains == 0));
       if (!local_err) failed(unpack_pending());
     }
     // (3)-(5) sizes + announce exchange (carrying this rank's error word), one bounded synchronisation
     { uint64_t lp = 0; for (size_t i = 0; i < nI; i++) if (R->owned[i]) lp += R->present[i]; R->last_local_pending = lp; }
-    if ((rc = round_report(R, true, &S.host_syncs, false, local_err, tick, &S))) return rc;
+    {
+      const bool was_spec = spec_valid;
+      // the next tick's speculative part: asynchronous ticks only, and not where a test makes that tick fail on the host (inject_fail_tick)
+      // ... and only behind a tick whose own round was small: a big round (the camera's, a large payload's) usually sends a big payload, the part would be void
+      const bool allow_spec = multi && R->world > 1 && !bsp && !local_err && C.inject_fail_tick != tick + 1 && stream_bind.K != nullptr && (was_spec || last_round_small);
+      if ((rc = round_report(R, true, &S.host_syncs, false, local_err, tick, &S, was_spec, allow_spec, &spec_valid))) return rc;
+      if (was_spec && R->h_report[nI + 13]) { S.chains++; R->spec_recent_rays = R->h_report[nI + 13]; }
+      if (spec_trace) { const auto now = std::chrono::steady_clock::now(); if (tick < 8) { R->tick_us[tick] += std::chrono::duration<double, std::micro>(now - t_mark).count(); R->tick_n[tick]++; } t_mark = now; } // (the speculative round traced rays: a launch chain like the host-driven ones)
+    }
     S.rounds++;
     if ((rc = peers_ok(tick))) return rc;
     // (6) the vote: every rank reads the same ballots
@@ -1549,6 +1713,7 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     if (C.frame_timing) { float ms = 0.f; if (hipEventElapsedTime(&ms, R->ev_comp0, R->ev_comm) == hipSuccess) S.ms_composite += ms; }
   }
   if (R->comm) { S.ms_host_wait = R->comm->ms_host_wait; S.exchanges = R->comm->groups; }
+  if (spec_trace && multi) R->comp_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_mark).count();
   const unsigned *tail = R->h_report + nI;
   S.rays_closest = (uint64_t)tail[0] | ((uint64_t)tail[1] << 32);
   S.rays_any = (uint64_t)tail[2] | ((uint64_t)tail[3] << 32);

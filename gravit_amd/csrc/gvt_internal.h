@@ -81,6 +81,9 @@ struct Knobs {
                          // rank must use the same value (the announce message has a fixed length).  0: always the two-step exchange
   int comm_cus = 0;      // Domain scheduler: payloads that move on the communicator's own stream (payload_overlap_kb) get this many compute units to themselves:
                          // the communicator's stream is created with a CU mask of that many CUs and the persistent traversal grids are sized for the rest (0: no reservation)
+  int spec_ticks = 1;    // Domain scheduler, asynchronous ticks: the next tick's local work (a small round through k_finish) and its report are enqueued BEHIND the
+                         // current tick's exchange before the host has read that exchange's result; the device itself voids them when the result calls for the
+                         // host (a payload beyond the inline area in or out, an error, more rays than finish_rays).  0: every tick waits for the host first
   int comm_stream = 0;   // Domain scheduler: 1 = every exchange of a frame on the communicator's OWN stream, ordered against the compute stream by events (round 3's
                          // arrangement; also GVT_HIP_COMM_STREAM in the environment); 0 = on the compute stream itself, only large payloads beside it (payload_overlap_kb)
   int frame_timing = 0;  // multi-rank frames: fill gvt_hip_frame_stats' ms_chain / ms_announce / ms_payload / ms_composite (five more event calls per exchange)
@@ -319,7 +322,8 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
                      bool defer_end = false, const unsigned *n_dev0_multi = nullptr, bool multi_packets = false, bool simple_meshes = false);
 // multi_packets (merged kernels, first pass): the queues hold camera rays in tile order over packet-friendly meshes -- closest hits through k_packet_multi
 int finish_round(const WaveSet &W, size_t n_total, const TraceParams &P, const gvt_hip_light *lights_host, const void *d_qdesc, const int *d_owner, int rank,
-                 unsigned *d_queue_overflow, unsigned *const *d_count_ptr, const unsigned char *d_mask);
+                 unsigned *d_queue_overflow, unsigned *const *d_count_ptr, const unsigned char *d_mask, const unsigned *spec_words = nullptr);
+bool finish_lights_resident(const gvt_hip_light *lights_host, int nL); // the context's device copy of the light list is this list (trace.hip)
 int convert_aos_to_planes(const gvt_hip_ray *d_src, size_t n, RayPlanes dst, size_t dst_off, bool keep_state);
 int convert_planes_to_aos(RayPlanes src, size_t src_off, size_t n, gvt_hip_ray *d_dst);
 int convert_od_to_planes(const float *d_org, const float *d_dir, size_t n, RayPlanes dst);

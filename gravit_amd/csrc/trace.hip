@@ -804,8 +804,16 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
 // A small round in ONE launch (finish_kernel.inc): the rays of the segments in W are traced, shaded, their shadow rays traced and
 // everything that moves on is followed through this rank's instances; rays for other ranks' instances are appended to their queues
 // (which must have room: n_total * (1 + n_lights * depth) each), everything else ends in the framebuffer.  No shuffle follows.
+// the context's device copy of the light list is this list (finish_round / wave_trace_chain upload it when it changes): a launch may use it without a copy
+bool finish_lights_resident(const gvt_hip_light *lights_host, int nL) {
+  Ctx &C = gctx();
+  const size_t bytes = sizeof(gvt_hip_light) * (size_t)nL;
+  return !nL || (C.lights_cached_dst && C.lights_cached_dst == C.scratch[5] && C.lights_cached.size() == bytes && std::memcmp(C.lights_cached.data(), lights_host, bytes) == 0);
+}
+// spec_words != nullptr: the launch is enqueued ahead of the host's knowledge (domain.hip): n_total is only the bound its grid is sized by, the count is
+// spec_words[2], the launch is void unless spec_words[1]; the light list must be resident already (no upload, no synchronisation in here)
 int finish_round(const WaveSet &W, size_t n_total, const TraceParams &P, const gvt_hip_light *lights_host, const void *d_qdesc, const int *d_owner, int rank,
-                 unsigned *d_queue_overflow, unsigned *const *d_count_ptr, const unsigned char *d_mask) {
+                 unsigned *d_queue_overflow, unsigned *const *d_count_ptr, const unsigned char *d_mask, const unsigned *spec_words) {
   Ctx &C = gctx();
   if (!n_total) return 0;
   hipStream_t st = C.stream;
@@ -817,6 +825,7 @@ int finish_round(const WaveSet &W, size_t n_total, const TraceParams &P, const g
     const void *&cached_dst = C.lights_cached_dst;
     const size_t bytes = sizeof(gvt_hip_light) * (size_t)nL;
     if (nL && (cached_dst != d_lights || cached.size() != bytes || std::memcmp(cached.data(), lights_host, bytes) != 0)) {
+      if (spec_words) { set_error("finish_round: a speculative launch needs the light list resident"); return GVT_HIP_ERR_INVALID; }
       cached.assign((const unsigned char *)lights_host, (const unsigned char *)lights_host + bytes);
       cached_dst = d_lights;
       HIPCHK(hipMemcpyAsync(d_lights, cached.data(), bytes, hipMemcpyHostToDevice, st));
@@ -824,6 +833,7 @@ int finish_round(const WaveSet &W, size_t n_total, const TraceParams &P, const g
     }
   }
   FinishArgs A;
+  A.n_dev = spec_words ? spec_words + 2 : nullptr; A.valid = spec_words ? spec_words + 1 : nullptr;
   A.W = W; A.n = (unsigned)n_total; A.lights = d_lights; A.n_lights = nL; A.normal_mode = P.normal_mode;
   A.top = P.sink.top; A.fb = P.sink.fb; A.n_pix = P.sink.n_pix;
   A.queues = (const QueueDesc *)d_qdesc; A.owner = d_owner; A.rank = rank;

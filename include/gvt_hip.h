@@ -382,6 +382,8 @@ int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
  *                                                per tick; default 16; the same on every rank; 0: the two-step exchange of SendRays, counts then rays)
  *                "comm_cus"                      Domain scheduler: compute units reserved for the communicator's own stream (CU mask; the persistent traversal grids
  *                                                are sized for the rest); set before gvt_hip_comm_create; default 0
+ *                "spec_ticks"                    Domain scheduler, asynchronous ticks: 1 (default) = the next tick's small round and report are enqueued behind the
+ *                                                current exchange before its result is read (the device voids them when the result needs the host); 0 = never
  *                "comm_stream"                   Domain scheduler: 1 = every exchange of a frame on the communicator's own stream, ordered against the compute stream
  *                                                by events (also GVT_HIP_COMM_STREAM in the environment); default 0: on the compute stream, large payloads beside it
  *                "abi_lanes" / "abi_chunk"     gvt_hip_trace on a host RayVector: pipeline lanes (0: one shot), rays per chunk

@@ -314,6 +314,28 @@ def test_small_payloads_ride_inside_the_announce(hip, world, bsp):
         assert max(x[1]["rounds"] for x in res[1024].values()) <= max(x[1]["rounds"] for x in res[0].values())
 
 
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_speculative_tick_parts_change_nothing_but_the_timing(hip, world):
+    """spec_ticks (default on): behind every announce exchange of an asynchronous Domain frame the library enqueues the NEXT tick's small round (k_finish, sized on
+    the device from the queues' count words) and its report before the host has read the exchange; k_publish voids them on the device when the exchange calls for
+    the host (a payload beyond the inline area in or out, an error, more than finish_rays local rays).  The exchange sequence is untouched, so with the knob on
+    or off the same rays cross the same boundaries in the same ticks and the image is the checker's -- also with an inline area so small that most parts are void,
+    and with finish_rays so small that every part is."""
+    sc = _toy_crossing_scene()
+    owner = [i % world for i in range(sc.n_inst)]
+    ref, st = oracle_render_domain(sc, owner, world, 0)
+    base = None
+    for opts in ((("spec_ticks", 0),), (("spec_ticks", 1),), (("spec_ticks", 1), ("inline_kb", 1)), (("spec_ticks", 1), ("finish_rays", 16)), (("spec_ticks", 1), ("inline_kb", 1024))):
+        r = run_native_ranks(sc, owner, world, NORMALS_FLAT, False, opts=opts)
+        assert np.array_equal(r[0][0][..., :3], ref[..., :3]) and np.array_equal(r[0][0][..., 3], ref[..., 3]), opts
+        got = (sum(x[1]["rays_sent"] for x in r.values()), sum(x[1]["rays_closest"] for x in r.values()), sum(x[1]["rays_any"] for x in r.values()))
+        assert got == (st.rays_sent, st.rays_closest, st.rays_any), opts
+        shape = ([x[1]["rounds"] for x in r.values()], [x[1]["exchanges"] for x in r.values()])
+        if dict(opts).get("inline_kb", 16) == 16 and "finish_rays" not in dict(opts):
+            base = base or shape
+            assert shape == base, (opts, shape, base)  # same ticks, same transport groups: the peers cannot tell
+
+
 @pytest.mark.parametrize("world,bsp", [(2, False), (3, False), (2, True)])
 def test_exchanges_on_the_communicators_own_stream(hip, world, bsp):
     """comm_stream = 1 (GVT_HIP_COMM_STREAM): the announce, k_publish's inline appends and the payloads run on the communicator's own stream; the compute
