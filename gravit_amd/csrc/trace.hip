@@ -573,6 +573,27 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     unsigned *c_next = c + ((pass & 1) ? 5 : 2);
     if (!(pass == 0 && single && single->pass0_begun))
       k_wave_pass_begin<<<1, 64, 0, st>>>(c, pass, (unsigned)n, out->d_count, nd0, (pass == 0 && n_dev0_multi && !single) ? const_cast<WaveSeg *>(W.segs) : nullptr, W.n_seg, d_count_ptr);
+    // ray sorting where it should pay (knob sort_rays, off by default: measured, profiles/r06_sort_cfg5.txt): a BOUNCE list -- secondary rays in their parents'
+    // order, i.e. neighbours in the list leave neighbouring surface points in unrelated directions -- is reordered by direction octant, then the Morton cell of the
+    // ray's origin (k_ray_keys) before the closest-hit launch; the pass's shadow rays inherit the order (k_shade allocates their slots in list order).  The list's
+    // length lives on the device: all n entries of the bound are sorted, the unused ones with the largest key
+    if (C.sort_rays && pass > 0 && single && n >= 8192 && single->mesh->d_nodes4) {
+      gvt_hip_mesh *Ms = single->mesh;
+      unsigned *k_in = (unsigned *)scratch_get(8, sizeof(unsigned) * n), *k_out = (unsigned *)scratch_get(9, sizeof(unsigned) * n);
+      unsigned *v_in = (unsigned *)scratch_get(10, sizeof(unsigned) * n), *v_out = (unsigned *)scratch_get(11, sizeof(unsigned) * n);
+      if (!k_in || !k_out || !v_in || !v_out) return GVT_HIP_ERR_DEVICE;
+      const float ex = Ms->hi[0] - Ms->lo[0], ey = Ms->hi[1] - Ms->lo[1], ez = Ms->hi[2] - Ms->lo[2];
+      const float3 blo = make_float3(Ms->lo[0], Ms->lo[1], Ms->lo[2]);
+      const float3 inv = make_float3(ex > 0 ? 1.f / ex : 0.f, ey > 0 ? 1.f / ey : 0.f, ez > 0 ? 1.f / ez : 0.f);
+      int rc_s;
+      {
+        ProfScope ps(KC_SORT);
+        k_ray_keys<<<blocks_for(n), 256, 0, st>>>(single->planes, idx, (unsigned)n, single->minv, blo, inv, k_in, v_in, C.sort_bits, n_dev);
+        if ((rc_s = sort_pairs_u32(k_in, k_out, v_in, v_out, n, C.sort_bits))) return rc_s;
+      }
+      HIPCHK(hipGetLastError());
+      idx = v_out;
+    }
     if (single) {
       // one segment (a single non-empty local queue, e.g. the one-domain benchmark): the single-mesh kernels -- no segment lookup and
       // no per-ray table loads at a refill -- with the same device-side counts

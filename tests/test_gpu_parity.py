@@ -917,6 +917,13 @@ def test_simd_cpu_baseline_equals_the_oracle_on_the_downloaded_tree(hip):
         assert (prim >= 0).sum() > 1000
         assert np.array_equal(om.occluded(org, d), T.occluded(org, d, nthreads=4)), name
         assert_hits_equal(ad.intersect(org, d), ref)
+        if simd.load8() is not None:  # the 8-wide baseline (AVX2: one ray against eight boxes of the tree collapsed once more on the host): the same answers
+            T8 = simd.Tree8(nodes4, slots)
+            assert 0 < T8.n8 < T8.n4 and 4.0 < T8.children_per_node <= 8.0, (name, T8.n8, T8.n4, T8.children_per_node)
+            t8, prim8, u8, v8 = T8.intersect(org, d, nthreads=4)
+            assert np.array_equal(ref["prim"], prim8) and np.array_equal(bits(ref["t"]), bits(t8)) and np.array_equal(bits(ref["u"]), bits(u8)) and np.array_equal(bits(ref["v"]), bits(v8)), name
+            assert np.array_equal(om.occluded(org, d), T8.occluded(org, d, nthreads=4)), name
+            assert T8.last_steps[0] > 0
 
 
 def test_host_appended_rays_start_fresh_whatever_their_padding_holds(hip):

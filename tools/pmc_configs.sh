@@ -56,3 +56,5 @@ json.dump({"config": cfg, "source_hash": h, "command": "rocprofv3 --pmc <group> 
 for k, e in sorted(res.items()):
     print(k, {c: ("%.4g" % v) for c, v in e.items() if c in ("avg_launch_us_trace_pass", "hbm_bytes_per_launch", "cycles_a_load_instruction_spends_in_L1", "wait_any_fraction", "l2_hit_rate", "launches_counted")})
 PY
+rm -rf $OUT/pmc_* $OUT/trace   # the raw counter dumps (tens of MiB) stay on the box: gpurun copies at most 64 MiB back; the summary is profiles/<tag>_pmc_cfg<N>.json, copied next
+cp $REPO/profiles/${TAG}_pmc_cfg$CFG.json $OUT/ 2>/dev/null
