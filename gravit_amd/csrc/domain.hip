@@ -207,8 +207,9 @@ static gvt_hip_comm *comm_new(int rank, int world) {
   K->count = world;
   return K;
 }
-// Knob comm_cus = k > 0: the communicator's own stream may only use the device's first k compute units (CU mask; on gfx950 the mask's bits go
-// round the eight XCDs, so k = 8 is one CU of every XCD) and the calling context's stream the others -- its persistent traversal grids are
+// Knob comm_cus = k > 0: the communicator's own stream may only use the device's first k compute units (CU mask) and the calling context's stream the others
+// (measured, profiles/r06_comm_cus.txt: 8 or 16 masked CUs cost a frame 16-28 % -- the persistent grids lose their even spread --, k = 32 costs 5.6 %: the first 32
+// bits are about one whole XCD, not one CU of every XCD as this comment used to assume) -- its persistent traversal grids are
 // then sized for those (Ctx::n_cu).  A payload that moves on the communicator's stream (payload_overlap_kb) then finds CUs that no
 // persistent wave holds; without the reservation an RCCL kernel beside k_trace waits for a block of it to leave.  Off by default.
 static int comm_reserve_cus(gvt_hip_comm *K) {
@@ -222,7 +223,14 @@ static int comm_reserve_cus(gvt_hip_comm *K) {
   if (C.cu_reserved && C.cu_reserved != k) { set_error("comm_cus = %d, but this context's stream already leaves %d compute units free", k, C.cu_reserved); return GVT_HIP_ERR_INVALID; }
   const int words = (total + 31) / 32;
   std::vector<uint32_t> m_comm(words, 0u), m_comp(words, 0u);
-  for (int b = 0; b < total; b++) (b < k ? m_comm : m_comp)[b >> 5] |= 1u << (b & 31);
+  // which k compute units?  GVT_HIP_CU_MASK_LAYOUT=1: bit b belongs to XCD b / (total / 8) -- the k are taken k / 8 from every XCD; default (0): the first k bits
+  // (right if the mask's bits go round the XCDs).  profiles/r06_comm_cus.txt has both measured
+  static const int layout = getenv("GVT_HIP_CU_MASK_LAYOUT") ? atoi(getenv("GVT_HIP_CU_MASK_LAYOUT")) : 0;
+  const int per_xcd = total / 8 > 0 ? total / 8 : total;
+  for (int b = 0; b < total; b++) {
+    const bool comm = layout == 1 ? (b % per_xcd) < (k + 7) / 8 : b < k;
+    (comm ? m_comm : m_comp)[b >> 5] |= 1u << (b & 31);
+  }
   hipStream_t s = nullptr;
   HIPCHK(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, m_comm.data()));
   hipStreamDestroy(K->stream);
