@@ -5,8 +5,8 @@
  * Why: the reference picks its packet / node width from the host ISA at build time (GVT_AVX_TARGET / GVT_AVX2_TARGET / GVT_AVX512KNL_TARGET select
  * rtcIntersect8 / 16 and the 8 / 16-wide ray packets, src/gvt/render/adapter/embree/EmbreeMeshAdapter.cpp:50-74, :474); on an AVX2 host Embree 2.x walks a BVH8,
  * one ray against EIGHT child boxes per step.  This file does that over the same tree the GPU built: simd8_build collapses the downloaded compressed 4-wide nodes
- * once more on the host -- a node's inner child of largest area is replaced by that child's children while the result fits eight slots, the rule of the device's own
- * collapse (csrc/lbvh.hip k_collapse4) -- into 256-byte nodes of eight float boxes (the 8-bit planes decoded, every plane moved outward by one ulp), and
+ * once more on the host -- the inner child of largest area whose own children still fit is replaced by them until none fits (the greedy rule of the device's own
+ * collapse, csrc/lbvh.hip k_collapse4, carried on to eight slots) -- into 256-byte nodes of eight float boxes (the 8-bit planes decoded, every plane moved outward by one ulp), and
  * simd8_intersect / simd8_occluded walk them with six 8-wide fused multiply-adds per step, nearest child first, a stack per ray; leaves of <= 2 triangles go through
  * the restated Moeller-Trumbore test of the kernels (strict IEEE, no contraction: the same (t, primID, u, v) bits -- boxes are conservative, they cannot change a
  * result).  The build is not timed (neither is the GPU's, nor Embree's rtcCommit in the reference's own timers).
@@ -65,23 +65,20 @@ long simd8_build(const uint32_t *nodes4, size_t n_nodes4, Node8 *nodes8) {
     const uint32_t *nd = nodes4 + 16 * (size_t)queue[head];
     Slot s[8], tmp[4];
     int n = children_of(nd, s);
-    for (;;) { /* open the inner child of largest area while its children fit */
-      int k = -1;
+    for (;;) { /* open the inner child of largest area whose children still fit, until none does */
+      int k = -1, m = 0;
       float best = -1.f;
-      for (int c = 0; c < n; c++) if (s[c].ref >= 0) { const float a = area_of(&s[c]); if (a > best) { best = a; k = c; } }
-      if (k < 0) break;
-      const int m = children_of(nodes4 + 16 * (size_t)s[k].ref, tmp);
-      if (n - 1 + m > 8 || m == 0) { /* does not fit: try the next largest once, then stop (the device's collapse stops at the first that does not fit, too) */
-        int k2 = -1;
-        float b2 = -1.f;
-        for (int c = 0; c < n; c++) if (c != k && s[c].ref >= 0) { const float a = area_of(&s[c]); if (a > b2) { b2 = a; k2 = c; } }
-        if (k2 < 0) break;
-        const int m2 = children_of(nodes4 + 16 * (size_t)s[k2].ref, tmp);
-        if (n - 1 + m2 > 8 || m2 == 0) break;
-        s[k2] = tmp[0];
-        for (int c = 1; c < m2; c++) s[n++] = tmp[c];
-        continue;
+      for (int c = 0; c < n; c++) {
+        if (s[c].ref < 0) continue;
+        const float a = area_of(&s[c]);
+        if (a <= best) continue;
+        Slot probe[4];
+        const int mc = children_of(nodes4 + 16 * (size_t)s[c].ref, probe);
+        if (mc == 0 || n - 1 + mc > 8) continue;
+        best = a; k = c; m = mc;
+        memcpy(tmp, probe, sizeof probe);
       }
+      if (k < 0) break;
       s[k] = tmp[0];
       for (int c = 1; c < m; c++) s[n++] = tmp[c];
     }

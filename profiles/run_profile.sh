@@ -19,3 +19,6 @@ done
 cd $REPO
 python3 profiles/summarize.py $TAG > $OUT/summary.log 2>&1
 tail -30 $OUT/summary.log
+# the raw counter dumps stay on the box (gpurun copies at most 64 MiB back): the summaries are profiles/<tag>_kernel_stats.csv, <tag>_pmc.json, traffic.json
+mkdir -p $OUT/keep && cp $REPO/profiles/${TAG}_kernel_stats.csv $REPO/profiles/${TAG}_pmc.json $REPO/profiles/traffic.json $OUT/keep/ 2>/dev/null
+rm -rf $OUT/pmc_* $OUT/trace
