@@ -50,7 +50,7 @@ for n in (2, 4, 8):
 d8 = last_json(os.path.join(src, "domains8.log"))
 open(os.path.join(dst, tag + "_domain_ticks.txt"), "w").write(
     "# bench.py --inproc-ranks N --steps 10 --warmup 2 at %s (source hash %s): the native multi-rank frame loop with N in-process ranks sharing ONE MI355X (hub transport).\n"
-    "# Tick counts, rays / bytes sent and the per-phase times (max over ranks, ms per frame; frame_timing on: five more event calls per tick) of the config-3 soup cut into N x-y tiles;\n"
+    "# Tick counts, rays / bytes sent and the per-phase times (max over ranks, ms per frame; frame_timing on: five more event calls per tick, and no speculative tick parts -- spec_ticks needs it off) of the config-3 soup cut into N x-y tiles;\n"
     "# NOT a scaling number: the ranks' launch chains serialise on one device.  Default = the reference's hop-by-hop shuffle rule; rows '+skip': the opt-in known-miss shortcut\n"
     "# (skip_known = 1: fewer hand-back hops between overlapping tiles, not image-identical in general -- DESIGN 6).  Payloads of at most inline_kb = 16 KiB per pair ride inside the announce.\n"
     "# N variant            ms/frame  ticks  chains  syncs  rays_sent  bytes_sent | chain announce payload composite host_wait\n" % (commit, h) + "\n".join(rows) +
