@@ -649,6 +649,29 @@ def test_round_results_do_not_depend_on_knobs(hip, opts):
             hip.set_option("defaults", 0)
 
 
+def test_sorted_bounce_lists_change_nothing_but_the_order(hip):
+    """sort_rays in the native chain (round 6): in a single-mesh round with bounces the list of secondary rays is reordered by direction octant and the Morton cell
+    of the ray's entry point before the closest-hit launch (its length lives on the device: the whole bound is sorted, unused entries last), the pass's shadow rays
+    inherit the order.  A ray's RNG stream travels with the ray, so the one-instance hall at depth 3 gives the oracle's image and ray counts with the knob on."""
+    sc = scenes.cathedral_scene(160, 160, samples=2, depth=3, eye=(0.0, 1.5, 13.0), light=(0.0, 2.5, 12.0))
+    assert sc.n_inst == 1
+    ref, st = oracle_render(sc, NORMALS_FLAT, nthreads=8)
+    try:
+        for on in (0, 1):
+            hip.set_option("sort_rays", on)
+            hip.stats_reset(); hip.profile(1)
+            tr = NativeTracer(sc, NORMALS_FLAT)
+            fb = tr().framebuffer(True)
+            sorted_ms = hip.stats()["ms_sort"]
+            hip.profile(False)
+            assert np.abs(fb[..., :3] - ref[..., :3]).max() <= 1e-5 and np.array_equal(fb[..., 3], ref[..., 3]), on
+            assert tr.stats["rays_closest"] == st.rays_closest > 150_000 and tr.stats["rays_any"] == st.rays_any, on
+            assert (sorted_ms > 0.0) == bool(on)  # the sort really ran (two bounce passes) / never ran
+            tr.close()
+    finally:
+        hip.set_option("defaults", 0)
+
+
 def test_shadow_rays_are_listed_by_their_primaries_step_counts(hip):
     """knob shadow_order: a single-mesh round with one light writes its shadow rays into eight regions, by the node steps the longest primary of their 64-ray
     tile took (the closest-hit launch leaves a byte per ray), and the any-hit launch walks the regions from the longest class down.  Same image, same ray
