@@ -665,7 +665,7 @@ def test_sorted_bounce_lists_change_nothing_but_the_order(hip):
             sorted_ms = hip.stats()["ms_sort"]
             hip.profile(False)
             assert np.abs(fb[..., :3] - ref[..., :3]).max() <= 1e-5 and np.array_equal(fb[..., 3], ref[..., 3]), on
-            assert tr.stats["rays_closest"] == st.rays_closest > 150_000 and tr.stats["rays_any"] == st.rays_any, on
+            assert tr.stats["rays_closest"] == st.rays_closest > 100_000 and tr.stats["rays_any"] == st.rays_any, on
             assert (sorted_ms > 0.0) == bool(on)  # the sort really ran (two bounce passes) / never ran
             tr.close()
     finally:
