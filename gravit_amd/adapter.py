@@ -175,6 +175,15 @@ class HipMeshAdapter:
         capi.check(self.lib.gvt_hip_mesh_download_wide(self.h, capi.ptr(nodes4), C.c_size_t(n4), capi.ptr(slots), C.c_size_t(i["n_tris"])), "gvt_hip_mesh_download_wide")
         return nodes4, slots
 
+    def download_clusters(self):
+        """Measurement: the cluster layout of the 4-wide nodes (built on first use) -- (n4, 16) uint32 and the root's entry, or (None, -1) when the mesh has none."""
+        i = self.info()
+        n4 = i["bytes_nodes"] // 64 - i["n_nodes"]
+        out = np.zeros((n4, 16), np.uint32)
+        root = C.c_int32(-1)
+        capi.check(self.lib.gvt_hip_mesh_download_clusters(self.h, capi.ptr(out), C.c_size_t(n4), C.byref(root)), "gvt_hip_mesh_download_clusters")
+        return (out, root.value) if root.value >= 0 else (None, -1)
+
     def upload_nodes(self, nodes):
         """Diagnostic: replace the binary nodes (visit-count diagnostics only) by a tree over the same leaves."""
         nodes = np.ascontiguousarray(nodes, np.float32)

@@ -26,7 +26,7 @@ SYMBOLS = [
     "gvt_hip_top_create", "gvt_hip_top_destroy", "gvt_hip_top_order", "gvt_hip_shuffle", "gvt_hip_queue_sizes",
     "gvt_hip_fb_create", "gvt_hip_fb_destroy", "gvt_hip_fb_clear", "gvt_hip_fb_download", "gvt_hip_fb_device_ptr",
     "gvt_hip_fb_write_ppm_bytes",
-    "gvt_hip_profile", "gvt_hip_stats_read", "gvt_hip_stats_reset", "gvt_hip_set_option", "gvt_hip_is_experiments_build", "gvt_hip_counters_peek", "gvt_hip_visit_stats", "gvt_hip_wide_visit_stats", "gvt_hip_mesh_download_nodes", "gvt_hip_mesh_download_wide", "gvt_hip_mesh_upload_nodes", "gvt_hip_marked_visit_stats", "gvt_hip_image_frame",
+    "gvt_hip_profile", "gvt_hip_stats_read", "gvt_hip_stats_reset", "gvt_hip_set_option", "gvt_hip_is_experiments_build", "gvt_hip_counters_peek", "gvt_hip_visit_stats", "gvt_hip_wide_visit_stats", "gvt_hip_mesh_download_nodes", "gvt_hip_mesh_download_wide", "gvt_hip_mesh_download_clusters", "gvt_hip_mesh_upload_nodes", "gvt_hip_marked_visit_stats", "gvt_hip_image_frame",
     "gvt_hip_math_probe", "gvt_hip_ctx_create", "gvt_hip_ctx_make_current", "gvt_hip_ctx_destroy",
     "gvt_hip_comm_unique_id", "gvt_hip_comm_create", "gvt_hip_hub_create", "gvt_hip_hub_abort", "gvt_hip_hub_destroy", "gvt_hip_comm_create_local",
     "gvt_hip_comm_destroy", "gvt_hip_comm_rank", "gvt_hip_comm_world", "gvt_hip_comm_count", "gvt_hip_comm_reserved_cus", "gvt_hip_comm_set_deadline_ms", "gvt_hip_comm_selftest",

@@ -237,7 +237,7 @@ extern "C" int gvt_hip_stats_reset(void) {
 namespace {
 struct KnobDef { const char *name; int Knobs::*field; int lo, hi; bool shipped; };
 const KnobDef g_knobs[] = {
-  // shipped (25)
+  // shipped (26)
   { "skip_known", &Knobs::skip_known, 0, 1, true },           { "frame_timing", &Knobs::frame_timing, 0, 1, true },
   { "term_sink", &Knobs::term_sink, 0, 1, true },
   { "sort_rays", &Knobs::sort_rays, 0, 1, true },             { "leaf_max", &Knobs::leaf_max, 1, 4, true },
@@ -254,6 +254,7 @@ const KnobDef g_knobs[] = {
 
   { "inline_kb", &Knobs::inline_kb, 0, 1024, true },          { "comm_cus", &Knobs::comm_cus, 0, 128, true },
   { "comm_stream", &Knobs::comm_stream, 0, 1, true },         { "spec_ticks", &Knobs::spec_ticks, 0, 1, true },
+  { "finish_clusters", &Knobs::finish_clusters, 0, 1, true },
   // experiments build only: the alternative was measured and lost, or the value is a tuned constant
   { "trav_kernel", &Knobs::trav_kernel, 0, 1, false },        { "wide4", &Knobs::wide4, 0, 1, false },
   { "coop_fetch", &Knobs::coop_fetch, 0, 1, false },          { "fused", &Knobs::fused, 0, 1, false },
@@ -369,7 +370,7 @@ extern "C" void gvt_hip_mesh_destroy(gvt_hip_mesh *M) {
   if (!M) return;
   if (g_ctx.ready) hipStreamSynchronize(g_ctx.stream);
   hipFree(M->d_verts); hipFree(M->d_tris); hipFree(M->d_normals); hipFree(M->d_vcolors); hipFree(M->d_materials);
-  hipFree(M->d_face_mat); hipFree(M->d_nodes); hipFree(M->d_tri); hipFree(M->d_slot_of); hipFree(M->d_nodes4); hipFree(M->d_nodes4q); hipFree(M->d_triq);
+  hipFree(M->d_face_mat); hipFree(M->d_nodes); hipFree(M->d_tri); hipFree(M->d_slot_of); hipFree(M->d_nodes4); hipFree(M->d_nodes4c); hipFree(M->d_nodes4q); hipFree(M->d_triq);
   delete M;
 }
 
@@ -835,6 +836,17 @@ extern "C" int gvt_hip_mesh_download_wide(gvt_hip_mesh *M, void *nodes4, size_t 
   HIPCHK(hipStreamSynchronize(g_ctx.stream));
   if (n_nodes4) HIPCHK(hipMemcpy(nodes4, M->d_nodes4, n_nodes4 * 64, hipMemcpyDeviceToHost));
   if (n_slots) HIPCHK(hipMemcpy(slots, M->d_tri, n_slots * 64, hipMemcpyDeviceToHost));
+  return 0;
+}
+extern "C" int gvt_hip_mesh_download_clusters(gvt_hip_mesh *M, void *nodes4c, size_t n_nodes4, int32_t *root_entry) {
+  if (ensure_init()) return GVT_HIP_ERR_NODEVICE;
+  if (!M || !nodes4c || !root_entry || n_nodes4 != M->nNodes4) {
+    set_error("mesh_download_clusters: null argument, or %zu nodes asked of %zu", n_nodes4, M ? M->nNodes4 : (size_t)0);
+    return GVT_HIP_ERR_INVALID;
+  }
+  if (int rc = build_nodes4c(M)) return rc;
+  *root_entry = M->d_nodes4c ? M->root_entry4c : -1;
+  if (M->d_nodes4c) HIPCHK(hipMemcpy(nodes4c, M->d_nodes4c, n_nodes4 * 64, hipMemcpyDeviceToHost));
   return 0;
 }
 // (diagnostic) replaces the binary nodes by a tree of the caller's over the SAME leaves (same node count, root = node 0): only the visit-count

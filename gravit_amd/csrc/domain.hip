@@ -967,7 +967,10 @@ extern "C" gvt_hip_tracer *gvt_hip_tracer_create(gvt_hip_top *T, gvt_hip_mesh *c
     cptr[i] = R->queues[i]->d_count;
     if (!M) continue; // an instance whose data lives on another rank (Domain scheduler): never traced here
     if (!M->d_nodes4 && M->nNodes) ok = build_nodes4(M) == 0; // the merged kernels traverse the 4-wide layout
+    // the cluster layout for k_finish (small rounds: several instances or ranks); knob finish_clusters = 0: the plain 4-wide nodes
+    if (ok && C.finish_clusters && C.finish_rays > 0 && n_inst > 1 && M->d_nodes4) ok = build_nodes4c(M) == 0; // (once per mesh, under its own lock)
     I.nodes4 = M->d_nodes4; I.tris = M->d_tri; I.nodes4q = M->d_nodes4q; I.trisq = M->d_triq;
+    I.nodes4c = C.finish_clusters ? M->d_nodes4c : nullptr; I.root_entry4c = M->root_entry4c;
     if (M->nNodes && !(M->d_nodes4q && M->d_triq)) R->all_quad = false;
     I.mv.slots = M->d_tri; I.mv.slot_of = M->d_slot_of; I.mv.verts = M->d_verts; I.mv.tris = M->d_tris; I.mv.normals = M->d_normals; I.mv.vcolors = M->d_vcolors;
     I.mv.materials = M->d_materials; I.mv.n_mat = (unsigned)M->nMat; I.mv.face_mat = M->d_face_mat; I.mv.mat = M->mesh_mat;

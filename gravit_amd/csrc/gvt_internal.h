@@ -81,6 +81,7 @@ struct Knobs {
                          // rank must use the same value (the announce message has a fixed length).  0: always the two-step exchange
   int comm_cus = 0;      // Domain scheduler: payloads that move on the communicator's own stream (payload_overlap_kb) get this many compute units to themselves:
                          // the communicator's stream is created with a CU mask of that many CUs and the persistent traversal grids are sized for the rest (0: no reservation)
+  int finish_clusters = 1; // k_finish walks the cluster layout of the 4-wide nodes (two levels per memory round trip; built per mesh when a tracer with several instances is made)
   int spec_ticks = 1;    // Domain scheduler, asynchronous ticks: the next tick's local work (a small round through k_finish) and its report are enqueued BEHIND the
                          // current tick's exchange before the host has read that exchange's result; the device itself voids them when the result calls for the
                          // host (a payload beyond the inline area in or out, an error, more rays than finish_rays).  0: every tick waits for the host first
@@ -179,6 +180,10 @@ struct gvt_hip_mesh {
   unsigned *d_slot_of = nullptr; // primID -> slot (the shading kernel reads the triangle from the slot the traversal touched)
   uint4 *d_nodes4 = nullptr;  // compressed 4-wide collapse: 4 x 16 B (64 B) per node
   size_t nNodes4 = 0;
+  std::vector<unsigned> levels4; // nodes per level of the breadth-first 4-wide array (build_nodes4)
+  uint4 *d_nodes4c = nullptr; // the same nodes in CLUSTER order for the wave-per-ray traversals (build_nodes4c, lbvh.hip): every even-level node followed by its
+                              // inner children; references out of a cluster = (slot of the even node << 4) | mask of its inner children.  Built on demand
+  int root_entry4c = 0;       // ... the root's reference in that form
   uint4 *d_nodes4q = nullptr; // the same nodes laid out for the quad-per-ray traversal: piece s = child s (quad_kernel.inc)
   float4 *d_triq = nullptr;   // leaf blocks, transposed (lbvh.hip k_emit_trisq)
   int leaf_max = 2;           // triangles per leaf this mesh was built with
@@ -271,9 +276,11 @@ struct WaveSeg { // one local queue: rays [begin, begin + n) of the launch
 struct WaveInst { // per instance (Adapter::trace arguments m / minv / normi + the adapter's mesh)
   Mat4 minv;
   Mat3 normi;
-  int pad[3];
+  int root_entry4c;      // the root's reference in the cluster layout (nodes4c)
+  int pad[2];
   const uint4 *nodes4;
   const float4 *tris;
+  const uint4 *nodes4c;  // cluster layout for the wave-per-ray traversals (null: not built; they walk nodes4 then)
   const uint4 *nodes4q;  // quad layouts (null: the mesh was built without them)
   const float4 *trisq;
   MeshView mv;
@@ -291,6 +298,7 @@ int build_lbvh(gvt_hip_mesh *M);
 int trav_overflow_fetch_async();
 int trav_overflow_result();
 int build_nodes4(gvt_hip_mesh *M); // lazily, when the wide4 option is on
+int build_nodes4c(gvt_hip_mesh *M); // the cluster layout of the 4-wide nodes (on demand: tracers with several instances / ranks)
 int sort_pairs_u32(unsigned *keys_in, unsigned *keys_out, unsigned *vals_in, unsigned *vals_out, size_t n, int end_bit);
 // trace.hip
 int queue_reserve(gvt_hip_queue *q, size_t cap);

@@ -17,6 +17,7 @@
 
 #include "gvt_internal.h"
 #include <chrono>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 
@@ -871,6 +872,8 @@ static int build_nodes4(gvt_hip_mesh *M, BuildArena *A) {
       more = h_levels[batch_end] != 0u;
     }
     M->nNodes4 = base;
+    M->levels4.clear();
+    for (int l = 0; l < GVT_COLLAPSE_LEVELS && h_levels[l]; l++) M->levels4.push_back(h_levels[l]);
     if (e != hipSuccess) { set_error("4-wide collapse: %s", hipGetErrorString(e)); rc = GVT_HIP_ERR_DEVICE; }
     if (getenv("GVT_HIP_BUILD_TRACE")) {
       int depth = 0;
@@ -883,6 +886,97 @@ static int build_nodes4(gvt_hip_mesh *M, BuildArena *A) {
   return rc;
 }
 int build_nodes4(gvt_hip_mesh *M) { return build_nodes4(M, nullptr); }
+
+// ------------------------------------------------------------------------------------------------
+// The CLUSTER layout of the 4-wide nodes, for the traversals that give a ray a whole wave (k_finish: trace_wave.inc wave_closest_run_c / wave_any_run_c).
+// Such a traversal is a chain of dependent node fetches, one per level of the tree (the wave opens its ray's whole frontier per step): ~12 steps of a microsecond
+// each for a tile of a million triangles.  Here every node of an EVEN level is followed in memory by its inner children (odd level), and a reference to an even
+// node carries, in its low four bits, which of its children are inner nodes: (slot << 4) | mask.  A step then fetches a node AND its children at once -- the
+// children's addresses follow from the reference alone -- and descends two levels per memory round trip.  The array is a permutation of nodes4 (every node once, the
+// same 64 bytes but for the references of the odd-level nodes); leaf references are unchanged.
+namespace {
+struct Levels4 { unsigned off[GVT_COLLAPSE_LEVELS + 2]; int n; }; // off[L] = index of level L's first node in the breadth-first array, off[n] = all nodes
+__device__ inline int level_of4(const Levels4 &T, unsigned i) {
+  int lo = 0, hi = T.n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (T.off[mid] <= i) lo = mid; else hi = mid - 1; }
+  return lo;
+}
+__device__ inline unsigned inner_mask4(const uint4 *__restrict__ nd) { // bit c: child c is an inner node
+  const uint4 w2 = nd[2], w3 = nd[3];
+  return ((int)w2.z >= 0 ? 1u : 0u) | ((int)w2.w >= 0 ? 2u : 0u) | ((int)w3.x >= 0 ? 4u : 0u) | ((int)w3.y >= 0 ? 8u : 0u);
+}
+// slots an even-level node's cluster takes (itself + its inner children); 0 for an odd-level node (it lives in its parent's cluster)
+__global__ __launch_bounds__(256) void k_cluster_weight(const uint4 *__restrict__ nodes4, unsigned n4, Levels4 T, unsigned *__restrict__ w) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  w[i] = (level_of4(T, i) & 1) ? 0u : 1u + (unsigned)__popc(inner_mask4(nodes4 + (size_t)GVT_NODE4_F4 * i));
+}
+__global__ __launch_bounds__(256) void k_cluster_emit(const uint4 *__restrict__ nodes4, unsigned n4, Levels4 T, const unsigned *__restrict__ pos, uint4 *__restrict__ out) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4 || (level_of4(T, i) & 1)) return;
+  const uint4 *nd = nodes4 + (size_t)GVT_NODE4_F4 * i;
+  uint4 *head = out + (size_t)GVT_NODE4_F4 * pos[i];
+  const uint4 h2 = nd[2], h3 = nd[3];
+  head[0] = nd[0]; head[1] = nd[1]; head[2] = h2; head[3] = h3; // (its references to inner children are not followed: the children sit behind it)
+  const int refs[4] = { (int)h2.z, (int)h2.w, (int)h3.x, (int)h3.y };
+  unsigned slot = pos[i] + 1u;
+  for (int c = 0; c < 4; c++) {
+    if (refs[c] < 0) continue;
+    const uint4 *ch = nodes4 + (size_t)GVT_NODE4_F4 * (unsigned)refs[c];
+    uint4 c2 = ch[2], c3 = ch[3];
+    int r[4] = { (int)c2.z, (int)c2.w, (int)c3.x, (int)c3.y };
+    for (int k = 0; k < 4; k++)
+      if (r[k] >= 0) r[k] = (int)((pos[(unsigned)r[k]] << 4) | inner_mask4(nodes4 + (size_t)GVT_NODE4_F4 * (unsigned)r[k])); // a grandchild: an even-level node again
+    c2.z = (unsigned)r[0]; c2.w = (unsigned)r[1]; c3.x = (unsigned)r[2]; c3.y = (unsigned)r[3];
+    uint4 *dst = out + (size_t)GVT_NODE4_F4 * slot;
+    dst[0] = ch[0]; dst[1] = ch[1]; dst[2] = c2; dst[3] = c3;
+    slot++;
+  }
+}
+} // namespace
+
+int build_nodes4c(gvt_hip_mesh *M) {
+  static std::mutex once; // (tracers of several contexts -- threads -- may be created over one mesh at the same time)
+  std::lock_guard<std::mutex> lock(once);
+  if (M->d_nodes4c || !M->d_nodes4 || !M->nNodes4 || M->levels4.empty()) return 0;
+  if (M->levels4.size() > (size_t)GVT_COLLAPSE_LEVELS || M->nNodes4 >= ((size_t)1 << 26)) return 0; // (the wave-per-ray traversals walk nodes4 then)
+  Ctx &C = gctx();
+  hipStream_t st = C.stream;
+  const unsigned n4 = (unsigned)M->nNodes4;
+  Levels4 T;
+  std::memset(&T, 0, sizeof T);
+  T.n = (int)M->levels4.size();
+  unsigned run = 0;
+  for (int l = 0; l < T.n; l++) { T.off[l] = run; run += M->levels4[l]; }
+  T.off[T.n] = run;
+  if (run != n4) { set_error("cluster layout: the level sizes add up to %u of %u nodes", run, n4); return GVT_HIP_ERR_DEVICE; }
+  unsigned *w = nullptr, *pos = nullptr;
+  void *tmp = nullptr;
+  size_t tb = 0;
+  int rc = dalloc(&w, n4);
+  if (!rc) rc = dalloc(&pos, n4);
+  if (!rc) rc = dalloc(&M->d_nodes4c, (size_t)GVT_NODE4_F4 * n4);
+  if (!rc && rocprim::exclusive_scan(nullptr, tb, w, pos, 0u, (size_t)n4, rocprim::plus<unsigned>(), st) != hipSuccess) rc = GVT_HIP_ERR_DEVICE;
+  if (!rc && hipMalloc(&tmp, tb ? tb : 16) != hipSuccess) rc = GVT_HIP_ERR_DEVICE;
+  uint4 root[4];
+  if (!rc) {
+    k_cluster_weight<<<(n4 + 255) / 256, 256, 0, st>>>(M->d_nodes4, n4, T, w);
+    hipError_t e = rocprim::exclusive_scan(tmp, tb, w, pos, 0u, (size_t)n4, rocprim::plus<unsigned>(), st);
+    if (e == hipSuccess) { k_cluster_emit<<<(n4 + 255) / 256, 256, 0, st>>>(M->d_nodes4, n4, T, pos, M->d_nodes4c); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(root, M->d_nodes4, 64, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { set_error("cluster layout: %s", hipGetErrorString(e)); rc = GVT_HIP_ERR_DEVICE; }
+  }
+  if (!rc) {
+    const int refs[4] = { (int)root[2].z, (int)root[2].w, (int)root[3].x, (int)root[3].y };
+    unsigned mask = 0;
+    for (int c = 0; c < 4; c++) if (refs[c] >= 0) mask |= 1u << c;
+    M->root_entry4c = (int)mask; // (the root's cluster starts at slot 0)
+  }
+  hipFree(w); hipFree(pos); hipFree(tmp);
+  if (rc) { hipFree(M->d_nodes4c); M->d_nodes4c = nullptr; if (!*gvt_hip_last_error()) set_error("cluster layout: device allocation failed"); }
+  return rc;
+}
 
 // diagnostic: marks[k] = 1 where binary node k is the root of a `width`-wide node (width 2..8); *n_wide = number of wide nodes
 int wide_root_marks(gvt_hip_mesh *M, int width, unsigned char *d_marks, size_t *n_wide) {

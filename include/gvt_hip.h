@@ -343,6 +343,11 @@ int gvt_hip_wide_visit_stats(gvt_hip_mesh *, const float *org, const float *dir,
  * first slot << 3 | triangles) and n_tris triangle slots of 64 bytes {v0, primID | e1 = v0 - v1, . | e2 = v2 - v0, . | .} in leaf order -- for the SIMD CPU
  * baseline of bench.py (oracle/simd_baseline.c) */
 int gvt_hip_mesh_download_wide(gvt_hip_mesh *, void *nodes4, size_t n_nodes4, void *slots, size_t n_slots);
+/* ... and the CLUSTER layout of the same nodes (built on first use; the Domain scheduler's small rounds, k_finish, walk it -- knob finish_clusters): a permutation of
+ * nodes4 in which every node of an even level is followed by its inner children, the references of the odd-level nodes to inner nodes being (slot << 4) | mask
+ * of the grandchild's inner children; *root_entry = the root's (slot 0).  rc 0 with *root_entry = -1: the mesh has no such layout (too deep or too large), the
+ * traversals walk nodes4 */
+int gvt_hip_mesh_download_clusters(gvt_hip_mesh *, void *nodes4c, size_t n_nodes4, int32_t *root_entry);
 /* diagnostics behind tools/wide_dp.py (is a cost-optimal wide collapse of the tree worth building?): the binary LBVH as built -- n_nodes x 64 bytes,
  * per node {c0.lo.x, c0.hi.x, c0.lo.y, c0.hi.y | c1.lo.x, c1.hi.x, c1.lo.y, c1.hi.y | c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z | child0, child1 (int32; < 0: leaf), -, -} --
  * and the visits of a collapse the CALLER chose: marks[k] = 1 where binary node k is the root of a wide node, counts[j] = marked nodes ray j visits */
@@ -384,6 +389,8 @@ int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
  *                                                are sized for the rest); set before gvt_hip_comm_create; default 0
  *                "spec_ticks"                    Domain scheduler, asynchronous ticks: 1 (default) = the next tick's small round and report are enqueued behind the
  *                                                current exchange before its result is read (the device voids them when the result needs the host); 0 = never
+ *                "finish_clusters"               small rounds of several instances (k_finish, a wave per ray): 1 (default) = walk the cluster layout of the 4-wide nodes
+ *                                                (two tree levels per memory round trip; built per mesh when such a tracer is created, + 64 bytes per node); 0 = the plain nodes
  *                "comm_stream"                   Domain scheduler: 1 = every exchange of a frame on the communicator's own stream, ordered against the compute stream
  *                                                by events (also GVT_HIP_COMM_STREAM in the environment); default 0: on the compute stream, large payloads beside it
  *                "abi_lanes" / "abi_chunk"     gvt_hip_trace on a host RayVector: pipeline lanes (0: one shot), rays per chunk

@@ -628,9 +628,10 @@ def test_top_level_bvh_with_1056_instances(hip):
 @pytest.mark.parametrize("opts", [dict(small_rays=0), dict(small_rays=1 << 30), dict(term_sink=0), dict(leaf_max=4, small_rays=0), dict(finish_rays=0), dict(round_room_mb=0),
                                   dict(round_room_mb=0, finish_rays=0, small_rays=0), dict(finish_rays=1 << 30), dict(finish_rays=1 << 30, leaf_max=4), dict(skip_known=1, finish_rays=0), dict(skip_known=1),
                                   dict(sort_rays=1), dict(packet=0), dict(packet=2), dict(packet=2, long_steps=0), dict(packet=2, term_sink=0), dict(packet=1, packet_min_rays=0),
-                                  dict(shadow_order=0), dict(shadow_order=1, shadow_order_min_rays=0, long_min_rays=0), dict(shadow_order=1, shadow_order_min_rays=0, long_min_rays=0, packet=0, term_sink=0)])
+                                  dict(finish_clusters=0), dict(finish_clusters=0, finish_rays=1 << 30), dict(shadow_order=0), dict(shadow_order=1, shadow_order_min_rays=0, long_min_rays=0), dict(shadow_order=1, shadow_order_min_rays=0, long_min_rays=0, packet=0, term_sink=0)])
 def test_round_results_do_not_depend_on_knobs(hip, opts):
-    """The round chain under every knob of the shipped library -- a wave per ray for small rounds or never, k_finish or rounds, exact
+    """The round chain under every knob of the shipped library -- a wave per ray for small rounds or never, k_finish or rounds (over the cluster layout of the
+    nodes, the default, or over the plain 4-wide nodes), exact
     growth, no terminal sink, the known-miss shortcut (against the checker's restatement of it) -- returns the oracle's image on a multi-domain depth-2 frame, on config 4
     and on a soup (the variants that lost -- merged kernels for one queue, compacted shadow slots, non-lean frames, k_fused / k_packet /
     k_traceq -- tests/experiment_cases.py, against the experiments build)."""

@@ -992,3 +992,51 @@ def test_builder_node_boxes_in_lds_equal_the_range_union_table(hip, case, monkey
     # (the 4-wide collapse numbers a level's nodes in block-arrival order: its array is a permutation from build to build; the slots are not)
     assert wa.shape == wb.shape and np.array_equal(sa.view(np.uint32), sb.view(np.uint32))
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("case", ["soup-300k", "bun_zipper", "one-leaf"])
+def test_cluster_layout_is_the_same_tree(hip, case):
+    """lbvh.hip build_nodes4c (round 6): the layout k_finish walks two levels per memory round trip.  Walked from the root's entry, level pair by level pair,
+    beside the 4-wide nodes it was made from: every node appears once, with the same boxes; leaves keep their references; an even-level node is followed by
+    its inner children in child order; the references of those to inner nodes are (slot << 4) | the mask of that node's inner children."""
+    if case == "soup-300k":
+        v, t = scenes.triangle_soup(300_000, seed=11)
+    elif case == "bun_zipper":
+        z = np.load(os.path.join(GOLDEN, "bun_zipper.npz"))
+        v, t = z["verts"], z["tris"]
+    else:
+        v, t = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2]], np.int32)
+    a = HipMeshAdapter(scenes.MeshData(np.ascontiguousarray(v, np.float32), np.ascontiguousarray(t, np.int32)))
+    w, _ = a.download_wide()
+    c, root = a.download_clusters()
+    assert c is not None and c.shape == w.shape and root >> 4 == 0
+    REF = [10, 11, 12, 13]  # the four child references' columns (gvt_hip.h gvt_hip_mesh_download_wide)
+    BOX = [i for i in range(16) if i not in REF]
+    refs_w, refs_c = w[:, REF].view(np.int32), c[:, REF].view(np.int32)
+    def inner_mask(r):  # (n, 4) int32 references -> bit c: child c is an inner node
+        return ((r >= 0) * (1 << np.arange(4))).sum(1).astype(np.int64)
+    seen = np.zeros(len(c), np.int64)
+    wi, slot, mask = np.array([0], np.int64), np.array([root >> 4], np.int64), np.array([root & 15], np.int64)  # pairs (node of nodes4, its cluster's entry)
+    levels = 0
+    while len(wi):
+        assert np.array_equal(w[wi][:, BOX], c[slot][:, BOX]) and np.array_equal(refs_w[wi] < 0, refs_c[slot] < 0)
+        assert np.array_equal(mask, inner_mask(refs_w[wi]))
+        leaf = refs_w[wi] < 0
+        assert np.array_equal(refs_w[wi][leaf], refs_c[slot][leaf])
+        np.add.at(seen, slot, 1)
+        # the inner children: slot + 1 + (inner children before it)
+        before = np.cumsum(~leaf, 1) - (~leaf)
+        k, ch = np.nonzero(~leaf)
+        cw, cs = refs_w[wi][k, ch].astype(np.int64), slot[k] + 1 + before[k, ch]
+        assert np.array_equal(w[cw][:, BOX], c[cs][:, BOX])
+        np.add.at(seen, cs, 1)
+        rw, rc = refs_w[cw], refs_c[cs]
+        gleaf = rw < 0
+        assert np.array_equal(gleaf, rc < 0) and np.array_equal(rw[gleaf], rc[gleaf])
+        k2, ch2 = np.nonzero(~gleaf)
+        wi, ent = rw[k2, ch2].astype(np.int64), rc[k2, ch2].astype(np.int64)
+        slot, mask = ent >> 4, ent & 15
+        levels += 2
+    assert np.all(seen == 1), "%d of %d cluster slots not reached exactly once" % (int((seen != 1).sum()), len(seen))
+    assert (case == "one-leaf") == (len(c) == 1) and levels <= 32
+    a.close()

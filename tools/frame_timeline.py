@@ -14,7 +14,7 @@ if sys.argv[1] == "run":
         if k == "domains": n_dom = int(v)
         else: capi.set_option(k, int(v))
     tr = NativeTracer(scenes.soup_scene(10_000_000) if n_dom == 1 else scenes.soup_domains_scene(10_000_000, n_dom), NORMALS_FLAT)
-    for _ in range(6):
+    for _ in range(6 if n_dom == 1 else 60):  # (several domains: the tracer first times its alternatives for the small rounds)
         tr()
     capi.synchronize()
 else:
