@@ -872,12 +872,16 @@ struct gvt_hip_tracer {
   int long_cur = 0;            // the parking threshold this tracer's frames run with (0: Knobs::long_steps), adapted frame by frame (long_auto)
   // finish_auto (one rank, several instances): small rounds through k_finish or through per-hop merged chains, decided by timing
   uint64_t frame_no = 0;
-  int fin_choice = -1;         // -1: probing (frames alternate), 0: per-hop chains, 1: k_finish
+  // ... and hops (rays without a hit taken on into the next local instance inside the merged launches, Knobs::hop_local) or the next round: a frame's ROUTE = bit 0
+  // k_finish, bit 1 hops
+  int fin_choice = -1;         // -1: probing (frames take the routes in turn), else the route
   int fin_limit = 0;           // the frame in progress: rounds of at most this many rays go through k_finish
-  bool fin_eligible = false;   // the frame in progress had a round small enough for k_finish (else its time says nothing)
+  bool hop_now = false;        // the frame in progress: hops
+  bool fin_eligible = false;   // the frame in progress had a round small enough for k_finish
   unsigned fin_probe = 0;
-  double fin_best[2] = { 1e30, 1e30 }; // fastest eligible frame seen with each variant, ms
-  int fin_n[2] = { 0, 0 };
+  double fin_best[4] = { 1e30, 1e30, 1e30, 1e30 }; // fastest frame seen with each route, ms
+  int fin_n[4] = { 0, 0, 0, 0 };
+  bool surfaces = false;       // every mesh of the scene is a surface by the builder's statistic (gvt_hip_mesh::packet_ok): the guess for hops where they are not timed
 };
 
 extern "C" void gvt_hip_tracer_destroy(gvt_hip_tracer *R) {
@@ -1125,6 +1129,10 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
     P.sink.top = R->top->dev(); P.sink.from = -1;
     P.sink.fb = R->fb->d_rgba; P.sink.n_pix = (unsigned)(R->fb->w * R->fb->h);
   }
+  // several instances on this rank: the merged launches take a ray that leaves one of them without a hit on into the next themselves (the frame's route:
+  // gvt_hip_tracer_frame; knob hop_local; not with the known-miss shortcut, whose list is kept by the shuffle kernels)
+  P.hop = R->hop_now ? 1 : 0;
+  P.hop_owner = R->world > 1 ? R->d_owner : nullptr; P.hop_rank = R->rank;
   WaveSet W{ R->d_segs, R->d_insts, n_seg, R->all_quad ? 1 : 0, (int)nI };
   if (C.finish_rays > 0 && N <= (size_t)C.finish_rays && P.sink.fb && !count_on_device && !exact) R->fin_eligible = true;
   if (R->fin_limit > 0 && N <= (size_t)R->fin_limit && P.sink.fb && !count_on_device && !exact) {
@@ -1384,13 +1392,39 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   // fall back towards the knob when fewer than 0.05 % were.  Results never depend on it.
   // small rounds: k_finish, or per-hop chains -- on one rank with several instances whichever a few timed frames say is faster here (finish_auto)
   const auto frame_t0 = std::chrono::steady_clock::now();
-  const bool fin_auto = C.finish_auto && C.finish_rays > 0 && R->world == 1 && nI > 1;
-  int fin_variant = 1;
-  if (fin_auto && R->frame_no >= 2) {
-    if ((R->frame_no & 2047u) == 0) { R->fin_choice = -1; R->fin_n[0] = R->fin_n[1] = 0; R->fin_best[0] = R->fin_best[1] = 1e30; } // look again now and then
-    fin_variant = R->fin_choice >= 0 ? R->fin_choice : (int)(R->fin_probe & 1u);
+  // ... and whether a ray that leaves an instance without a hit goes on into the next local one inside the launch (hops: the hall cut into 8 slabs 11.5 -> 4.7 ms,
+  // the soup tiles, whose grazing rays are better off with a wave each, 1.47 -> 1.75) -- timed the same way on one rank, by the meshes' kind on several
+  if (R->frame_no == 0) {
+    R->surfaces = true;
+    for (size_t i = 0; i < nI; i++) if (R->meshes[i] && !R->meshes[i]->packet_ok) R->surfaces = false;
   }
-  R->fin_limit = fin_variant ? C.finish_rays : 0;
+  size_t n_mine = 0; // (a rank with one instance has nowhere to hop to)
+  for (size_t i = 0; i < nI && n_mine < 2; i++) n_mine += (R->world == 1 || image_split || R->owned[i]) ? 1 : 0;
+  const bool hop_ok = C.hop_local > 0 && C.term_sink && !C.skip_known && n_mine > 1;
+  const bool one_rank_many = R->world == 1 && nI > 1;
+  unsigned allowed = 0; // bit v: route v (bit 0 k_finish, bit 1 hops) may be taken
+  for (int v = 0; v < 4; v++) {
+    const bool f = (v & 1) != 0, h = (v & 2) != 0;
+    if (f ? C.finish_rays <= 0 : (C.finish_rays > 0 && !(C.finish_auto && one_rank_many))) continue;
+    if (h ? !hop_ok : (hop_ok && C.hop_local == 2)) continue;
+    if (hop_ok && C.hop_local == 1 && !one_rank_many && h != R->surfaces) continue;
+    allowed |= 1u << v;
+  }
+  int n_allowed = 0, route_list[4] = { 0, 0, 0, 0 };
+  for (int v = 0; v < 4; v++) if ((allowed >> v) & 1u) route_list[n_allowed++] = v;
+  const bool fin_auto = n_allowed > 1;
+  // (the first frames and the un-timed case: k_finish where it is on, hops where the meshes are surfaces)
+  int fin_variant = route_list[n_allowed - 1];
+  for (int k = 0; k < n_allowed; k++) if (((route_list[k] & 2) != 0) == (hop_ok && (C.hop_local == 2 || R->surfaces)) && ((route_list[k] & 1) != 0) == (C.finish_rays > 0)) fin_variant = route_list[k];
+  if (fin_auto && R->frame_no >= 2) {
+    if ((R->frame_no & 2047u) == 0 || (R->fin_choice >= 0 && !((allowed >> R->fin_choice) & 1u))) { // look again now and then (or the knobs have moved)
+      R->fin_choice = -1;
+      for (int v = 0; v < 4; v++) { R->fin_n[v] = 0; R->fin_best[v] = 1e30; }
+    }
+    fin_variant = R->fin_choice >= 0 ? R->fin_choice : route_list[R->fin_probe % (unsigned)n_allowed];
+  }
+  R->fin_limit = (fin_variant & 1) ? C.finish_rays : 0;
+  R->hop_now = (fin_variant & 2) != 0;
   R->fin_eligible = false;
   struct LongOverride { Ctx &C; ~LongOverride() { C.long_steps_override = 0; } } long_override{ C };
   C.long_steps_override = (C.long_auto && C.long_steps > 0 && R->long_cur > C.long_steps) ? R->long_cur : 0;
@@ -1739,12 +1773,18 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   }
   C.stats.rays_closest += S.rays_closest;
   C.stats.rays_any += S.rays_any;
-  if (fin_auto && R->frame_no >= 2 && R->fin_choice < 0 && R->fin_eligible) { // a probing frame that had a small round: its time counts
+  if (fin_auto && R->frame_no >= 2 && R->fin_choice < 0) { // a probing frame: its time counts
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - frame_t0).count();
     R->fin_best[fin_variant] = std::min(R->fin_best[fin_variant], ms);
     R->fin_n[fin_variant]++;
     R->fin_probe++;
-    if (R->fin_n[0] >= 3 && R->fin_n[1] >= 3) R->fin_choice = R->fin_best[1] <= R->fin_best[0] ? 1 : 0;
+    bool all = true;
+    int best = route_list[0];
+    for (int k = 0; k < n_allowed; k++) {
+      all = all && R->fin_n[route_list[k]] >= 3;
+      if (R->fin_best[route_list[k]] < R->fin_best[best] || (R->fin_best[route_list[k]] == R->fin_best[best] && route_list[k] > best)) best = route_list[k];
+    }
+    if (all) R->fin_choice = best;
   }
   R->frame_no++;
   if (out) *out = S;

@@ -553,6 +553,15 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       HIPCHK(hipStreamSynchronize(st)); // pageable source: finish the copy before `cached` can change (first frame only)
     }
   }
+  // hops (MultiSrc, trace_lane.inc): in a merged chain a ray that leaves its instance without a hit goes on into the next instance of this rank inside the launch;
+  // d_hop[virtual index] = the instance it is in now (-1: its segment's), for the kernels behind (k_long_closest, k_shade, the next pass's refill)
+  int *d_hop = nullptr;
+  if (!single && P.hop && P.sink.fb) {
+    d_hop = (int *)scratch_get(23, sizeof(int) * n);
+    if (!d_hop) return GVT_HIP_ERR_DEVICE;
+    HIPCHK(hipMemsetAsync(d_hop, 0xff, sizeof(int) * n, st));
+  }
+  unsigned long long *hop_tot = (unsigned long long *)(C.d_counters + 16); // (the chain's closest-hit total: k_wave_pass_begin)
   RayPlanes shadow = make_planes(d_shadow, shadow_slots);
   shadow.p4 = nullptr; shadow.p5 = nullptr;
   RayPlanes outp = make_planes(out->d_planes, out->cap);
@@ -749,6 +758,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     LongQ LQ{};
     if (use_long) { LQ.recs = d_long; LQ.count = c + 3; long_limits(LQ, n); }
     MultiSrc MS{ W, nullptr, nullptr, nullptr };
+    if (d_hop) { MS.hop_inst = d_hop; MS.hop_read = pass > 0; MS.hop_owner = P.hop_owner; MS.hop_rank = P.hop_rank; MS.hop_tot = hop_tot; }
     // the round's queues hold camera rays in tile order, over packet-friendly meshes only: the closest hits a packet of 64 rays per wave
     const bool pktm = multi_packets && pass == 0 && !small && idx == nullptr;
     if (pktm) {
@@ -760,7 +770,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     if (small) {
       ProfScope ps(KC_CLOSEST);
       k_long_seed<<<blocks_for(n), 256, 0, st>>>(d_long, c + 3, idx, (unsigned)n, n_dev);
-      k_long_closest<true, true><<<small_grid, 256, 0, st>>>(none, d_long, c + 3, id, T, GVT_RAY_EPSILON, d_hits, c + 4, W);
+      k_long_closest<true, true><<<small_grid, 256, 0, st>>>(none, d_long, c + 3, id, T, GVT_RAY_EPSILON, d_hits, c + 4, W, nullptr, pass > 0 ? d_hop : nullptr);
     }
 #ifdef GVT_EXPERIMENTS
     else if (C.quad && W.quad_ok) {
@@ -773,11 +783,11 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
       ProfScope ps(KC_CLOSEST);
       k_trace<false, true, 0, false, true, true><<<trav_grid2(n, true), TRAV_BLOCK, 0, st>>>(none, idx, (unsigned)n, id, T, GVT_RAY_EPSILON, d_hits, nullptr, none, nullptr,
                                                                                       c + 0, C.d_spill, C.refill_min, C.inner_min, n_dev, C.share, (unsigned)C.share_min_rays,
-                                                                                      TermSink{}, LQ, MS);
+                                                                                      d_hop ? P.sink : TermSink{}, LQ, MS);
     }
     if (use_long && !small && !pktm) {
       ProfScope ps(KC_LONG);
-      k_long_closest<true, true><<<C.n_cu * 3, 256, 0, st>>>(none, d_long, c + 3, id, T, GVT_RAY_EPSILON, d_hits, c + 4, W, LQ.stk);
+      k_long_closest<true, true><<<C.n_cu * 3, 256, 0, st>>>(none, d_long, c + 3, id, T, GVT_RAY_EPSILON, d_hits, c + 4, W, LQ.stk, d_hop);
     }
     ShadeArgs A{};
     A.in = none; A.idx = idx; A.n = (unsigned)n; A.index_base = 0; A.hits = d_hits;
@@ -785,7 +795,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     A.next_idx = next; A.next_count = c_next; A.lights = d_lights; A.normi = P.normi; A.normal_mode = P.normal_mode;
     A.n_lights = nL; A.seed = P.seed; A.zero_word = c + 0;
     A.sink = P.sink; A.update_in_place = 0;
-    A.n_dev = n_dev; A.W = W; A.out_from = d_out_from; A.shadow_inst = d_shadow_inst;
+    A.n_dev = n_dev; A.W = W; A.out_from = d_out_from; A.shadow_inst = d_shadow_inst; A.hop_inst = d_hop;
     const bool direct = C.shadow_direct && pass == 0 && !small; // later passes and small rounds hold few rays: compacted slots
     // (k_shade marks every slot below the stride -- the bound -- empty or taken; with one light the list is as long as the traced one,
     // and where only the device knows that length the any-hit launch stops there instead of skipping empty slots up to the bound)
@@ -801,6 +811,7 @@ int wave_trace_chain(const WaveSet &W, size_t n_total, int passes, gvt_hip_queue
     if (nL) {
       ProfScope ps(KC_ANY);
       MultiSrc MA{ W, d_shadow_inst, d_out_from, direct ? (unsigned long long *)(c + 18) : nullptr };
+      if (d_hop && P.sink.fb) { MA.hop_owner = P.hop_owner; MA.hop_rank = P.hop_rank; MA.hop_tot = hop_tot; } // (an un-occluded shadow ray goes on the same way)
       if (small) k_wave_any<true><<<(int)std::min<size_t>((shadow_cap + 3) / 4, (size_t)C.n_cu * 3), 256, 0, st>>>(shadow, c + 1, id, T, GVT_RAY_EPSILON, outp, out->d_count, c + 0, P.sink, MA);
 #ifdef GVT_EXPERIMENTS
       else if (C.quad && W.quad_ok)

@@ -389,6 +389,10 @@ int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
  *                                                are sized for the rest); set before gvt_hip_comm_create; default 0
  *                "spec_ticks"                    Domain scheduler, asynchronous ticks: 1 (default) = the next tick's small round and report are enqueued behind the
  *                                                current exchange before its result is read (the device voids them when the result needs the host); 0 = never
+ *                "hop_local"                     Domain / Image scheduler, merged launches over several instances: a ray that leaves its instance without a hit and has another
+ *                                                instance of THIS rank ahead goes on there inside the traversal launch (shuffleRays' rule applied by the lane) instead of waiting
+ *                                                for the next round -- 0 never, 2 always, 1 (default) per tracer: timed like finish_auto on one rank, on several by the meshes'
+ *                                                kind (surfaces yes, volume-filling soups no: their grazing rays are better off with a wave each).  Results never depend on it
  *                "finish_clusters"               small rounds of several instances (k_finish, a wave per ray): 1 (default) = walk the cluster layout of the 4-wide nodes
  *                                                (two tree levels per memory round trip; built per mesh when such a tracer is created, + 64 bytes per node); 0 = the plain nodes
  *                "comm_stream"                   Domain scheduler: 1 = every exchange of a frame on the communicator's own stream, ordered against the compute stream

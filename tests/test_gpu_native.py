@@ -628,7 +628,7 @@ def test_top_level_bvh_with_1056_instances(hip):
 @pytest.mark.parametrize("opts", [dict(small_rays=0), dict(small_rays=1 << 30), dict(term_sink=0), dict(leaf_max=4, small_rays=0), dict(finish_rays=0), dict(round_room_mb=0),
                                   dict(round_room_mb=0, finish_rays=0, small_rays=0), dict(finish_rays=1 << 30), dict(finish_rays=1 << 30, leaf_max=4), dict(skip_known=1, finish_rays=0), dict(skip_known=1),
                                   dict(sort_rays=1), dict(packet=0), dict(packet=2), dict(packet=2, long_steps=0), dict(packet=2, term_sink=0), dict(packet=1, packet_min_rays=0),
-                                  dict(finish_clusters=0), dict(finish_clusters=0, finish_rays=1 << 30), dict(shadow_order=0), dict(shadow_order=1, shadow_order_min_rays=0, long_min_rays=0), dict(shadow_order=1, shadow_order_min_rays=0, long_min_rays=0, packet=0, term_sink=0)])
+                                  dict(finish_clusters=0), dict(finish_clusters=0, finish_rays=1 << 30), dict(hop_local=0), dict(hop_local=2), dict(hop_local=2, term_sink=0), dict(hop_local=2, skip_known=1), dict(shadow_order=0), dict(shadow_order=1, shadow_order_min_rays=0, long_min_rays=0), dict(shadow_order=1, shadow_order_min_rays=0, long_min_rays=0, packet=0, term_sink=0)])
 def test_round_results_do_not_depend_on_knobs(hip, opts):
     """The round chain under every knob of the shipped library -- a wave per ray for small rounds or never, k_finish or rounds (over the cluster layout of the
     nodes, the default, or over the plain 4-wide nodes), exact
@@ -878,12 +878,13 @@ def test_small_rounds_through_one_launch_or_per_hop_whichever_the_tracer_times_f
     """finish_auto (default on; one rank, several instances): frames 2.. alternate between k_finish (a small round followed to its end in
     one launch) and per-hop merged chains until each has been timed three times, then the tracer keeps the faster.  Every frame -- probing
     or settled, either route -- is the oracle's image bit for bit with the oracle's ray counts.  On the soup tiles the routes differ in
-    their number of launch chains (rays hop several times), which shows that the probing frames took both and that the choice settled."""
+    their number of launch chains (rays hop several times), which shows that the probing frames took both and that the choice settled.
+    (hop_local = 0 here: the third and fourth route, hops inside the merged launches, have their own test below.)"""
     for sc, mode in ((scenes.bunny_grid_scene(width=760, height=432), NORMALS_SMOOTH), (scenes.soup_domains_scene(200_000, 4, 480, 270), NORMALS_FLAT)):
         ref, st = oracle_render(sc, mode, nthreads=8)
         pinned = {}
         for fin in (32768, 0):  # the two routes pinned
-            hip.set_option("finish_auto", 0); hip.set_option("finish_rays", fin)
+            hip.set_option("finish_auto", 0); hip.set_option("finish_rays", fin); hip.set_option("hop_local", 0)
             try:
                 tr = NativeTracer(sc, mode)
                 fb = tr().framebuffer(True)
@@ -893,19 +894,71 @@ def test_small_rounds_through_one_launch_or_per_hop_whichever_the_tracer_times_f
                 tr.close()
             finally:
                 hip.set_option("defaults", 0)
-        tr = NativeTracer(sc, mode)
         chains = []
-        for _ in range(12):
-            fb = tr().framebuffer(True)
-            assert np.array_equal(fb[..., :3].view(np.uint32), ref[..., :3].view(np.uint32))
-            assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any
-            chains.append(tr.stats["chains"])
-        tr.close()
+        try:
+            hip.set_option("hop_local", 0)
+            tr = NativeTracer(sc, mode)
+            for _ in range(12):
+                fb = tr().framebuffer(True)
+                assert np.array_equal(fb[..., :3].view(np.uint32), ref[..., :3].view(np.uint32))
+                assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any
+                chains.append(tr.stats["chains"])
+            tr.close()
+        finally:
+            hip.set_option("defaults", 0)
         assert set(chains) <= set(pinned.values())
         if pinned[0] != pinned[32768]:
             assert chains[:2] == [pinned[32768]] * 2 and set(chains[2:8]) == set(pinned.values()), (chains, pinned)  # probing: both routes
             assert len(set(chains[8:])) == 1, chains  # settled
     assert pinned[0] > pinned[32768]  # (the soup tiles: per-hop rounds need more chains)
+
+
+def test_hops_into_the_next_local_instance_change_nothing_but_the_rounds(hip):
+    """hop_local (round 6): in a merged launch a ray that leaves its instance without a hit and has another instance of THIS rank ahead goes on there inside the
+    launch -- the lane applies shuffleRays' rule (origin advanced by 95 % of the entry distance, TracerBase.h:392-400) and starts again in the next instance --
+    instead of waiting in that instance's queue for the next round; an un-occluded shadow ray likewise.  Never (0) or always (2), on one rank and on two and three
+    (only instances the rank owns are entered), with rays parked for a wave after a few steps (they keep their new instance) and through bounces (a bounce starts
+    where its parent was hit): the oracle's image, the oracle's ray counts, the same rays sent; on one rank fewer launch chains.  hop_local = 1 (default): the
+    tracer times the routes like finish_auto and every frame, whichever route it took, is the same image."""
+    cases = ((scenes.bunny_grid_scene(width=380, height=216), NORMALS_SMOOTH, 0.0), (config5(192, 4), NORMALS_FLAT, 1e-5), (scenes.soup_domains_scene(100_000, 4, 240, 136), NORMALS_FLAT, 0.0))
+    for sc, mode, tol in cases:
+        ref, st = oracle_render(sc, mode, nthreads=8)
+        chains = {}
+        for opts in (dict(hop_local=0), dict(hop_local=2), dict(hop_local=2, finish_rays=0), dict(hop_local=2, long_steps=6, long_min_rays=0), dict(hop_local=2, small_rays=0, packet=0)):
+            try:
+                for k, v in opts.items():
+                    hip.set_option(k, v)
+                tr = NativeTracer(sc, mode)
+                for _ in range(2):
+                    fb = tr().framebuffer(True)
+                    assert np.abs(fb[..., :3] - ref[..., :3]).max() <= tol and np.array_equal(fb[..., 3], ref[..., 3]), opts
+                    assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any, opts
+                chains[tuple(opts.items())] = tr.stats["chains"]
+                tr.close()
+            finally:
+                hip.set_option("defaults", 0)
+        assert chains[(("hop_local", 2),)] <= chains[(("hop_local", 0),)], chains
+        if sc.n_inst == 8:
+            assert chains[(("hop_local", 2),)] < chains[(("hop_local", 0),)], chains  # the bunny grid: one chain instead of two
+        tr = NativeTracer(sc, mode)  # default: timed
+        seen = set()
+        for _ in range(16):
+            fb = tr().framebuffer(True)
+            assert np.abs(fb[..., :3] - ref[..., :3]).max() <= tol and np.array_equal(fb[..., 3], ref[..., 3])
+            assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any
+            seen.add(tr.stats["chains"])
+        tr.close()
+        assert len(seen) >= 1
+        for world in (2, 3):
+            owner = [i % world for i in range(sc.n_inst)]
+            refd, std = oracle_render_domain(sc, owner, world, 0 if mode == NORMALS_FLAT else 1)
+            for hop in (0, 2):
+                for bsp in (False, True):
+                    res = run_native_ranks(sc, owner, world, mode, bsp, opts=(("hop_local", hop),))
+                    fb = res[0][0]
+                    assert np.abs(fb[..., :3] - refd[..., :3]).max() <= tol and np.array_equal(fb[..., 3], refd[..., 3]), (world, hop, bsp)
+                    assert sum(r[1]["rays_sent"] for r in res.values()) == std.rays_sent, (world, hop, bsp)
+                    assert sum(r[1]["rays_closest"] for r in res.values()) == std.rays_closest and sum(r[1]["rays_any"] for r in res.values()) == std.rays_any, (world, hop, bsp)
 
 
 def _random_scene(seed):

@@ -1,5 +1,5 @@
 """Soak of the native Domain scheduler on in-process ranks: many frames, every frame's composited image compared with the first.
-   python tools/soak_domain.py [world] [frames]"""
+   python tools/soak_domain.py [world] [frames] [option=value ...]     (library options, set in every rank's context)"""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,8 +8,10 @@ from gravit_amd.layouts import NORMALS_FLAT, NORMALS_SMOOTH
 from gravit_amd.scheduler import Comm, Context, NativeTracer
 
 capi.init(0)
-world = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-frames = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+pos = [a for a in sys.argv[1:] if "=" not in a]
+lib_opts = [(a.split("=")[0], int(a.split("=")[1])) for a in sys.argv[1:] if "=" in a]
+world = int(pos[0]) if len(pos) > 0 else 4
+frames = int(pos[1]) if len(pos) > 1 else 100
 one = scenes.cathedral_scene(256, 256, samples=2, depth=2, eye=(0.0, 1.5, 13.0), light=(0.0, 2.5, 12.0))
 cases = [("config 4", scenes.bunny_grid_scene(width=380, height=216), NORMALS_SMOOTH, 0.0), ("config 5 x8", scenes.split_into_domains(one, 8), NORMALS_FLAT, 1e-5)]
 for name, sc, mode, tol in cases:
@@ -20,6 +22,8 @@ for name, sc, mode, tol in cases:
         def work(rank):
             try:
                 ctx = Context(0)
+                for k, v in lib_opts:
+                    capi.set_option(k, v)
                 comm = Comm.local(hub, rank)
                 tr = NativeTracer(sc, mode, owner, comm)
                 first = None
