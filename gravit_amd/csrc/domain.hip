@@ -1142,7 +1142,9 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
     return 0;
   }
   WaveSingle one{};
-  if (n_seg == 1 && R->meshes[R->h_segs[0].inst] && C.wave_single) {
+  // (a frame that hops keeps to the merged lane kernels: a round with ONE non-empty queue -- the camera outside the scene: every ray enters the first slab -- would
+  //  otherwise take the single-mesh kernels, which know no other instance, and leave all its misses to a second chain: the hall in 8 slabs 4.78 -> 4.50 ms)
+  if (n_seg == 1 && R->meshes[R->h_segs[0].inst] && C.wave_single && !P.hop) {
     const int i0 = R->h_segs[0].inst;
     one.planes = make_planes(R->h_segs[0].planes, R->h_segs[0].cap);
     if (nI == 1) one.planes.p5 = nullptr; // no other instance a ray could have missed: the list is neither read nor written
@@ -1159,7 +1161,7 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
   // several queues of camera rays in tile order, every traced mesh packet-friendly (or packets forced): the merged closest-hit launch walks packets too
   // (launches of a few hundred thousand rays over small meshes lose with packets -- 4 K waves, each a long serial walk: bunny.conf 0.243 -> 0.254 ms, the
   // 8-bunny grid 0.368 -> 0.407 -- where the hall cut into 8 slabs, 4.2 M camera rays, gains: 7.57 -> 7.25 ms; hence packet_min_rays)
-  bool multi_packets = !single && fresh_from_camera && C.camera_tile == 8 && (C.packet == 2 || (C.packet == 1 && N >= (size_t)C.packet_min_rays));
+  bool multi_packets = !single && !P.hop && fresh_from_camera && C.camera_tile == 8 && (C.packet == 2 || (C.packet == 1 && N >= (size_t)C.packet_min_rays));
   for (int k = 0; k < n_seg && multi_packets; k++) {
     const gvt_hip_mesh *Mk = R->meshes[R->h_segs[k].inst];
     multi_packets = Mk && Mk->d_nodes4 && (C.packet == 2 || Mk->packet_ok);
