@@ -876,7 +876,7 @@ int finish_round(const WaveSet &W, size_t n_total, const TraceParams &P, const g
   // (the work counter is 0: the frame's start and every round's report leave it so -- k_zero_totals, k_round_report)
   {
     ProfScope ps(KC_CLOSEST);
-    k_finish<<<(int)std::min<size_t>((n_total + 3) / 4, (size_t)C.n_cu * 3), 256, 0, st>>>(A); // 48 KiB of LDS per block
+    k_finish<<<(int)std::min<size_t>((n_total + 3) / 4, (size_t)C.n_cu * 4), 256, 0, st>>>(A); // 40 KiB of LDS per block: four blocks per CU
   }
   HIPCHK(hipGetLastError());
   C.stats.launches_closest++;
