@@ -748,9 +748,9 @@ def main():
                 tracer.composite(download=False)
 
     barrier()
-    # the tracer's per-scene choices (the frame's route -- small rounds through k_finish or per-hop chains, hops inside the merged launches or not: up to four routes, three timed frames each; the parking
+    # the tracer's per-scene choices (the frame's route -- small rounds through k_finish or per-hop chains, hops inside the merged launches never / early / always: up to six routes, three timed frames each; the parking
     # threshold: long_auto) settle in untimed frames BEFORE the W warm-up frames, so that neither the warm-up nor the timed steps contain a probing frame
-    settle_frames = 20 if (on_gpu and world == 1 and n_dom > 1 and args.harness == "native") else 0
+    settle_frames = 26 if (on_gpu and world == 1 and n_dom > 1 and args.harness == "native") else 0
     for _ in range(settle_frames):
         frame()
     # One GPU: the warm-up frames are bracketed kernel class by kernel class (closest hit, long rays, any hit) to find the DOMINANT class; the timed

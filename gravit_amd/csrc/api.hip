@@ -254,7 +254,7 @@ const KnobDef g_knobs[] = {
 
   { "inline_kb", &Knobs::inline_kb, 0, 1024, true },          { "comm_cus", &Knobs::comm_cus, 0, 128, true },
   { "comm_stream", &Knobs::comm_stream, 0, 1, true },         { "spec_ticks", &Knobs::spec_ticks, 0, 1, true },
-  { "finish_clusters", &Knobs::finish_clusters, 0, 1, true }, { "hop_local", &Knobs::hop_local, 0, 2, true },
+  { "finish_clusters", &Knobs::finish_clusters, 0, 1, true }, { "hop_local", &Knobs::hop_local, 0, 3, true },
   // experiments build only: the alternative was measured and lost, or the value is a tuned constant
   { "trav_kernel", &Knobs::trav_kernel, 0, 1, false },        { "wide4", &Knobs::wide4, 0, 1, false },
   { "coop_fetch", &Knobs::coop_fetch, 0, 1, false },          { "fused", &Knobs::fused, 0, 1, false },

@@ -872,15 +872,15 @@ struct gvt_hip_tracer {
   int long_cur = 0;            // the parking threshold this tracer's frames run with (0: Knobs::long_steps), adapted frame by frame (long_auto)
   // finish_auto (one rank, several instances): small rounds through k_finish or through per-hop merged chains, decided by timing
   uint64_t frame_no = 0;
-  // ... and hops (rays without a hit taken on into the next local instance inside the merged launches, Knobs::hop_local) or the next round: a frame's ROUTE = bit 0
-  // k_finish, bit 1 hops
+  // ... and hops (rays without a hit taken on into the next local instance inside the merged launches, Knobs::hop_local) or the next round: a frame's ROUTE =
+  // k_finish (0 / 1) + 2 x hops (0 never, 1 while the launch still hands out rays, 2 always)
   int fin_choice = -1;         // -1: probing (frames take the routes in turn), else the route
   int fin_limit = 0;           // the frame in progress: rounds of at most this many rays go through k_finish
-  bool hop_now = false;        // the frame in progress: hops
+  int hop_now = 0;             // the frame in progress: hops (TraceParams::hop)
   bool fin_eligible = false;   // the frame in progress had a round small enough for k_finish
   unsigned fin_probe = 0;
-  double fin_best[4] = { 1e30, 1e30, 1e30, 1e30 }; // fastest frame seen with each route, ms
-  int fin_n[4] = { 0, 0, 0, 0 };
+  double fin_best[6] = { 1e30, 1e30, 1e30, 1e30, 1e30, 1e30 }; // fastest frame seen with each route, ms
+  int fin_n[6] = { 0, 0, 0, 0, 0, 0 };
   bool surfaces = false;       // every mesh of the scene is a surface by the builder's statistic (gvt_hip_mesh::packet_ok): the guess for hops where they are not timed
 };
 
@@ -1131,7 +1131,7 @@ int local_chain(gvt_hip_tracer *R, const std::vector<size_t> *extra_in, uint64_t
   }
   // several instances on this rank: the merged launches take a ray that leaves one of them without a hit on into the next themselves (the frame's route:
   // gvt_hip_tracer_frame; knob hop_local; not with the known-miss shortcut, whose list is kept by the shuffle kernels)
-  P.hop = R->hop_now ? 1 : 0;
+  P.hop = R->hop_now == 1 ? 1 : R->hop_now == 2 ? 2 : 0;
   P.hop_owner = R->world > 1 ? R->d_owner : nullptr; P.hop_rank = R->rank;
   WaveSet W{ R->d_segs, R->d_insts, n_seg, R->all_quad ? 1 : 0, (int)nI };
   if (C.finish_rays > 0 && N <= (size_t)C.finish_rays && P.sink.fb && !count_on_device && !exact) R->fin_eligible = true;
@@ -1404,29 +1404,35 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   for (size_t i = 0; i < nI && n_mine < 2; i++) n_mine += (R->world == 1 || image_split || R->owned[i]) ? 1 : 0;
   const bool hop_ok = C.hop_local > 0 && C.term_sink && !C.skip_known && n_mine > 1;
   const bool one_rank_many = R->world == 1 && nI > 1;
-  unsigned allowed = 0; // bit v: route v (bit 0 k_finish, bit 1 hops) may be taken
-  for (int v = 0; v < 4; v++) {
-    const bool f = (v & 1) != 0, h = (v & 2) != 0;
+  unsigned allowed = 0; // bit v: route v (v = k_finish + 2 x hop mode) may be taken
+  for (int v = 0; v < 6; v++) {
+    const bool f = (v & 1) != 0;
+    const int h = v >> 1; // 0 never, 1 early, 2 always
     if (f ? C.finish_rays <= 0 : (C.finish_rays > 0 && !(C.finish_auto && one_rank_many))) continue;
-    if (h ? !hop_ok : (hop_ok && C.hop_local == 2)) continue;
-    if (hop_ok && C.hop_local == 1 && !one_rank_many && h != R->surfaces) continue;
+    if (!hop_ok) { if (h) continue; }
+    else if (C.hop_local == 2) { if (h != 2) continue; }
+    else if (C.hop_local == 3) { if (h != 1) continue; }
+    else if (!one_rank_many && h != (R->surfaces ? 2 : 0)) continue; // (several ranks: not timed)
     allowed |= 1u << v;
   }
-  int n_allowed = 0, route_list[4] = { 0, 0, 0, 0 };
-  for (int v = 0; v < 4; v++) if ((allowed >> v) & 1u) route_list[n_allowed++] = v;
+  int n_allowed = 0, route_list[6] = { 0, 0, 0, 0, 0, 0 };
+  for (int v = 0; v < 6; v++) if ((allowed >> v) & 1u) route_list[n_allowed++] = v;
   const bool fin_auto = n_allowed > 1;
   // (the first frames and the un-timed case: k_finish where it is on, hops where the meshes are surfaces)
   int fin_variant = route_list[n_allowed - 1];
-  for (int k = 0; k < n_allowed; k++) if (((route_list[k] & 2) != 0) == (hop_ok && (C.hop_local == 2 || R->surfaces)) && ((route_list[k] & 1) != 0) == (C.finish_rays > 0)) fin_variant = route_list[k];
+  {
+    const int h0 = !hop_ok ? 0 : C.hop_local == 2 ? 2 : C.hop_local == 3 ? 1 : R->surfaces ? 2 : 0, f0 = C.finish_rays > 0 ? 1 : 0;
+    for (int k = 0; k < n_allowed; k++) if ((route_list[k] >> 1) == h0 && (route_list[k] & 1) == f0) fin_variant = route_list[k];
+  }
   if (fin_auto && R->frame_no >= 2) {
     if ((R->frame_no & 2047u) == 0 || (R->fin_choice >= 0 && !((allowed >> R->fin_choice) & 1u))) { // look again now and then (or the knobs have moved)
       R->fin_choice = -1;
-      for (int v = 0; v < 4; v++) { R->fin_n[v] = 0; R->fin_best[v] = 1e30; }
+      for (int v = 0; v < 6; v++) { R->fin_n[v] = 0; R->fin_best[v] = 1e30; }
     }
     fin_variant = R->fin_choice >= 0 ? R->fin_choice : route_list[R->fin_probe % (unsigned)n_allowed];
   }
   R->fin_limit = (fin_variant & 1) ? C.finish_rays : 0;
-  R->hop_now = (fin_variant & 2) != 0;
+  R->hop_now = fin_variant >> 1;
   R->fin_eligible = false;
   struct LongOverride { Ctx &C; ~LongOverride() { C.long_steps_override = 0; } } long_override{ C };
   C.long_steps_override = (C.long_auto && C.long_steps > 0 && R->long_cur > C.long_steps) ? R->long_cur : 0;

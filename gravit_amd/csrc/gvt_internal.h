@@ -82,7 +82,8 @@ struct Knobs {
   int comm_cus = 0;      // Domain scheduler: payloads that move on the communicator's own stream (payload_overlap_kb) get this many compute units to themselves:
                          // the communicator's stream is created with a CU mask of that many CUs and the persistent traversal grids are sized for the rest (0: no reservation)
   int hop_local = 1;     // merged chains: a ray without a hit goes on into the next LOCAL instance inside the traversal launch (shuffleRays' rule applied by the lane) instead of waiting
-                         // for the next round: 0 never, 2 always, 1 = per tracer -- timed like finish_auto on one rank, by the meshes' kind (surfaces: yes) on several
+                         // for the next round: 0 never, 2 always, 3 = early: in the closest-hit launch only and only while it still has rays to hand out (a ray that goes on during the drain stretches the launch's tail), 1 = per tracer --
+                         // never / early / always timed like finish_auto on one rank; by the meshes' kind (surfaces: always, else never) on several
   int finish_clusters = 1; // k_finish walks the cluster layout of the 4-wide nodes (two levels per memory round trip; built per mesh when a tracer with several instances is made)
   int spec_ticks = 1;    // Domain scheduler, asynchronous ticks: the next tick's local work (a small round through k_finish) and its report are enqueued BEHIND the
                          // current tick's exchange before the host has read that exchange's result; the device itself voids them when the result calls for the
@@ -249,7 +250,7 @@ struct TraceParams {
   int update_in_place; // Adapter::trace updates rayList in place; device-queue callers clear the list afterwards and skip that write
   int carried_rng;     // device-queue callers: a ray's RNG stream is the word it carries (gvt_device.h, plane 4)
   // merged chains of the schedulers: rays that leave an instance without a hit go on into the next instance of this rank inside the launch (trace_lane.inc MultiSrc)
-  int hop;
+  int hop;              // 0 no, 2 yes, 1 = the closest-hit launch only, and only while it still has rays to hand out (MultiSrc::hop_early)
   const int *hop_owner; // instance -> rank on the device (null: all local)
   int hop_rank;
 };

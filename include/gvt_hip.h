@@ -391,8 +391,9 @@ int gvt_hip_math_probe(int kind, const float *in, size_t n, float *out);
  *                                                current exchange before its result is read (the device voids them when the result needs the host); 0 = never
  *                "hop_local"                     Domain / Image scheduler, merged launches over several instances: a ray that leaves its instance without a hit and has another
  *                                                instance of THIS rank ahead goes on there inside the traversal launch (shuffleRays' rule applied by the lane) instead of waiting
- *                                                for the next round -- 0 never, 2 always, 1 (default) per tracer: timed like finish_auto on one rank, on several by the meshes'
- *                                                kind (surfaces yes, volume-filling soups no: their grazing rays are better off with a wave each).  Results never depend on it
+ *                                                for the next round -- 0 never, 2 always, 3 early: in the closest-hit launch only and only while it still has rays to hand out (a ray that
+ *                                                goes on during the launch's drain stretches its tail), 1 (default) per tracer: never / early / always timed like finish_auto on one rank, on several
+ *                                                by the meshes' kind (surfaces always, volume-filling soups never).  Results never depend on it
  *                "finish_clusters"               small rounds of several instances (k_finish, a wave per ray): 1 (default) = walk the cluster layout of the 4-wide nodes
  *                                                (two tree levels per memory round trip; built per mesh when such a tracer is created, + 64 bytes per node); 0 = the plain nodes
  *                "comm_stream"                   Domain scheduler: 1 = every exchange of a frame on the communicator's own stream, ordered against the compute stream

@@ -628,7 +628,7 @@ def test_top_level_bvh_with_1056_instances(hip):
 @pytest.mark.parametrize("opts", [dict(small_rays=0), dict(small_rays=1 << 30), dict(term_sink=0), dict(leaf_max=4, small_rays=0), dict(finish_rays=0), dict(round_room_mb=0),
                                   dict(round_room_mb=0, finish_rays=0, small_rays=0), dict(finish_rays=1 << 30), dict(finish_rays=1 << 30, leaf_max=4), dict(skip_known=1, finish_rays=0), dict(skip_known=1),
                                   dict(sort_rays=1), dict(packet=0), dict(packet=2), dict(packet=2, long_steps=0), dict(packet=2, term_sink=0), dict(packet=1, packet_min_rays=0),
-                                  dict(finish_clusters=0), dict(finish_clusters=0, finish_rays=1 << 30), dict(hop_local=0), dict(hop_local=2), dict(hop_local=2, term_sink=0), dict(hop_local=2, skip_known=1), dict(shadow_order=0), dict(shadow_order=1, shadow_order_min_rays=0, long_min_rays=0), dict(shadow_order=1, shadow_order_min_rays=0, long_min_rays=0, packet=0, term_sink=0)])
+                                  dict(finish_clusters=0), dict(finish_clusters=0, finish_rays=1 << 30), dict(hop_local=0), dict(hop_local=2), dict(hop_local=3), dict(hop_local=2, term_sink=0), dict(hop_local=2, skip_known=1), dict(shadow_order=0), dict(shadow_order=1, shadow_order_min_rays=0, long_min_rays=0), dict(shadow_order=1, shadow_order_min_rays=0, long_min_rays=0, packet=0, term_sink=0)])
 def test_round_results_do_not_depend_on_knobs(hip, opts):
     """The round chain under every knob of the shipped library -- a wave per ray for small rounds or never, k_finish or rounds (over the cluster layout of the
     nodes, the default, or over the plain 4-wide nodes), exact
@@ -924,7 +924,7 @@ def test_hops_into_the_next_local_instance_change_nothing_but_the_rounds(hip):
     for sc, mode, tol in cases:
         ref, st = oracle_render(sc, mode, nthreads=8)
         chains = {}
-        for opts in (dict(hop_local=0), dict(hop_local=2), dict(hop_local=2, finish_rays=0), dict(hop_local=2, long_steps=6, long_min_rays=0), dict(hop_local=2, small_rays=0, packet=0)):
+        for opts in (dict(hop_local=0), dict(hop_local=2), dict(hop_local=3), dict(hop_local=2, finish_rays=0), dict(hop_local=3, finish_rays=0), dict(hop_local=2, long_steps=6, long_min_rays=0), dict(hop_local=2, small_rays=0, packet=0)):
             try:
                 for k, v in opts.items():
                     hip.set_option(k, v)
@@ -942,7 +942,7 @@ def test_hops_into_the_next_local_instance_change_nothing_but_the_rounds(hip):
             assert chains[(("hop_local", 2),)] < chains[(("hop_local", 0),)], chains  # the bunny grid: one chain instead of two
         tr = NativeTracer(sc, mode)  # default: timed
         seen = set()
-        for _ in range(16):
+        for _ in range(24):
             fb = tr().framebuffer(True)
             assert np.abs(fb[..., :3] - ref[..., :3]).max() <= tol and np.array_equal(fb[..., 3], ref[..., 3])
             assert tr.stats["rays_closest"] == st.rays_closest and tr.stats["rays_any"] == st.rays_any
@@ -952,7 +952,7 @@ def test_hops_into_the_next_local_instance_change_nothing_but_the_rounds(hip):
         for world in (2, 3):
             owner = [i % world for i in range(sc.n_inst)]
             refd, std = oracle_render_domain(sc, owner, world, 0 if mode == NORMALS_FLAT else 1)
-            for hop in (0, 2):
+            for hop in (0, 2, 3):
                 for bsp in (False, True):
                     res = run_native_ranks(sc, owner, world, mode, bsp, opts=(("hop_local", hop),))
                     fb = res[0][0]

@@ -49,7 +49,7 @@ for name, mk, mode in cfgs:
         if NOREF and label != "rounds":
             continue
         tr = mk_tr()
-        for _ in range(24):  # (warm-up; the tracer's per-scene choices -- parking threshold, the frame's route: k_finish or per-hop rounds, hops or not -- settle within 14 frames)
+        for _ in range(30):  # (warm-up; the tracer's per-scene choices -- parking threshold, the frame's route: k_finish or per-hop rounds, hops never / early / always -- settle within 20 frames)
             tr()
         capi.synchronize(); capi.stats_reset()
         n = FRAMES

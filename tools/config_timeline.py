@@ -17,7 +17,7 @@ if sys.argv[1] == "run":
                 "5": lambda: (hall(1), NORMALS_FLAT), "58": lambda: (hall(8), NORMALS_FLAT),
                 "d8": lambda: (scenes.soup_domains_scene(10_000_000, 8, 1920, 1080), NORMALS_FLAT)}[cfg]()   # bench.py --domains 8
     tr = NativeTracer(sc, mode)
-    for _ in range(14):  # (finish_auto has settled by then)
+    for _ in range(24):  # (the frame's route has settled by then)
         tr()
     capi.synchronize()
 else:
