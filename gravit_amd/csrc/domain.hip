@@ -1429,7 +1429,12 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
       R->fin_choice = -1;
       for (int v = 0; v < 6; v++) { R->fin_n[v] = 0; R->fin_best[v] = 1e30; }
     }
-    fin_variant = R->fin_choice >= 0 ? R->fin_choice : route_list[R->fin_probe % (unsigned)n_allowed];
+    if (R->fin_choice >= 0) fin_variant = R->fin_choice;
+    else { // probing: the allowed route with the fewest timed frames so far (the guess above first among equals)
+      int pick = fin_variant;
+      for (int k = 0; k < n_allowed; k++) if (R->fin_n[route_list[k]] < R->fin_n[pick]) pick = route_list[k];
+      fin_variant = pick;
+    }
   }
   R->fin_limit = (fin_variant & 1) ? C.finish_rays : 0;
   R->hop_now = fin_variant >> 1;
@@ -1786,13 +1791,26 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
     R->fin_best[fin_variant] = std::min(R->fin_best[fin_variant], ms);
     R->fin_n[fin_variant]++;
     R->fin_probe++;
+    // once every route has been timed once: a route 30 % behind the best needs no second look (a short run does not spend its frames on them)
+    bool once = true;
+    double lead = 1e30;
+    for (int k = 0; k < n_allowed; k++) { once = once && R->fin_n[route_list[k]] >= 1; lead = std::min(lead, R->fin_best[route_list[k]]); }
+    if (once) for (int k = 0; k < n_allowed; k++) if (R->fin_best[route_list[k]] > 1.3 * lead) R->fin_n[route_list[k]] = std::max(R->fin_n[route_list[k]], 3);
     bool all = true;
     int best = route_list[0];
     for (int k = 0; k < n_allowed; k++) {
       all = all && R->fin_n[route_list[k]] >= 3;
       if (R->fin_best[route_list[k]] < R->fin_best[best] || (R->fin_best[route_list[k]] == R->fin_best[best] && route_list[k] > best)) best = route_list[k];
     }
-    if (all) R->fin_choice = best;
+    if (all) {
+      R->fin_choice = best;
+      if (getenv("GVT_HIP_ROUTE_TRACE")) {
+        fprintf(stderr, "[tracer] frame %llu: route settled -- k_finish %d, hops %s; fastest frame per route timed, ms:", (unsigned long long)R->frame_no, best & 1,
+                (best >> 1) == 0 ? "never" : (best >> 1) == 1 ? "early" : "always");
+        for (int k = 0; k < n_allowed; k++) fprintf(stderr, " [k_finish %d hops %d] %.3f", route_list[k] & 1, route_list[k] >> 1, R->fin_best[route_list[k]]);
+        fprintf(stderr, "\n");
+      }
+    }
   }
   R->frame_no++;
   if (out) *out = S;

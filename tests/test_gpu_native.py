@@ -916,7 +916,8 @@ def test_small_rounds_through_one_launch_or_per_hop_whichever_the_tracer_times_f
 def test_hops_into_the_next_local_instance_change_nothing_but_the_rounds(hip):
     """hop_local (round 6): in a merged launch a ray that leaves its instance without a hit and has another instance of THIS rank ahead goes on there inside the
     launch -- the lane applies shuffleRays' rule (origin advanced by 95 % of the entry distance, TracerBase.h:392-400) and starts again in the next instance --
-    instead of waiting in that instance's queue for the next round; an un-occluded shadow ray likewise.  Never (0) or always (2), on one rank and on two and three
+    instead of waiting in that instance's queue for the next round; an un-occluded shadow ray likewise.  Never (0), always (2) or early (3: the closest-hit launch
+    only, before its drain), on one rank and on two and three
     (only instances the rank owns are entered), with rays parked for a wave after a few steps (they keep their new instance) and through bounces (a bounce starts
     where its parent was hit): the oracle's image, the oracle's ray counts, the same rays sent; on one rank fewer launch chains.  hop_local = 1 (default): the
     tracer times the routes like finish_auto and every frame, whichever route it took, is the same image."""
