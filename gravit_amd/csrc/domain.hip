@@ -1394,8 +1394,9 @@ extern "C" int gvt_hip_tracer_frame(gvt_hip_tracer *R, int flags, gvt_hip_frame_
   // fall back towards the knob when fewer than 0.05 % were.  Results never depend on it.
   // small rounds: k_finish, or per-hop chains -- on one rank with several instances whichever a few timed frames say is faster here (finish_auto)
   const auto frame_t0 = std::chrono::steady_clock::now();
-  // ... and whether a ray that leaves an instance without a hit goes on into the next local one inside the launch (hops: the hall cut into 8 slabs 11.5 -> 4.7 ms,
-  // the soup tiles, whose grazing rays are better off with a wave each, 1.47 -> 1.75) -- timed the same way on one rank, by the meshes' kind on several
+  // ... and whether a ray that leaves an instance without a hit goes on into the next local one inside the launch -- hops: never, early (the closest-hit launch only,
+  // before its drain) or always: the hall cut into 8 slabs 11.5 -> 4.3 ms with "always", the soup tiles 1.46 -> 1.34 with "early" and 1.75 with "always" (their grazing
+  // rays stretch a launch's tail), bunny.conf best without -- timed like finish_auto on one rank (profiles/r06_hops.txt), by the meshes' kind on several
   if (R->frame_no == 0) {
     R->surfaces = true;
     for (size_t i = 0; i < nI; i++) if (R->meshes[i] && !R->meshes[i]->packet_ok) R->surfaces = false;
